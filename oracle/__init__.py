@@ -178,3 +178,25 @@ def backward(st, dL_dcolor, dL_dothers, dL_dextra=None):
                         _p(g["dL_dsh"]), _p(g["dL_dmeans2D"]), _p(g["dL_dmeans3D"]), _p(g["dL_dscales"]),
                         _p(g["dL_drotations"]))
     return g
+
+
+def test_quat_to_rot(q):
+    q = _f32(q)
+    out = np.zeros((q.shape[0], 3, 3), np.float32)
+    lib().so_test_quat_to_rot(c_int(q.shape[0]), _p(q), _p(out))
+    return out
+
+
+def test_sh_to_rgb(deg, pos, cam, shs):
+    pos, cam, shs = _f32(pos), _f32(cam), _f32(shs)
+    n = pos.shape[0]
+    rgb = np.zeros((n, 3), np.float32)
+    cl = np.zeros((n, 3), np.uint8)
+    lib().so_test_sh_to_rgb(c_int(n), c_int(deg), _p(pos), _p(cam), _p(shs), _p(rgb), _p(cl))
+    return rgb, cl.astype(bool)
+
+
+def test_tile_rect(cx, cy, r, gx, gy):
+    out = np.zeros(4, np.uint32)
+    lib().so_test_tile_rect(c_float(cx), c_float(cy), c_int(r), c_int(gx), c_int(gy), _p(out))
+    return tuple(int(v) for v in out)

@@ -793,6 +793,28 @@ void so_dist2_3nn(int P, const float* pts, float* out) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Unit hooks so individual helpers can be pinned against fixtures produced by
+// the reference's Python (utils/general_utils.build_rotation, utils/sh_utils.eval_sh).
+void so_test_quat_to_rot(int n, const float* q, float* R_rowmajor) {
+    for (int i = 0; i < n; i++) {
+        M3 R = quat_to_rot(q + 4 * i);
+        float* o = R_rowmajor + 9 * i;
+        for (int c = 0; c < 3; c++) { o[0 * 3 + c] = R.c[c].x; o[1 * 3 + c] = R.c[c].y; o[2 * 3 + c] = R.c[c].z; }
+    }
+}
+void so_test_sh_to_rgb(int n, int deg, const float* pos, const float* cam, const float* shs, float* rgb, uint8_t* clamped) {
+    for (int i = 0; i < n; i++) {
+        V3 c = sh_to_rgb(deg, 16, V3{pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]}, V3{cam[0], cam[1], cam[2]},
+                         shs + (size_t)i * 48, clamped + 3 * i);
+        rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
+    }
+}
+void so_test_tile_rect(float cx, float cy, int r, int gx, int gy, uint32_t* out4) {
+    float c[2] = {cx, cy};
+    tile_rect(c, r, gx, gy, out4, out4 + 2);
+}
+
 int so_num_threads() {
 #if defined(_OPENMP)
     return omp_get_max_threads();

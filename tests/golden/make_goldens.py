@@ -1,0 +1,283 @@
+#!/usr/bin/env python
+"""Generate the committed golden fixtures by IMPORTING the reference's own Python
+on CPU.  Run only in the build container:
+
+    python tests/golden/make_goldens.py [/root/reference]
+
+Nothing from the reference is copied: only seeded inputs and the numeric
+outputs the reference code produced for them are written (``*.npz``).
+The reference's CUDA rasterizer cannot run here, so ``render()`` is exercised
+around a *fake* rasterizer returning seeded tensors — this pins the reference's
+post-processing of ``allmap`` (gaussian_renderer/__init__.py:118-169), not the
+kernels.
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+if not os.path.isdir(REF):
+    print("reference not present; nothing to do")
+    sys.exit(0)
+sys.path.insert(0, REF)
+
+# ---- stub third-party modules that are absent in this image -----------------
+from typing import NamedTuple
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+for name in ["open3d", "cv2", "trimesh", "einsum", "lpips", "pyrender", "e3nn", "kornia", "plyfile"]:
+    if name not in sys.modules:
+        try:
+            __import__(name)
+        except Exception:
+            _stub(name)
+sys.modules["plyfile"].__dict__.setdefault("PlyData", object)
+sys.modules["plyfile"].__dict__.setdefault("PlyElement", object)
+sys.modules["kornia"].__dict__.setdefault("create_meshgrid", None)
+sys.modules["e3nn"].__dict__.setdefault("o3", None)
+_stub("simple_knn")
+_stub("simple_knn._C", distCUDA2=None)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+FAKE = {}
+
+
+class FakeRasterizer(torch.nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+        FAKE["settings"] = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, extra_attrs=None):
+        FAKE["extra_in"] = None if extra_attrs is None else extra_attrs.detach().clone()
+        return FAKE["color"], FAKE["radii"], FAKE["allmap"], FAKE["extra"], FAKE["grp"]
+
+
+_stub("diff_surfel_rasterization", GaussianRasterizationSettings=GaussianRasterizationSettings,
+      GaussianRasterizer=FakeRasterizer)
+
+torch.Tensor.cuda = lambda self, *a, **k: self
+_orig_tensor_to = torch.Tensor.to
+
+from torch.overrides import TorchFunctionMode
+
+
+class CpuMode(TorchFunctionMode):
+    def __torch_function__(self, func, types_, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if "device" in kwargs and kwargs["device"] is not None and "cuda" in str(kwargs["device"]):
+            kwargs["device"] = "cpu"
+        return func(*args, **kwargs)
+
+
+def save(name, **arrs):
+    arrs = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()}
+    np.savez_compressed(os.path.join(OUT, name), **arrs)
+    print("wrote", name, {k: v.shape for k, v in arrs.items()})
+
+
+with CpuMode():
+    # ------------------------------------------------------------------ G3
+    from utils.contrastive_utils import contrastive_loss
+
+    g = torch.Generator().manual_seed(1234)
+    cases = {}
+    for tag, (Nb, F, K, consider_negative, predef) in {
+        "computed": (512, 16, 9, False, False),
+        "predef": (384, 16, 12, False, True),
+        "negative": (256, 8, 6, True, False),
+        "f32dim": (1024, 32, 20, False, True),
+    }.items():
+        feats = torch.randn(Nb, F, generator=g)
+        labels = torch.randint(0, K + 1, (Nb,), generator=g)      # 0 = unlabeled
+        predef_u = None
+        if predef:
+            predef_u = torch.nn.functional.normalize(torch.randn(K + 1, F, generator=g), dim=1)
+        f = feats.clone().requires_grad_(True)
+        loss = contrastive_loss(f, labels, predef_u_list=predef_u, consider_negative=consider_negative)
+        loss.backward()
+        cases[f"{tag}_features"] = feats
+        cases[f"{tag}_labels"] = labels
+        cases[f"{tag}_predef"] = predef_u if predef_u is not None else torch.zeros(0)
+        cases[f"{tag}_consider_negative"] = np.array(consider_negative)
+        cases[f"{tag}_loss"] = loss.detach()
+        cases[f"{tag}_grad"] = f.grad
+    # min_pixnum variant
+    feats = torch.randn(300, 8, generator=g)
+    labels = torch.randint(0, 15, (300,), generator=g)
+    f = feats.clone().requires_grad_(True)
+    loss = contrastive_loss(f, labels, min_pixnum=18)
+    loss.backward()
+    cases.update(minpix_features=feats, minpix_labels=labels, minpix_loss=loss.detach(), minpix_grad=f.grad,
+                 minpix_min_pixnum=np.array(18))
+    save("contrastive_loss.npz", **cases)
+
+    # ------------------------------------------------------------------ G5 cameras
+    from scene.cameras import Camera
+    from utils.graphics_utils import getProjectionMatrix, getWorld2View2
+
+    cam_out = {}
+    rng = np.random.RandomState(7)
+    cams = []
+    for i in range(4):
+        A = rng.randn(3, 3)
+        Q, _ = np.linalg.qr(A)
+        if np.linalg.det(Q) < 0:
+            Q[:, 0] = -Q[:, 0]
+        T = rng.randn(3) * 2.0
+        fovx = math.radians(40 + 15 * i)
+        W, H = [(64, 48), (80, 48), (128, 96), (40, 40)][i]
+        fovy = 2 * math.atan(math.tan(fovx / 2) * H / W)
+        cam = Camera(colmap_id=i, R=Q, T=T, FoVx=fovx, FoVy=fovy, image=torch.zeros(3, H, W), image_name=str(i), uid=i,
+                     data_device="cpu")
+        cams.append(cam)
+        cam_out.update({f"R{i}": Q, f"T{i}": T, f"fov{i}": np.array([fovx, fovy]), f"wh{i}": np.array([W, H]),
+                        f"wvt{i}": cam.world_view_transform, f"proj{i}": cam.projection_matrix,
+                        f"full{i}": cam.full_proj_transform, f"center{i}": cam.camera_center})
+    save("cameras.npz", **cam_out)
+
+    # ------------------------------------------------------------------ G4 render() post-processing
+    import gaussian_renderer
+
+    class FakePC:
+        active_sh_degree = 3
+        max_sh_degree = 3
+
+        def __init__(self, P, F, gen):
+            self._xyz = torch.randn(P, 3, generator=gen)
+            self._seg = torch.randn(P, F, generator=gen) if F else None
+            self._op = torch.rand(P, 1, generator=gen)
+            self._sc = torch.rand(P, 2, generator=gen) * 0.1
+            self._rot = torch.nn.functional.normalize(torch.randn(P, 4, generator=gen))
+            self._sh = torch.randn(P, 16, 3, generator=gen)
+
+        get_xyz = property(lambda s: s._xyz)
+        get_opacity = property(lambda s: s._op)
+        get_seg_feature = property(lambda s: s._seg)
+        get_scaling = property(lambda s: s._sc)
+        get_rotation = property(lambda s: s._rot)
+        get_features = property(lambda s: s._sh)
+
+    class Pipe:
+        compute_cov3D_python = False
+        convert_SHs_python = False
+        depth_ratio = 1.0
+        debug = False
+
+    rp = {}
+    for i, cam in enumerate(cams[:3]):
+        gen = torch.Generator().manual_seed(100 + i)
+        W, H = cam.image_width, cam.image_height
+        P, F = 50, 6
+        pc = FakePC(P, F, gen)
+        alpha = torch.rand(1, H, W, generator=gen)
+        alpha[:, : H // 4] = 0.0            # empty region -> nan_to_num path
+        allmap = torch.cat([alpha * (1.0 + 3.0 * torch.rand(1, H, W, generator=gen)), alpha,
+                            torch.randn(3, H, W, generator=gen) * alpha,
+                            (1.0 + 3.0 * torch.rand(1, H, W, generator=gen)) * (alpha > 0),
+                            torch.rand(1, H, W, generator=gen) * 0.01], dim=0)
+        FAKE.update(color=torch.rand(3, H, W, generator=gen), radii=torch.randint(0, 5, (P,), generator=gen).int(),
+                    allmap=allmap, extra=torch.randn(F, H, W, generator=gen),
+                    grp=torch.randint(0, P, (17, 2), generator=gen).int())
+        for ratio in (1.0, 0.0):
+            pipe = Pipe()
+            pipe.depth_ratio = ratio
+            out = gaussian_renderer.render(cam, pc, pipe, torch.zeros(3))
+            tag = f"c{i}_r{int(ratio)}"
+            rp[f"{tag}_allmap"] = allmap
+            for k in ["rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal", "rend_depth",
+                      "rend_median_depth", "visibility_filter"]:
+                rp[f"{tag}_{k}"] = out[k]
+        rp[f"c{i}_seg_raw"] = pc._seg
+        rp[f"c{i}_seg_passed_to_rasterizer"] = FAKE["extra_in"]
+        s = FAKE["settings"]
+        rp[f"c{i}_settings"] = np.array([s.image_height, s.image_width, s.tanfovx, s.tanfovy, s.scale_modifier,
+                                         s.sh_degree], dtype=np.float64)
+    save("render_post.npz", **rp)
+
+    # ------------------------------------------------------------------ SH + rotation helpers
+    from utils.sh_utils import eval_sh
+    from utils.general_utils import build_rotation
+
+    gen = torch.Generator().manual_seed(55)
+    shs = torch.randn(200, 16, 3, generator=gen)
+    dirs = torch.nn.functional.normalize(torch.randn(200, 3, generator=gen), dim=1)
+    sh_out = {"shs": shs, "dirs": dirs}
+    for deg in range(4):
+        sh_out[f"rgb_deg{deg}"] = eval_sh(deg, shs.transpose(1, 2), dirs)
+    q = torch.randn(200, 4, generator=gen)
+    sh_out["quats"] = q
+    sh_out["rotmats"] = build_rotation(q)
+    save("sh_rot.npz", **sh_out)
+
+    # ------------------------------------------------------------------ losses (H2)
+    from utils.loss_utils import l1_loss, ssim
+
+    gen = torch.Generator().manual_seed(77)
+    a = torch.rand(3, 40, 56, generator=gen).requires_grad_(True)
+    b = torch.rand(3, 40, 56, generator=gen)
+    l1 = l1_loss(a, b)
+    ss = ssim(a, b)
+    (0.8 * l1 + 0.2 * (1.0 - ss)).backward()
+    save("losses.npz", img=a.detach(), gt=b, l1=l1.detach(), ssim=ss.detach(), grad=a.grad)
+
+    # ------------------------------------------------------------------ depth_to_normal
+    from utils.point_utils import depth_to_normal
+
+    dn = {}
+    for i, cam in enumerate(cams[:2]):
+        gen = torch.Generator().manual_seed(200 + i)
+        depth = 1.0 + 2.0 * torch.rand(1, cam.image_height, cam.image_width, generator=gen)
+        dn[f"depth{i}"] = depth
+        dn[f"normal{i}"] = depth_to_normal(cam, depth)
+    save("depth_to_normal.npz", **dn)
+
+    # ------------------------------------------------------------------ Gram-Schmidt class features (L3)
+    from scene.gaussian_model import GaussianModel
+
+    try:
+        gm = GaussianModel(3)
+        gm.seg_feat_dim = 16
+        gm._seg_feature = None
+        gm._xyz = torch.zeros(40, 3)
+        torch.manual_seed(9)
+        masks = np.zeros((40, 5), dtype=bool)
+        for k in range(5):
+            masks[k * 8:(k + 1) * 8, k] = True
+        state = torch.get_rng_state()
+        gm.set_3d_feat(masks, gram_feat=True)
+        torch.set_rng_state(state)
+        seg0 = torch.rand((40, 16))
+        init = torch.rand((5, 16))
+        save("gram_schmidt.npz", init_rand=init, class_feat=gm.class_feat, seg_feature=gm._seg_feature.detach(),
+             seg_rand=seg0, masks=masks)
+    except Exception as e:  # pragma: no cover
+        print("gram-schmidt golden skipped:", repr(e))

@@ -1,0 +1,127 @@
+"""Closed-form known-answer cases derived from the reference source
+ — pins the oracle where no reference output can be produced."""
+import math
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from instascene_amd import scenes
+
+
+def _axis_camera(W=33, H=33, fovx_deg=60.0):
+    fovx = math.radians(fovx_deg)
+    fovy = 2 * math.atan(math.tan(fovx / 2) * H / W)
+    return scenes.camera_from_w2c(torch.eye(4), fovx, fovy, W, H)
+
+
+def _fwd(cam, xyz, opac, colors, scales=None, bg=(0, 0, 0), extra=None, tracer=False):
+    P = len(xyz)
+    scales = np.full((P, 2), 0.05, np.float32) if scales is None else scales
+    rots = np.tile(np.array([1, 0, 0, 0], np.float32), (P, 1))
+    return oracle.forward(np.asarray(xyz, np.float32), np.asarray(opac, np.float32), cam.world_view_transform.numpy(),
+                          cam.full_proj_transform.numpy(), cam.camera_center.numpy(), np.asarray(bg, np.float32),
+                          cam.image_width, cam.image_height, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2),
+                          scales=scales, rotations=rots, colors_precomp=np.asarray(colors, np.float32), extra=extra,
+                          tracer=tracer)
+
+
+def test_single_gaussian_on_axis_centre_pixel():
+    cam = _axis_camera()
+    z, op = 2.5, 0.6
+    c = np.array([[0.2, 0.5, 0.9]], np.float32)
+    bg = (0.1, 0.3, 0.7)
+    ex = np.array([[1.0, -2.0, 0.5]], np.float32)
+    st = _fwd(cam, [[0, 0, z]], [op], c, bg=bg, extra=ex, tracer=True)
+    y = x = 16                                      # ndc 0 -> pixel (W-1)/2
+    a = np.float32(op)
+    np.testing.assert_allclose(st["color"][:, y, x], a * c[0] + (1 - a) * np.array(bg, np.float32), rtol=1e-6)
+    np.testing.assert_allclose(st["others"][0, y, x], a * z, rtol=1e-6)
+    np.testing.assert_allclose(st["others"][1, y, x], a, rtol=1e-6)
+    np.testing.assert_allclose(st["others"][2:5, y, x], a * np.array([0, 0, -1.0]), atol=1e-7)
+    np.testing.assert_allclose(st["others"][5, y, x], z, rtol=1e-6)
+    assert abs(st["others"][6, y, x]) < 1e-9
+    np.testing.assert_allclose(st["extra"][:, y, x], a * ex[0], rtol=1e-6)   # no background term on features
+    assert st["n_contrib"][0, y * 33 + x] == 1 and st["n_contrib"][1, y * 33 + x] == 1
+    # tracer: w = 0.6 > 0.1 at the centre pixel
+    pairs = {(int(g), int(p)) for g, p in st["tracer"]}
+    assert (0, y * 33 + x) in pairs
+    assert st["radii"][0] > 0 and st["depths"][0] == np.float32(z)
+
+
+def test_two_stacked_gaussians_distortion_closed_form():
+    cam = _axis_camera()
+    z1, z2, o1, o2 = 2.0, 3.0, 0.5, 0.7
+    st = _fwd(cam, [[0, 0, z1], [0, 0, z2]], [o1, o2], np.ones((2, 3)))
+    y = x = 16
+    m = lambda d: (100.0 / 99.8) * (1 - 0.2 / d)
+    w1, w2 = o1, o2 * (1 - o1)
+    np.testing.assert_allclose(st["others"][6, y, x], w1 * w2 * (m(z2) - m(z1)) ** 2, rtol=2e-4)
+    np.testing.assert_allclose(st["others"][1, y, x], 1 - (1 - o1) * (1 - o2), rtol=1e-6)
+    np.testing.assert_allclose(st["others"][0, y, x], w1 * z1 + w2 * z2, rtol=1e-6)
+    # T before 2nd gaussian = 0.5, not > 0.5 -> median stays at the first
+    np.testing.assert_allclose(st["others"][5, y, x], z1, rtol=1e-6)
+    # sort order is front-to-back
+    tile = (16 // 16) * 3 + (16 // 16)
+    r0, r1 = st["ranges"][tile]
+    assert list(st["point_list"][r0:r1]) == [0, 1]
+
+
+def test_alpha_below_1_over_255_is_skipped_and_near_cull():
+    cam = _axis_camera()
+    st = _fwd(cam, [[0, 0, 2.0], [0, 0, 0.2], [0, 0, -1.0]], [0.0039, 0.9, 0.9], np.ones((3, 3)))
+    assert st["radii"][1] == 0 and st["radii"][2] == 0            # p_view.z <= 0.2 (auxiliary.h:201)
+    assert st["tiles_touched"][1] == 0
+    assert st["others"][1].max() == 0.0                            # 0.0039 < 1/255
+    assert st["n_contrib"][0].max() == 0
+    vis = oracle.mark_visible(np.array([[0, 0, 2.0], [0, 0, 0.2], [0, 0, 0.21]], np.float32),
+                              cam.world_view_transform.numpy(), cam.full_proj_transform.numpy())
+    assert list(vis) == [True, False, True]
+
+
+def test_transmittance_termination_before_blending():
+    cam = _axis_camera()
+    st = _fwd(cam, [[0, 0, 2.0], [0, 0, 2.5], [0, 0, 3.0]], [1.0, 1.0, 1.0],
+              np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32))
+    pix = 16 * 33 + 16
+    # alpha clamps to 0.99; second test_T = 0.01*0.01 < 1e-4 -> stop before blending it
+    assert st["n_contrib"][0, pix] == 1
+    np.testing.assert_allclose(st["color"][:, 16, 16], [0.99, 0, 0], rtol=1e-6)
+    np.testing.assert_allclose(st["final_T"][0, pix], 1 - np.float32(0.99), rtol=1e-6)
+
+
+def test_key_layout_and_ranges():
+    cam = _axis_camera(64, 48)
+    st = _fwd(cam, [[0.3, 0.1, 2.0], [-0.4, -0.2, 3.0]], [0.5, 0.5], np.ones((2, 3)),
+              scales=np.full((2, 2), 0.2, np.float32))
+    gx = 4
+    assert st["R"] == int(st["tiles_touched"].sum())
+    keys = st["keys"]
+    assert (np.diff(keys.astype(np.uint64)) >= 0).all()
+    for k, g in zip(keys, st["point_list"]):
+        tile = int(k) >> 32
+        bits = int(k) & 0xFFFFFFFF
+        assert bits == struct.unpack("<I", struct.pack("<f", st["depths"][g]))[0]
+        assert 0 <= tile < gx * 3
+    for t, (a, b) in enumerate(st["ranges"]):
+        assert all((int(k) >> 32) == t for k in keys[a:b])
+
+
+@pytest.mark.parametrize("cx,cy,r,expect", [
+    (8.0, 8.0, 3, (0, 0, 1, 1)),
+    (16.0, 16.0, 1, (0, 0, 2, 2)),          # (16-1)/16 -> 0 ; (16+1+15)/16 -> 2
+    (-50.0, 8.0, 3, (0, 0, 0, 1)),          # left of the image: empty in x
+    (1000.0, 1000.0, 5, (4, 3, 4, 3)),      # clamped to the grid
+    (31.5, 47.9, 2, (1, 2, 3, 3)),
+])
+def test_tile_rect_integer_semantics(cx, cy, r, expect):
+    assert oracle.test_tile_rect(cx, cy, r, 4, 3) == expect
+
+
+def test_dist2_3nn_regular_grid_interior_is_one():
+    g = np.stack(np.meshgrid(np.arange(5), np.arange(5), np.arange(5), indexing="ij"), -1).reshape(-1, 3)
+    d = oracle.dist2_3nn(g.astype(np.float32)).reshape(5, 5, 5)
+    assert d[2, 2, 2] == 1.0 and d[1, 3, 2] == 1.0
+    assert d[0, 0, 0] == 1.0                       # corner: 3 axis neighbours at distance 1
