@@ -1,0 +1,126 @@
+/*
+ * instascene_rasterizer.h — C-ABI of the MI355X-native 2D-Gaussian ("surfel")
+ * rasterizer.  This is the drop-in boundary for the reference's
+ *
+ *   CudaRasterizer::Rasterizer::forward      cuda_rasterizer/rasterizer.h:35-66
+ *   CudaRasterizer::Rasterizer::backward     cuda_rasterizer/rasterizer.h:68-93
+ *   CudaRasterizer::Rasterizer::markVisible  cuda_rasterizer/rasterizer.h:28-33
+ *
+ * (paths relative to submodules/diff-surfel-rasterization/ of zju3dv/InstaScene).
+ *
+ * Differences from the reference interface, all at the ABI level only:
+ *   - the three std::function<char*(size_t)> resize callbacks are replaced by
+ *     size queries (isr_*_bytes) + caller-provided workspaces; forward is split
+ *     at the one point where the instance count R must be known to size the
+ *     binning workspace (rasterizer_impl.cu:283-291);
+ *   - every call takes the HIP stream to launch on (the reference uses the
+ *     legacy default stream); pass NULL for the default stream;
+ *   - optional inputs are NULL (shs xor colors_precomp; (scales,rotations) xor
+ *     transMat_precomp; extra_attrs with ED = 0);
+ *   - all pointers are DEVICE pointers to contiguous row-major fp32/int32 data
+ *     unless stated; no torch types.
+ *
+ * Return value: 0 on success, a negative ISR_E* code otherwise;
+ * isr_last_error() returns a human-readable message for the calling thread.
+ */
+#ifndef INSTASCENE_RASTERIZER_H
+#define INSTASCENE_RASTERIZER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISR_OK 0
+#define ISR_EINVAL (-1)    /* bad argument combination (reference: AT_ERROR / std::runtime_error) */
+#define ISR_EHIP (-2)      /* a HIP runtime call or kernel launch failed */
+#define ISR_ECAPACITY (-3) /* binning workspace smaller than the instance count */
+
+/* arithmetic mode of the blend kernels */
+#define ISR_MODE_EXACT 0 /* op-for-op IEEE fp32, bit-identical to oracle/surfel_oracle.cpp */
+#define ISR_MODE_FAST 1  /* explicit FMA contraction + hardware rcp/exp in the per-pixel loops */
+
+/* which gradients isr_backward must produce (bit mask) */
+#define ISR_GRAD_EXTRA 1u    /* dL_dextra only needs the blend weights */
+#define ISR_GRAD_GEOMETRY 2u /* everything else (colors, opacity, means, scales, rotations, sh, transMat, means2D) */
+
+const char* isr_last_error(void);
+int isr_version(void);
+
+/* ---- workspace sizes (bytes); the layouts are opaque forward->backward hand-offs
+ *      (reference: GeometryState / ImageState / BinningState, rasterizer_impl.h:29-65). */
+size_t isr_geom_bytes(int P);
+size_t isr_image_bytes(int width, int height);
+size_t isr_binning_bytes(int64_t num_rendered, int width, int height);
+/* scratch for the deterministic (atomic-free) gradient reduction in isr_backward */
+size_t isr_backward_scratch_bytes(int64_t num_rendered, int ED, unsigned grad_mask);
+
+/* ---- forward, part 1: per-Gaussian preprocess (K1), per-tile counting and scans.
+ * Replaces rasterizer_impl.cu:233-287.  Writes radii[P].  If num_rendered_host is
+ * non-NULL the call synchronises the stream and stores R there (the reference
+ * always does this blocking read, rasterizer_impl.cu:287); pass NULL to stay
+ * asynchronous and read R later with isr_read_num_rendered(). */
+int isr_forward_prepare(int P, int D, int M, int width, int height,
+                        const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* opacities, const float* scales, float scale_modifier,
+                        const float* rotations, const float* transMat_precomp,
+                        const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                        float tan_fovx, float tan_fovy, int prefiltered,
+                        int* radii, void* geom_buffer, void* image_buffer,
+                        int64_t* num_rendered_host, void* stream);
+
+int isr_read_num_rendered(const void* geom_buffer, int64_t* num_rendered_host, void* stream);
+
+/* ---- forward, part 2: binning (K4-K7 equivalent) and the per-tile blend (K8).
+ * Replaces rasterizer_impl.cu:289-351.  binning_capacity is the R the binning
+ * workspace was sized for.  out_extra may be NULL when ED == 0.  The tracer
+ * ("gau_related_pixels", forward.cu:422-428) is optional: pass NULL to skip it;
+ * otherwise tracer_pairs[tracer_capacity][2] receives (gaussian, pixel) pairs
+ * with blend weight > 0.1 in unspecified order and *tracer_count (device int32)
+ * their number (entries beyond capacity are counted but not stored). */
+int isr_forward_render(int P, int ED, int width, int height, int mode,
+                       const float* background, const float* colors_precomp,
+                       const float* transMat_precomp, const float* extra_attrs,
+                       void* geom_buffer, void* binning_buffer, int64_t binning_capacity,
+                       void* image_buffer,
+                       float* out_color, float* out_others, float* out_extra,
+                       int32_t* tracer_pairs, int64_t tracer_capacity, int32_t* tracer_count,
+                       void* stream);
+
+/* ---- backward (K9 + K10).  Replaces rasterizer_impl.cu:355-463.  Gradient
+ * outputs are fully written by the call (no zero-initialisation needed); the
+ * ones not selected by grad_mask may be NULL.  dL_dout_* may be NULL meaning
+ * "all zeros" (autograd passes no gradient for an unused output). */
+int isr_backward(int P, int D, int M, int64_t num_rendered, int ED, int width, int height, int mode,
+                 unsigned grad_mask,
+                 const float* background, const float* means3D, const float* shs,
+                 const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* transMat_precomp, const float* extra_attrs,
+                 const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                 float tan_fovx, float tan_fovy, const int* radii,
+                 const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                 const float* dL_dout_color, const float* dL_dout_others, const float* dL_dout_extra,
+                 float* dL_dmean2D /*[P,3]*/, float* dL_dnormal /*[P,3]*/, float* dL_dopacity /*[P]*/,
+                 float* dL_dcolor /*[P,3]*/, float* dL_dmean3D /*[P,3]*/, float* dL_dtransMat /*[P,9]*/,
+                 float* dL_dsh /*[P,M,3]*/, float* dL_dscale /*[P,2]*/, float* dL_drot /*[P,4]*/,
+                 float* dL_dextra /*[P,ED]*/,
+                 void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---- rasterizer_impl.cu:141-153 */
+int isr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/* ---- introspection for the parity tests (device->host copies of integer state;
+ * any output pointer may be NULL).  Host pointers. */
+int isr_debug_state(int P, int width, int height, int64_t num_rendered,
+                    const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                    uint32_t* tiles_touched /*[P]*/, uint32_t* point_list /*[R]*/,
+                    uint32_t* ranges /*[tiles,2]*/, uint32_t* n_contrib /*[2,N]*/,
+                    float* final_T /*[3,N]*/, float* splat_records /*[P,20]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,77 @@
+"""ctypes binding of the C-ABI library (include/instascene_rasterizer.h,
+include/instascene_ops.h).  The library is the product: if it is missing or a
+symbol cannot be resolved this module raises — there is no CPU or PyTorch
+fallback anywhere in ``instascene_amd``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint, c_uint8, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinstascene_hip.so")
+_lib = None
+
+MODE_EXACT, MODE_FAST = 0, 1
+GRAD_EXTRA, GRAD_GEOMETRY = 1, 2
+
+# every exported symbol and its signature (checked by tests/test_abi.py against include/*.h)
+_P = c_void_p
+SIGNATURES = {
+    "isr_last_error": (c_char_p, []),
+    "isr_version": (c_int, []),
+    "isr_geom_bytes": (c_size_t, [c_int]),
+    "isr_image_bytes": (c_size_t, [c_int, c_int]),
+    "isr_binning_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "isr_backward_scratch_bytes": (c_size_t, [c_int64, c_int, c_uint]),
+    "isr_forward_prepare": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
+                                    c_float, c_float, c_int, _P, _P, _P, _P, _P]),
+    "isr_read_num_rendered": (c_int, [_P, _P, _P]),
+    "isr_forward_render": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
+                                   _P, c_int64, _P, _P]),
+    "isr_backward": (c_int, [c_int, c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_uint,
+                             _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, c_float, c_float, _P,
+                             _P, _P, _P, _P, _P, _P,
+                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                             _P, c_size_t, _P]),
+    "isr_mark_visible": (c_int, [c_int, _P, _P, _P, _P, _P]),
+    "isr_debug_state": (c_int, [c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    args = ["make", "-C", src_dir, "-s"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"instascene_amd: {LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)        # AttributeError if the symbol is not exported: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class IsrError(RuntimeError):
+    """Mirrors the reference's RuntimeError raised from C++ (AT_ERROR / std::runtime_error)."""
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().isr_last_error()
+        raise IsrError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,698 @@
+// Backward path of the MI355X surfel rasterizer (K9 reference backward.cu:143-466,
+// K10 backward.cu:469-656, K11 rasterizer_impl.cu:54-66).
+//
+// Design (MI355X-first; the reference issues ~(16+F) float atomics per
+// (pixel, Gaussian) pair):
+//   * No global atomics at all.  Every (tile, Gaussian) instance owns one row of a
+//     scratch matrix, addressed by  slot = point_offsets[g] + rank(tile in g's rect),
+//     so a Gaussian's rows are contiguous and a second, coalesced pass sums them.
+//     Gradients are therefore bit-reproducible run to run.
+//   * Inside a tile the sum over the 64 pixels of a wavefront of  w(pix,g) * dL/dout(pix,ch)
+//     is a GEMM  [32 splats x 64 pixels] . [64 pixels x channels]  — it runs on the
+//     matrix cores with the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 for the feature
+//     channels, v_mfma_f32_16x16x4_f32 for colour+normal), fed from a per-wave LDS
+//     transpose of the blend weights.  MFMA is a separate pipe from the VALU that
+//     recomputes the alphas, so the reduction is nearly free.
+//   * The 12 gradient terms that are not weight-linear (dL/dT, dL/dcentre, dL/dopacity)
+//     are reduced across the wavefront with butterflies, only for (wave, splat) pairs
+//     where some pixel contributes.
+//   * The per-channel feature recurrences of the reference (2F registers) collapse to
+//     one scalar recurrence on q = <feature_g, dL/dfeature(pix)> (same algebra).
+#include "isr_common.hpp"
+
+namespace isr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GEOM_ROW = 20;   // [0..8] dL_dT  [9,10] dL_dcentre  [11..13] dL_dnormal  [14] dL_dopacity  [15..17] dL_dcolor
+constexpr int BB = 32;         // instances per backward batch
+constexpr int WPAD = 65;       // row pitch (floats) of the per-wave weight transpose
+
+__host__ __device__ inline int feat_row(int ED) { return ED > 0 ? ((ED + 31) / 32) * 32 : 0; }
+__host__ __device__ inline int row_floats(int ED, unsigned mask) {
+    return ((mask & 2u) ? GEOM_ROW : 0) + ((mask & 1u) ? feat_row(ED) : 0);
+}
+size_t backward_scratch_bytes(int64_t R, int ED, unsigned mask) {
+    const size_t rows = (size_t)(R > 0 ? R : 1);
+    return align_up(rows * row_floats(ED, mask) * sizeof(float), 256) + 256;
+}
+
+__global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D,
+                                                      const float* __restrict__ view, uint8_t* __restrict__ present) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float x = means3D[3 * (size_t)i], y = means3D[3 * (size_t)i + 1], z = means3D[3 * (size_t)i + 2];
+    const float vz = view[2] * x + view[6] * y + view[10] * z + view[14];
+    present[i] = vz > 0.2f ? 1 : 0;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ----------------------------------------------------------------------------
+// K9.  One workgroup (4 waves) per tile, wave w owns the 8x8 pixel block (w&1, w>>1).
+// GEOM: produce the 18 geometry/appearance terms.  FEAT: produce dL/dextra for the
+// 32-channel chunk starting at ch_base.  Rows are written for EVERY instance.
+template <class Math, bool GEOM, bool FEAT>
+__global__ __launch_bounds__(256) void k_render_bwd(
+    int W, int H, int ED, int ch_base, int gx, const uint32_t* __restrict__ tile_offset,
+    const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ col_pre,
+    const float* __restrict__ tm_pre, const float* __restrict__ extras, const float* __restrict__ bg,
+    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dC,
+    const float* __restrict__ dO, const float* __restrict__ dE, const uint32_t* __restrict__ point_offsets,
+    const Rect16* __restrict__ rects, float* __restrict__ partial, int row_stride, int geom_off, int feat_off,
+    int64_t capacity) {
+    constexpr int RS = 16;
+    constexpr int PART = (GEOM ? GEOM_ROW : 0) + (FEAT ? 32 : 0);   // floats per instance per wave in LDS
+    __shared__ __attribute__((aligned(16))) float s_rec[BB * RS];
+    __shared__ __attribute__((aligned(16))) float s_rgb[BB * 4];
+    __shared__ __attribute__((aligned(16))) float s_feat[(GEOM && FEAT) ? BB * 32 : 4];
+    __shared__ int s_id[BB];
+    __shared__ unsigned s_slot[BB];
+    __shared__ float s_W[4 * BB * WPAD];
+    __shared__ __attribute__((aligned(16))) float s_part[4 * BB * PART];
+    __shared__ unsigned s_max[4];
+
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned px = tx * TILE + (wv & 1) * 8 + (lane & 7);
+    const unsigned py = ty * TILE + (wv >> 1) * 8 + (lane >> 3);
+    const bool inside = px < (unsigned)W && py < (unsigned)H;
+    const size_t N = (size_t)W * H;
+    const size_t pix = (size_t)W * py + px;
+    const float pxf = (float)px, pyf = (float)py;
+
+    const int64_t r0 = tile_offset[tile];
+    int64_t r1 = tile_offset[tile + 1];
+    if (r1 > capacity) r1 = capacity;
+    const int len = (int)(r1 - r0);
+    if (len <= 0) return;
+
+    float* Ww = s_W + wv * BB * WPAD;
+    float* Pw = s_part + wv * BB * PART;
+
+    const unsigned last_contributor = inside ? n_contrib[pix] : 0u;
+    {   // tile-wide bound: nothing behind the deepest last contributor blends
+        unsigned m = last_contributor;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if (lane == 0) s_max[wv] = m;
+    }
+    __syncthreads();
+    const unsigned tile_max = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+
+    // ---- MFMA B operands (constant for the whole tile) -------------------------
+    // feature tile: B[k][j] with k = lane>>5 (pixel 2s+k of this wave), j = lane&31 (channel)
+    float Bf[FEAT ? 32 : 1];
+    if constexpr (FEAT) {
+        const int ch = ch_base + (lane & 31);
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+            const int q = 2 * s + (lane >> 5);
+            const unsigned qx = tx * TILE + (wv & 1) * 8 + (q & 7), qy = ty * TILE + (wv >> 1) * 8 + (q >> 3);
+            Bf[s] = (dE != nullptr && ch < ED && qx < (unsigned)W && qy < (unsigned)H)
+                        ? dE[(size_t)ch * N + (size_t)W * qy + qx] : 0.0f;
+        }
+    }
+    // colour+normal tile (16x16x4): B[k][j], k = lane>>4 (pixel 4s+k), j = lane&15 (0..2 dC, 3..5 dN)
+    float Bl[GEOM ? 16 : 1];
+    if constexpr (GEOM) {
+        const int j = lane & 15;
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const int q = 4 * s + (lane >> 4);
+            const unsigned qx = tx * TILE + (wv & 1) * 8 + (q & 7), qy = ty * TILE + (wv >> 1) * 8 + (q >> 3);
+            float v = 0.0f;
+            if (qx < (unsigned)W && qy < (unsigned)H) {
+                const size_t qp = (size_t)W * qy + qx;
+                if (j < 3) v = dC ? dC[(size_t)j * N + qp] : 0.0f;
+                else if (j < 6) v = dO ? dO[(size_t)(2 + j - 3) * N + qp] : 0.0f;
+            }
+            Bl[s] = v;
+        }
+    }
+
+    // ---- per-pixel state (GEOM) -------------------------------------------------
+    float dpx0 = 0, dpx1 = 0, dpx2 = 0, dL_ddepth = 0, dL_daccum = 0, dL_dreg = 0, dn0 = 0, dn1 = 0, dn2 = 0, dL_dmedian = 0;
+    float T_final = 0, final_D = 0, final_D2 = 0;
+    unsigned median_contributor = 0;
+    float dEp[(GEOM && FEAT) ? 32 : 1];
+    if (inside) {
+        T_final = final_T[pix];
+        if (GEOM) {
+            final_D = final_T[pix + N];
+            final_D2 = final_T[pix + 2 * N];
+            median_contributor = n_contrib[pix + N];
+            if (dC) { dpx0 = dC[pix]; dpx1 = dC[N + pix]; dpx2 = dC[2 * N + pix]; }
+            if (dO) {
+                dL_ddepth = dO[pix]; dL_daccum = dO[N + pix]; dn0 = dO[2 * N + pix]; dn1 = dO[3 * N + pix];
+                dn2 = dO[4 * N + pix]; dL_dmedian = dO[5 * N + pix]; dL_dreg = dO[6 * N + pix];
+            }
+        }
+    }
+    if constexpr (GEOM && FEAT) {
+#pragma unroll
+        for (int c = 0; c < 32; c++)
+            dEp[c] = (inside && dE != nullptr && ch_base + c < ED) ? dE[(size_t)(ch_base + c) * N + pix] : 0.0f;
+    }
+    const float final_A = 1 - T_final;
+    const float mscale = FAR_N / (FAR_N - NEAR_N);
+    float T = GEOM ? T_final : 1.0f;
+    float acc_r0 = 0, acc_r1 = 0, acc_r2 = 0, lc0 = 0, lc1 = 0, lc2 = 0;
+    float accum_depth_rec = 0, last_depth = 0, accum_alpha_rec = 0, an0 = 0, an1 = 0, an2 = 0, ln0 = 0, ln1 = 0, ln2 = 0;
+    float last_dL_dT = 0, last_alpha = 0, accum_q = 0, last_q = 0;
+    const float bg_dot = GEOM ? (bg[0] * dpx0 + bg[1] * dpx1) + bg[2] * dpx2 : 0.0f;
+
+    // GEOM walks back to front (reference order); features-only walks front to back.
+    const int nbatch = (len + BB - 1) / BB;
+    for (int bi = 0; bi < nbatch; bi++) {
+        // batch covers list positions [lo, lo+nb) (0-based from r0)
+        int lo, nb;
+        if (GEOM) { const int hi = len - bi * BB; lo = max(0, hi - BB); nb = hi - lo; }
+        else { lo = bi * BB; nb = min(BB, len - lo); }
+        __syncthreads();   // previous batch's rows are out of s_part / s_rec
+        if (threadIdx.x < nb) {
+            const int t = threadIdx.x;
+            const int id = (int)point_list[r0 + lo + t];
+            s_id[t] = id;
+            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
+            float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3], e = r4[4];
+            if (tm_pre != nullptr) {
+                const float* tp = tm_pre + 9 * (size_t)id;
+                a = make_float4(tp[0], tp[1], tp[2], tp[3]);
+                b = make_float4(tp[4], tp[5], tp[6], tp[7]);
+                c.x = tp[8];
+            }
+            if (col_pre != nullptr) {
+                d.w = col_pre[3 * (size_t)id]; e.x = col_pre[3 * (size_t)id + 1]; e.y = col_pre[3 * (size_t)id + 2];
+            }
+            const float opa = d.z;
+            float skip = __builtin_inff();
+            if (opa <= 1.0f) {
+                const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
+                skip = 2.0f * l * 1.01f + 0.05f;
+            }
+            float4* s4 = reinterpret_cast<float4*>(s_rec + t * RS);
+            s4[0] = a; s4[1] = b; s4[2] = c; s4[3] = make_float4(d.x, d.y, opa, skip);
+            reinterpret_cast<float4*>(s_rgb)[t] = make_float4(d.w, e.x, e.y, 0.0f);
+            const Rect16 rc = rects[id];
+            s_slot[t] = point_offsets[id] + (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
+        }
+        __syncthreads();
+        if constexpr (GEOM && FEAT) {
+            for (int e = threadIdx.x; e < nb * 32; e += 256) {
+                const int inst = e >> 5, c = e & 31;
+                s_feat[e] = (ch_base + c < ED) ? extras[(size_t)s_id[inst] * ED + ch_base + c] : 0.0f;
+            }
+        }
+        // zero this wave's partial block
+        for (int e = lane; e < BB * PART; e += 64) Pw[e] = 0.0f;
+        __syncthreads();
+
+        const bool batch_live = (unsigned)lo < tile_max;   // some pixel may still blend an entry of this batch
+        if (batch_live) {
+            // ---- phase A: every lane evaluates its pixel against the batch ----------
+            for (int jj = 0; jj < nb; jj++) {
+                const int j = GEOM ? nb - 1 - jj : jj;
+                const unsigned contributor = (unsigned)(lo + j);     // 0-based index == reference's decremented counter
+                float w = 0.0f;
+                bool act = inside && contributor < last_contributor;
+                float G = 0, alpha = 0, sx = 0, sy = 0, c_d = 0, rho3d = 0, rho2d = 0, dx = 0, dy = 0;
+                F3 kk = {0, 0, 0}, ll = {0, 0, 0}, p = {0, 0, 1};
+                const float4 a = reinterpret_cast<const float4*>(s_rec + j * RS)[0];
+                const float4 b = reinterpret_cast<const float4*>(s_rec + j * RS)[1];
+                const float4 c = reinterpret_cast<const float4*>(s_rec + j * RS)[2];
+                const float4 d = reinterpret_cast<const float4*>(s_rec + j * RS)[3];
+                const F3 Tw = {b.z, b.w, c.x};
+                if (act) {
+                    const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y};
+                    kk = {Math::msub(pxf, Tw.x, Tu.x), Math::msub(pxf, Tw.y, Tu.y), Math::msub(pxf, Tw.z, Tu.z)};
+                    ll = {Math::msub(pyf, Tw.x, Tv.x), Math::msub(pyf, Tw.y, Tv.y), Math::msub(pyf, Tw.z, Tv.z)};
+                    p = {Math::msub(kk.y, ll.z, kk.z * ll.y), Math::msub(kk.z, ll.x, kk.x * ll.z),
+                         Math::msub(kk.x, ll.y, kk.y * ll.x)};
+                    dx = c.y - pxf; dy = c.z - pyf;
+                    rho2d = FILTER_INV_SQ * Math::mad(dy, dy, dx * dx);
+                    const float skip = d.w;
+                    if (rho2d > skip && Math::mad(p.y, p.y, p.x * p.x) > skip * (p.z * p.z) * 1.01f) act = false;
+                    else if (p.z == 0.0f) act = false;
+                }
+                if (act) {
+                    sx = Math::div(p.x, p.z); sy = Math::div(p.y, p.z);
+                    rho3d = Math::mad(sy, sy, sx * sx);
+                    const float rho = fminf(rho3d, rho2d);
+                    c_d = (rho3d <= rho2d) ? Math::mad(sy, Tw.y, sx * Tw.x) + Tw.z : Tw.z;
+                    const float power = -0.5f * rho;
+                    if (c_d < NEAR_N || power > 0.0f) act = false;
+                    else {
+                        G = Math::ex(power);
+                        alpha = fminf(0.99f, d.z * G);
+                        if (alpha < 1.0f / 255.0f) act = false;
+                    }
+                }
+                if (act) {
+                    if (GEOM) { T = T / (1.f - alpha); w = alpha * T; }
+                    else { w = alpha * T; T = T * (1 - alpha); }
+                }
+                Ww[j * WPAD + lane] = w;
+                if constexpr (GEOM) {
+                    float g[12];
+#pragma unroll
+                    for (int q = 0; q < 12; q++) g[q] = 0.0f;
+                    if (act) {
+                        const float4 col = reinterpret_cast<const float4*>(s_rgb)[j];
+                        float dL_dalpha = 0.0f;
+                        acc_r0 = last_alpha * lc0 + (1.f - last_alpha) * acc_r0; lc0 = col.x; dL_dalpha += (col.x - acc_r0) * dpx0;
+                        acc_r1 = last_alpha * lc1 + (1.f - last_alpha) * acc_r1; lc1 = col.y; dL_dalpha += (col.y - acc_r1) * dpx1;
+                        acc_r2 = last_alpha * lc2 + (1.f - last_alpha) * acc_r2; lc2 = col.z; dL_dalpha += (col.z - acc_r2) * dpx2;
+                        float dL_dz = 0.0f;
+                        const float m_d = mscale * (1 - NEAR_N / c_d);
+                        const float dmd_dd = (FAR_N * NEAR_N) / ((FAR_N - NEAR_N) * c_d * c_d);
+                        if (contributor == median_contributor - 1u) dL_dz += dL_dmedian;
+                        const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
+                        dL_dalpha += dL_dweight - last_dL_dT;
+                        last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
+                        const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
+                        dL_dz += dL_dmd * dmd_dd;
+                        accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                        last_depth = c_d;
+                        dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
+                        accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
+                        dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
+                        const float nx = c.w, ny = d.x, nz = d.y;
+                        an0 = last_alpha * ln0 + (1.f - last_alpha) * an0; ln0 = nx; dL_dalpha += (nx - an0) * dn0;
+                        an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = ny; dL_dalpha += (ny - an1) * dn1;
+                        an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = nz; dL_dalpha += (nz - an2) * dn2;
+                        if constexpr (FEAT) {
+                            const float* fj = s_feat + j * 32;
+                            float q = 0.0f;
+#pragma unroll
+                            for (int ch = 0; ch < 32; ch++) q = __builtin_fmaf(fj[ch], dEp[ch], q);
+                            accum_q = last_alpha * last_q + (1.f - last_alpha) * accum_q;
+                            last_q = q;
+                            dL_dalpha += q - accum_q;
+                        }
+                        dL_dalpha *= T;
+                        last_alpha = alpha;
+                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                        const float dL_dG = d.z * dL_dalpha;
+                        dL_dz += alpha * T * dL_ddepth;
+                        if (rho3d <= rho2d) {
+                            const float dsx = dL_dG * -G * sx + dL_dz * Tw.x;
+                            const float dsy = dL_dG * -G * sy + dL_dz * Tw.y;
+                            const float dsx_pz = dsx / p.z, dsy_pz = dsy / p.z;
+                            const F3 dL_dp = {dsx_pz, dsy_pz, -(dsx_pz * sx + dsy_pz * sy)};
+                            const F3 dL_dk = cross3(ll, dL_dp);
+                            const F3 dL_dl = cross3(dL_dp, kk);
+                            g[0] = -dL_dk.x; g[1] = -dL_dk.y; g[2] = -dL_dk.z;
+                            g[3] = -dL_dl.x; g[4] = -dL_dl.y; g[5] = -dL_dl.z;
+                            g[6] = pxf * dL_dk.x + pyf * dL_dl.x + dL_dz * sx;
+                            g[7] = pxf * dL_dk.y + pyf * dL_dl.y + dL_dz * sy;
+                            g[8] = pxf * dL_dk.z + pyf * dL_dl.z + dL_dz * 1.0f;
+                        } else {
+                            g[9] = dL_dG * (-G * FILTER_INV_SQ * dx);
+                            g[10] = dL_dG * (-G * FILTER_INV_SQ * dy);
+                            g[8] = dL_dz;
+                        }
+                        g[11] = G * dL_dalpha;
+                    }
+                    if (__ballot(act) != 0ull) {
+                        float sred[12];
+#pragma unroll
+                        for (int q = 0; q < 12; q++) sred[q] = wave_sum(g[q]);
+                        if (lane == 0) {
+                            float* o = Pw + j * PART;
+#pragma unroll
+                            for (int q = 0; q < 11; q++) o[q] = sred[q];
+                            o[14] = sred[11];
+                        }
+                    }
+                }
+            }
+            // ---- phase M: matrix-core reduction over the wave's 64 pixels -----------
+            if constexpr (FEAT) {
+                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < 32; s++) {
+                    const float av = Ww[(lane & 31) * WPAD + 2 * s + (lane >> 5)];   // A[i = splat][k = pixel]
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bf[s], acc, 0, 0, 0);
+                }
+                // D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
+                constexpr int FO = GEOM ? GEOM_ROW : 0;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    Pw[row * PART + FO + (lane & 31)] = acc[r];
+                }
+            }
+            if constexpr (GEOM) {
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++) {
+                    f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+                    for (int s = 0; s < 16; s++) {
+                        const float av = Ww[(mt * 16 + (lane & 15)) * WPAD + 4 * s + (lane >> 4)];
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bl[s], acc, 0, 0, 0);
+                    }
+                    // D[row = 4*(lane>>4) + r][col = lane&15]; cols 0..2 -> dL_dcolor, 3..5 -> dL_dnormal
+                    const int col = lane & 15;
+                    if (col < 6) {
+                        const int dst = col < 3 ? 15 + col : 11 + (col - 3);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) Pw[(mt * 16 + 4 * (lane >> 4) + r) * PART + dst] = acc[r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- combine the four waves in a fixed order and emit one row per instance ---
+        constexpr int Q4 = PART / 4;
+        for (int e = threadIdx.x; e < nb * Q4; e += 256) {
+            const int inst = e / Q4, q = e - inst * Q4;
+            const float4 v0 = reinterpret_cast<const float4*>(s_part + (0 * BB + inst) * PART)[q];
+            const float4 v1 = reinterpret_cast<const float4*>(s_part + (1 * BB + inst) * PART)[q];
+            const float4 v2 = reinterpret_cast<const float4*>(s_part + (2 * BB + inst) * PART)[q];
+            const float4 v3 = reinterpret_cast<const float4*>(s_part + (3 * BB + inst) * PART)[q];
+            const float4 v = make_float4((v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y),
+                                         (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w));
+            // q indexes [geom 5 float4][feat 8 float4]; map to the global row
+            int dst;
+            if (GEOM && q < GEOM_ROW / 4) dst = geom_off + 4 * q;
+            else dst = feat_off + 4 * (q - (GEOM ? GEOM_ROW / 4 : 0));
+            *reinterpret_cast<float4*>(partial + (size_t)s_slot[inst] * row_stride + dst) = v;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// Row reduction: out[g, c] = sum over the Gaussian's tiles of partial[slot, src_off + c].
+__global__ __launch_bounds__(256) void k_reduce_rows(int P, int ncol, const uint32_t* __restrict__ point_offsets,
+                                                     const uint32_t* __restrict__ tiles_touched,
+                                                     const float* __restrict__ partial, int row_stride, int src_off,
+                                                     float* __restrict__ out, int out_stride) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)P * ncol) return;
+    const int g = (int)(e / ncol), c = (int)(e - (size_t)g * ncol);
+    const uint32_t n = tiles_touched[g];
+    const float* src = partial + (size_t)point_offsets[g] * row_stride + src_off + c;
+    float s = 0.0f;
+    for (uint32_t r = 0; r < n; r++) s += src[(size_t)r * row_stride];
+    out[(size_t)g * out_stride + c] = s;
+}
+
+// ----------------------------------------------------------------------------
+// K10 (reference backward.cu:469-656) fused with the geometry row reduction.
+__device__ __forceinline__ void quat_cols_b(const float* q, F3& c0, F3& c1, F3& c2, float& w, float& x, float& y, float& z) {
+    float s = 1.0f / __builtin_sqrtf(q[3] * q[3] + q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    w = q[0] * s; x = q[1] * s; y = q[2] * s; z = q[3] * s;
+    c0 = {1.f - 2.f * (y * y + z * z), 2.f * (x * y + w * z), 2.f * (x * z - w * y)};
+    c1 = {2.f * (x * y - w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + w * x)};
+    c2 = {2.f * (x * z + w * y), 2.f * (y * z - w * x), 1.f - 2.f * (x * x + y * y)};
+}
+__device__ __forceinline__ F3 dnorm_dv(F3 v, F3 dv) {
+    float s2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    float inv = 1.0f / __builtin_sqrtf(s2 * s2 * s2);
+    F3 r;
+    r.x = ((+s2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * inv;
+    r.y = (-v.x * v.y * dv.x + (s2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * inv;
+    r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (s2 - v.z * v.z) * dv.z) * inv;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_preprocess_bwd(
+    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ tm_pre,
+    const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos, int Wd, int Hd,
+    GeomView g, const float* __restrict__ partial, int row_stride, int geom_off, float* __restrict__ dL_dmean2D,
+    float* __restrict__ dL_dnormal, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
+    float* __restrict__ dL_dmean3D, float* __restrict__ dL_dtransMat, float* __restrict__ dL_dsh,
+    float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
+    constexpr float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    constexpr float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                             0.5462742152960396f};
+    constexpr float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                             -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const size_t I = (size_t)i;
+    // every output row is fully written (no zero-initialisation by the caller)
+    float gs[18];
+#pragma unroll
+    for (int q = 0; q < 18; q++) gs[q] = 0.0f;
+    const uint32_t nt = g.tiles_touched[i];
+    if (nt > 0) {
+        const float* src = partial + (size_t)g.point_offsets[i] * row_stride + geom_off;
+        for (uint32_t r = 0; r < nt; r++) {
+            const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)r * row_stride);
+            const float4 a = s4[0], b = s4[1], c = s4[2], d = s4[3], e = s4[4];
+            gs[0] += a.x; gs[1] += a.y; gs[2] += a.z; gs[3] += a.w; gs[4] += b.x; gs[5] += b.y; gs[6] += b.z; gs[7] += b.w;
+            gs[8] += c.x; gs[9] += c.y; gs[10] += c.z; gs[11] += c.w; gs[12] += d.x; gs[13] += d.y; gs[14] += d.z;
+            gs[15] += d.w; gs[16] += e.x; gs[17] += e.y;
+        }
+    }
+    F3 g0 = {gs[0], gs[1], gs[2]}, g1 = {gs[3], gs[4], gs[5]}, g2 = {gs[6], gs[7], gs[8]};
+    const float dmx = gs[9], dmy = gs[10];
+    dL_dnormal[3 * I] = gs[11]; dL_dnormal[3 * I + 1] = gs[12]; dL_dnormal[3 * I + 2] = gs[13];
+    dL_dopacity[I] = gs[14];
+    dL_dcolor[3 * I] = gs[15]; dL_dcolor[3 * I + 1] = gs[16]; dL_dcolor[3 * I + 2] = gs[17];
+    float m3x = 0, m3y = 0, m3z = 0, dsc0 = 0, dsc1 = 0, dq[4] = {0, 0, 0, 0};
+    float m2x = 0, m2y = 0;
+    const bool vis = g.radii[i] > 0;
+    const bool precomp = (tm_pre != nullptr);
+    if (dL_dsh != nullptr)
+        for (int k = 0; k < M * 3; k++) dL_dsh[I * M * 3 + k] = 0.0f;
+    if (vis) {
+        const float* rec = g.rec + I * REC;
+        F3 Tu, Tv, Tw, normal = {0, 0, 0}, R0 = {0, 0, 0}, R1 = {0, 0, 0}, R2 = {0, 0, 0};
+        float Pm[3][4];
+        F3 p = {0, 0, 0};
+        float qw = 0, qx = 0, qy = 0, qz = 0;
+        if (precomp) {
+            const float* t = tm_pre + 9 * I;
+            Tu = {t[0], t[1], t[2]}; Tv = {t[3], t[4], t[5]}; Tw = {t[6], t[7], t[8]};
+        } else {
+            p = {means3D[3 * I], means3D[3 * I + 1], means3D[3 * I + 2]};
+            const float q[4] = {rots[4 * I], rots[4 * I + 1], rots[4 * I + 2], rots[4 * I + 3]};
+            quat_cols_b(q, R0, R1, R2, qw, qx, qy, qz);
+            const float sx = 1.0f * scales[2 * I], sy = 1.0f * scales[2 * I + 1];   // modifier ignored, backward.cu:507
+            const F3 L0 = R0 * sx, L1 = R1 * sy, L2 = R2;
+            const float S[3][4] = {{L0.x, L0.y, L0.z, 0.f}, {L1.x, L1.y, L1.z, 0.f}, {p.x, p.y, p.z, 1.f}};
+            float n[3][4];
+            n[0][0] = (float)((double)(float)Wd / 2.0); n[0][1] = 0.f; n[0][2] = 0.f; n[0][3] = (float)((double)(float)(Wd - 1) / 2.0);
+            n[1][0] = 0.f; n[1][1] = (float)((double)(float)Hd / 2.0); n[1][2] = 0.f; n[1][3] = (float)((double)(float)(Hd - 1) / 2.0);
+            n[2][0] = 0.f; n[2][1] = 0.f; n[2][2] = 0.f; n[2][3] = 1.f;
+            float T[3][3];
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    Pm[c][k] = proj[4 * k + 0] * n[c][0] + proj[4 * k + 1] * n[c][1] + proj[4 * k + 2] * n[c][2] + proj[4 * k + 3] * n[c][3];
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+                    T[c][r] = S[r][0] * Pm[c][0] + S[r][1] * Pm[c][1] + S[r][2] * Pm[c][2] + S[r][3] * Pm[c][3];
+            Tu = {T[0][0], T[0][1], T[0][2]}; Tv = {T[1][0], T[1][1], T[1][2]}; Tw = {T[2][0], T[2][1], T[2][2]};
+            normal = {view[0] * L2.x + view[4] * L2.y + view[8] * L2.z, view[1] * L2.x + view[5] * L2.y + view[9] * L2.z,
+                      view[2] * L2.x + view[6] * L2.y + view[10] * L2.z};
+        }
+        const float raw_gT2 = g0.z, raw_gT5 = g1.z;
+        bool early = false;
+        if (dmx != 0 || dmy != 0) {
+            const F3 tv = {9.0f, 9.0f, -1.0f};
+            const float d = dot3(tv, Tw * Tw);
+            const F3 f = tv * (1.0f / d);
+            const F3 a0 = (dmx * f) * Tw;
+            const F3 a1 = (dmy * f) * Tw;
+            F3 a3 = (dmx * f) * Tu + (dmy * f) * Tv;
+            const F3 dL_df = (dmx * Tu) * Tw + (dmy * Tv) * Tw;
+            const float dL_dd = (float)((double)dot3(dL_df, f) * (-1.0 / (double)d));
+            const F3 dd_dT3 = (tv * Tw) * 2.0f;
+            a3 = a3 + dL_dd * dd_dT3;
+            g0 = g0 + a0; g1 = g1 + a1; g2 = g2 + a3;
+            if (precomp) early = true;
+        }
+        float hack2 = raw_gT2, hack5 = raw_gT5;
+        if (precomp) {
+            if (early) { hack2 = g0.z; hack5 = g1.z; }
+            else { g0 = {gs[0], gs[1], gs[2]}; g1 = {gs[3], gs[4], gs[5]}; g2 = {gs[6], gs[7], gs[8]}; }
+        }
+        if (!precomp) {
+            auto gT = [&](int c, int r) { const F3& v = (c == 0 ? g0 : (c == 1 ? g1 : g2)); return r == 0 ? v.x : (r == 1 ? v.y : v.z); };
+            float dM[3][4];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) dM[r][k] = Pm[0][k] * gT(0, r) + Pm[1][k] * gT(1, r) + Pm[2][k] * gT(2, r);
+            const F3 dn = {gs[11], gs[12], gs[13]};
+            F3 dL_dtn = {view[0] * dn.x + view[1] * dn.y + view[2] * dn.z, view[4] * dn.x + view[5] * dn.y + view[6] * dn.z,
+                         view[8] * dn.x + view[9] * dn.y + view[10] * dn.z};
+            const F3 pv = {view[0] * p.x + view[4] * p.y + view[8] * p.z + view[12],
+                           view[1] * p.x + view[5] * p.y + view[9] * p.z + view[13],
+                           view[2] * p.x + view[6] * p.y + view[10] * p.z + view[14]};
+            const F3 pn = pv * normal;
+            const float cosv = -(pn.x + pn.y + pn.z);
+            dL_dtn = (cosv > 0 ? 1.0f : -1.0f) * dL_dtn;
+            const F3 rs0 = {dM[0][0], dM[0][1], dM[0][2]}, rs1 = {dM[1][0], dM[1][1], dM[1][2]}, rs2 = dL_dtn;
+            const float sx = scales[2 * I], sy = scales[2 * I + 1];
+            const F3 r0 = rs0 * F3{sx, sx, sx}, r1 = rs1 * F3{sy, sy, sy}, r2 = rs2;
+            // v_R(col,row)
+            auto G = [&](int col, int row) { const F3& v = (col == 0 ? r0 : (col == 1 ? r1 : r2)); return row == 0 ? v.x : (row == 1 ? v.y : v.z); };
+            const float w = qw, x = qx, y = qy, z = qz;
+            dq[0] = 2.f * (x * (G(1, 2) - G(2, 1)) + y * (G(2, 0) - G(0, 2)) + z * (G(0, 1) - G(1, 0)));
+            dq[1] = 2.f * (-2.f * x * (G(1, 1) + G(2, 2)) + y * (G(0, 1) + G(1, 0)) + z * (G(0, 2) + G(2, 0)) + w * (G(1, 2) - G(2, 1)));
+            dq[2] = 2.f * (x * (G(0, 1) + G(1, 0)) - 2.f * y * (G(0, 0) + G(2, 2)) + z * (G(1, 2) + G(2, 1)) + w * (G(2, 0) - G(0, 2)));
+            dq[3] = 2.f * (x * (G(0, 2) + G(2, 0)) + y * (G(1, 2) + G(2, 1)) - 2.f * z * (G(0, 0) + G(1, 1)) + w * (G(0, 1) - G(1, 0)));
+            dsc0 = dot3(rs0, R0);
+            dsc1 = dot3(rs1, R1);
+            m3x = dM[2][0]; m3y = dM[2][1]; m3z = dM[2][2];
+            // the reference does not write the AABB-augmented dL_dT back in this branch
+            g0 = {gs[0], gs[1], gs[2]}; g1 = {gs[3], gs[4], gs[5]}; g2 = {gs[6], gs[7], gs[8]};
+        }
+        if (shs != nullptr) {
+            const F3 pos = {means3D[3 * I], means3D[3 * I + 1], means3D[3 * I + 2]};
+            const F3 dir_orig = pos - F3{campos[0], campos[1], campos[2]};
+            const float len = __builtin_sqrtf(dot3(dir_orig, dir_orig));
+            const F3 dir = {dir_orig.x / len, dir_orig.y / len, dir_orig.z / len};
+            const float* shp = shs + I * M * 3;
+            auto sh = [&](int k) { return F3{shp[3 * k], shp[3 * k + 1], shp[3 * k + 2]}; };
+            const unsigned cm = g.clamped[i];
+            F3 dRGB = {gs[15], gs[16], gs[17]};
+            dRGB.x *= (cm & 1u) ? 0.f : 1.f; dRGB.y *= (cm & 2u) ? 0.f : 1.f; dRGB.z *= (cm & 4u) ? 0.f : 1.f;
+            F3 ddx = {0, 0, 0}, ddy = {0, 0, 0}, ddz = {0, 0, 0};
+            const float x = dir.x, y = dir.y, z = dir.z;
+            float* out = dL_dsh + I * M * 3;
+            auto put = [&](int k, float c) { out[3 * k] = c * dRGB.x; out[3 * k + 1] = c * dRGB.y; out[3 * k + 2] = c * dRGB.z; };
+            put(0, C0);
+            if (D > 0) {
+                put(1, -C1 * y); put(2, C1 * z); put(3, -C1 * x);
+                ddx = -C1 * sh(3); ddy = -C1 * sh(1); ddz = C1 * sh(2);
+                if (D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    put(4, C2[0] * xy); put(5, C2[1] * yz); put(6, C2[2] * (2.f * zz - xx - yy));
+                    put(7, C2[3] * xz); put(8, C2[4] * (xx - yy));
+                    ddx = ddx + (C2[0] * y) * sh(4) + (C2[2] * 2.f * -x) * sh(6) + (C2[3] * z) * sh(7) + (C2[4] * 2.f * x) * sh(8);
+                    ddy = ddy + (C2[0] * x) * sh(4) + (C2[1] * z) * sh(5) + (C2[2] * 2.f * -y) * sh(6) + (C2[4] * 2.f * -y) * sh(8);
+                    ddz = ddz + (C2[1] * y) * sh(5) + (C2[2] * 2.f * 2.f * z) * sh(6) + (C2[3] * x) * sh(7);
+                    if (D > 2) {
+                        put(9, C3[0] * y * (3.f * xx - yy)); put(10, C3[1] * xy * z);
+                        put(11, C3[2] * y * (4.f * zz - xx - yy));
+                        put(12, C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+                        put(13, C3[4] * x * (4.f * zz - xx - yy)); put(14, C3[5] * z * (xx - yy));
+                        put(15, C3[6] * x * (xx - 3.f * yy));
+                        ddx = ddx + ((C3[0] * sh(9)) * (3.f * 2.f * xy) + (C3[1] * sh(10)) * yz + (C3[2] * sh(11)) * (-2.f * xy) +
+                                     (C3[3] * sh(12)) * (-3.f * 2.f * xz) + (C3[4] * sh(13)) * (-3.f * xx + 4.f * zz - yy) +
+                                     (C3[5] * sh(14)) * (2.f * xz) + (C3[6] * sh(15)) * (3.f * (xx - yy)));
+                        ddy = ddy + ((C3[0] * sh(9)) * (3.f * (xx - yy)) + (C3[1] * sh(10)) * xz +
+                                     (C3[2] * sh(11)) * (-3.f * yy + 4.f * zz - xx) + (C3[3] * sh(12)) * (-3.f * 2.f * yz) +
+                                     (C3[4] * sh(13)) * (-2.f * xy) + (C3[5] * sh(14)) * (-2.f * yz) +
+                                     (C3[6] * sh(15)) * (-3.f * 2.f * xy));
+                        ddz = ddz + ((C3[1] * sh(10)) * xy + (C3[2] * sh(11)) * (4.f * 2.f * yz) +
+                                     (C3[3] * sh(12)) * (3.f * (2.f * zz - xx - yy)) + (C3[4] * sh(13)) * (4.f * 2.f * xz) +
+                                     (C3[5] * sh(14)) * (xx - yy));
+                    }
+                }
+            }
+            const F3 dL_ddir = {dot3(ddx, dRGB), dot3(ddy, dRGB), dot3(ddz, dRGB)};
+            const F3 dmean = dnorm_dv(dir_orig, dL_ddir);
+            m3x += dmean.x; m3y += dmean.y; m3z += dmean.z;
+        }
+        const float depth = precomp ? tm_pre[9 * I + 8] : rec[8];
+        m2x = (float)((double)hack2 * depth * 0.5 * (double)(float)Wd);
+        m2y = (float)((double)hack5 * depth * 0.5 * (double)(float)Hd);
+    } else {
+        m2x = dmx; m2y = dmy;   // untouched accumulators (zero: an invisible Gaussian has no instances)
+    }
+    dL_dtransMat[9 * I + 0] = g0.x; dL_dtransMat[9 * I + 1] = g0.y; dL_dtransMat[9 * I + 2] = g0.z;
+    dL_dtransMat[9 * I + 3] = g1.x; dL_dtransMat[9 * I + 4] = g1.y; dL_dtransMat[9 * I + 5] = g1.z;
+    dL_dtransMat[9 * I + 6] = g2.x; dL_dtransMat[9 * I + 7] = g2.y; dL_dtransMat[9 * I + 8] = g2.z;
+    dL_dmean2D[3 * I] = m2x; dL_dmean2D[3 * I + 1] = m2y; dL_dmean2D[3 * I + 2] = 0.0f;
+    dL_dmean3D[3 * I] = m3x; dL_dmean3D[3 * I + 1] = m3y; dL_dmean3D[3 * I + 2] = m3z;
+    dL_dscale[2 * I] = dsc0; dL_dscale[2 * I + 1] = dsc1;
+    dL_drot[4 * I] = dq[0]; dL_drot[4 * I + 1] = dq[1]; dL_drot[4 * I + 2] = dq[2]; dL_drot[4 * I + 3] = dq[3];
+}
+
+// ----------------------------------------------------------------------------
+#define ISR_CHECK_LAUNCH_B(name)                                                  \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) return -2;                                          \
+    } while (0)
+
+template <class Math>
+static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int H, unsigned mask, const float* bg,
+                             const float* means3D, const float* shs, const float* col_pre, const float* scales,
+                             const float* rots, const float* tm_pre, const float* extras, const float* view,
+                             const float* proj, const float* campos, float tan_fovx, float tan_fovy, const void* geom,
+                             const void* binning, const void* image, const float* dC, const float* dO, const float* dE,
+                             float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
+                             float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                             float* dL_dextra, void* scratch, hipStream_t s) {
+    const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
+    GeomView g = geom_view(const_cast<void*>(geom), P < 1 ? 1 : P);
+    ImageView iv = image_view(const_cast<void*>(image), W, H);
+    BinView bv = bin_view(const_cast<void*>(binning), R);
+    const bool geomg = (mask & 2u) != 0, featg = (mask & 1u) != 0 && ED > 0;
+    const int stride = row_floats(ED, (geomg ? 2u : 0u) | (featg ? 1u : 0u));
+    const int geom_off = 0, feat_base = geomg ? GEOM_ROW : 0;
+    float* partial = (float*)scratch;
+    if (P == 0) return 0;
+    if (R > 0) {
+        bool first = true;
+        int ch = 0;
+        do {
+            const bool do_geom = geomg && first, do_feat = featg;
+#define ISR_GOB(GM, FT)                                                                                              \
+    hipLaunchKernelGGL((k_render_bwd<Math, GM, FT>), dim3(T), dim3(256), 0, s, W, H, ED, ch, gx, iv.tile_offset,      \
+                       bv.point_list, g.rec, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib, dC, dO, dE,      \
+                       g.point_offsets, g.rect, partial, stride, geom_off, feat_base + ch, R)
+            if (do_geom && do_feat) ISR_GOB(true, true);
+            else if (do_geom) ISR_GOB(true, false);
+            else if (do_feat) ISR_GOB(false, true);
+#undef ISR_GOB
+            ISR_CHECK_LAUNCH_B("k_render_bwd");
+            first = false;
+            ch += 32;
+        } while (featg && ch < ED);
+    }
+    if (featg) {
+        const size_t total = (size_t)P * ED;
+        hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P, ED, g.point_offsets,
+                           g.tiles_touched, partial, stride, feat_base, dL_dextra, ED);
+        ISR_CHECK_LAUNCH_B("k_reduce_rows");
+    }
+    if (geomg) {
+        const float focal_y = H / (2.0f * tan_fovy), focal_x = W / (2.0f * tan_fovx);
+        const int Wd = (int)(focal_x * tan_fovx * 2), Hd = (int)(focal_y * tan_fovy * 2);   // backward.cu:633-634
+        hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, shs, scales, rots,
+                           tm_pre, view, proj, campos, Wd, Hd, g, partial, stride, geom_off, dL_dmean2D, dL_dnormal,
+                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot);
+        ISR_CHECK_LAUNCH_B("k_preprocess_bwd");
+    }
+    return 0;
+}
+
+int launch_backward(int P, int D, int M, int64_t R, int ED, int W, int H, int mode, unsigned grad_mask, const float* bg,
+                    const float* means3D, const float* shs, const float* col_pre, const float* scales, float,
+                    const float* rots, const float* tm_pre, const float* extras, const float* view, const float* proj,
+                    const float* campos, float tan_fovx, float tan_fovy, const int*, const void* geom,
+                    const void* binning, const void* image, const float* dC, const float* dO, const float* dE,
+                    float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                    float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dextra,
+                    void* scratch, size_t, hipStream_t stream) {
+    if (mode == 0)
+        return launch_backward_t<ExactMath>(P, D, M, R, ED, W, H, grad_mask, bg, means3D, shs, col_pre, scales, rots,
+                                            tm_pre, extras, view, proj, campos, tan_fovx, tan_fovy, geom, binning, image,
+                                            dC, dO, dE, dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor, dL_dmean3D,
+                                            dL_dtransMat, dL_dsh, dL_dscale, dL_drot, dL_dextra, scratch, stream);
+    return launch_backward_t<FastMath>(P, D, M, R, ED, W, H, grad_mask, bg, means3D, shs, col_pre, scales, rots, tm_pre,
+                                       extras, view, proj, campos, tan_fovx, tan_fovy, geom, binning, image, dC, dO, dE,
+                                       dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh,
+                                       dL_dscale, dL_drot, dL_dextra, scratch, stream);
+}
+
+}  // namespace isr

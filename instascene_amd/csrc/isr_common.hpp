@@ -1,0 +1,173 @@
+// Shared device helpers for the MI355X (gfx950) surfel rasterizer.
+//
+// The whole library is compiled with -ffp-contract=off: every fused multiply-add
+// in device code is written explicitly (__builtin_fmaf), so the EXACT arithmetic
+// mode is op-for-op IEEE fp32 (bit-identical to the CPU oracle) and the FAST mode
+// contracts only where this file says so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace isr {
+
+constexpr int TILE = 16;                    // reference config.h:16-17
+constexpr int TILE_PIX = TILE * TILE;
+constexpr float NEAR_N = 0.2f;              // reference auxiliary.h:38-41
+constexpr float FAR_N = 100.0f;
+constexpr float FILTER_SIZE = 0.707106f;
+constexpr float FILTER_INV_SQ = 2.0f;
+constexpr int REC = 20;                     // floats per splat record (80 B)
+// record layout: [0..2]=Tu [3..5]=Tv [6..8]=Tw [9..10]=centre [11..13]=normal [14]=opacity
+//                [15..17]=rgb [18]=view depth [19]=unused
+constexpr int MAX_FCHUNK = 32;              // feature channels handled per pass of the blend kernels
+
+struct alignas(8) Rect16 { uint16_t x0, y0, x1, y1; };
+
+struct GeomView {          // carved from the caller's geometry workspace
+    int64_t* header;       // [0]=num_rendered, [1]=P, [2..7] reserved
+    float* rec;            // [P, REC]
+    uint32_t* tiles_touched;   // [P]
+    uint32_t* point_offsets;   // [P] exclusive scan of tiles_touched
+    Rect16* rect;          // [P]
+    uint8_t* clamped;      // [P] bit mask (bit c set = channel c clamped)
+    int* radii;            // [P] private copy (caller's radii may be freed before backward)
+    uint32_t* scan_tmp;    // block sums for the scan
+};
+
+struct ImageView {
+    float* final_T;        // [3, N]  T, M1, M2
+    uint32_t* n_contrib;   // [2, N]  last contributor, median contributor
+    uint32_t* tile_count;  // [tiles]
+    uint32_t* tile_offset; // [tiles + 1] exclusive scan of tile_count (ranges[t] = off[t], off[t+1])
+    uint32_t* tile_cursor; // [tiles]
+};
+
+struct BinView {
+    unsigned long long* keys;  // [R] (depth_bits << 32) | gaussian, bucketed by tile
+    uint32_t* point_list;      // [R] sorted gaussian ids
+};
+
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <typename T>
+__host__ __device__ inline T* carve(char*& p, size_t count) {
+    p = (char*)align_up((size_t)p, 256);
+    T* r = (T*)p;
+    p += count * sizeof(T);
+    return r;
+}
+
+__host__ __device__ inline int tiles_x(int W) { return (W + TILE - 1) / TILE; }
+__host__ __device__ inline int tiles_y(int H) { return (H + TILE - 1) / TILE; }
+
+inline GeomView geom_view(void* buf, int P) {
+    char* p = (char*)buf;
+    GeomView g;
+    g.header = carve<int64_t>(p, 8);
+    g.rec = carve<float>(p, (size_t)P * REC);
+    g.tiles_touched = carve<uint32_t>(p, P);
+    g.point_offsets = carve<uint32_t>(p, P);
+    g.rect = carve<Rect16>(p, P);
+    g.clamped = carve<uint8_t>(p, P);
+    g.radii = carve<int>(p, P);
+    g.scan_tmp = carve<uint32_t>(p, (size_t)(P / 1024 + 2) * 2);
+    return g;
+}
+inline size_t geom_bytes(int P) {
+    GeomView g = geom_view((void*)0, P);
+    return (size_t)(g.scan_tmp + (size_t)(P / 1024 + 2) * 2) + 256;
+}
+inline ImageView image_view(void* buf, int W, int H) {
+    char* p = (char*)buf;
+    size_t N = (size_t)W * H, T = (size_t)tiles_x(W) * tiles_y(H);
+    ImageView v;
+    v.final_T = carve<float>(p, 3 * N);
+    v.n_contrib = carve<uint32_t>(p, 2 * N);
+    v.tile_count = carve<uint32_t>(p, T);
+    v.tile_offset = carve<uint32_t>(p, T + 1);
+    v.tile_cursor = carve<uint32_t>(p, T);
+    return v;
+}
+inline size_t image_bytes(int W, int H) {
+    ImageView v = image_view((void*)0, W, H);
+    return (size_t)(v.tile_cursor + (size_t)tiles_x(W) * tiles_y(H)) + 256;
+}
+inline BinView bin_view(void* buf, int64_t R) {
+    char* p = (char*)buf;
+    BinView b;
+    b.keys = carve<unsigned long long>(p, (size_t)(R > 0 ? R : 1));
+    b.point_list = carve<uint32_t>(p, (size_t)(R > 0 ? R : 1));
+    return b;
+}
+inline size_t bin_bytes(int64_t R) {
+    BinView b = bin_view((void*)0, R);
+    return (size_t)(b.point_list + (size_t)(R > 0 ? R : 1)) + 256;
+}
+
+// ---------------------------------------------------------------------------
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ F3 operator*(float s, F3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ F3 cross3(F3 a, F3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// Saturating float -> int (v_cvt_i32_f32 saturates and maps NaN to 0; written
+// out so the semantics do not depend on undefined behaviour).
+__device__ __forceinline__ int sat_i32(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+
+// Tile rectangle of a disc (reference auxiliary.h:68-78), same fp32 op order.
+__device__ __forceinline__ void tile_rect(float cx, float cy, int r, int gx, int gy, int& x0, int& y0, int& x1,
+                                          int& y1) {
+    const float fr = (float)r;
+    x0 = min(gx, max(0, sat_i32((cx - fr) / (float)TILE)));
+    y0 = min(gy, max(0, sat_i32((cy - fr) / (float)TILE)));
+    x1 = min(gx, max(0, sat_i32((cx + fr + (float)TILE - 1.0f) / (float)TILE)));
+    y1 = min(gy, max(0, sat_i32((cy + fr + (float)TILE - 1.0f) / (float)TILE)));
+}
+
+// exp(x), x <= 0: fixed fma sequence shared with the oracle (oracle/surfel_oracle.cpp: exp_fixed).
+__device__ __forceinline__ float exp_fixed(float x) {
+    if (x < -87.0f) return 0.0f;
+    float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = __builtin_fmaf(p, r2, r) + 1.0f;
+    int e = (int)n + 127;
+    return y * __uint_as_float((unsigned)e << 23);
+}
+
+// Arithmetic policies for the per-pixel loops.
+struct ExactMath {
+    static constexpr bool fast = false;
+    __device__ static __forceinline__ float mad(float a, float b, float c) { return a * b + c; }   // two roundings
+    __device__ static __forceinline__ float msub(float a, float b, float c) { return a * b - c; }
+    __device__ static __forceinline__ float div(float a, float b) { return a / b; }                // IEEE
+    __device__ static __forceinline__ float ex(float x) { return exp_fixed(x); }
+};
+struct FastMath {
+    static constexpr bool fast = true;
+    __device__ static __forceinline__ float mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    __device__ static __forceinline__ float msub(float a, float b, float c) { return __builtin_fmaf(a, b, -c); }
+    __device__ static __forceinline__ float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+    __device__ static __forceinline__ float ex(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+};
+
+}  // namespace isr

@@ -1,0 +1,511 @@
+// Forward path of the MI355X surfel rasterizer: per-Gaussian preprocess (K1),
+// per-tile bucket binning (replaces the reference's duplicate + 64-bit global
+// radix sort + range scan, rasterizer_impl.cu:70-138,283-323) and the per-tile
+// front-to-back blend (K8, forward.cu:256-462).
+//
+// Binning design (MI355X-first, not a translation of the reference):
+//   1. K1 also counts, per tile, how many splats touch it (non-returning atomics).
+//   2. One small scan over tiles gives every tile its [start,end) range directly —
+//      the reference derives ranges from the sorted keys.
+//   3. A scatter pass drops (depth_bits<<32 | gaussian) into the tile's bucket.
+//   4. One workgroup per tile sorts its bucket in LDS (bitonic, all-ascending
+//      "flip" network with virtual +inf padding; in-place global fallback for
+//      buckets larger than the LDS budget).
+//   Because a Gaussian appears at most once per tile, ordering a bucket by
+//   (depth_bits, gaussian) is exactly the order the reference's stable radix
+//   sort on (tile, depth_bits) produces: point_list and ranges are bit-identical.
+//   HBM traffic is ~20 B/instance instead of ~144 B/instance for six radix passes.
+#include "isr_common.hpp"
+
+namespace isr {
+
+// ----------------------------------------------------------------------------
+// K1: reference forward.cu:148-251 (+ auxiliary.h:186-236,286-293; forward.cu:20-145)
+__device__ __forceinline__ void quat_to_cols(const float* q, F3& c0, F3& c1, F3& c2) {
+    float s = 1.0f / __builtin_sqrtf(q[3] * q[3] + q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    float w = q[0] * s, x = q[1] * s, y = q[2] * s, z = q[3] * s;
+    c0 = {1.f - 2.f * (y * y + z * z), 2.f * (x * y + w * z), 2.f * (x * z - w * y)};
+    c1 = {2.f * (x * y - w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + w * x)};
+    c2 = {2.f * (x * z + w * y), 2.f * (y * z - w * x), 1.f - 2.f * (x * x + y * y)};
+}
+
+__device__ __forceinline__ F3 sh_to_rgb(int deg, F3 pos, F3 cam, const float* shp, unsigned& clamp_mask) {
+    constexpr float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    constexpr float C2a = 1.0925484305920792f, C2b = -1.0925484305920792f, C2c = 0.31539156525252005f,
+                    C2d = -1.0925484305920792f, C2e = 0.5462742152960396f;
+    constexpr float C3a = -0.5900435899266435f, C3b = 2.890611442640554f, C3c = -0.4570457994644658f,
+                    C3d = 0.3731763325901154f, C3e = -0.4570457994644658f, C3f = 1.445305721320277f,
+                    C3g = -0.5900435899266435f;
+    F3 dir = pos - cam;
+    float len = __builtin_sqrtf(dot3(dir, dir));
+    dir = {dir.x / len, dir.y / len, dir.z / len};
+    auto sh = [&](int k) { return F3{shp[3 * k], shp[3 * k + 1], shp[3 * k + 2]}; };
+    F3 res = C0 * sh(0);
+    if (deg > 0) {
+        float x = dir.x, y = dir.y, z = dir.z;
+        res = res - (C1 * y) * sh(1) + (C1 * z) * sh(2) - (C1 * x) * sh(3);
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            res = res + (C2a * xy) * sh(4) + (C2b * yz) * sh(5) + (C2c * (2.0f * zz - xx - yy)) * sh(6) +
+                  (C2d * xz) * sh(7) + (C2e * (xx - yy)) * sh(8);
+            if (deg > 2) {
+                res = res + (C3a * y * (3.0f * xx - yy)) * sh(9) + (C3b * xy * z) * sh(10) +
+                      (C3c * y * (4.0f * zz - xx - yy)) * sh(11) +
+                      (C3d * z * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * sh(12) +
+                      (C3e * x * (4.0f * zz - xx - yy)) * sh(13) + (C3f * z * (xx - yy)) * sh(14) +
+                      (C3g * x * (xx - 3.0f * yy)) * sh(15);
+            }
+        }
+    }
+    res = {res.x + 0.5f, res.y + 0.5f, res.z + 0.5f};
+    clamp_mask = (res.x < 0 ? 1u : 0u) | (res.y < 0 ? 2u : 0u) | (res.z < 0 ? 4u : 0u);
+    return {res.x < 0.0f ? 0.0f : res.x, res.y < 0.0f ? 0.0f : res.y, res.z < 0.0f ? 0.0f : res.z};
+}
+
+__global__ __launch_bounds__(256) void k_preprocess(
+    int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
+    const float* __restrict__ rots, const float* __restrict__ opacities, const float* __restrict__ shs,
+    const float* __restrict__ tm_pre, const float* __restrict__ col_pre, const float* __restrict__ view,
+    const float* __restrict__ proj, const float* __restrict__ campos, int W, int H, int gx, int gy,
+    int* __restrict__ radii_out, GeomView g, uint32_t* __restrict__ tile_count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    int radius_i = 0;
+    uint32_t touched = 0;
+    Rect16 rc = {0, 0, 0, 0};
+    do {
+        const F3 p = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
+        const F3 pv = {view[0] * p.x + view[4] * p.y + view[8] * p.z + view[12],
+                       view[1] * p.x + view[5] * p.y + view[9] * p.z + view[13],
+                       view[2] * p.x + view[6] * p.y + view[10] * p.z + view[14]};
+        if (pv.z <= 0.2f) break;   // near cull, auxiliary.h:201
+        F3 Tu, Tv, Tw, normal;
+        if (tm_pre == nullptr) {
+            F3 c0, c1, c2;
+            const float q[4] = {rots[4 * (size_t)i], rots[4 * (size_t)i + 1], rots[4 * (size_t)i + 2],
+                                rots[4 * (size_t)i + 3]};
+            quat_to_cols(q, c0, c1, c2);
+            const float sx = mod * scales[2 * (size_t)i], sy = mod * scales[2 * (size_t)i + 1];
+            const F3 L0 = c0 * sx, L1 = c1 * sy, L2 = c2;
+            const float S[3][4] = {{L0.x, L0.y, L0.z, 0.f}, {L1.x, L1.y, L1.z, 0.f}, {p.x, p.y, p.z, 1.f}};
+            float n[3][4];
+            n[0][0] = (float)((double)(float)W / 2.0); n[0][1] = 0.f; n[0][2] = 0.f; n[0][3] = (float)((double)(float)(W - 1) / 2.0);
+            n[1][0] = 0.f; n[1][1] = (float)((double)(float)H / 2.0); n[1][2] = 0.f; n[1][3] = (float)((double)(float)(H - 1) / 2.0);
+            n[2][0] = 0.f; n[2][1] = 0.f; n[2][2] = 0.f; n[2][3] = 1.f;
+            float A[3][4], T[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    A[r][j] = S[r][0] * proj[j] + S[r][1] * proj[4 + j] + S[r][2] * proj[8 + j] + S[r][3] * proj[12 + j];
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+                    T[c][r] = A[r][0] * n[c][0] + A[r][1] * n[c][1] + A[r][2] * n[c][2] + A[r][3] * n[c][3];
+            Tu = {T[0][0], T[0][1], T[0][2]};
+            Tv = {T[1][0], T[1][1], T[1][2]};
+            Tw = {T[2][0], T[2][1], T[2][2]};
+            normal = {view[0] * L2.x + view[4] * L2.y + view[8] * L2.z, view[1] * L2.x + view[5] * L2.y + view[9] * L2.z,
+                      view[2] * L2.x + view[6] * L2.y + view[10] * L2.z};
+        } else {
+            const float* t = tm_pre + 9 * (size_t)i;
+            Tu = {t[0], t[1], t[2]}; Tv = {t[3], t[4], t[5]}; Tw = {t[6], t[7], t[8]};
+            normal = {0.f, 0.f, 1.f};
+        }
+        const F3 pn = pv * normal;
+        const float cosv = -(pn.x + pn.y + pn.z);
+        if (cosv == 0.0f) break;
+        normal = (cosv > 0 ? 1.0f : -1.0f) * normal;
+        // 3-sigma screen-space box, forward.cu:119-145
+        const F3 tt = {9.0f, 9.0f, -1.0f};
+        const float d = dot3(tt, Tw * Tw);
+        if (d == 0.0f) break;
+        const F3 f = (1.0f / d) * tt;
+        const float cx = dot3(f, Tu * Tw), cy = dot3(f, Tv * Tw);
+        const float hx = cx * cx - dot3(f, Tu * Tu);
+        const float hy = cy * cy - dot3(f, Tv * Tv);
+        const float ex = __builtin_sqrtf(1e-4f < hx ? hx : 1e-4f);
+        const float ey = __builtin_sqrtf(1e-4f < hy ? hy : 1e-4f);
+        const float em = ex < ey ? ey : ex;
+        const float fmin_r = 3.0f * FILTER_SIZE;
+        const float radius = __builtin_ceilf(em < fmin_r ? fmin_r : em);
+        int x0, y0, x1, y1;
+        tile_rect(cx, cy, sat_i32(radius), gx, gy, x0, y0, x1, y1);
+        if ((unsigned)(x1 - x0) * (unsigned)(y1 - y0) == 0u) break;
+
+        float* rec = g.rec + (size_t)i * REC;
+        F3 rgb = {0.f, 0.f, 0.f};
+        unsigned cm = 0;
+        if (col_pre == nullptr) {
+            rgb = sh_to_rgb(D, p, F3{campos[0], campos[1], campos[2]}, shs + (size_t)i * M * 3, cm);
+        } else {
+            rgb = {col_pre[3 * (size_t)i], col_pre[3 * (size_t)i + 1], col_pre[3 * (size_t)i + 2]};
+        }
+        g.clamped[i] = (uint8_t)cm;
+        float4* r4 = reinterpret_cast<float4*>(rec);
+        r4[0] = make_float4(Tu.x, Tu.y, Tu.z, Tv.x);
+        r4[1] = make_float4(Tv.y, Tv.z, Tw.x, Tw.y);
+        r4[2] = make_float4(Tw.z, cx, cy, normal.x);
+        r4[3] = make_float4(normal.y, normal.z, opacities[i], rgb.x);
+        r4[4] = make_float4(rgb.y, rgb.z, pv.z, 0.0f);
+        radius_i = sat_i32(radius);
+        touched = (unsigned)(y1 - y0) * (unsigned)(x1 - x0);
+        rc = {(uint16_t)x0, (uint16_t)y0, (uint16_t)x1, (uint16_t)y1};
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) atomicAdd(tile_count + (size_t)y * gx + x, 1u);
+    } while (false);
+    radii_out[i] = radius_i;
+    g.radii[i] = radius_i;
+    g.tiles_touched[i] = touched;
+    g.rect[i] = rc;
+}
+
+// ----------------------------------------------------------------------------
+// Scans (exact u32).  Small single-block scan over tiles; three-pass scan over Gaussians.
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* s_warp, uint32_t& total) {
+    // blockDim.x == 1024: 16 waves
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) s_warp[wid] = x;
+    __syncthreads();
+    if (wid == 0) {
+        uint32_t w = lane < 16 ? s_warp[lane] : 0;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            uint32_t y = __shfl_up(w, o);
+            if (lane >= o) w += y;
+        }
+        if (lane < 16) s_warp[16 + lane] = w;   // inclusive
+    }
+    __syncthreads();
+    const uint32_t base = wid == 0 ? 0u : s_warp[16 + wid - 1];
+    total = s_warp[16 + 15];
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(1024) void k_tile_scan(int T, const uint32_t* __restrict__ count, uint32_t* __restrict__ offset,
+                                                    uint32_t* __restrict__ cursor, int64_t* header) {
+    __shared__ uint32_t s_warp[32];
+    uint32_t carry = 0;
+    for (int base = 0; base < T; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < T ? count[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan_1024(v, s_warp, total);
+        if (i < T) {
+            offset[i] = carry + ex;
+            cursor[i] = 0u;
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        offset[T] = carry;
+        header[0] = (int64_t)carry;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_scan_blocks(int n, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                      uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t s_warp[32];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t v = i < n ? in[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan_1024(v, s_warp, total);
+    if (i < n) out[i] = ex;
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void k_scan_tops(int nb, uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t s_warp[32];
+    uint32_t carry = 0;
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nb ? block_sums[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan_1024(v, s_warp, total);
+        if (i < nb) block_sums[i] = carry + ex;
+        carry += total;
+    }
+}
+__global__ __launch_bounds__(1024) void k_scan_add(int n, uint32_t* __restrict__ out, const uint32_t* __restrict__ block_sums) {
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < n) out[i] += block_sums[blockIdx.x];
+}
+
+// ----------------------------------------------------------------------------
+// Scatter: one (depth_bits, gaussian) key per touched tile into that tile's bucket.
+__global__ __launch_bounds__(256) void k_scatter(int P, int gx, GeomView g, const uint32_t* __restrict__ tile_offset,
+                                                 uint32_t* __restrict__ tile_cursor, unsigned long long* __restrict__ keys,
+                                                 int64_t capacity) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    if (g.tiles_touched[i] == 0) return;
+    const Rect16 rc = g.rect[i];
+    const unsigned dbits = __float_as_uint(g.rec[(size_t)i * REC + 18]);
+    const unsigned long long key = ((unsigned long long)dbits << 32) | (unsigned)i;
+    for (int y = rc.y0; y < rc.y1; y++)
+        for (int x = rc.x0; x < rc.x1; x++) {
+            const size_t t = (size_t)y * gx + x;
+            const uint32_t pos = atomicAdd(tile_cursor + t, 1u);
+            const int64_t at = (int64_t)tile_offset[t] + pos;
+            if (at < capacity) keys[at] = key;
+        }
+}
+
+// ----------------------------------------------------------------------------
+// Per-tile bucket sort.  All comparators are ascending (min to the lower index), so
+// indices >= n behave as +inf without being stored.
+constexpr int SORT_LDS_KEYS = 4096;
+
+template <typename KeyPtr>
+__device__ __forceinline__ void bitonic_flip_sort(KeyPtr a, int n) {
+    int npad = 1;
+    while (npad < n) npad <<= 1;
+    const int half = npad >> 1;
+    for (int k = 2; k <= npad; k <<= 1) {
+        const int hk = k >> 1;
+        for (int i = threadIdx.x; i < half; i += blockDim.x) {
+            const int blk = i / hk, off = i - blk * hk;
+            const int lo = blk * k + off, hi = blk * k + k - 1 - off;
+            if (hi < n) {
+                const unsigned long long x = a[lo], y = a[hi];
+                if (y < x) { a[lo] = y; a[hi] = x; }
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j >= 1; j >>= 1) {
+            for (int i = threadIdx.x; i < half; i += blockDim.x) {
+                const int lo = (i / j) * 2 * j + (i % j), hi = lo + j;
+                if (hi < n) {
+                    const unsigned long long x = a[lo], y = a[hi];
+                    if (y < x) { a[lo] = y; a[hi] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ tile_offset, unsigned long long* keys,
+                                                   uint32_t* __restrict__ point_list, int64_t capacity) {
+    __shared__ unsigned long long s_keys[SORT_LDS_KEYS];
+    const uint32_t t = blockIdx.x;
+    const int64_t r0 = tile_offset[t];
+    int64_t r1 = tile_offset[t + 1];
+    if (r1 > capacity) r1 = capacity;
+    const int n = (int)(r1 - r0);
+    if (n <= 0) return;
+    unsigned long long* seg = keys + r0;
+    if (n <= SORT_LDS_KEYS) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) s_keys[i] = seg[i];
+        __syncthreads();
+        bitonic_flip_sort(s_keys, n);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) point_list[r0 + i] = (uint32_t)s_keys[i];
+    } else {
+        // rare: bucket larger than the LDS budget — same network, in place in global memory
+        // (one workgroup; __syncthreads() orders the workgroup's own global accesses).
+        bitonic_flip_sort(seg, n);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) point_list[r0 + i] = (uint32_t)seg[i];
+    }
+}
+
+// ----------------------------------------------------------------------------
+// K8: per-tile front-to-back blend.  256 threads = 4 waves; wave w owns the 8x8
+// pixel block (w&1, w>>1) of the tile so that a splat's footprint diverges as
+// little as possible inside a 64-lane wavefront.
+template <class Math, int FCH, int BATCH>
+__global__ __launch_bounds__(256) void k_render_fwd(
+    int W, int H, int ED, int ch_base, int first_pass, int gx, const uint32_t* __restrict__ tile_offset,
+    const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ col_pre,
+    const float* __restrict__ tm_pre, const float* __restrict__ extras, const float* __restrict__ bg,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+    float* __restrict__ out_others, float* __restrict__ out_extra, int32_t* __restrict__ tracer, long long tracer_cap,
+    int32_t* __restrict__ tracer_count, int64_t capacity) {
+    constexpr int RS = 16;   // staged floats per instance: Tu Tv Tw cx cy nx ny nz opa skip = 16
+    __shared__ __attribute__((aligned(16))) float s_rec[BATCH * RS];
+    __shared__ __attribute__((aligned(16))) float s_rgb[BATCH * 4];
+    __shared__ __attribute__((aligned(16))) float s_feat[(FCH > 0 ? BATCH * FCH : 4)];
+    __shared__ int s_id[BATCH];
+
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned px = tx * TILE + (wv & 1) * 8 + (lane & 7);
+    const unsigned py = ty * TILE + (wv >> 1) * 8 + (lane >> 3);
+    const bool inside = px < (unsigned)W && py < (unsigned)H;
+    const size_t N = (size_t)W * H;
+    const size_t pix = (size_t)W * py + px;
+    const float pxf = (float)px, pyf = (float)py;
+
+    const int64_t r0 = tile_offset[tile];
+    int64_t r1 = tile_offset[tile + 1];
+    if (r1 > capacity) r1 = capacity;
+    const int nfeat = FCH > 0 ? min(FCH, ED - ch_base) : 0;
+
+    bool done = !inside;
+    float T = 1.0f;
+    unsigned contributor = 0, last_contributor = 0, median_contributor = 0;
+    float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, D = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
+    float E[FCH > 0 ? FCH : 1];
+#pragma unroll
+    for (int c = 0; c < (FCH > 0 ? FCH : 1); c++) E[c] = 0.0f;
+    const float mscale = FAR_N / (FAR_N - NEAR_N);
+
+    for (int64_t base = r0; base < r1; base += BATCH) {
+        if (__syncthreads_and(done)) break;
+        const int nb = (int)min((int64_t)BATCH, r1 - base);
+        // ---- cooperative staging: one instance per thread (records), then features by float4 column
+        for (int t = threadIdx.x; t < nb; t += 256) {
+            const int id = (int)point_list[base + t];
+            s_id[t] = id;
+            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
+            float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3], e = r4[4];
+            if (tm_pre != nullptr) {
+                const float* tp = tm_pre + 9 * (size_t)id;
+                a = make_float4(tp[0], tp[1], tp[2], tp[3]);
+                b = make_float4(tp[4], tp[5], tp[6], tp[7]);
+                c.x = tp[8];
+            }
+            if (col_pre != nullptr) {
+                d.w = col_pre[3 * (size_t)id]; e.x = col_pre[3 * (size_t)id + 1]; e.y = col_pre[3 * (size_t)id + 2];
+            }
+            const float opa = d.z;
+            // conservative skip bound: opa*exp(-rho/2) < 1/255 for every rho > skip (1% + 0.05 margin)
+            float skip = __builtin_inff();
+            if (opa <= 1.0f) {
+                const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
+                skip = 2.0f * l * 1.01f + 0.05f;
+            }
+            float4* s4 = reinterpret_cast<float4*>(s_rec + t * RS);
+            s4[0] = a;                                      // Tu.xyz Tv.x
+            s4[1] = b;                                      // Tv.yz Tw.xy
+            s4[2] = make_float4(c.x, c.y, c.z, c.w);        // Tw.z cx cy nx
+            s4[3] = make_float4(d.x, d.y, opa, skip);       // ny nz opa skip
+            reinterpret_cast<float4*>(s_rgb)[t] = make_float4(d.w, e.x, e.y, 0.0f);
+        }
+        __syncthreads();
+        if (FCH > 0) {
+            if ((ED & 3) == 0 && nfeat == FCH) {
+                constexpr int Q = FCH / 4;
+                for (int e = threadIdx.x; e < nb * Q; e += 256) {
+                    const int inst = e / Q, part = e - inst * Q;
+                    reinterpret_cast<float4*>(s_feat)[e] =
+                        *reinterpret_cast<const float4*>(extras + (size_t)s_id[inst] * ED + ch_base + part * 4);
+                }
+            } else {
+                for (int e = threadIdx.x; e < nb * FCH; e += 256) {
+                    const int inst = e / FCH, c = e - inst * FCH;
+                    s_feat[e] = c < nfeat ? extras[(size_t)s_id[inst] * ED + ch_base + c] : 0.0f;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- walk the batch
+        for (int j = 0; !done && j < nb; j++) {
+            contributor++;
+            const float4 a = reinterpret_cast<const float4*>(s_rec + j * RS)[0];
+            const float4 b = reinterpret_cast<const float4*>(s_rec + j * RS)[1];
+            const float4 c = reinterpret_cast<const float4*>(s_rec + j * RS)[2];
+            const float4 d = reinterpret_cast<const float4*>(s_rec + j * RS)[3];
+            const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y}, Tw = {b.z, b.w, c.x};
+            const F3 kk = {Math::msub(pxf, Tw.x, Tu.x), Math::msub(pxf, Tw.y, Tu.y), Math::msub(pxf, Tw.z, Tu.z)};
+            const F3 ll = {Math::msub(pyf, Tw.x, Tv.x), Math::msub(pyf, Tw.y, Tv.y), Math::msub(pyf, Tw.z, Tv.z)};
+            const F3 p = {Math::msub(kk.y, ll.z, kk.z * ll.y), Math::msub(kk.z, ll.x, kk.x * ll.z),
+                          Math::msub(kk.x, ll.y, kk.y * ll.x)};
+            const float dx = c.y - pxf, dy = c.z - pyf;
+            const float rho2d = FILTER_INV_SQ * Math::mad(dy, dy, dx * dx);
+            // exact-preserving early out: both candidate rho's certainly beyond the alpha<1/255 cut
+            const float skip = d.w;
+            if (rho2d > skip && Math::mad(p.y, p.y, p.x * p.x) > skip * (p.z * p.z) * 1.01f) continue;
+            if (p.z == 0.0f) continue;
+            const float sx = Math::div(p.x, p.z), sy = Math::div(p.y, p.z);
+            const float rho3d = Math::mad(sy, sy, sx * sx);
+            const float rho = fminf(rho3d, rho2d);
+            const float depth = (rho3d <= rho2d) ? Math::mad(sy, Tw.y, sx * Tw.x) + Tw.z : Tw.z;
+            if (depth < NEAR_N) continue;
+            const float opa = d.z;
+            const float power = -0.5f * rho;
+            if (power > 0.0f) continue;
+            const float alpha = fminf(0.99f, opa * Math::ex(power));
+            if (alpha < 1.0f / 255.0f) continue;
+            const float test_T = T * (1 - alpha);
+            if (test_T < 0.0001f) { done = true; continue; }
+            const float w = alpha * T;
+            if (first_pass) {
+                const float A = 1 - T;
+                const float m = mscale * (1 - NEAR_N / depth);
+                distortion += (Math::mad(m * m, A, M2) - 2 * m * M1) * w;
+                D = Math::mad(depth, w, D);
+                M1 = Math::mad(m, w, M1);
+                M2 = Math::mad(m * m, w, M2);
+                if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }
+                N0 = Math::mad(c.w, w, N0); N1 = Math::mad(d.x, w, N1); N2 = Math::mad(d.y, w, N2);
+                const float4 col = reinterpret_cast<const float4*>(s_rgb)[j];
+                C0 = Math::mad(col.x, w, C0); C1 = Math::mad(col.y, w, C1); C2 = Math::mad(col.z, w, C2);
+                if (tracer != nullptr && w >= 0.1f) {   // (double)w > 0.1  <=>  w >= 0.1f
+                    const int slot = atomicAdd(tracer_count, 1);
+                    if (slot < tracer_cap) { tracer[2 * (size_t)slot] = s_id[j]; tracer[2 * (size_t)slot + 1] = (int)pix; }
+                }
+            }
+            if (FCH > 0) {
+                const float* fj = s_feat + j * FCH;
+                if (Math::fast) {
+#pragma unroll
+                    for (int q = 0; q < FCH; q++) E[q] = __builtin_fmaf(fj[q], w, E[q]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < FCH; q++) E[q] += fj[q] * alpha * T;   // reference forward.cu:415 order
+                }
+            }
+            T = test_T;
+            last_contributor = contributor;
+        }
+    }
+    if (inside) {
+        if (first_pass) {
+            final_T[pix] = T;
+            final_T[pix + N] = M1;
+            final_T[pix + 2 * N] = M2;
+            n_contrib[pix] = last_contributor;
+            n_contrib[pix + N] = median_contributor;
+            out_color[pix] = C0 + T * bg[0];
+            out_color[N + pix] = C1 + T * bg[1];
+            out_color[2 * N + pix] = C2 + T * bg[2];
+            out_others[pix] = D;
+            out_others[N + pix] = 1 - T;
+            out_others[2 * N + pix] = N0;
+            out_others[3 * N + pix] = N1;
+            out_others[4 * N + pix] = N2;
+            out_others[5 * N + pix] = median_depth;
+            out_others[6 * N + pix] = distortion;
+        }
+        if (FCH > 0) {
+#pragma unroll
+            for (int q = 0; q < FCH; q++)
+                if (q < nfeat) out_extra[(size_t)(ch_base + q) * N + pix] = E[q];
+        }
+    }
+}
+
+// explicit instantiations used by the host API (isr_api.hip)
+#define ISR_INST_FWD(M, F, B)                                                                                          \
+    template __global__ void k_render_fwd<M, F, B>(int, int, int, int, int, int, const uint32_t*, const uint32_t*,     \
+                                                   const float*, const float*, const float*, const float*,            \
+                                                   const float*, float*, uint32_t*, float*, float*, float*, int32_t*, \
+                                                   long long, int32_t*, int64_t);
+ISR_INST_FWD(ExactMath, 0, 256)
+ISR_INST_FWD(ExactMath, 8, 256)
+ISR_INST_FWD(ExactMath, 16, 256)
+ISR_INST_FWD(ExactMath, 32, 128)
+ISR_INST_FWD(FastMath, 0, 256)
+ISR_INST_FWD(FastMath, 8, 256)
+ISR_INST_FWD(FastMath, 16, 256)
+ISR_INST_FWD(FastMath, 32, 128)
+
+}  // namespace isr

@@ -1,0 +1,324 @@
+"""Host-side mirror of the reference's ``diff_surfel_rasterization`` package
+(submodules/diff-surfel-rasterization/diff_surfel_rasterization/__init__.py):
+``GaussianRasterizationSettings`` (:179-191), ``GaussianRasterizer`` (:194-248),
+the autograd function (:49-176) and the three ``_C`` entry points
+(rasterize_points.h:18-74) — same names, argument order, return tuples and
+exception types — on top of the C-ABI HIP library.
+
+PyTorch is used only for device memory, the current stream and autograd
+plumbing; all arithmetic happens in ``libinstascene_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import GRAD_EXTRA, GRAD_GEOMETRY, MODE_EXACT, MODE_FAST, check, lib
+
+_CONFIG = {
+    # arithmetic mode of the per-pixel loops: "exact" (bit-identical to the CPU oracle) or "fast"
+    "mode": MODE_FAST if os.environ.get("ISR_MODE", "exact").lower() == "fast" else MODE_EXACT,
+    # produce the (gaussian, pixel) tracer list like the reference does on every forward
+    "tracer": os.environ.get("ISR_TRACER", "1") != "0",
+}
+
+
+def set_mode(mode: str):
+    _CONFIG["mode"] = {"exact": MODE_EXACT, "fast": MODE_FAST}[mode]
+
+
+def get_mode() -> str:
+    return "fast" if _CONFIG["mode"] == MODE_FAST else "exact"
+
+
+def set_tracer(enabled: bool):
+    _CONFIG["tracer"] = bool(enabled)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None or t.numel() == 0:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t: Optional[torch.Tensor], name: str):
+    if t is None or t.numel() == 0:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")     # reference: CHECK_INPUT, rasterize_points.cu:27-28
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class _State:
+    """Opaque forward->backward hand-off (the reference's geomBuffer/binningBuffer/imgBuffer)."""
+    __slots__ = ("geom", "binning", "image", "R", "P", "W", "H", "ED", "mode")
+
+
+def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
+                        extra_attrs, attr_degree, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
+                        image_width, sh, degree, campos, prefiltered, debug, *, tracer=None, mode=None):
+    """Equivalent of ``_C.rasterize_gaussians`` (rasterize_points.cu:39-151).
+
+    Returns ``(num_rendered, out_color, out_others, radii, out_extra, geomBuffer, binningBuffer, imgBuffer,
+    gau_related_pixels, gau_pixel_indices)``.  ``gau_related_pixels`` holds ``H*W*10`` rows (a pixel has at most 9
+    entries with weight > 0.1) instead of the reference's ``H*W*100`` and is not pre-filled;
+    ``gau_pixel_indices`` is the reference's *last valid index* (count - 1) so that
+    ``gau_related_pixels[:gau_pixel_indices + 1]`` is the list, as in the reference wrapper (:106)."""
+    L = lib()
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    dev = means3D.device
+    P, H, W, F = means3D.shape[0], int(image_height), int(image_width), int(attr_degree)
+    mode = _CONFIG["mode"] if mode is None else mode
+    tracer = _CONFIG["tracer"] if tracer is None else tracer
+    means3D = _f32c(means3D, "means3D")
+    bg = _f32c(bg, "background")
+    colors, opacity = _f32c(colors, "colors"), _f32c(opacity, "opacity")
+    scales, rotations = _f32c(scales, "scales"), _f32c(rotations, "rotations")
+    transMat_precomp = _f32c(transMat_precomp, "transMat_precomp")
+    viewmatrix, projmatrix = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix")
+    sh, campos = _f32c(sh, "sh"), _f32c(campos, "campos")
+    extra = _f32c(extra_attrs.to(dev) if (extra_attrs is not None and extra_attrs.numel() and not extra_attrs.is_cuda)
+                  else extra_attrs, "extra_attrs") if F > 0 else None
+
+    out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    out_others = torch.empty((7, H, W), dtype=torch.float32, device=dev)
+    out_extra = torch.empty((F, H, W), dtype=torch.float32, device=dev) if F > 0 else torch.empty(0, device=dev)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
+    img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
+    M = sh.shape[1] if (sh is not None and sh.dim() == 3) else 0
+    num_rendered = ctypes.c_int64(0)
+    if P == 0:
+        out_color.zero_()
+        out_color += bg.view(3, 1, 1)
+        out_others.zero_()
+        if F > 0:
+            out_extra.zero_()
+        return (0, out_color, out_others, radii, out_extra, geom, torch.empty(0, dtype=torch.uint8, device=dev), img,
+                torch.empty((0, 2), dtype=torch.int32, device=dev), torch.full((1,), -1, dtype=torch.int32, device=dev))
+    with torch.cuda.device(dev):
+        st = _stream()
+        check(L.isr_forward_prepare(P, int(degree), M, W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
+                                    _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(transMat_precomp),
+                                    _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                                    int(bool(prefiltered)), _ptr(radii), _ptr(geom), _ptr(img),
+                                    ctypes.byref(num_rendered), st), "isr_forward_prepare")
+        R = int(num_rendered.value)
+        binning = torch.empty(L.isr_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
+        if tracer:
+            grp = torch.empty((H * W * 10, 2), dtype=torch.int32, device=dev)
+            gcount = torch.empty((1,), dtype=torch.int32, device=dev)
+        else:
+            grp, gcount = None, None
+        check(L.isr_forward_render(P, F, W, H, int(mode), _ptr(bg), _ptr(colors), _ptr(transMat_precomp), _ptr(extra),
+                                   _ptr(geom), _ptr(binning), R, _ptr(img), _ptr(out_color), _ptr(out_others),
+                                   _ptr(out_extra), _ptr(grp), H * W * 10 if tracer else 0, _ptr(gcount), st),
+              "isr_forward_render")
+    if tracer:
+        gidx = gcount - 1
+    else:
+        grp = torch.empty((0, 2), dtype=torch.int32, device=dev)
+        gidx = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    return R, out_color, out_others, radii, out_extra, geom, binning, img, grp, gidx
+
+
+def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, extra_attrs, scale_modifier,
+                                 transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                 dL_dout_others, dL_dout_extra, sh, degree, campos, geomBuffer, R, binningBuffer,
+                                 imageBuffer, debug, *, grad_mask=GRAD_EXTRA | GRAD_GEOMETRY, mode=None):
+    """Equivalent of ``_C.rasterize_gaussians_backward`` (rasterize_points.cu:153-262).  Returns
+    ``(dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dtransMat[P,9], dL_dsh[P,M,3],
+    dL_dscales[P,2], dL_drotations[P,4], dL_dextra[P,F])``; gradients not selected by ``grad_mask`` are None."""
+    L = lib()
+    dev = means3D.device
+    P = means3D.shape[0]
+    H, W = dL_dout_color.shape[1], dL_dout_color.shape[2]
+    mode = _CONFIG["mode"] if mode is None else mode
+    means3D = _f32c(means3D, "means3D")
+    colors, scales, rotations = _f32c(colors, "colors"), _f32c(scales, "scales"), _f32c(rotations, "rotations")
+    transMat_precomp = _f32c(transMat_precomp, "transMat_precomp")
+    sh, campos, bg = _f32c(sh, "sh"), _f32c(campos, "campos"), _f32c(bg, "background")
+    viewmatrix, projmatrix = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix")
+    F = extra_attrs.shape[1] if (extra_attrs is not None and extra_attrs.numel()) else 0
+    extra = _f32c(extra_attrs, "extra_attrs") if F else None
+    M = sh.shape[1] if (sh is not None and sh.dim() == 3) else 0
+    dC, dO = _f32c(dL_dout_color, "dL_dout_color"), _f32c(dL_dout_others, "dL_dout_others")
+    dE = _f32c(dL_dout_extra, "dL_dout_extra") if F else None
+    if F == 0:
+        grad_mask &= ~GRAD_EXTRA
+    geomg = bool(grad_mask & GRAD_GEOMETRY)
+
+    def new(*shape):
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+
+    g2 = new(P, 3) if geomg else None
+    gn = new(P, 3) if geomg else None
+    go = new(P, 1) if geomg else None
+    gc = new(P, 3) if geomg else None
+    g3 = new(P, 3) if geomg else None
+    gt = new(P, 9) if geomg else None
+    gsh = new(P, M, 3) if geomg else None
+    gs = new(P, 2) if geomg else None
+    gr = new(P, 4) if geomg else None
+    ge = new(P, F) if (grad_mask & GRAD_EXTRA) else None
+    if P == 0 or grad_mask == 0:
+        return g2, gc, go, g3, gt, gsh, gs, gr, (ge if F else torch.empty(0, device=dev))
+    nbytes = L.isr_backward_scratch_bytes(int(R), F, grad_mask)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(L.isr_backward(P, int(degree), M, int(R), F, W, H, int(mode), grad_mask, _ptr(bg), _ptr(means3D), _ptr(sh),
+                             _ptr(colors), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(transMat_precomp),
+                             _ptr(extra), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx),
+                             float(tan_fovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                             _ptr(dC), _ptr(dO), _ptr(dE), _ptr(g2), _ptr(gn), _ptr(go), _ptr(gc), _ptr(g3), _ptr(gt),
+                             _ptr(gsh), _ptr(gs), _ptr(gr), _ptr(ge), _ptr(scratch), nbytes, _stream()),
+              "isr_backward")
+    if ge is None:
+        ge = torch.empty(0, device=dev)
+    return g2, gc, go, g3, gt, gsh, gs, gr, ge
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """Equivalent of ``_C.mark_visible`` (rasterize_points.cu:264-283)."""
+    L = lib()
+    P = means3D.shape[0]
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P:
+        means3D = _f32c(means3D, "means3D")
+        with torch.cuda.device(means3D.device):
+            check(L.isr_mark_visible(P, _ptr(means3D), _ptr(_f32c(viewmatrix, "viewmatrix")),
+                                     _ptr(_f32c(projmatrix, "projmatrix")), _ptr(present), _stream()), "isr_mark_visible")
+    return present
+
+
+def debug_state(P, W, H, R, geom, binning, img):
+    """Integer/forward state as numpy arrays (parity tests only)."""
+    import numpy as np
+    L = lib()
+    N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    out = dict(tiles_touched=np.zeros(P, np.uint32), point_list=np.zeros(max(R, 1), np.uint32),
+               ranges=np.zeros((T, 2), np.uint32), n_contrib=np.zeros((2, N), np.uint32),
+               final_T=np.zeros((3, N), np.float32), records=np.zeros((P, 20), np.float32))
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    check(L.isr_debug_state(P, W, H, R, _ptr(geom), _ptr(binning) if R > 0 else None, _ptr(img), vp(out["tiles_touched"]),
+                            vp(out["point_list"]), vp(out["ranges"]), vp(out["n_contrib"]), vp(out["final_T"]),
+                            vp(out["records"]), _stream()), "isr_debug_state")
+    out["point_list"] = out["point_list"][:R]
+    return out
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, extra_attrs,
+                raster_settings):
+        rs = raster_settings
+        attr_degree = extra_attrs.shape[1] if extra_attrs.shape[0] != 0 else 0
+        (num_rendered, color, depth, radii, extra, geomBuffer, binningBuffer, imgBuffer, gau_related_pixels,
+         gau_pixel_indices) = rasterize_gaussians(
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            extra_attrs, attr_degree, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
+            rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        if gau_related_pixels.shape[0]:
+            gau_related_pixels = gau_related_pixels[:(gau_pixel_indices + 1)]   # same slicing as the reference (:106)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.mode = _CONFIG["mode"]
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, extra_attrs, sh,
+                              geomBuffer, binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii, gau_related_pixels)
+        return color, radii, depth, extra, gau_related_pixels
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_out_extra, grad_gau_related_pixels):
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, extra_attrs, sh, geomBuffer, binningBuffer,
+         imgBuffer) = ctx.saved_tensors
+        # needs_input_grad order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D, extra
+        need = ctx.needs_input_grad
+        mask = 0
+        if any(need[i] for i in (0, 1, 2, 3, 4, 5, 6, 7)):
+            mask |= GRAD_GEOMETRY
+        if need[8] and extra_attrs.numel():
+            mask |= GRAD_EXTRA
+        if mask == 0:
+            return (None,) * 10
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations, grad_extra_attrs) = rasterize_gaussians_backward(
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, extra_attrs, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_out_extra, sh,
+            rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug, grad_mask=mask,
+            mode=ctx.mode)
+
+        def pick(i, g, ref):
+            if not need[i] or g is None or ref.numel() == 0:
+                return None
+            return g
+
+        return (pick(0, grad_means3D, means3D), grad_means2D if need[1] else None, pick(2, grad_sh, sh),
+                pick(3, grad_colors_precomp, colors_precomp), grad_opacities if need[4] else None,
+                pick(5, grad_scales, scales), pick(6, grad_rotations, rotations),
+                pick(7, grad_cov3Ds_precomp, cov3Ds_precomp),
+                grad_extra_attrs if (need[8] and extra_attrs.numel()) else None, None)
+
+
+def rasterize_gaussians_autograd(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                 extra_attrs, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, extra_attrs, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            return mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, extra_attrs=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        dev = means3D.device
+        empty = lambda: torch.empty(0, dtype=torch.float32, device=dev)
+        shs = empty() if shs is None else shs
+        colors_precomp = empty() if colors_precomp is None else colors_precomp
+        scales = empty() if scales is None else scales
+        rotations = empty() if rotations is None else rotations
+        cov3D_precomp = empty() if cov3D_precomp is None else cov3D_precomp
+        extra_attrs = empty() if extra_attrs is None else extra_attrs
+        return rasterize_gaussians_autograd(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                            cov3D_precomp, extra_attrs, rs)

@@ -200,3 +200,10 @@ def test_tile_rect(cx, cy, r, gx, gy):
     out = np.zeros(4, np.uint32)
     lib().so_test_tile_rect(c_float(cx), c_float(cy), c_int(r), c_int(gx), c_int(gy), _p(out))
     return tuple(int(v) for v in out)
+
+
+def test_exp(x):
+    x = _f32(x)
+    y = np.zeros_like(x)
+    lib().so_test_exp(c_int(x.size), _p(x), _p(y))
+    return y

@@ -81,6 +81,32 @@ inline uint32_t sat_u32(float v) {
     return (uint32_t)v;
 }
 
+
+// exp() of a non-positive argument.  The reference calls CUDA's expf (<= 2 ulp,
+// forward.cu:385, backward.cu:319); no two libm's agree bit-for-bit, so the
+// oracle pins a fixed, fma-based evaluation (Cephes-style range reduction and a
+// degree-5 polynomial, < 1 ulp) that is reproducible on any IEEE-754 machine —
+// the HIP kernels' "exact" mode evaluates the identical sequence.
+inline float exp_fixed(float x) {
+    if (x < -87.0f) return 0.0f;
+    float n = std::nearbyint(x * 1.44269504088896341f);
+    float r = std::fmaf(n, -0.693359375f, x);
+    r = std::fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = std::fmaf(p, r, 1.3981999507e-3f);
+    p = std::fmaf(p, r, 8.3334519073e-3f);
+    p = std::fmaf(p, r, 4.1665795894e-2f);
+    p = std::fmaf(p, r, 1.6666665459e-1f);
+    p = std::fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = std::fmaf(p, r2, r) + 1.0f;
+    int32_t e = (int32_t)n + 127;           // n in [-126, 0] here
+    uint32_t bits = (uint32_t)e << 23;
+    float scale;
+    std::memcpy(&scale, &bits, 4);
+    return y * scale;
+}
+
 // auxiliary.h:214-236 — rotation matrix from a (w,x,y,z) quaternion, columns.
 struct M3 { V3 c[3]; };   // column-major: c[j] is column j
 inline M3 quat_to_rot(const float* q) {
@@ -415,7 +441,7 @@ void so_render_fwd(int W, int H, int ED, const uint32_t* ranges, const uint32_t*
                     float opa = no[3];
                     float power = -0.5f * rho;
                     if (power > 0.0f) continue;
-                    float alpha = std::min(0.99f, opa * std::exp(power));
+                    float alpha = std::min(0.99f, opa * exp_fixed(power));
                     if (alpha < 1.0f / 255.0f) continue;
                     float test_T = T * (1 - alpha);
                     if (test_T < 0.0001f) break;   // `done = true` — nothing after it blends
@@ -544,7 +570,7 @@ void so_render_bwd(int W, int H, int ED, int P, const uint32_t* ranges, const ui
                     float opa = no[3];
                     float power = -0.5f * rho;
                     if (power > 0.0f) continue;
-                    const float G = std::exp(power);
+                    const float G = exp_fixed(power);
                     const float alpha = std::min(0.99f, opa * G);
                     if (alpha < 1.0f / 255.0f) continue;
 
@@ -814,6 +840,8 @@ void so_test_tile_rect(float cx, float cy, int r, int gx, int gy, uint32_t* out4
     float c[2] = {cx, cy};
     tile_rect(c, r, gx, gy, out4, out4 + 2);
 }
+
+void so_test_exp(int n, const float* x, float* y) { for (int i = 0; i < n; i++) y[i] = exp_fixed(x[i]); }
 
 int so_num_threads() {
 #if defined(_OPENMP)

@@ -1,0 +1,278 @@
+"""GPU parity: the HIP rasterizer (through the C-ABI library) vs the CPU oracle on the
+same seeded inputs.  EXACT mode must be bit-identical on every forward output and
+on all integer state; gradients within 1e-3 (relative to the tensor's max)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import small_scene, oracle_forward, assert_close
+
+pytestmark = pytest.mark.gpu
+
+gpu = pytest.importorskip("torch").cuda.is_available()
+if gpu:
+    from instascene_amd import rasterizer as rz
+    from instascene_amd._lib import GRAD_EXTRA, GRAD_GEOMETRY, MODE_EXACT, MODE_FAST
+
+
+def _dev(t):
+    return None if t is None else t.cuda()
+
+
+def hip_forward(inp, cam, bg=(0.0, 0.0, 0.0), sh_degree=3, mode=None, tracer=False, scale_modifier=1.0,
+                colors_precomp=None, transMat_precomp=None, use_sh=True, use_extra=True):
+    dev = "cuda"
+    e = lambda: torch.empty(0, device=dev)
+    extra = _dev(inp["extra"]) if (use_extra and inp.get("extra") is not None) else e()
+    F = extra.shape[1] if extra.numel() else 0
+    sh = _dev(inp["shs"]) if (use_sh and colors_precomp is None) else e()
+    col = e() if colors_precomp is None else torch.as_tensor(colors_precomp).cuda()
+    tm = e() if transMat_precomp is None else torch.as_tensor(transMat_precomp).cuda()
+    sc = e() if transMat_precomp is not None else _dev(inp["scales"])
+    ro = e() if transMat_precomp is not None else _dev(inp["rotations"])
+    args = dict(bg=torch.tensor(bg, dtype=torch.float32, device=dev), means3D=_dev(inp["means3D"]), colors=col,
+                opacity=_dev(inp["opacities"]), scales=sc, rotations=ro, scale_modifier=scale_modifier,
+                transMat_precomp=tm, extra_attrs=extra, attr_degree=F, viewmatrix=cam.world_view_transform.cuda(),
+                projmatrix=cam.full_proj_transform.cuda(), tan_fovx=math.tan(cam.FoVx * 0.5),
+                tan_fovy=math.tan(cam.FoVy * 0.5), image_height=cam.image_height, image_width=cam.image_width, sh=sh,
+                degree=sh_degree, campos=cam.camera_center.cuda(), prefiltered=False, debug=False)
+    out = rz.rasterize_gaussians(**args, tracer=tracer, mode=mode)
+    return args, out
+
+
+def check_forward_exact(st, args, out, tracer=False):
+    R, color, others, radii, extra, geom, binning, img, grp, gidx = out
+    P, W, H = st["P"], st["W"], st["H"]
+    assert R == st["R"]
+    np.testing.assert_array_equal(radii.cpu().numpy(), st["radii"])
+    dbg = rz.debug_state(P, W, H, R, geom, binning, img)
+    np.testing.assert_array_equal(dbg["tiles_touched"], st["tiles_touched"])
+    np.testing.assert_array_equal(dbg["point_list"], st["point_list"])
+    np.testing.assert_array_equal(dbg["ranges"], st["ranges"])
+    np.testing.assert_array_equal(dbg["n_contrib"], st["n_contrib"])
+    np.testing.assert_array_equal(dbg["final_T"], st["final_T"])
+    np.testing.assert_array_equal(color.cpu().numpy(), st["color"])
+    np.testing.assert_array_equal(others.cpu().numpy(), st["others"])
+    if st["ED"]:
+        np.testing.assert_array_equal(extra.cpu().numpy(), st["extra"])
+    if tracer:
+        n = int(gidx.item()) + 1
+        got = {(int(a), int(b)) for a, b in grp[:n].cpu().numpy()}
+        want = {(int(a), int(b)) for a, b in st["tracer"]}
+        assert n == len(st["tracer"]) and got == want
+
+
+@pytest.mark.parametrize("P,F,W,H,seed,bg", [
+    (400, 6, 64, 48, 3, (0.0, 0.0, 0.0)),
+    (1500, 16, 100, 70, 4, (0.2, 0.4, 0.9)),        # W,H not multiples of 16
+    (800, 32, 96, 64, 5, (1.0, 1.0, 1.0)),
+    (600, 40, 80, 48, 6, (0.0, 0.0, 0.0)),          # F > 32: two feature passes
+    (700, 0, 64, 64, 7, (0.1, 0.1, 0.1)),           # no feature channel
+    (3000, 8, 160, 112, 8, (0.0, 0.0, 0.0)),
+])
+def test_forward_exact_mode_is_bit_identical_to_oracle(P, F, W, H, seed, bg):
+    sc, cams, inp = small_scene(P=P, F=F, W=W, H=H, seed=seed, mu_s=math.log(0.05))
+    for cam in cams[:2]:
+        st = oracle_forward(inp, cam, bg=bg, tracer=True)
+        args, out = hip_forward(inp, cam, bg=bg, mode=MODE_EXACT, tracer=True)
+        check_forward_exact(st, args, out, tracer=True)
+
+
+def test_forward_large_splats_and_long_tile_lists():
+    # big, dense splats: tile lists of several thousand entries exercise the multi-batch blend
+    # and the bitonic sort beyond one pass
+    sc, cams, inp = small_scene(P=6000, F=4, W=64, H=64, seed=11, mu_s=math.log(0.25))
+    st = oracle_forward(inp, cams[0])
+    lens = st["ranges"][:, 1].astype(np.int64) - st["ranges"][:, 0]
+    assert lens.max() > 2000
+    args, out = hip_forward(inp, cams[0], mode=MODE_EXACT)
+    check_forward_exact(st, args, out)
+
+
+def test_forward_bucket_larger_than_lds_sort_budget():
+    sc, cams, inp = small_scene(P=9000, F=0, W=32, H=32, seed=12, mu_s=math.log(0.4))
+    st = oracle_forward(inp, cams[0])
+    lens = st["ranges"][:, 1].astype(np.int64) - st["ranges"][:, 0]
+    assert lens.max() > 4096          # SORT_LDS_KEYS: global-memory fallback path
+    args, out = hip_forward(inp, cams[0], mode=MODE_EXACT)
+    check_forward_exact(st, args, out)
+
+
+def test_forward_precomputed_colors_and_transmat():
+    sc, cams, inp = small_scene(P=500, F=4, W=64, H=48, seed=13)
+    cam = cams[1]
+    st0 = oracle_forward(inp, cam)
+    colors = np.random.RandomState(0).rand(500, 3).astype(np.float32)
+    st = oracle_forward(inp, cam, colors_precomp=colors, shs=None)
+    args, out = hip_forward(inp, cam, mode=MODE_EXACT, colors_precomp=colors)
+    check_forward_exact(st, args, out)
+    tm = st0["transMats"].copy()
+    st2 = oracle_forward(inp, cam, transMat_precomp=tm, scales=None, rotations=None)
+    args, out = hip_forward(inp, cam, mode=MODE_EXACT, transMat_precomp=tm)
+    check_forward_exact(st2, args, out)
+
+
+def test_forward_scale_modifier_and_sh_degrees():
+    sc, cams, inp = small_scene(P=500, F=0, W=64, H=48, seed=14)
+    for deg, mod in [(0, 1.0), (1, 0.7), (2, 1.3)]:
+        st = oracle_forward(inp, cams[0], sh_degree=deg, scale_modifier=mod)
+        args, out = hip_forward(inp, cams[0], sh_degree=deg, scale_modifier=mod, mode=MODE_EXACT)
+        check_forward_exact(st, args, out)
+
+
+def test_empty_and_fully_culled():
+    sc, cams, inp = small_scene(P=50, F=3, W=32, H=32, seed=15)
+    inp2 = dict(inp)
+    inp2["means3D"] = inp["means3D"] + torch.tensor([100.0, 0.0, 0.0])     # everything off-screen / behind
+    st = oracle_forward(inp2, cams[0], bg=(0.3, 0.2, 0.1))
+    args, out = hip_forward(inp2, cams[0], bg=(0.3, 0.2, 0.1), mode=MODE_EXACT)
+    check_forward_exact(st, args, out)
+    # P = 0
+    e = torch.empty(0, device="cuda")
+    out = rz.rasterize_gaussians(torch.zeros(3, device="cuda"), torch.empty(0, 3, device="cuda"), e, e, e, e, 1.0, e, e, 0,
+                                 cams[0].world_view_transform.cuda(), cams[0].full_proj_transform.cuda(), 0.5, 0.5, 32,
+                                 32, torch.empty(0, 16, 3, device="cuda"), 3, cams[0].camera_center.cuda(), False, False)
+    assert out[0] == 0 and float(out[1].abs().sum()) == 0.0
+
+
+def _rand_grads(st, seed):
+    g = np.random.RandomState(seed)
+    dC = g.randn(*st["color"].shape).astype(np.float32)
+    dO = g.randn(*st["others"].shape).astype(np.float32)
+    dE = g.randn(*st["extra"].shape).astype(np.float32)
+    return dC, dO, dE
+
+
+def hip_backward(args, out, dC, dO, dE, mask, mode):
+    R, color, others, radii, extra, geom, binning, img, grp, gidx = out
+    return rz.rasterize_gaussians_backward(
+        args["bg"], args["means3D"], radii, args["colors"], args["scales"], args["rotations"], args["extra_attrs"],
+        args["scale_modifier"], args["transMat_precomp"], args["viewmatrix"], args["projmatrix"], args["tan_fovx"],
+        args["tan_fovy"], torch.tensor(dC).cuda(), torch.tensor(dO).cuda(), torch.tensor(dE).cuda(), args["sh"],
+        args["degree"], args["campos"], geom, R, binning, img, False, grad_mask=mask, mode=mode)
+
+
+GRAD_NAMES = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dtransMat", "dL_dsh", "dL_dscales",
+              "dL_drotations", "dL_dextra"]
+
+
+@pytest.mark.parametrize("P,F,W,H,seed,bg", [
+    (400, 6, 64, 48, 21, (0.0, 0.0, 0.0)),
+    (1200, 32, 96, 64, 22, (0.3, 0.6, 0.1)),
+    (900, 40, 80, 48, 23, (0.0, 0.0, 0.0)),
+    (2500, 16, 112, 80, 24, (1.0, 1.0, 1.0)),
+])
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_backward_matches_oracle(P, F, W, H, seed, bg, mode):
+    m = MODE_EXACT if mode == "exact" else MODE_FAST
+    sc, cams, inp = small_scene(P=P, F=F, W=W, H=H, seed=seed, mu_s=math.log(0.05))
+    cam = cams[2]
+    st = oracle_forward(inp, cam, bg=bg)
+    args, out = hip_forward(inp, cam, bg=bg, mode=m)
+    dC, dO, dE = _rand_grads(st, seed)
+    want = oracle.backward(st, dC, dO, dE)
+    got = hip_backward(args, out, dC, dO, dE, GRAD_EXTRA | GRAD_GEOMETRY, m)
+    for name, t in zip(GRAD_NAMES, got):
+        assert_close(t.cpu().numpy().reshape(want[name].shape), want[name], 1e-3, f"{mode}:{name}")
+    # features-only backward (train_semantic: only the feature parameter needs a gradient)
+    got_e = hip_backward(args, out, dC, dO, dE, GRAD_EXTRA, m)
+    want_e = oracle.backward(st, np.zeros_like(dC), np.zeros_like(dO), dE)
+    assert_close(got_e[8].cpu().numpy(), want_e["dL_dextra"], 1e-3, f"{mode}:extra-only")
+    assert got_e[0] is None and got_e[3] is None
+
+
+def test_backward_is_run_to_run_deterministic():
+    sc, cams, inp = small_scene(P=1500, F=16, W=96, H=64, seed=31, mu_s=math.log(0.06))
+    st = oracle_forward(inp, cams[0])
+    args, out = hip_forward(inp, cams[0], mode=MODE_EXACT)
+    dC, dO, dE = _rand_grads(st, 1)
+    a = hip_backward(args, out, dC, dO, dE, GRAD_EXTRA | GRAD_GEOMETRY, MODE_EXACT)
+    b = hip_backward(args, out, dC, dO, dE, GRAD_EXTRA | GRAD_GEOMETRY, MODE_EXACT)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)        # no float atomics anywhere in the backward
+
+
+def test_backward_precomputed_paths():
+    sc, cams, inp = small_scene(P=500, F=4, W=64, H=48, seed=32)
+    cam = cams[1]
+    st0 = oracle_forward(inp, cam)
+    colors = np.random.RandomState(0).rand(500, 3).astype(np.float32)
+    tm = st0["transMats"].copy()
+    st = oracle_forward(inp, cam, colors_precomp=colors, shs=None, transMat_precomp=tm, scales=None, rotations=None)
+    args, out = hip_forward(inp, cam, mode=MODE_EXACT, colors_precomp=colors, transMat_precomp=tm)
+    dC, dO, dE = _rand_grads(st, 2)
+    want = oracle.backward(st, dC, dO, dE)
+    got = hip_backward(args, out, dC, dO, dE, GRAD_EXTRA | GRAD_GEOMETRY, MODE_EXACT)
+    for name in ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dtransMat", "dL_dextra"]:
+        t = got[GRAD_NAMES.index(name)]
+        assert_close(t.cpu().numpy().reshape(want[name].shape), want[name], 1e-3, name)
+
+
+@pytest.mark.parametrize("P,F,W,H,seed", [(1500, 16, 100, 70, 41), (3000, 32, 160, 112, 42)])
+def test_fast_mode_forward_within_tolerance(P, F, W, H, seed):
+    """FAST mode contracts FMAs and uses hardware rcp/exp: decisions at the alpha=1/255 and
+    T=1e-4 thresholds may flip for isolated pixels, so the comparison is max-norm 1e-4 on all
+    but a vanishing fraction of pixels, and those outliers stay within one skipped contribution."""
+    sc, cams, inp = small_scene(P=P, F=F, W=W, H=H, seed=seed, mu_s=math.log(0.05))
+    st = oracle_forward(inp, cams[0], bg=(0.1, 0.2, 0.3))
+    args, out = hip_forward(inp, cams[0], bg=(0.1, 0.2, 0.3), mode=MODE_FAST)
+    R, color, others, radii, extra = out[:5]
+    assert R == st["R"]
+    np.testing.assert_array_equal(radii.cpu().numpy(), st["radii"])
+    dbg = rz.debug_state(P, W, H, R, out[5], out[6], out[7])
+    np.testing.assert_array_equal(dbg["point_list"], st["point_list"])      # binning is mode-independent
+    for name, got, want in [("color", color, st["color"]), ("extra", extra, st["extra"]),
+                            ("alpha", others[1], st["others"][1]), ("depth", others[0], st["others"][0])]:
+        got = got.cpu().numpy()
+        scale = np.abs(want).max()
+        bad = np.abs(got - want) > 1e-4 * scale
+        assert bad.mean() <= 1e-4, f"{name}: {bad.sum()} outlier pixels"
+        assert np.abs(got - want).max() <= 1e-2 * scale
+
+
+def test_mark_visible():
+    sc, cams, inp = small_scene(P=2000, F=0, W=64, H=48, seed=51)
+    cam = cams[0]
+    want = oracle.mark_visible(inp["means3D"].numpy(), cam.world_view_transform.numpy(), cam.full_proj_transform.numpy())
+    got = rz.mark_visible(inp["means3D"].cuda(), cam.world_view_transform.cuda(), cam.full_proj_transform.cuda())
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_autograd_module_matches_reference_interface():
+    sc, cams, inp = small_scene(P=600, F=8, W=64, H=48, seed=61)
+    cam = cams[0]
+    settings = rz.GaussianRasterizationSettings(
+        image_height=48, image_width=64, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.zeros(3, device="cuda"), scale_modifier=1.0, viewmatrix=cam.world_view_transform.cuda(),
+        projmatrix=cam.full_proj_transform.cuda(), sh_degree=3, campos=cam.camera_center.cuda(), prefiltered=False,
+        debug=False)
+    r = rz.GaussianRasterizer(settings)
+    with pytest.raises(Exception):
+        r(means3D=inp["means3D"].cuda(), means2D=None, opacities=inp["opacities"].cuda())      # neither shs nor colours
+    leaves = {k: v.cuda().requires_grad_(True) for k, v in inp.items()}
+    means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    color, radii, allmap, extra, grp = r(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                                         shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"],
+                                         extra_attrs=leaves["extra"])
+    assert color.shape == (3, 48, 64) and allmap.shape == (7, 48, 64) and extra.shape == (8, 48, 64)
+    assert radii.dtype == torch.int32 and grp.shape[1] == 2
+    st = oracle_forward(inp, cam)
+    g = torch.Generator().manual_seed(0)
+    dC, dO, dE = torch.randn(3, 48, 64, generator=g), torch.randn(7, 48, 64, generator=g), torch.randn(8, 48, 64, generator=g)
+    ((color * dC.cuda()).sum() + (allmap * dO.cuda()).sum() + (extra * dE.cuda()).sum()).backward()
+    want = oracle.backward(st, dC.numpy(), dO.numpy(), dE.numpy())
+    assert_close(leaves["means3D"].grad.cpu().numpy(), want["dL_dmeans3D"], 1e-3, "means3D.grad")
+    assert_close(leaves["extra"].grad.cpu().numpy(), want["dL_dextra"], 1e-3, "extra.grad")
+    assert_close(leaves["shs"].grad.cpu().numpy(), want["dL_dsh"], 1e-3, "shs.grad")
+    assert_close(means2D.grad.cpu().numpy(), want["dL_dmeans2D"], 1e-3, "means2D.grad")
+    assert_close(leaves["opacities"].grad.cpu().numpy(), want["dL_dopacity"], 1e-3, "opacity.grad")
+    # frozen geometry (train_semantic): only the feature leaf gets a gradient
+    feat = inp["extra"].cuda().requires_grad_(True)
+    out = r(means3D=inp["means3D"].cuda(), means2D=torch.zeros(600, 3, device="cuda"), opacities=inp["opacities"].cuda(),
+            shs=inp["shs"].cuda(), scales=inp["scales"].cuda(), rotations=inp["rotations"].cuda(), extra_attrs=feat)
+    (out[3] * dE.cuda()).sum().backward()
+    want_e = oracle.backward(st, np.zeros((3, 48, 64), np.float32), np.zeros((7, 48, 64), np.float32), dE.numpy())
+    assert_close(feat.grad.cpu().numpy(), want_e["dL_dextra"], 1e-3, "feature-only grad")
