@@ -1,0 +1,53 @@
+/*
+ * instascene_ops.h — C-ABI of the two companion ops on the InstaScene hot path.
+ *
+ *   iso_dist2_3nn            replaces  simple_knn._C.distCUDA2
+ *                            (submodules/simple-knn/spatial.cu:15-26, simple_knn.cu:186-222)
+ *   iso_contrastive_forward/ replace the arithmetic core of
+ *   iso_contrastive_backward utils/contrastive_utils.py:41-71 (contrastive_loss) after the
+ *                            label filtering / dense relabelling of :25-50, which stays on the
+ *                            host side (instascene_amd/contrastive.py) exactly as in the reference.
+ *
+ * All pointers are DEVICE pointers to contiguous row-major data; `stream` is a
+ * hipStream_t (NULL = default stream).  Return 0 on success, negative on error
+ * (isr_last_error() in instascene_rasterizer.h carries the message).
+ */
+#ifndef INSTASCENE_OPS_H
+#define INSTASCENE_OPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mean of the squared distances to the 3 nearest neighbours of every point (self excluded).
+ * Exact (equal to brute force; the reference's Morton-box pruning is exact too).  Points
+ * with fewer than 3 neighbours keep FLT_MAX terms like the reference (P < 4). */
+size_t iso_knn_scratch_bytes(int P);
+int iso_dist2_3nn(int P, const float* points /*[P,3]*/, float* mean_dist2 /*[P]*/, void* scratch,
+                  size_t scratch_bytes, void* stream);
+
+/* ProtoNCE loss on N samples with dense labels in [0,K):
+ *   f_i   = x_i / (|x_i| + 1e-9)                       (norm detached, :41)
+ *   u_k   = mean_{i in k} f_i   or  predef_u[k]         (:44-45,:54-58)
+ *   phi_k = clip(10 * sum_{i in k}|f_i - u_k| / (n_k * log(n_k + temp_lambda)), 0.5, 1)   (detached, :60-66)
+ *   loss  = - sum_i log( exp(f_i.u_{y_i}/phi_{y_i}) / (sum_k exp(f_i.u_k/phi_k) + 1e-9) )  (:68-71)
+ * `state` (iso_contrastive_scratch_bytes) is the opaque forward->backward hand-off.
+ * Every cluster id in [0,K) must occur at least once.  predef_u may be NULL.
+ * The similarity  [N,F].[F,K]  and the backward products run on the matrix cores with
+ * the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32). */
+size_t iso_contrastive_scratch_bytes(int N, int F, int K);
+int iso_contrastive_forward(int N, int F, int K, const float* features /*[N,F]*/, const int32_t* labels /*[N]*/,
+                            const float* predef_u /*[K,F] or NULL*/, float temp_lambda, float* loss /*[1]*/,
+                            void* state, size_t state_bytes, void* stream);
+/* dL_dfeatures[N,F] = dL/dloss * d loss / d features  (dL_dloss: device scalar). */
+int iso_contrastive_backward(int N, int F, int K, const int32_t* labels, const float* predef_u,
+                             const float* dL_dloss /*[1]*/, float* dL_dfeatures /*[N,F]*/, void* state,
+                             size_t state_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -57,7 +57,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // K9.  One workgroup (4 waves) per tile, wave w owns the 8x8 pixel block (w&1, w>>1).
 // GEOM: produce the 18 geometry/appearance terms.  FEAT: produce dL/dextra for the
 // 32-channel chunk starting at ch_base.  Rows are written for EVERY instance.
-template <class Math, bool GEOM, bool FEAT>
+// QF: feature channels whose dL/dfeature(pixel) is kept in registers for the q-dot of the geometry pass
+//     (channels beyond QF are read from global memory; QF = 0 when there is no geometry pass or no feature).
+template <class Math, bool GEOM, bool FEAT, int QF>
 __global__ __launch_bounds__(256) void k_render_bwd(
     int W, int H, int ED, int ch_base, int gx, const uint32_t* __restrict__ tile_offset,
     const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ col_pre,
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(
     constexpr int PART = (GEOM ? GEOM_ROW : 0) + (FEAT ? 32 : 0);   // floats per instance per wave in LDS
     __shared__ __attribute__((aligned(16))) float s_rec[BB * RS];
     __shared__ __attribute__((aligned(16))) float s_rgb[BB * 4];
-    __shared__ __attribute__((aligned(16))) float s_feat[(GEOM && FEAT) ? BB * 32 : 4];
+    __shared__ __attribute__((aligned(16))) float s_feat[QF > 0 ? BB * QF : 4];
     __shared__ int s_id[BB];
     __shared__ unsigned s_slot[BB];
     __shared__ float s_W[4 * BB * WPAD];
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(
     float dpx0 = 0, dpx1 = 0, dpx2 = 0, dL_ddepth = 0, dL_daccum = 0, dL_dreg = 0, dn0 = 0, dn1 = 0, dn2 = 0, dL_dmedian = 0;
     float T_final = 0, final_D = 0, final_D2 = 0;
     unsigned median_contributor = 0;
-    float dEp[(GEOM && FEAT) ? 32 : 1];
+    float dEp[QF > 0 ? QF : 1];
     if (inside) {
         T_final = final_T[pix];
         if (GEOM) {
@@ -155,10 +157,9 @@ __global__ __launch_bounds__(256) void k_render_bwd(
             }
         }
     }
-    if constexpr (GEOM && FEAT) {
+    if constexpr (QF > 0) {
 #pragma unroll
-        for (int c = 0; c < 32; c++)
-            dEp[c] = (inside && dE != nullptr && ch_base + c < ED) ? dE[(size_t)(ch_base + c) * N + pix] : 0.0f;
+        for (int c = 0; c < QF; c++) dEp[c] = (inside && dE != nullptr && c < ED) ? dE[(size_t)c * N + pix] : 0.0f;
     }
     const float final_A = 1 - T_final;
     const float mscale = FAR_N / (FAR_N - NEAR_N);
@@ -204,10 +205,10 @@ __global__ __launch_bounds__(256) void k_render_bwd(
             s_slot[t] = point_offsets[id] + (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
         }
         __syncthreads();
-        if constexpr (GEOM && FEAT) {
-            for (int e = threadIdx.x; e < nb * 32; e += 256) {
-                const int inst = e >> 5, c = e & 31;
-                s_feat[e] = (ch_base + c < ED) ? extras[(size_t)s_id[inst] * ED + ch_base + c] : 0.0f;
+        if constexpr (QF > 0) {
+            for (int e = threadIdx.x; e < nb * QF; e += 256) {
+                const int inst = e / QF, c = e - inst * QF;
+                s_feat[e] = (c < ED) ? extras[(size_t)s_id[inst] * ED + c] : 0.0f;
             }
         }
         // zero this wave's partial block
@@ -287,11 +288,15 @@ __global__ __launch_bounds__(256) void k_render_bwd(
                         an0 = last_alpha * ln0 + (1.f - last_alpha) * an0; ln0 = nx; dL_dalpha += (nx - an0) * dn0;
                         an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = ny; dL_dalpha += (ny - an1) * dn1;
                         an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = nz; dL_dalpha += (nz - an2) * dn2;
-                        if constexpr (FEAT) {
-                            const float* fj = s_feat + j * 32;
+                        if constexpr (QF > 0) {
+                            const float* fj = s_feat + j * QF;
                             float q = 0.0f;
 #pragma unroll
-                            for (int ch = 0; ch < 32; ch++) q = __builtin_fmaf(fj[ch], dEp[ch], q);
+                            for (int ch = 0; ch < QF; ch++) q = __builtin_fmaf(fj[ch], dEp[ch], q);
+                            if (ED > QF && dE != nullptr) {     // rare: more feature channels than the register budget
+                                const float* fg = extras + (size_t)s_id[j] * ED;
+                                for (int ch = QF; ch < ED; ch++) q = __builtin_fmaf(fg[ch], dE[(size_t)ch * N + pix], q);
+                            }
                             accum_q = last_alpha * last_q + (1.f - last_alpha) * accum_q;
                             last_q = q;
                             dL_dalpha += q - accum_q;
@@ -646,13 +651,16 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
         int ch = 0;
         do {
             const bool do_geom = geomg && first, do_feat = featg;
-#define ISR_GOB(GM, FT)                                                                                              \
-    hipLaunchKernelGGL((k_render_bwd<Math, GM, FT>), dim3(T), dim3(256), 0, s, W, H, ED, ch, gx, iv.tile_offset,      \
+#define ISR_GOB(GM, FT, Q)                                                                                           \
+    hipLaunchKernelGGL((k_render_bwd<Math, GM, FT, Q>), dim3(T), dim3(256), 0, s, W, H, ED, ch, gx, iv.tile_offset,   \
                        bv.point_list, g.rec, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib, dC, dO, dE,      \
                        g.point_offsets, g.rect, partial, stride, geom_off, feat_base + ch, R)
-            if (do_geom && do_feat) ISR_GOB(true, true);
-            else if (do_geom) ISR_GOB(true, false);
-            else if (do_feat) ISR_GOB(false, true);
+            // the geometry pass needs <feature_g, dL/dfeature(pix)> over ALL channels (dL/dalpha), whatever
+            // chunk of dL/dextra it emits itself
+            if (do_geom && ED > 32) { if (do_feat) ISR_GOB(true, true, 64); else ISR_GOB(true, false, 64); }
+            else if (do_geom && ED > 0) { if (do_feat) ISR_GOB(true, true, 32); else ISR_GOB(true, false, 32); }
+            else if (do_geom) ISR_GOB(true, false, 0);
+            else if (do_feat) ISR_GOB(false, true, 0);
 #undef ISR_GOB
             ISR_CHECK_LAUNCH_B("k_render_bwd");
             first = false;
