@@ -49,6 +49,12 @@ extern "C" {
 const char* isr_last_error(void);
 int isr_version(void);
 
+/* ---- optional per-kernel timing (HIP events on the launch stream), used by bench.py.
+ * isr_profile_enable(1) clears and starts recording; isr_profile_summary() synchronises and writes
+ * one "kernel_name launches total_ms" line per kernel into buf (returns bytes written). */
+void isr_profile_enable(int on);
+size_t isr_profile_summary(char* buf, size_t len);
+
 /* ---- workspace sizes (bytes); the layouts are opaque forward->backward hand-offs
  *      (reference: GeometryState / ImageState / BinningState, rasterizer_impl.h:29-65). */
 size_t isr_geom_bytes(int P);

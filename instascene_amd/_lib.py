@@ -22,6 +22,8 @@ _P = c_void_p
 SIGNATURES = {
     "isr_last_error": (c_char_p, []),
     "isr_version": (c_int, []),
+    "isr_profile_enable": (None, [c_int]),
+    "isr_profile_summary": (c_size_t, [_P, c_size_t]),
     "isr_geom_bytes": (c_size_t, [c_int]),
     "isr_image_bytes": (c_size_t, [c_int, c_int]),
     "isr_binning_bytes": (c_size_t, [c_int64, c_int, c_int]),
@@ -38,6 +40,12 @@ SIGNATURES = {
                              _P, c_size_t, _P]),
     "isr_mark_visible": (c_int, [c_int, _P, _P, _P, _P, _P]),
     "isr_debug_state": (c_int, [c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    # include/instascene_ops.h
+    "iso_knn_scratch_bytes": (c_size_t, [c_int]),
+    "iso_dist2_3nn": (c_int, [c_int, _P, _P, _P, c_size_t, _P]),
+    "iso_contrastive_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "iso_contrastive_forward": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, c_size_t, _P]),
+    "iso_contrastive_backward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
 }
 
 

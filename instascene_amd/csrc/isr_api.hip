@@ -5,7 +5,10 @@
 #include "isr_common.hpp"
 #include "isr_forward.hip"    // unity build: kernels are defined before the entry points
 #include "isr_backward.hip"
+#include "iso_knn.hip"
+#include "iso_contrastive.hip"
 #include "../../include/instascene_rasterizer.h"
+#include "../../include/instascene_ops.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -42,6 +45,7 @@ static int launch_render_fwd(int tiles, hipStream_t s, int W, int H, int ED, int
     // first pass: geometry/colour/aux + the first feature chunk; further passes add 32 channels each
     int ch = 0, first = 1;
     do {
+        ProfScope ps_("k_render_fwd", s);
         const int rem = ED - ch;
 #define ISR_GO(F, B)                                                                                                 \
     hipLaunchKernelGGL((k_render_fwd<Math, F, B>), dim3(tiles), dim3(256), 0, s, W, H, ED, ch, first, gx,             \
@@ -67,6 +71,40 @@ extern "C" {
 
 const char* isr_last_error(void) { return g_err; }
 int isr_version(void) { return 1; }
+
+void isr_profile_enable(int on) {
+    Prof& p = prof();
+    for (auto& r : p.recs) { p.pool.push_back(r.a); p.pool.push_back(r.b); }
+    p.recs.clear();
+    p.on = on != 0;
+}
+
+/* Writes "name count total_ms" lines for everything recorded since isr_profile_enable(1); synchronises
+ * on the recorded events.  Returns the number of bytes written (0 if nothing / buffer too small). */
+size_t isr_profile_summary(char* buf, size_t len) {
+    Prof& p = prof();
+    std::vector<std::string> names;
+    std::vector<double> tot;
+    std::vector<int> cnt;
+    for (auto& r : p.recs) {
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        size_t k = 0;
+        for (; k < names.size(); k++) if (names[k] == r.name) break;
+        if (k == names.size()) { names.push_back(r.name); tot.push_back(0); cnt.push_back(0); }
+        tot[k] += ms; cnt[k] += 1;
+    }
+    std::string out;
+    for (size_t k = 0; k < names.size(); k++) {
+        char line[256];
+        snprintf(line, sizeof(line), "%s %d %.6f\n", names[k].c_str(), cnt[k], tot[k]);
+        out += line;
+    }
+    if (out.size() + 1 > len) return 0;
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return out.size();
+}
 
 size_t isr_geom_bytes(int P) { return geom_bytes(P < 1 ? 1 : P); }
 size_t isr_image_bytes(int width, int height) { return image_bytes(width, height); }
@@ -98,17 +136,20 @@ int isr_forward_prepare(int P, int D, int M, int width, int height, const float*
     ImageView iv = image_view(image_buffer, width, height);
     ISR_HIP(hipMemsetAsync(iv.tile_count, 0, sizeof(uint32_t) * T, s));
     if (P > 0) {
+        { ProfScope ps_("k_preprocess", s);
         hipLaunchKernelGGL(k_preprocess, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales,
                            scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, viewmatrix,
-                           projmatrix, cam_pos, width, height, gx, gy, radii, g, iv.tile_count);
+                           projmatrix, cam_pos, width, height, gx, gy, radii, g, iv.tile_count); }
         ISR_LAUNCH_CHECK("k_preprocess");
         const int nb = (P + 1023) / 1024;
+        ProfScope ps2_("k_scan_gaussians", s);
         hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, P, g.tiles_touched, g.point_offsets, g.scan_tmp);
         hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, g.scan_tmp);
         hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, P, g.point_offsets, g.scan_tmp);
         ISR_LAUNCH_CHECK("k_scan");
     }
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, iv.tile_count, iv.tile_offset, iv.tile_cursor, g.header);
+    { ProfScope ps3_("k_tile_scan", s);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, iv.tile_count, iv.tile_offset, iv.tile_cursor, g.header); }
     ISR_LAUNCH_CHECK("k_tile_scan");
     if (num_rendered_host) return isr_read_num_rendered(geom_buffer, num_rendered_host, stream);
     return ISR_OK;
@@ -139,10 +180,12 @@ int isr_forward_render(int P, int ED, int width, int height, int mode, const flo
     BinView bv = bin_view(binning_buffer, binning_capacity);
     if (tracer_pairs) ISR_HIP(hipMemsetAsync(tracer_count, 0, sizeof(int32_t), s));
     if (P > 0 && binning_capacity > 0) {
+        { ProfScope ps_("k_scatter", s);
         hipLaunchKernelGGL(k_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, g, iv.tile_offset, iv.tile_cursor,
-                           bv.keys, binning_capacity);
+                           bv.keys, binning_capacity); }
         ISR_LAUNCH_CHECK("k_scatter");
-        hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity);
+        { ProfScope ps_("k_tile_sort", s);
+        hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity); }
         ISR_LAUNCH_CHECK("k_tile_sort");
     }
     if (mode == ISR_MODE_EXACT)
@@ -218,6 +261,70 @@ int isr_debug_state(int P, int width, int height, int64_t num_rendered, const vo
         }
         delete[] off;
     }
+    return ISR_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// include/instascene_ops.h
+extern "C" {
+
+size_t iso_knn_scratch_bytes(int P) { return iso::knn_bytes(P); }
+
+int iso_dist2_3nn(int P, const float* points, float* mean_dist2, void* scratch, size_t scratch_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || (P > 0 && (!points || !mean_dist2 || !scratch))) return fail(ISR_EINVAL, "null argument");
+    if (P == 0) return ISR_OK;
+    if (scratch_bytes < iso::knn_bytes(P)) return fail(ISR_EINVAL, "knn scratch too small");
+    iso::KnnView v = iso::knn_view(scratch, P);
+    const int ccap = iso::knn_cell_cap(P);
+    const int nblk = 256, pb = (P + 255) / 256;
+    hipLaunchKernelGGL(iso::kk_minmax, dim3(nblk), dim3(256), 0, s, P, points, v.partial);
+    hipLaunchKernelGGL(iso::kk_setup, dim3(1), dim3(64), 0, s, P, nblk, ccap, v.partial, v.grid);
+    ISR_HIP(hipMemsetAsync(v.count, 0, sizeof(uint32_t) * ccap, s));
+    ISR_HIP(hipMemsetAsync(v.cursor, 0, sizeof(uint32_t) * ccap, s));
+    hipLaunchKernelGGL(iso::kk_count, dim3(pb), dim3(256), 0, s, P, points, v.grid, v.count);
+    const int nb = (ccap + 1023) / 1024;      // scan the whole capacity: unused cells hold zero
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, ccap, v.count, v.offset, v.sums);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, v.sums);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, ccap, v.offset, v.sums);
+    hipLaunchKernelGGL(iso::kk_scatter, dim3(pb), dim3(256), 0, s, P, points, v.grid, v.offset, v.cursor, v.sorted);
+    hipLaunchKernelGGL(iso::kk_query, dim3(pb), dim3(256), 0, s, P, v.grid, v.offset, v.count, v.sorted, mean_dist2);
+    ISR_LAUNCH_CHECK("iso_dist2_3nn");
+    return ISR_OK;
+}
+
+size_t iso_contrastive_scratch_bytes(int N, int F, int K) { return iso::cstate_bytes(N < 1 ? 1 : N, F < 1 ? 1 : F, K < 1 ? 1 : K); }
+
+int iso_contrastive_forward(int N, int F, int K, const float* features, const int32_t* labels, const float* predef_u,
+                            float temp_lambda, float* loss, void* state, size_t state_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (N <= 0 || F <= 0 || K <= 0 || !features || !labels || !loss || !state) return fail(ISR_EINVAL, "bad contrastive arguments");
+    if (F > 1024) return fail(ISR_EINVAL, "feature dimension %d > 1024 unsupported", F);
+    if (state_bytes < iso::cstate_bytes(N, F, K)) return fail(ISR_EINVAL, "contrastive state too small");
+    iso::CState st = iso::cstate(state, N, F, K);
+    const int nblk = (N + 127) / 128;
+    hipLaunchKernelGGL(iso::ck_normalize, dim3((N + 255) / 256), dim3(256), 0, s, N, F, features, st.f, st.inv);
+    hipLaunchKernelGGL(iso::ck_clusters, dim3(K), dim3(256), 0, s, N, F, st.f, labels, predef_u, temp_lambda, st.U, st.phi, st.cnt);
+    hipLaunchKernelGGL(iso::ck_similarity, dim3(nblk), dim3(256), 0, s, N, F, K, st.f, st.U, st.phi, labels, st.G, st.part);
+    hipLaunchKernelGGL(iso::ck_loss_reduce, dim3(1), dim3(256), 0, s, nblk, st.part, loss);
+    ISR_LAUNCH_CHECK("iso_contrastive_forward");
+    return ISR_OK;
+}
+
+int iso_contrastive_backward(int N, int F, int K, const int32_t* labels, const float* predef_u, const float* dL_dloss,
+                             float* dL_dfeatures, void* state, size_t state_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (N <= 0 || F <= 0 || K <= 0 || !labels || !dL_dloss || !dL_dfeatures || !state) return fail(ISR_EINVAL, "bad contrastive arguments");
+    if (state_bytes < iso::cstate_bytes(N, F, K)) return fail(ISR_EINVAL, "contrastive state too small");
+    iso::CState st = iso::cstate(state, N, F, K);
+    const int use_mean = predef_u == nullptr ? 1 : 0;
+    if (use_mean)
+        hipLaunchKernelGGL(iso::ck_grad_u, dim3((K + 31) / 32, (F + 31) / 32), dim3(256), 0, s, N, F, K, st.f, st.G, st.phi, st.dU);
+    hipLaunchKernelGGL(iso::ck_grad_f, dim3((N + 127) / 128), dim3(256), 0, s, N, F, K, st.G, st.U, st.phi, st.cnt, st.dU, labels,
+                       st.inv, dL_dloss, use_mean, dL_dfeatures);
+    ISR_LAUNCH_CHECK("iso_contrastive_backward");
     return ISR_OK;
 }
 

@@ -650,6 +650,7 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
         bool first = true;
         int ch = 0;
         do {
+            ProfScope ps_("k_render_bwd", s);
             const bool do_geom = geomg && first, do_feat = featg;
 #define ISR_GOB(GM, FT, Q)                                                                                           \
     hipLaunchKernelGGL((k_render_bwd<Math, GM, FT, Q>), dim3(T), dim3(256), 0, s, W, H, ED, ch, gx, iv.tile_offset,   \
@@ -669,6 +670,7 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
     }
     if (featg) {
         const size_t total = (size_t)P * ED;
+        ProfScope ps_("k_reduce_rows", s);
         hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P, ED, g.point_offsets,
                            g.tiles_touched, partial, stride, feat_base, dL_dextra, ED);
         ISR_CHECK_LAUNCH_B("k_reduce_rows");
@@ -676,6 +678,7 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
     if (geomg) {
         const float focal_y = H / (2.0f * tan_fovy), focal_x = W / (2.0f * tan_fovx);
         const int Wd = (int)(focal_x * tan_fovx * 2), Hd = (int)(focal_y * tan_fovy * 2);   // backward.cu:633-634
+        ProfScope ps_("k_preprocess_bwd", s);
         hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, shs, scales, rots,
                            tm_pre, view, proj, campos, Wd, Hd, g, partial, stride, geom_off, dL_dmean2D, dL_dnormal,
                            dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot);

@@ -171,3 +171,29 @@ struct FastMath {
 };
 
 }  // namespace isr
+
+// ---------------------------------------------------------------------------
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's
+// `roofline` object).  Off by default: zero overhead.
+#include <string>
+#include <vector>
+namespace isr {
+struct ProfRec { const char* name; hipEvent_t a, b; };
+struct Prof {
+    bool on = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+};
+inline Prof& prof() { static Prof p; return p; }
+struct ProfScope {
+    hipStream_t s; ProfRec r; bool on;
+    ProfScope(const char* name, hipStream_t st) : s(st), on(prof().on) {
+        if (on) { r.name = name; r.a = prof().get(); r.b = prof().get(); (void)hipEventRecord(r.a, s); }
+    }
+    ~ProfScope() { if (on) { (void)hipEventRecord(r.b, s); prof().recs.push_back(r); } }
+};
+}  // namespace isr

@@ -1,0 +1,154 @@
+"""Train-step harness: the build's own counterpart of the reference's feature-training loop
+(train_semantic.py:95-208) on synthetic scenes, plus the data-parallel
+variant the north-star adds (one view per rank, RCCL sum all-reduce of the parameter gradient).
+
+Per iteration, like the reference:
+  1. pick a view (here: deterministic round-robin, ``views[(it * world + rank) % len]``);
+  2. ``render()`` — full forward (RGB + depth + normal + F-dim feature), as the reference does even
+     though only the feature is trained (:102);
+  3. for each label map (``segmap``, and ``sorted_segmap`` iff class prototypes exist, :110-141):
+     sample ``sample_batchsize`` labelled pixels with replacement, ``contrastive_loss`` * lambda_sv * {0.5|1};
+  4. optional multi-view loss every 10th iteration over 5 consecutive views (:143-172);
+  5. 3-D loss on visible Gaussians' features vs their 3-D labels (:174-197), lambda 2.5e-6;
+  6. backward; all-reduce(sum) of ``_seg_feature.grad`` across ranks; Adam(lr .025, eps 1e-15) (:203-208).
+Geometry parameters are frozen, exactly like ``GaussianModel.training_setup`` does for this stage
+(scene/gaussian_model.py:217-232).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import scenes
+from .contrastive import contrastive_loss
+from .render import render
+
+
+class PipelineParams:
+    compute_cov3D_python = False
+    convert_SHs_python = False
+    depth_ratio = 1.0
+    debug = False
+
+
+class SegGaussianModel:
+    """The subset of the reference ``GaussianModel`` that ``render()`` and the loop touch
+    (getters scene/gaussian_model.py:109-138; ``_seg_feature`` is the only trainable tensor)."""
+
+    def __init__(self, scene: scenes.Scene, device, class_feat: Optional[torch.Tensor] = None):
+        s = scene.to(device)
+        self._xyz = s.xyz
+        self._scaling = s.log_scale
+        self._rotation = s.rot
+        self._opacity = s.opacity_logit
+        self._features_dc = s.features_dc
+        self._features_rest = s.features_rest
+        self._seg_feature = nn.Parameter(s.seg_feature.clone().requires_grad_(True)) if s.seg_feature is not None else None
+        self.active_sh_degree = 3
+        self.max_sh_degree = 3
+        self.class_feat = class_feat
+
+    get_xyz = property(lambda s: s._xyz)
+    get_scaling = property(lambda s: torch.exp(s._scaling))
+    get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation))
+    get_opacity = property(lambda s: torch.sigmoid(s._opacity))
+    get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
+
+    @property
+    def get_seg_feature(self):
+        if self._seg_feature is None:
+            return None
+        return self._seg_feature / (torch.norm(self._seg_feature, p=2, dim=1, keepdim=True) + 1e-6)
+
+
+def gram_schmidt(vectors: torch.Tensor) -> torch.Tensor:
+    """scene/gaussian_model.py:161-167 (--gram_feat_3d class prototypes)."""
+    out: List[torch.Tensor] = []
+    for v in vectors:
+        for u in out:
+            v = v - torch.dot(v, u) * u
+        out.append(v / (torch.norm(v) + 1e-9))
+    return torch.stack(out)
+
+
+class SegTrainer:
+    def __init__(self, scene: scenes.Scene, cameras: List[scenes.Camera], device="cuda", sample_batchsize=8192,
+                 n_labels=64, lambda_sv=1e-6, lambda_mv=1e-6, lambda_3d=2.5e-6, sample_mv_frames=5, use_class_feat=False,
+                 multiview=False, seed=0, rank=0, world=1):
+        self.device = torch.device(device)
+        self.rank, self.world = rank, world
+        F = scene.seg_feature.shape[1]
+        class_feat = None
+        if use_class_feat:
+            g = torch.Generator().manual_seed(seed + 17)
+            class_feat = gram_schmidt(torch.rand(n_labels + 1, F, generator=g)).to(self.device)
+        self.model = SegGaussianModel(scene, self.device, class_feat)
+        self.labels3d = scene.labels3d.to(self.device)
+        self.cams = [c.to(self.device) for c in cameras]
+        self.pipe = PipelineParams()
+        self.bg = torch.zeros(3, dtype=torch.float32, device=self.device)
+        self.batch = sample_batchsize
+        self.lsv, self.lmv, self.l3d = lambda_sv, lambda_mv, lambda_3d
+        self.mv_frames, self.multiview = sample_mv_frames, multiview
+        self.opt = torch.optim.Adam([{"params": [self.model._seg_feature], "lr": 0.025, "name": "seg_feature"}], lr=0.0,
+                                    eps=1e-15)
+        self.gen = torch.Generator(device=self.device).manual_seed(1000 + seed * 131 + rank)
+        # label maps are static per view: index the labelled pixels once (the reference re-derives the
+        # boolean mask every iteration, train_semantic.py:118-125)
+        self.valid_idx = {}
+        for i, c in enumerate(self.cams):
+            if c.segmap is None:
+                c.segmap = scenes.voronoi_labels(c.image_width, c.image_height, n_labels, 5000 + i, device=self.device)
+                c.sorted_segmap = c.segmap
+            self.valid_idx[i] = torch.nonzero(c.segmap.reshape(-1) > 0).reshape(-1)
+
+    def _sample_view_loss(self, vi, seg_feature, segmap, predef, weight):
+        idx_pool = self.valid_idx[vi]
+        if idx_pool.numel() == 0:
+            return 0.0
+        pick = torch.randint(0, idx_pool.numel(), (self.batch,), device=self.device, generator=self.gen)
+        pix = idx_pool[pick]
+        feats = seg_feature.reshape(seg_feature.shape[0], -1)[:, pix].T
+        labels = segmap.reshape(-1)[pix]
+        return contrastive_loss(feats, labels, predef_u_list=predef) * self.lsv * weight
+
+    def view_index(self, it):
+        return (it * self.world + self.rank) % len(self.cams)
+
+    def step(self, it: int):
+        m = self.model
+        vi = self.view_index(it)
+        cam = self.cams[vi]
+        pkg = render(cam, m, self.pipe, self.bg)
+        seg_feature, vis = pkg["seg_feature"], pkg["visibility_filter"]
+        loss = self._sample_view_loss(vi, seg_feature, cam.segmap, None, 0.5)
+        if m.class_feat is not None:
+            loss = loss + self._sample_view_loss(vi, seg_feature, cam.sorted_segmap, m.class_feat, 1.0)
+        if self.multiview and self.lmv > 0 and it % 10 == 0:
+            first = (vi + 1) % max(1, len(self.cams) - self.mv_frames)
+            feats, labs = [], []
+            for k in range(first, first + self.mv_frames):
+                p2 = render(self.cams[k], m, self.pipe, self.bg)
+                sf = p2["seg_feature"]
+                feats.append(sf.reshape(sf.shape[0], -1))
+                labs.append(self.cams[k].sorted_segmap.reshape(-1))
+            allf, alll = torch.cat(feats, dim=1), torch.cat(labs)
+            pool = torch.nonzero(alll > 0).reshape(-1)
+            pick = pool[torch.randint(0, pool.numel(), (self.batch,), device=self.device, generator=self.gen)]
+            loss = loss + contrastive_loss(allf[:, pick].T, alll[pick], predef_u_list=m.class_feat) * self.lmv
+        if self.l3d > 0:
+            vis_feat = m.get_seg_feature[vis]
+            vis_lab = self.labels3d[vis]
+            keep = torch.nonzero(vis_lab > 0).reshape(-1)
+            if keep.numel() > 0:
+                pick = keep[torch.randint(0, keep.numel(), (self.batch,), device=self.device, generator=self.gen)]
+                loss = loss + contrastive_loss(vis_feat[pick], vis_lab[pick], predef_u_list=m.class_feat) * self.l3d
+        loss.backward()
+        if self.world > 1:
+            dist.all_reduce(m._seg_feature.grad, op=dist.ReduceOp.SUM)
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        return loss.detach()

@@ -28,6 +28,9 @@ _CONFIG = {
 }
 
 
+LAST_NUM_RENDERED = 0   # instance count of the most recent forward (reporting only)
+
+
 def set_mode(mode: str):
     _CONFIG["mode"] = {"exact": MODE_EXACT, "fast": MODE_FAST}[mode]
 
@@ -116,6 +119,8 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
                                     int(bool(prefiltered)), _ptr(radii), _ptr(geom), _ptr(img),
                                     ctypes.byref(num_rendered), st), "isr_forward_prepare")
         R = int(num_rendered.value)
+        global LAST_NUM_RENDERED
+        LAST_NUM_RENDERED = R
         binning = torch.empty(L.isr_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
         if tracer:
             grp = torch.empty((H * W * 10, 2), dtype=torch.int32, device=dev)

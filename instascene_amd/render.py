@@ -1,0 +1,116 @@
+"""``render()`` — mirror of the reference's ``gaussian_renderer.render``
+(gaussian_renderer/__init__.py:20-169): same signature, same returned dict
+(13 entries), built on the HIP rasterizer.  The post-processing of the 7-channel
+``allmap`` (:127-167) and ``depth_to_normal`` (utils/point_utils.py:10-40) are
+restated here in torch (thin elementwise work)."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def depths_to_points(view, depthmap):
+    """utils/point_utils.py:10-27"""
+    dev = depthmap.device
+    c2w = (view.world_view_transform.T).inverse()
+    W, H = view.image_width, view.image_height
+    ndc2pix = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], dtype=torch.float32,
+                           device=dev).T
+    projection_matrix = c2w.T @ view.full_proj_transform
+    intrins = (projection_matrix @ ndc2pix)[:3, :3].T
+    grid_x, grid_y = torch.meshgrid(torch.arange(W, device=dev).float(), torch.arange(H, device=dev).float(),
+                                    indexing="xy")
+    points = torch.stack([grid_x, grid_y, torch.ones_like(grid_x)], dim=-1).reshape(-1, 3)
+    rays_d = points @ intrins.inverse().T @ c2w[:3, :3].T
+    rays_o = c2w[:3, 3]
+    return depthmap.reshape(-1, 1) * rays_d + rays_o
+
+
+def depth_to_normal(view, depth):
+    """utils/point_utils.py:30-40"""
+    points = depths_to_points(view, depth).reshape(*depth.shape[1:], 3)
+    output = torch.zeros_like(points)
+    dx = points[2:, 1:-1] - points[:-2, 1:-1]
+    dy = points[1:-1, 2:] - points[1:-1, :-2]
+    output[1:-1, 1:-1, :] = torch.nn.functional.normalize(torch.linalg.cross(dx, dy, dim=-1), dim=-1)
+    return output
+
+
+def post_process(viewpoint_camera, allmap, depth_ratio):
+    """gaussian_renderer/__init__.py:127-167"""
+    render_alpha = allmap[1:2]
+    render_normal = allmap[2:5]
+    render_normal = (render_normal.permute(1, 2, 0) @ (viewpoint_camera.world_view_transform[:3, :3].T)).permute(2, 0, 1)
+    render_depth_median = torch.nan_to_num(allmap[5:6], 0, 0)
+    render_depth_expected = torch.nan_to_num(allmap[0:1] / render_alpha, 0, 0)
+    render_dist = allmap[6:7]
+    surf_depth = render_depth_expected * (1 - depth_ratio) + depth_ratio * render_depth_median
+    surf_normal = depth_to_normal(viewpoint_camera, surf_depth).permute(2, 0, 1)
+    surf_normal = surf_normal * render_alpha.detach()
+    return {'rend_alpha': render_alpha, 'rend_normal': render_normal, 'rend_dist': render_dist,
+            'surf_depth': surf_depth, 'surf_normal': surf_normal, 'rend_depth': render_depth_expected,
+            'rend_median_depth': render_depth_median}
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
+           norm_seg_feat=True):
+    """Render the scene (reference gaussian_renderer/__init__.py:20).  ``pc`` needs the reference
+    ``GaussianModel`` getters (get_xyz, get_opacity, get_scaling, get_rotation, get_features,
+    get_seg_feature, active_sh_degree); background tensor must be on the GPU."""
+    xyz = pc.get_xyz
+    # The reference always makes this carrier require grad (:29-33).  Its gradient is only consumed by
+    # train.py's densification; when the geometry is frozen (train_semantic) nothing reads it, so the
+    # carrier follows xyz and the rasterizer can run its feature-only backward.
+    need_geom_grad = bool(xyz.requires_grad) or bool(getattr(pipe, "force_viewspace_grad", False))
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=need_geom_grad, device=xyz.device)
+    if need_geom_grad:
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    means3D = xyz
+    means2D = screenspace_points
+    opacity = pc.get_opacity
+    seg_feature = pc.get_seg_feature
+    if seg_feature is not None and norm_seg_feat:
+        seg_feature = seg_feature / (seg_feature.norm(dim=-1, keepdim=True) + 1e-9)
+
+    scales = rotations = cov3D_precomp = None
+    if getattr(pipe, "compute_cov3D_python", False):
+        splat2world = pc.get_covariance(scaling_modifier)
+        W, H = viewpoint_camera.image_width, viewpoint_camera.image_height
+        near, far = viewpoint_camera.znear, viewpoint_camera.zfar
+        ndc2pix = torch.tensor([[W / 2, 0, 0, (W - 1) / 2], [0, H / 2, 0, (H - 1) / 2], [0, 0, far - near, near],
+                                [0, 0, 0, 1]], dtype=torch.float32, device=xyz.device).T
+        world2pix = viewpoint_camera.full_proj_transform @ ndc2pix
+        cov3D_precomp = (splat2world[:, [0, 1, 3]] @ world2pix[:, [0, 1, 3]]).permute(0, 2, 1).reshape(-1, 9)
+    else:
+        scales = pc.get_scaling
+        rotations = pc.get_rotation
+
+    shs = colors_precomp = None
+    if override_color is None:
+        shs = pc.get_features          # the reference forces convert_SHs_python = False (:88)
+    else:
+        colors_precomp = override_color
+
+    rendered_image, radii, allmap, extra_attrs, gau_related_pixels = rasterizer(
+        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity, scales=scales,
+        rotations=rotations, cov3D_precomp=cov3D_precomp, extra_attrs=seg_feature)
+
+    rets = {"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii,
+            "seg_feature": extra_attrs, "gau_related_pixels": gau_related_pixels}
+    rets.update(post_process(viewpoint_camera, allmap, pipe.depth_ratio))
+    return rets

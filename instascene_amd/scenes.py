@@ -159,16 +159,18 @@ def config_scene(name: str, scale: float = 1.0) -> tuple:
     return scene, cams, cfg
 
 
-def voronoi_labels(W: int, H: int, K: int, seed: int, zero_frac: float = 0.1) -> torch.Tensor:
+def voronoi_labels(W: int, H: int, K: int, seed: int, zero_frac: float = 0.1, device="cpu") -> torch.Tensor:
     """Voronoi partition of the image by K seeded random sites; ``zero_frac`` of
     the sites carry label 0 (= unlabeled, like the reference's filtered masks)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
-    sites = torch.rand(K, 2, generator=g) * torch.tensor([W, H], dtype=torch.float32)
+    sites = (torch.rand(K, 2, generator=g) * torch.tensor([W, H], dtype=torch.float32)).to(device)
     lab = torch.arange(1, K + 1)
     lab[torch.rand(K, generator=g) < zero_frac] = 0
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
-    best = torch.full((H, W), float("inf"))
-    out = torch.zeros(H, W, dtype=torch.int64)
+    lab = lab.to(device)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=device),
+                            torch.arange(W, dtype=torch.float32, device=device), indexing="ij")
+    best = torch.full((H, W), float("inf"), device=device)
+    out = torch.zeros(H, W, dtype=torch.int64, device=device)
     for k in range(K):
         d = (xs - sites[k, 0]) ** 2 + (ys - sites[k, 1]) ** 2
         m = d < best

@@ -1,0 +1,129 @@
+"""GPU parity for the companion ops: HIP contrastive loss vs the reference's own outputs (golden
+fixtures) and vs the torch oracle on seeded inputs; HIP 3-NN vs brute force; render() dict."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import torch_ops
+from helpers import assert_close, small_scene
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from instascene_amd.contrastive import contrastive_loss
+    from instascene_amd.knn import distCUDA2
+    from instascene_amd.render import render
+    from instascene_amd import rasterizer as rz
+
+
+@pytest.mark.parametrize("tag", ["computed", "predef", "negative", "f32dim", "minpix"])
+def test_contrastive_matches_reference_golden(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, "contrastive_loss.npz"))
+    f = torch.tensor(z[f"{tag}_features"]).cuda().requires_grad_(True)
+    lab = torch.tensor(z[f"{tag}_labels"]).cuda()
+    kw = {}
+    if tag == "minpix":
+        kw["min_pixnum"] = int(z["minpix_min_pixnum"])
+    else:
+        pre = z[f"{tag}_predef"]
+        kw["predef_u_list"] = torch.tensor(pre).cuda() if pre.size else None
+        kw["consider_negative"] = bool(z[f"{tag}_consider_negative"])
+    loss = contrastive_loss(f, lab, **kw)
+    loss.backward()
+    want = float(z[f"{tag}_loss"])
+    assert abs(float(loss.detach()) - want) <= 1e-4 * abs(want)
+    assert_close(f.grad.cpu().numpy(), z[f"{tag}_grad"], 1e-3, tag + " grad")
+
+
+@pytest.mark.parametrize("N,F,K,predef", [(8192, 32, 64, False), (8192, 32, 64, True), (5000, 16, 37, False),
+                                          (3000, 64, 130, True), (777, 6, 5, False)])
+def test_contrastive_matches_oracle_on_seeded_inputs(N, F, K, predef):
+    g = torch.Generator().manual_seed(N + F + K)
+    feats = torch.randn(N, F, generator=g)
+    labels = torch.randint(0, K + 1, (N,), generator=g)
+    pre = torch.nn.functional.normalize(torch.randn(K + 1, F, generator=g), dim=1) if predef else None
+    a = feats.clone().requires_grad_(True)
+    want = torch_ops.contrastive_loss(a, labels, predef_u=pre)
+    (want * 0.37).backward()
+    b = feats.cuda().requires_grad_(True)
+    got = contrastive_loss(b, labels.cuda(), predef_u_list=None if pre is None else pre.cuda())
+    (got * 0.37).backward()
+    assert abs(float(got.detach()) - float(want.detach())) <= 1e-4 * abs(float(want.detach()))
+    assert_close(b.grad.cpu().numpy(), a.grad.numpy(), 1e-3, "grad")
+    # deterministic: no float atomics
+    c = feats.cuda().requires_grad_(True)
+    got2 = contrastive_loss(c, labels.cuda(), predef_u_list=None if pre is None else pre.cuda())
+    (got2 * 0.37).backward()
+    assert torch.equal(got2.detach(), got.detach()) and torch.equal(c.grad, b.grad)
+
+
+@pytest.mark.parametrize("P,kind", [(5000, "uniform"), (4097, "clustered"), (3000, "planar"), (10, "uniform"),
+                                    (3, "uniform"), (2000, "duplicates")])
+def test_dist2_3nn_matches_brute_force(P, kind):
+    g = np.random.RandomState(P)
+    if kind == "uniform":
+        pts = g.rand(P, 3).astype(np.float32) * 3 - 1.5
+    elif kind == "clustered":
+        c = g.randn(8, 3) * 2
+        pts = (c[g.randint(0, 8, P)] + g.randn(P, 3) * 0.02).astype(np.float32)
+        pts[:5] += 50.0                               # far outliers: ring expansion
+    elif kind == "planar":
+        pts = np.concatenate([g.rand(P, 2), np.zeros((P, 1))], 1).astype(np.float32)
+    else:
+        pts = g.rand(P // 2, 3).astype(np.float32)
+        pts = np.concatenate([pts, pts], 0)           # exact duplicates -> zero distances
+    want = oracle.dist2_3nn(pts)
+    got = distCUDA2(torch.tensor(pts).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(got, want)          # same fp32 distance expression, exact neighbours
+
+
+def test_dist2_regular_grid_closed_form():
+    g = np.stack(np.meshgrid(np.arange(6), np.arange(6), np.arange(6), indexing="ij"), -1).reshape(-1, 3)
+    d = distCUDA2(torch.tensor(g, dtype=torch.float32).cuda()).cpu().numpy().reshape(6, 6, 6)
+    assert d[2, 3, 2] == 1.0 and d[0, 0, 0] == 1.0
+
+
+class _PC:
+    def __init__(self, inp, active_sh_degree=3):
+        self._i = {k: (v.cuda() if v is not None else None) for k, v in inp.items()}
+        self.active_sh_degree = active_sh_degree
+    get_xyz = property(lambda s: s._i["means3D"])
+    get_opacity = property(lambda s: s._i["opacities"])
+    get_scaling = property(lambda s: s._i["scales"])
+    get_rotation = property(lambda s: s._i["rotations"])
+    get_features = property(lambda s: s._i["shs"])
+    get_seg_feature = property(lambda s: s._i["extra"])
+
+
+class _Pipe:
+    compute_cov3D_python = False
+    convert_SHs_python = False
+    depth_ratio = 1.0
+    debug = False
+
+
+def test_render_returns_reference_dict_and_matches_oracle():
+    from helpers import oracle_forward
+    sc, cams, inp = small_scene(P=700, F=8, W=64, H=48, seed=71)
+    cam = cams[0]
+    pc = _PC(inp)
+    camg = cams[0].to("cuda")
+    rz.set_mode("exact")
+    out = render(camg, pc, _Pipe(), torch.zeros(3, device="cuda"))
+    keys = {"render", "viewspace_points", "visibility_filter", "radii", "seg_feature", "gau_related_pixels",
+            "rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal", "rend_depth", "rend_median_depth"}
+    assert set(out.keys()) == keys
+    # render() re-normalises the feature with +1e-9 (reference :61-62) before rasterising
+    feat = inp["extra"] / (inp["extra"].norm(dim=-1, keepdim=True) + 1e-9)
+    st = oracle_forward(dict(inp, extra=feat), cams[0])
+    np.testing.assert_array_equal(out["render"].cpu().numpy(), st["color"])
+    np.testing.assert_array_equal(out["seg_feature"].cpu().numpy(), st["extra"])
+    np.testing.assert_array_equal(out["radii"].cpu().numpy(), st["radii"])
+    want = torch_ops.render_post(torch.tensor(st["others"]), cam.world_view_transform.cpu(), cam.full_proj_transform.cpu(),
+                                 64, 48, 1.0)
+    for k, v in want.items():
+        assert_close(out[k].cpu().numpy(), v.numpy(), 1e-4, k)
