@@ -24,6 +24,7 @@ import torch.nn as nn
 
 from . import scenes
 from .contrastive import contrastive_loss
+from .dist_utils import allreduce_grads, view_for
 from .render import render
 
 
@@ -116,7 +117,7 @@ class SegTrainer:
         return contrastive_loss(feats, labels, predef_u_list=predef) * self.lsv * weight
 
     def view_index(self, it):
-        return (it * self.world + self.rank) % len(self.cams)
+        return view_for(it, self.rank, self.world, len(self.cams))
 
     def step(self, it: int):
         m = self.model
@@ -147,8 +148,7 @@ class SegTrainer:
                 pick = keep[torch.randint(0, keep.numel(), (self.batch,), device=self.device, generator=self.gen)]
                 loss = loss + contrastive_loss(vis_feat[pick], vis_lab[pick], predef_u_list=m.class_feat) * self.l3d
         loss.backward()
-        if self.world > 1:
-            dist.all_reduce(m._seg_feature.grad, op=dist.ReduceOp.SUM)
+        allreduce_grads([m._seg_feature], self.world)
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
         return loss.detach()

@@ -109,9 +109,10 @@ class _Pipe:
 def test_render_returns_reference_dict_and_matches_oracle():
     from helpers import oracle_forward
     sc, cams, inp = small_scene(P=700, F=8, W=64, H=48, seed=71)
+    import copy
     cam = cams[0]
     pc = _PC(inp)
-    camg = cams[0].to("cuda")
+    camg = copy.deepcopy(cams[0]).to("cuda")
     rz.set_mode("exact")
     out = render(camg, pc, _Pipe(), torch.zeros(3, device="cuda"))
     keys = {"render", "viewspace_points", "visibility_filter", "radii", "seg_feature", "gau_related_pixels",
