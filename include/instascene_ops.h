@@ -29,23 +29,31 @@ size_t iso_knn_scratch_bytes(int P);
 int iso_dist2_3nn(int P, const float* points /*[P,3]*/, float* mean_dist2 /*[P]*/, void* scratch,
                   size_t scratch_bytes, void* stream);
 
-/* ProtoNCE loss on N samples with dense labels in [0,K):
+/* ProtoNCE loss on N samples:
  *   f_i   = x_i / (|x_i| + 1e-9)                       (norm detached, :41)
  *   u_k   = mean_{i in k} f_i   or  predef_u[k]         (:44-45,:54-58)
  *   phi_k = clip(10 * sum_{i in k}|f_i - u_k| / (n_k * log(n_k + temp_lambda)), 0.5, 1)   (detached, :60-66)
  *   loss  = - sum_i log( exp(f_i.u_{y_i}/phi_{y_i}) / (sum_k exp(f_i.u_k/phi_k) + 1e-9) )  (:68-71)
- * `state` (iso_contrastive_scratch_bytes) is the opaque forward->backward hand-off.
- * Every cluster id in [0,K) must occur at least once.  predef_u may be NULL.
+ * `state` (iso_contrastive_scratch_bytes) is the opaque forward->backward hand-off.  predef_u may be NULL.
+ * No host synchronisation (the reference's three torch.unique calls per loss each force one).
  * The similarity  [N,F].[F,K]  and the backward products run on the matrix cores with
  * the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32). */
 size_t iso_contrastive_scratch_bytes(int N, int F, int K);
-int iso_contrastive_forward(int N, int F, int K, const float* features /*[N,F]*/, const int32_t* labels /*[N]*/,
-                            const float* predef_u /*[K,F] or NULL*/, float temp_lambda, float* loss /*[1]*/,
-                            void* state, size_t state_bytes, void* stream);
-/* dL_dfeatures[N,F] = dL/dloss * d loss / d features  (dL_dloss: device scalar). */
-int iso_contrastive_backward(int N, int F, int K, const int32_t* labels, const float* predef_u,
-                             const float* dL_dloss /*[1]*/, float* dL_dfeatures /*[N,F]*/, void* state,
-                             size_t state_bytes, void* stream);
+/* labels: the RAW label of every sample (int64 if labels_are_int64 else int32), exactly what the reference's
+ * `masks` argument holds.  Samples are dropped like the reference drops them (:25-40): label <= 0 unless
+ * consider_negative, and labels with <= min_pixnum samples.  K bounds the column ids: column = label - 1
+ * (label when consider_negative) must be < K to survive; predef_u (if given) has K rows indexed the same way. */
+int iso_contrastive_forward(int N, int F, int K, const float* features /*[N,F]*/, const void* labels /*[N]*/,
+                            int labels_are_int64, const float* predef_u /*[K,F] or NULL*/, int consider_negative,
+                            int min_pixnum, float temp_lambda, float* loss /*[1]*/, void* state, size_t state_bytes,
+                            void* stream);
+/* dL_dfeatures[N,F] = dL/dloss * d loss / d features  (dL_dloss: device scalar); zero rows for dropped samples. */
+int iso_contrastive_backward(int N, int F, int K, int prototypes_predefined, const float* dL_dloss /*[1]*/,
+                             float* dL_dfeatures /*[N,F]*/, void* state, size_t state_bytes, void* stream);
+
+/* Row normalisation y = x / (|x|_2 + eps) on [N,F] (scene/gaussian_model.py:122-125, gaussian_renderer/__init__.py:61-62):
+ * backward == 0: out = y;  backward != 0: out = dL/dx given dy = dL/dy (x is the forward input). */
+int iso_rownorm(long long N, int F, float eps, int backward, const float* x, const float* dy, float* out, void* stream);
 
 #ifdef __cplusplus
 }

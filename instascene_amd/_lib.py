@@ -44,8 +44,9 @@ SIGNATURES = {
     "iso_knn_scratch_bytes": (c_size_t, [c_int]),
     "iso_dist2_3nn": (c_int, [c_int, _P, _P, _P, c_size_t, _P]),
     "iso_contrastive_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "iso_contrastive_forward": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, c_size_t, _P]),
-    "iso_contrastive_backward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "iso_contrastive_forward": (c_int, [c_int, c_int, c_int, _P, _P, c_int, _P, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
+    "iso_contrastive_backward": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "iso_rownorm": (c_int, [ctypes.c_longlong, c_int, c_float, c_int, _P, _P, _P, _P]),
 }
 
 

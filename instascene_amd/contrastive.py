@@ -1,9 +1,9 @@
 """``contrastive_loss`` — host-side mirror of the reference's
-``utils/contrastive_utils.contrastive_loss`` (utils/contrastive_utils.py:18-73):
-same signature, same label filtering / dense relabelling (:25-50, torch ops, as
-in the reference), with the arithmetic core (:41-71) running in the HIP library
-(``iso_contrastive_forward/backward``: exact-fp32 MFMA similarity, atomic-free
-deterministic reductions)."""
+``utils/contrastive_utils.contrastive_loss`` (utils/contrastive_utils.py:18-73): same signature and
+semantics, with the whole computation — label filtering, prototypes, concentration, similarity, loss
+and backward — inside the HIP library (``iso_contrastive_forward/backward``: exact-fp32 MFMA products,
+atomic-free deterministic reductions, no device->host synchronisation; the reference syncs three times
+per call through ``torch.unique``)."""
 from __future__ import annotations
 
 import ctypes
@@ -23,58 +23,85 @@ def _stream():
 
 class _ProtoNCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, features, labels, predef_u, K, temp_lambda):
+    def forward(ctx, features, labels, predef_u, K, temp_lambda, consider_negative, min_pixnum):
         L = lib()
         feats = features.contiguous().float()
         N, F = feats.shape
-        labels = labels.to(torch.int32).contiguous()
+        if labels.dtype not in (torch.int64, torch.int32):
+            labels = labels.to(torch.int64)
+        labels = labels.contiguous()
         pre = predef_u.contiguous().float() if predef_u is not None else None
         nbytes = L.iso_contrastive_scratch_bytes(N, F, K)
         state = torch.empty(nbytes, dtype=torch.uint8, device=feats.device)
         loss = torch.empty(1, dtype=torch.float32, device=feats.device)
         with torch.cuda.device(feats.device):
-            check(L.iso_contrastive_forward(N, F, K, _p(feats), _p(labels), _p(pre), float(temp_lambda), _p(loss),
+            check(L.iso_contrastive_forward(N, F, K, _p(feats), _p(labels), int(labels.dtype == torch.int64), _p(pre),
+                                            int(bool(consider_negative)), int(min_pixnum), float(temp_lambda), _p(loss),
                                             _p(state), nbytes, _stream()), "iso_contrastive_forward")
-        ctx.save_for_backward(labels, state, pre if pre is not None else torch.empty(0, device=feats.device))
+        ctx.save_for_backward(state)
         ctx.dims = (N, F, K, nbytes, pre is not None)
         return loss[0]
 
     @staticmethod
     def backward(ctx, grad_loss):
         L = lib()
-        labels, state, pre = ctx.saved_tensors
+        (state,) = ctx.saved_tensors
         N, F, K, nbytes, has_pre = ctx.dims
         g = grad_loss.reshape(1).contiguous().float()
-        out = torch.empty((N, F), dtype=torch.float32, device=labels.device)
-        with torch.cuda.device(labels.device):
-            check(L.iso_contrastive_backward(N, F, K, _p(labels), _p(pre) if has_pre else None, _p(g), _p(out),
-                                             _p(state), nbytes, _stream()), "iso_contrastive_backward")
-        return out, None, None, None, None
+        out = torch.empty((N, F), dtype=torch.float32, device=state.device)
+        with torch.cuda.device(state.device):
+            check(L.iso_contrastive_backward(N, F, K, int(has_pre), _p(g), _p(out), _p(state), nbytes, _stream()),
+                  "iso_contrastive_backward")
+        return out, None, None, None, None, None, None
 
 
-def contrastive_loss(features, masks, predef_u_list=None, min_pixnum=0, temp_lambda=1000, consider_negative=False):
+def contrastive_loss(features, masks, predef_u_list=None, min_pixnum=0, temp_lambda=1000, consider_negative=False,
+                     num_labels=None):
     """Drop-in for ``utils.contrastive_utils.contrastive_loss`` (reference :18-73).
 
-    features [N,F] float (CUDA), masks [N] integer labels; returns the summed ProtoNCE loss."""
+    features [N,F] float (CUDA), masks [N] integer labels; returns the summed ProtoNCE loss.
+    ``num_labels`` (extension, optional): an upper bound on ``masks.max() + 1``.  When neither it nor
+    ``predef_u_list`` is given the bound is read from ``masks`` (one host sync, still fewer than the reference)."""
     if not features.is_cuda:
         raise RuntimeError("contrastive_loss: features must be a CUDA tensor (the HIP library is the only backend)")
-    if not consider_negative:
-        valid = masks > 0
+    if features.shape[0] == 0:
+        return features.sum() * 0.0
+    if predef_u_list is not None:
+        K = int(predef_u_list.shape[0])
+    elif num_labels is not None:
+        K = int(num_labels)
     else:
-        valid = torch.ones_like(masks, dtype=torch.bool)
-    mask_ids, mask_nums = torch.unique(masks, return_counts=True)
-    valid_mask_ids = mask_ids[mask_nums > min_pixnum]
-    valid = valid & torch.isin(masks, valid_mask_ids)
-    labels = masks[valid].to(torch.int64)
-    if not consider_negative:
-        labels = labels - 1
-    feats = features[valid, :]
-    present = torch.unique(labels)                  # sorted, like the reference's remapping (:43-50)
-    K = int(present.numel())
-    if K == 0:
-        return feats.sum() * 0.0
-    remap = torch.zeros(int(present.max().item()) + 1, dtype=torch.long, device=labels.device)
-    remap[present] = torch.arange(K, device=labels.device)
-    dense = remap[labels]
-    u = predef_u_list[present] if predef_u_list is not None else None
-    return _ProtoNCE.apply(feats, dense, u, K, float(temp_lambda))
+        K = int(masks.max().item()) + 1
+    K = max(K, 1)
+    return _ProtoNCE.apply(features, masks, predef_u_list, K, float(temp_lambda), bool(consider_negative), int(min_pixnum))
+
+
+class _RowNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        L = lib()
+        xc = x.contiguous().float()
+        out = torch.empty_like(xc)
+        with torch.cuda.device(xc.device):
+            check(L.iso_rownorm(xc.shape[0], xc.shape[1], float(eps), 0, _p(xc), None, _p(out), _stream()), "iso_rownorm")
+        ctx.save_for_backward(xc)
+        ctx.eps = float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = lib()
+        (xc,) = ctx.saved_tensors
+        dyc = dy.contiguous().float()
+        out = torch.empty_like(xc)
+        with torch.cuda.device(xc.device):
+            check(L.iso_rownorm(xc.shape[0], xc.shape[1], ctx.eps, 1, _p(xc), _p(dyc), _p(out), _stream()), "iso_rownorm")
+        return out, None
+
+
+def row_normalize(x: torch.Tensor, eps: float) -> torch.Tensor:
+    """``x / (x.norm(dim=1, keepdim=True) + eps)`` for a [N,F] CUDA tensor in one streaming HIP kernel each way
+    (scene/gaussian_model.py:122-125 with eps 1e-6; gaussian_renderer/__init__.py:61-62 with eps 1e-9)."""
+    if not x.is_cuda or x.dim() != 2:
+        return x / (x.norm(dim=-1, keepdim=True) + eps)
+    return _RowNorm.apply(x, eps)

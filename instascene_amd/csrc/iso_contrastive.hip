@@ -1,58 +1,60 @@
-// Prototype-contrastive (ProtoNCE) loss core — reference utils/contrastive_utils.py:41-71.
+// Prototype-contrastive (ProtoNCE) loss — reference utils/contrastive_utils.py:18-73, entirely on the
+// device: label filtering (:25-40), prototypes (:43-58), concentration (:60-66), similarity + loss (:68-71)
+// and the full backward, with no host synchronisation (the reference calls torch.unique three times per
+// loss, each a device->host sync) and no float atomics (bit-reproducible).
 //
-// Deterministic, atomic-free pipeline:
-//   ck_normalize   : f = x / (|x| + 1e-9), 1/(|x|+1e-9)            (thread per sample)
-//   ck_clusters    : n_k, u_k (mean or predefined), phi_k           (workgroup per cluster, fixed-order sums)
-//   ck_similarity  : Z = F.U^T on the matrix cores (exact-fp32 MFMA 32x32x2), exp, row sums,
-//                    G = softmax - onehot, per-workgroup loss partials
-//   ck_loss_reduce : fixed-order sum of the partials
-// backward:
-//   ck_grad_u      : dU = G^T.F / phi   (MFMA over the sample dimension, fixed-order combine)
-//   ck_grad_f      : dF = G.(U/phi) (+ dU[y]/n_y when prototypes are computed), dX = g * dF / (|x|+1e-9)
+// Columns: the reference relabels the labels that survive filtering to dense ids.  Here column c is simply
+// (label - 1) (or label when consider_negative) in [0, K) for a caller-supplied bound K; columns without a
+// surviving sample are masked out of every sum, which is the same arithmetic as dropping them.
+//
+// Pipeline (all launches on the caller's stream):
+//   ck_count       integer histogram of the raw labels                       (int atomics: exact)
+//   ck_normalize   f = x/(|x|+1e-9), 1/(|x|+1e-9), column id or -1 per sample
+//   ck_gemm_tn     cluster sums  onehot^T.f   on the matrix cores (exact-fp32 MFMA 32x32x2), split over samples
+//   ck_finish_u    fixed-order sum of the split partials -> U (mean or predefined), present mask, counts
+//   ck_phi         phi_c = clip(10 * sum|f-u_c| / (n_c log(n_c+lambda)), .5, 1)
+//   ck_similarity  Z = f.U^T (MFMA), exp, masked row sums, G = softmax - onehot, loss partials
+//   ck_loss_reduce fixed-order sum
+// backward: ck_gemm_tn (G^T.f) + ck_finish_du, ck_grad_f (G.(U/phi) MFMA + prototype path, scaled by 1/(|x|+1e-9)).
 #include "isr_common.hpp"
 
 namespace iso {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int CK_NSPLIT = 64;
 
 struct CState {          // carved from the caller's state buffer
     float* f;            // [N,F] normalised features
     float* inv;          // [N]
+    int* col;            // [N] column id or -1
+    int* hist;           // [K+2] raw-label histogram
     float* U;            // [K,F]
     float* phi;          // [K]
-    float* cnt;          // [K] n_k as float
-    float* G;            // [N,K] softmax - onehot
+    float* cnt;          // [K] surviving samples per column (0 = column absent)
+    float* G;            // [N,K] softmax - onehot (0 for dropped samples / absent columns)
     float* part;         // [blocks] loss partials
     float* dU;           // [K,F]
+    float* split;        // [CK_NSPLIT, K, F] GEMM partials
 };
 inline CState cstate(void* buf, int N, int F, int K) {
     char* p = (char*)buf;
     CState s;
     s.f = isr::carve<float>(p, (size_t)N * F);
     s.inv = isr::carve<float>(p, N);
+    s.col = isr::carve<int>(p, N);
+    s.hist = isr::carve<int>(p, K + 2);
     s.U = isr::carve<float>(p, (size_t)K * F);
     s.phi = isr::carve<float>(p, K);
     s.cnt = isr::carve<float>(p, K);
     s.G = isr::carve<float>(p, (size_t)N * K);
     s.part = isr::carve<float>(p, (size_t)(N + 127) / 128 + 1);
     s.dU = isr::carve<float>(p, (size_t)K * F);
+    s.split = isr::carve<float>(p, (size_t)CK_NSPLIT * K * F);
     return s;
 }
 inline size_t cstate_bytes(int N, int F, int K) {
     CState s = cstate((void*)0, N, F, K);
-    return (size_t)(s.dU + (size_t)K * F) + 256;
-}
-
-__global__ __launch_bounds__(256) void ck_normalize(int N, int F, const float* __restrict__ x, float* __restrict__ f,
-                                                    float* __restrict__ inv) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const float* xi = x + (size_t)i * F;
-    float s = 0.0f;
-    for (int c = 0; c < F; c++) s += xi[c] * xi[c];
-    const float r = 1.0f / (__builtin_sqrtf(s) + 1e-9f);
-    inv[i] = r;
-    for (int c = 0; c < F; c++) f[(size_t)i * F + c] = xi[c] * r;
+    return (size_t)(s.split + (size_t)CK_NSPLIT * K * F) + 256;
 }
 
 __device__ __forceinline__ float block_sum_256(float v, float* s_red) {
@@ -64,33 +66,116 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red) {
     return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
-// one workgroup per cluster; channels handled in chunks of 256 threads / members striped over threads
-__global__ __launch_bounds__(256) void ck_clusters(int N, int F, const float* __restrict__ f,
-                                                   const int32_t* __restrict__ labels, const float* __restrict__ predef,
-                                                   float temp_lambda, float* __restrict__ U, float* __restrict__ phi,
-                                                   float* __restrict__ cnt) {
+// raw labels are int64 (torch.long) or int32; shift = 1 unless consider_negative
+__device__ __forceinline__ long long load_label(const void* labels, int is64, int i) {
+    return is64 ? ((const long long*)labels)[i] : (long long)((const int*)labels)[i];
+}
+
+__global__ __launch_bounds__(256) void ck_count(int N, int K, int shift, const void* __restrict__ labels, int is64,
+                                                int* __restrict__ hist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const long long c = load_label(labels, is64, i) - shift;      // histogram slot c+1 (slot 0: label == shift-1, e.g. 0)
+    if (c >= -1 && c < K) atomicAdd(hist + (int)(c + 1), 1);
+}
+
+__global__ __launch_bounds__(256) void ck_normalize(int N, int F, int K, int shift, int consider_negative, int min_pixnum,
+                                                    const float* __restrict__ x, const void* __restrict__ labels, int is64,
+                                                    const int* __restrict__ hist, float* __restrict__ f,
+                                                    float* __restrict__ inv, int* __restrict__ col) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const long long lab = load_label(labels, is64, i);
+    const long long c = lab - shift;
+    bool ok = (consider_negative || lab > 0) && c >= 0 && c < K;
+    if (ok) ok = hist[(int)c + 1] > min_pixnum;
+    col[i] = ok ? (int)c : -1;
+    const float* xi = x + (size_t)i * F;
+    float s = 0.0f;
+    for (int ch = 0; ch < F; ch++) s += xi[ch] * xi[ch];
+    const float r = 1.0f / (__builtin_sqrtf(s) + 1e-9f);
+    inv[i] = r;
+    for (int ch = 0; ch < F; ch++) f[(size_t)i * F + ch] = xi[ch] * r;
+}
+
+// C[k][c] (partial over a slice of the samples) = sum_i A[i][k] * f[i][c]
+//   onehot != 0 : A[i][k] = (col[i] == k)      (cluster sums)
+//   onehot == 0 : A[i][k] = G[i][k]            (prototype gradient)
+// grid (ceil(K/32), ceil(F/32), CK_NSPLIT); the block's 4 waves stripe its slice; fixed-order combine.
+__global__ __launch_bounds__(256) void ck_gemm_tn(int N, int F, int K, int onehot, const int* __restrict__ col,
+                                                  const float* __restrict__ G, const float* __restrict__ f,
+                                                  float* __restrict__ split) {
+    __shared__ float s_acc[4][32][33];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int kidx = k0 + (lane & 31), cidx = c0 + (lane & 31), kk = lane >> 5;
+    const int chunk = (N + CK_NSPLIT - 1) / CK_NSPLIT;
+    const int i_lo = blockIdx.z * chunk, i_hi = min(N, i_lo + chunk);
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = i_lo + 2 * wv; i < i_hi; i += 8) {       // A[m = cluster][k = sample], B[k = sample][n = channel]
+        const int smp = i + kk;
+        float a = 0.0f, b = 0.0f;
+        if (smp < i_hi) {
+            if (kidx < K) a = onehot ? (col[smp] == kidx ? 1.0f : 0.0f) : G[(size_t)smp * K + kidx];
+            if (cidx < F) b = f[(size_t)smp * F + cidx];
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) s_acc[wv][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = acc[r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+        const int m = e >> 5, c = e & 31;
+        if (k0 + m < K && c0 + c < F)
+            split[((size_t)blockIdx.z * K + k0 + m) * F + c0 + c] =
+                (s_acc[0][m][c] + s_acc[1][m][c]) + (s_acc[2][m][c] + s_acc[3][m][c]);
+    }
+}
+
+// U = cluster mean (or predefined prototype), cnt = surviving samples per column
+__global__ __launch_bounds__(256) void ck_finish_u(int F, int K, int min_pixnum, const int* __restrict__ hist,
+                                                   const float* __restrict__ split, const float* __restrict__ predef,
+                                                   float* __restrict__ U, float* __restrict__ cnt) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= K * F) return;
+    const int k = e / F;
+    const int h = hist[k + 1];
+    const float n = h > min_pixnum ? (float)h : 0.0f;     // every sample of a surviving label survives
+    if (e == k * F) cnt[k] = n;
+    float v = 0.0f;
+    if (n > 0.0f) {
+        if (predef != nullptr) v = predef[e];
+        else {
+            float s = 0.0f;
+            for (int z = 0; z < CK_NSPLIT; z++) s += split[(size_t)z * K * F + e];
+            v = s / n;
+        }
+    }
+    U[e] = v;
+}
+
+__global__ __launch_bounds__(256) void ck_finish_du(int F, int K, const float* __restrict__ split,
+                                                    const float* __restrict__ phi, const float* __restrict__ cnt,
+                                                    float* __restrict__ dU) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= K * F) return;
+    const int k = e / F;
+    float s = 0.0f;
+    for (int z = 0; z < CK_NSPLIT; z++) s += split[(size_t)z * K * F + e];
+    dU[e] = cnt[k] > 0.0f ? s / phi[k] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void ck_phi(int N, int F, const float* __restrict__ f, const int* __restrict__ col,
+                                              const float* __restrict__ U, const float* __restrict__ cnt,
+                                              float temp_lambda, float* __restrict__ phi) {
     __shared__ float s_red[4];
     __shared__ float s_u[1024];
     const int k = blockIdx.x;
-    float c = 0.0f;
-    for (int i = threadIdx.x; i < N; i += 256) c += (labels[i] == k) ? 1.0f : 0.0f;
-    const float n = block_sum_256(c, s_red);
-    if (predef != nullptr) {
-        for (int ch = threadIdx.x; ch < F; ch += 256) s_u[ch] = predef[(size_t)k * F + ch];
-    } else {
-        // mean: thread t owns channels t, t+256, ...; members visited in index order (deterministic)
-        for (int ch = threadIdx.x; ch < F; ch += 256) {
-            float a = 0.0f;
-            for (int i = 0; i < N; i++)
-                if (labels[i] == k) a += f[(size_t)i * F + ch];
-            s_u[ch] = a / n;
-        }
-    }
+    for (int ch = threadIdx.x; ch < F; ch += 256) s_u[ch] = U[(size_t)k * F + ch];
     __syncthreads();
-    for (int ch = threadIdx.x; ch < F; ch += 256) U[(size_t)k * F + ch] = s_u[ch];
     float d = 0.0f;
     for (int i = threadIdx.x; i < N; i += 256) {
-        if (labels[i] != k) continue;
+        if (col[i] != k) continue;
         float s = 0.0f;
         for (int ch = 0; ch < F; ch++) {
             const float t = f[(size_t)i * F + ch] - s_u[ch];
@@ -100,18 +185,21 @@ __global__ __launch_bounds__(256) void ck_clusters(int N, int F, const float* __
     }
     const float dsum = block_sum_256(d, s_red);
     if (threadIdx.x == 0) {
-        float p = dsum / (n * __logf(n + temp_lambda)) * 10.0f;
-        p = p < 0.5f ? 0.5f : (p > 1.0f ? 1.0f : p);
+        const float n = cnt[k];
+        float p = 1.0f;
+        if (n > 0.0f) {
+            p = dsum / (n * __logf(n + temp_lambda)) * 10.0f;
+            p = p < 0.5f ? 0.5f : (p > 1.0f ? 1.0f : p);
+        }
         phi[k] = p;
-        cnt[k] = n;
     }
 }
 
 // 4 waves x 32 samples per workgroup.  A[i][k] = f[row i][chan k]; B[k][j] = U[proto j][chan k].
 __global__ __launch_bounds__(256) void ck_similarity(int N, int F, int K, const float* __restrict__ f,
                                                      const float* __restrict__ U, const float* __restrict__ phi,
-                                                     const int32_t* __restrict__ labels, float* __restrict__ G,
-                                                     float* __restrict__ part) {
+                                                     const float* __restrict__ cnt, const int* __restrict__ colid,
+                                                     float* __restrict__ G, float* __restrict__ part) {
     __shared__ float s_red[4];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i0 = (blockIdx.x * 4 + wv) * 32;
@@ -123,7 +211,7 @@ __global__ __launch_bounds__(256) void ck_similarity(int N, int F, int K, const 
     for (int r = 0; r < 16; r++) {
         rsum[r] = 0.0f;
         const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        lab[r] = row < N ? labels[row] : -1;
+        lab[r] = row < N ? colid[row] : -1;
     }
     float lpart = 0.0f;
     for (int sweep = 0; sweep < 2; sweep++) {
@@ -136,22 +224,27 @@ __global__ __launch_bounds__(256) void ck_similarity(int N, int F, int K, const 
                 const float b = (col < K && ch < F) ? U[(size_t)col * F + ch] : 0.0f;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
             }
-            const float ph = col < K ? phi[col] : 1.0f;
+            const bool present = col < K && cnt[col] > 0.0f;
+            const float ph = present ? phi[col] : 1.0f;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const float z = acc[r] / ph;
-                const float e = (col < K && row < N) ? __expf(z) : 0.0f;
+                const float e = (present && lab[r] >= 0) ? __expf(z) : 0.0f;
                 if (sweep == 0) {
                     float t = e;   // sum over the 32 columns held by the 32 lanes of this half-wave
 #pragma unroll
                     for (int o = 16; o >= 1; o >>= 1) t += __shfl_xor(t, o);
                     rsum[r] += t;
                 } else if (row < N && col < K) {
-                    const float S = rsum[r] + 1e-9f;
-                    const bool pos = (col == lab[r]);
-                    G[(size_t)row * K + col] = e / S - (pos ? 1.0f : 0.0f);
-                    if (pos) lpart += __logf(S) - z;     // -log(e_pos / S)
+                    float g = 0.0f;
+                    if (lab[r] >= 0 && present) {
+                        const float S = rsum[r] + 1e-9f;
+                        const bool pos = (col == lab[r]);
+                        g = e / S - (pos ? 1.0f : 0.0f);
+                        if (pos) lpart += __logf(S) - z;     // -log(e_pos / S)
+                    }
+                    G[(size_t)row * K + col] = g;
                 }
             }
         }
@@ -168,38 +261,11 @@ __global__ __launch_bounds__(256) void ck_loss_reduce(int nb, const float* __res
     if (threadIdx.x == 0) loss[0] = t;
 }
 
-// dU[k][c] = sum_i G[i][k] f[i][c] / phi_k.  Workgroup per (32-cluster tile, 32-channel tile); its 4 waves stripe the samples.
-__global__ __launch_bounds__(256) void ck_grad_u(int N, int F, int K, const float* __restrict__ f,
-                                                 const float* __restrict__ G, const float* __restrict__ phi,
-                                                 float* __restrict__ dU) {
-    __shared__ float s_acc[4][32][33];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-    const int kidx = k0 + (lane & 31), cidx = c0 + (lane & 31), kk = lane >> 5;
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 2 * wv; i < N; i += 8) {       // A[m = cluster][k = sample], B[k = sample][n = channel]
-        const int smp = i + kk;
-        const float a = (smp < N && kidx < K) ? G[(size_t)smp * K + kidx] : 0.0f;
-        const float b = (smp < N && cidx < F) ? f[(size_t)smp * F + cidx] : 0.0f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; r++) s_acc[wv][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = acc[r];
-    __syncthreads();
-    for (int e = threadIdx.x; e < 1024; e += 256) {
-        const int m = e >> 5, c = e & 31;
-        if (k0 + m < K && c0 + c < F) {
-            const float v = (s_acc[0][m][c] + s_acc[1][m][c]) + (s_acc[2][m][c] + s_acc[3][m][c]);
-            dU[(size_t)(k0 + m) * F + c0 + c] = v / phi[k0 + m];
-        }
-    }
-}
-
 // dF = G.(U/phi) [+ dU[y]/n_y];  dX = g * dF * inv.   4 waves x 32 samples, 32-channel tiles.
 __global__ __launch_bounds__(256) void ck_grad_f(int N, int F, int K, const float* __restrict__ G,
                                                  const float* __restrict__ U, const float* __restrict__ phi,
                                                  const float* __restrict__ cnt, const float* __restrict__ dU,
-                                                 const int32_t* __restrict__ labels, const float* __restrict__ inv,
+                                                 const int* __restrict__ colid, const float* __restrict__ inv,
                                                  const float* __restrict__ gloss, int use_mean, float* __restrict__ dX) {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i0 = (blockIdx.x * 4 + wv) * 32;
@@ -212,7 +278,7 @@ __global__ __launch_bounds__(256) void ck_grad_f(int N, int F, int K, const floa
         for (int s = 0; s < ksteps; s++) {       // A[m = sample][k = cluster], B[k = cluster][n = channel]
             const int kc = 2 * s + kk;
             const float a = (arow < N && kc < K) ? G[(size_t)arow * K + kc] : 0.0f;
-            const float b = (kc < K && ch < F) ? U[(size_t)kc * F + ch] / phi[kc] : 0.0f;
+            const float b = (kc < K && ch < F && cnt[kc] > 0.0f) ? U[(size_t)kc * F + ch] / phi[kc] : 0.0f;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
 #pragma unroll
@@ -220,14 +286,76 @@ __global__ __launch_bounds__(256) void ck_grad_f(int N, int F, int K, const floa
             const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < N && ch < F) {
                 float v = acc[r];
-                if (use_mean) {
-                    const int y = labels[row];
-                    v += dU[(size_t)y * F + ch] / cnt[y];
-                }
-                dX[(size_t)row * F + ch] = g * v * inv[row];
+                const int y = colid[row];
+                if (use_mean && y >= 0) v += dU[(size_t)y * F + ch] / cnt[y];
+                dX[(size_t)row * F + ch] = y >= 0 ? g * v * inv[row] : 0.0f;
             }
         }
     }
+}
+
+}  // namespace iso
+
+// ---------------------------------------------------------------------------
+// Row normalisation y = x / (|x| + eps) and its exact backward — the reference applies it twice to the
+// [P,F] feature every step in torch (scene/gaussian_model.py:122-125 eps 1e-6, gaussian_renderer/__init__.py:61-62
+// eps 1e-9): ~10 elementwise/reduction launches forward+backward; here one streaming kernel each way.
+namespace iso {
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void rn_kernel(long long N, int F, float eps, const float* __restrict__ x,
+                                                 const float* __restrict__ dy, float* __restrict__ out) {
+    // LPR lanes cooperate on one row (float4 per lane per step); LPR = power of two >= F/4, <= 64
+    const int q = F >> 2;
+    int lpr = 1;
+    while (lpr < q && lpr < 64) lpr <<= 1;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (lpr - 1);
+    const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) / lpr;
+    const bool ok = row < N;
+    const float4* xr = reinterpret_cast<const float4*>(x + (ok ? row : 0) * F);
+    const float4* dr = BWD ? reinterpret_cast<const float4*>(dy + (ok ? row : 0) * F) : nullptr;
+    float ss = 0.0f, sd = 0.0f;
+    for (int c = sub; c < q; c += lpr) {
+        const float4 v = ok ? xr[c] : make_float4(0, 0, 0, 0);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        if (BWD) {
+            const float4 g = ok ? dr[c] : make_float4(0, 0, 0, 0);
+            sd += v.x * g.x + v.y * g.y + v.z * g.z + v.w * g.w;
+        }
+    }
+    for (int o = lpr >> 1; o >= 1; o >>= 1) {
+        ss += __shfl_xor(ss, o);
+        if (BWD) sd += __shfl_xor(sd, o);
+    }
+    if (!ok) return;
+    const float n = __builtin_sqrtf(ss);
+    const float r = 1.0f / (n + eps);
+    float4* o4 = reinterpret_cast<float4*>(out + row * F);
+    if (!BWD) {
+        for (int c = sub; c < q; c += lpr) {
+            const float4 v = xr[c];
+            o4[c] = make_float4(v.x * r, v.y * r, v.z * r, v.w * r);
+        }
+    } else {
+        const float k = n > 0.0f ? r * r * sd / n : 0.0f;     // d(1/(n+eps))/dx = -r^2 x/n ; subgradient 0 at x = 0
+        for (int c = sub; c < q; c += lpr) {
+            const float4 v = xr[c], g = dr[c];
+            o4[c] = make_float4(r * g.x - k * v.x, r * g.y - k * v.y, r * g.z - k * v.z, r * g.w - k * v.w);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rn_scalar(long long N, int F, float eps, int bwd, const float* __restrict__ x,
+                                                 const float* __restrict__ dy, float* __restrict__ out) {
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= N) return;
+    const float* xr = x + row * F;
+    float ss = 0.0f, sd = 0.0f;
+    for (int c = 0; c < F; c++) { ss += xr[c] * xr[c]; if (bwd) sd += xr[c] * dy[row * F + c]; }
+    const float n = __builtin_sqrtf(ss), r = 1.0f / (n + eps);
+    const float k = n > 0.0f ? r * r * sd / n : 0.0f;
+    for (int c = 0; c < F; c++) out[row * F + c] = bwd ? r * dy[row * F + c] - k * xr[c] : xr[c] * r;
 }
 
 }  // namespace iso

@@ -297,34 +297,65 @@ int iso_dist2_3nn(int P, const float* points, float* mean_dist2, void* scratch, 
 
 size_t iso_contrastive_scratch_bytes(int N, int F, int K) { return iso::cstate_bytes(N < 1 ? 1 : N, F < 1 ? 1 : F, K < 1 ? 1 : K); }
 
-int iso_contrastive_forward(int N, int F, int K, const float* features, const int32_t* labels, const float* predef_u,
-                            float temp_lambda, float* loss, void* state, size_t state_bytes, void* stream) {
+int iso_contrastive_forward(int N, int F, int K, const float* features, const void* labels, int labels_are_int64,
+                            const float* predef_u, int consider_negative, int min_pixnum, float temp_lambda, float* loss,
+                            void* state, size_t state_bytes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (N <= 0 || F <= 0 || K <= 0 || !features || !labels || !loss || !state) return fail(ISR_EINVAL, "bad contrastive arguments");
     if (F > 1024) return fail(ISR_EINVAL, "feature dimension %d > 1024 unsupported", F);
     if (state_bytes < iso::cstate_bytes(N, F, K)) return fail(ISR_EINVAL, "contrastive state too small");
     iso::CState st = iso::cstate(state, N, F, K);
-    const int nblk = (N + 127) / 128;
-    hipLaunchKernelGGL(iso::ck_normalize, dim3((N + 255) / 256), dim3(256), 0, s, N, F, features, st.f, st.inv);
-    hipLaunchKernelGGL(iso::ck_clusters, dim3(K), dim3(256), 0, s, N, F, st.f, labels, predef_u, temp_lambda, st.U, st.phi, st.cnt);
-    hipLaunchKernelGGL(iso::ck_similarity, dim3(nblk), dim3(256), 0, s, N, F, K, st.f, st.U, st.phi, labels, st.G, st.part);
+    const int shift = consider_negative ? 0 : 1;
+    const int nblk = (N + 127) / 128, nt = (N + 255) / 256;
+    ISR_HIP(hipMemsetAsync(st.hist, 0, sizeof(int) * (K + 2), s));
+    hipLaunchKernelGGL(iso::ck_count, dim3(nt), dim3(256), 0, s, N, K, shift, labels, labels_are_int64, st.hist);
+    hipLaunchKernelGGL(iso::ck_normalize, dim3(nt), dim3(256), 0, s, N, F, K, shift, consider_negative, min_pixnum, features,
+                       labels, labels_are_int64, st.hist, st.f, st.inv, st.col);
+    if (predef_u == nullptr)
+        hipLaunchKernelGGL(iso::ck_gemm_tn, dim3((K + 31) / 32, (F + 31) / 32, iso::CK_NSPLIT), dim3(256), 0, s, N, F, K, 1,
+                           st.col, (const float*)nullptr, st.f, st.split);
+    hipLaunchKernelGGL(iso::ck_finish_u, dim3((K * F + 255) / 256), dim3(256), 0, s, F, K, min_pixnum, st.hist, st.split,
+                       predef_u, st.U, st.cnt);
+    hipLaunchKernelGGL(iso::ck_phi, dim3(K), dim3(256), 0, s, N, F, st.f, st.col, st.U, st.cnt, temp_lambda, st.phi);
+    hipLaunchKernelGGL(iso::ck_similarity, dim3(nblk), dim3(256), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, st.col, st.G, st.part);
     hipLaunchKernelGGL(iso::ck_loss_reduce, dim3(1), dim3(256), 0, s, nblk, st.part, loss);
     ISR_LAUNCH_CHECK("iso_contrastive_forward");
     return ISR_OK;
 }
 
-int iso_contrastive_backward(int N, int F, int K, const int32_t* labels, const float* predef_u, const float* dL_dloss,
-                             float* dL_dfeatures, void* state, size_t state_bytes, void* stream) {
+int iso_contrastive_backward(int N, int F, int K, int prototypes_predefined, const float* dL_dloss, float* dL_dfeatures,
+                             void* state, size_t state_bytes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (N <= 0 || F <= 0 || K <= 0 || !labels || !dL_dloss || !dL_dfeatures || !state) return fail(ISR_EINVAL, "bad contrastive arguments");
+    if (N <= 0 || F <= 0 || K <= 0 || !dL_dloss || !dL_dfeatures || !state) return fail(ISR_EINVAL, "bad contrastive arguments");
     if (state_bytes < iso::cstate_bytes(N, F, K)) return fail(ISR_EINVAL, "contrastive state too small");
     iso::CState st = iso::cstate(state, N, F, K);
-    const int use_mean = predef_u == nullptr ? 1 : 0;
-    if (use_mean)
-        hipLaunchKernelGGL(iso::ck_grad_u, dim3((K + 31) / 32, (F + 31) / 32), dim3(256), 0, s, N, F, K, st.f, st.G, st.phi, st.dU);
-    hipLaunchKernelGGL(iso::ck_grad_f, dim3((N + 127) / 128), dim3(256), 0, s, N, F, K, st.G, st.U, st.phi, st.cnt, st.dU, labels,
+    const int use_mean = prototypes_predefined ? 0 : 1;
+    if (use_mean) {
+        hipLaunchKernelGGL(iso::ck_gemm_tn, dim3((K + 31) / 32, (F + 31) / 32, iso::CK_NSPLIT), dim3(256), 0, s, N, F, K, 0,
+                           st.col, st.G, st.f, st.split);
+        hipLaunchKernelGGL(iso::ck_finish_du, dim3((K * F + 255) / 256), dim3(256), 0, s, F, K, st.split, st.phi, st.cnt, st.dU);
+    }
+    hipLaunchKernelGGL(iso::ck_grad_f, dim3((N + 127) / 128), dim3(256), 0, s, N, F, K, st.G, st.U, st.phi, st.cnt, st.dU, st.col,
                        st.inv, dL_dloss, use_mean, dL_dfeatures);
     ISR_LAUNCH_CHECK("iso_contrastive_backward");
+    return ISR_OK;
+}
+
+int iso_rownorm(long long N, int F, float eps, int backward, const float* x, const float* dy, float* out, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (N < 0 || F <= 0 || (N > 0 && (!x || !out || (backward && !dy)))) return fail(ISR_EINVAL, "bad rownorm arguments");
+    if (N == 0) return ISR_OK;
+    if ((F & 3) == 0 && F <= 1024) {
+        int q = F >> 2, lpr = 1;
+        while (lpr < q && lpr < 64) lpr <<= 1;
+        const long long threads = N * lpr;
+        const unsigned blocks = (unsigned)((threads + 255) / 256);
+        if (backward) hipLaunchKernelGGL(iso::rn_kernel<true>, dim3(blocks), dim3(256), 0, s, N, F, eps, x, dy, out);
+        else hipLaunchKernelGGL(iso::rn_kernel<false>, dim3(blocks), dim3(256), 0, s, N, F, eps, x, dy, out);
+    } else {
+        hipLaunchKernelGGL(iso::rn_scalar, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, F, eps, backward, x, dy, out);
+    }
+    ISR_LAUNCH_CHECK("iso_rownorm");
     return ISR_OK;
 }
 

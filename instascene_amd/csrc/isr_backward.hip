@@ -75,9 +75,9 @@ __global__ __launch_bounds__(256) void k_render_bwd(
     __shared__ __attribute__((aligned(16))) float s_feat[QF > 0 ? BB * QF : 4];
     __shared__ int s_id[BB];
     __shared__ unsigned s_slot[BB];
+    __shared__ __attribute__((aligned(16))) float4 s_box[BB];
     __shared__ float s_W[4 * BB * WPAD];
     __shared__ __attribute__((aligned(16))) float s_part[4 * BB * PART];
-    __shared__ unsigned s_max[4];
 
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
@@ -99,15 +99,6 @@ __global__ __launch_bounds__(256) void k_render_bwd(
     float* Pw = s_part + wv * BB * PART;
 
     const unsigned last_contributor = inside ? n_contrib[pix] : 0u;
-    {   // tile-wide bound: nothing behind the deepest last contributor blends
-        unsigned m = last_contributor;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-        if (lane == 0) s_max[wv] = m;
-    }
-    __syncthreads();
-    const unsigned tile_max = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-
     // ---- MFMA B operands (constant for the whole tile) -------------------------
     // feature tile: B[k][j] with k = lane>>5 (pixel 2s+k of this wave), j = lane&31 (channel)
     float Bf[FEAT ? 32 : 1];
@@ -161,6 +152,39 @@ __global__ __launch_bounds__(256) void k_render_bwd(
 #pragma unroll
         for (int c = 0; c < QF; c++) dEp[c] = (inside && dE != nullptr && c < ED) ? dE[(size_t)c * N + pix] : 0.0f;
     }
+    // ---- which pixels of this wave carry any upstream gradient?  A pixel whose dL/dout is exactly zero
+    // contributes exactly zero to every sum, so it is skipped, and splats are culled against the bounding
+    // rectangle of the wave's live pixels (train_semantic samples ~16k of 2M pixels: most waves go idle).
+    bool has_grad;
+    if constexpr (GEOM) {
+        has_grad = (dpx0 != 0.0f) || (dpx1 != 0.0f) || (dpx2 != 0.0f) || (dL_ddepth != 0.0f) || (dL_daccum != 0.0f) ||
+                   (dL_dreg != 0.0f) || (dn0 != 0.0f) || (dn1 != 0.0f) || (dn2 != 0.0f) || (dL_dmedian != 0.0f);
+        if constexpr (QF > 0) {
+#pragma unroll
+            for (int c = 0; c < QF; c++) has_grad = has_grad || (dEp[c] != 0.0f);
+            if (ED > QF) has_grad = true;
+        }
+    } else {
+        unsigned long long pm = 0ull;       // bit q: row q of the wave's dL/dfeature block is non-zero
+#pragma unroll
+        for (int s = 0; s < 32; s++) {
+            const unsigned long long bal = __ballot(Bf[s] != 0.0f);
+            if (bal & 0xffffffffull) pm |= 1ull << (2 * s);
+            if (bal >> 32) pm |= 1ull << (2 * s + 1);
+        }
+        has_grad = (pm >> lane) & 1ull;
+    }
+    const bool lane_live = inside && has_grad && last_contributor > 0u;
+    const bool wave_live = __ballot(lane_live) != 0ull;
+    float ax0 = lane_live ? pxf : 3.0e38f, ax1 = lane_live ? pxf : -3.0e38f;
+    float ay0 = lane_live ? pyf : 3.0e38f, ay1 = lane_live ? pyf : -3.0e38f;
+    unsigned wave_last = lane_live ? last_contributor : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        ax0 = fminf(ax0, __shfl_xor(ax0, o)); ax1 = fmaxf(ax1, __shfl_xor(ax1, o));
+        ay0 = fminf(ay0, __shfl_xor(ay0, o)); ay1 = fmaxf(ay1, __shfl_xor(ay1, o));
+        wave_last = max(wave_last, (unsigned)__shfl_xor((int)wave_last, o));
+    }
     const float final_A = 1 - T_final;
     const float mscale = FAR_N / (FAR_N - NEAR_N);
     float T = GEOM ? T_final : 1.0f;
@@ -200,6 +224,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(
             }
             float4* s4 = reinterpret_cast<float4*>(s_rec + t * RS);
             s4[0] = a; s4[1] = b; s4[2] = c; s4[3] = make_float4(d.x, d.y, opa, skip);
+            s_box[t] = splat_cull_box(F3{a.x, a.y, a.z}, F3{a.w, b.x, b.y}, F3{b.z, b.w, c.x}, c.y, c.z, skip);
             reinterpret_cast<float4*>(s_rgb)[t] = make_float4(d.w, e.x, e.y, 0.0f);
             const Rect16 rc = rects[id];
             s_slot[t] = point_offsets[id] + (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
@@ -215,14 +240,27 @@ __global__ __launch_bounds__(256) void k_render_bwd(
         for (int e = lane; e < BB * PART; e += 64) Pw[e] = 0.0f;
         __syncthreads();
 
-        const bool batch_live = (unsigned)lo < tile_max;   // some pixel may still blend an entry of this batch
-        if (batch_live) {
-            // ---- phase A: every lane evaluates its pixel against the batch ----------
-            for (int jj = 0; jj < nb; jj++) {
-                const int j = GEOM ? nb - 1 - jj : jj;
+        // splats of this batch that can matter to this wave: index below the wave's deepest last contributor
+        // and cull box meeting the rectangle of the wave's live pixels
+        unsigned long long m = 0ull;
+        if (wave_live) {
+            bool hit = false;
+            if (lane < nb && (unsigned)(lo + lane) < wave_last) {
+                const float4 bb = s_box[lane];
+                hit = !(bb.x > ax1) && !(bb.y < ax0) && !(bb.z > ay1) && !(bb.w < ay0);
+            }
+            m = __ballot(hit);
+        }
+        if (m != 0ull) {
+            for (int e = lane; e < BB * WPAD; e += 64) Ww[e] = 0.0f;     // culled splats have zero weight
+            // ---- phase A: every live lane evaluates its pixel against the surviving splats ----------
+            while (m != 0ull) {
+                int j;
+                if (GEOM) { j = 63 - __builtin_clzll(m); m &= ~(1ull << j); }     // back to front
+                else { j = __builtin_ctzll(m); m &= m - 1ull; }                     // front to back
                 const unsigned contributor = (unsigned)(lo + j);     // 0-based index == reference's decremented counter
                 float w = 0.0f;
-                bool act = inside && contributor < last_contributor;
+                bool act = lane_live && contributor < last_contributor;
                 float G = 0, alpha = 0, sx = 0, sy = 0, c_d = 0, rho3d = 0, rho2d = 0, dx = 0, dy = 0;
                 F3 kk = {0, 0, 0}, ll = {0, 0, 0}, p = {0, 0, 1};
                 const float4 a = reinterpret_cast<const float4*>(s_rec + j * RS)[0];

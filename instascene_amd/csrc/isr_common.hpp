@@ -154,6 +154,37 @@ __device__ __forceinline__ float exp_fixed(float x) {
     return y * __uint_as_float((unsigned)e << 23);
 }
 
+// Conservative screen-space box outside of which a splat certainly contributes nothing to a pixel
+// (alpha < 1/255), i.e. BOTH rho3d > skip and rho2d > skip hold there:
+//   * rho3d <= skip is the perspective image of the disc u^2+v^2 <= skip of the splat plane; when that disc
+//     lies entirely in front of the camera plane (d < 0) its exact axis-aligned bound is the reference's own
+//     AABB formula (forward.cu:119-145) evaluated with cutoff^2 = skip; otherwise the image is unbounded and
+//     no culling is done;
+//   * rho2d <= skip is the disc of radius sqrt(skip/2) around the low-pass centre.
+// 1% + 0.5 px safety margins; any NaN yields an infinite box (never culls).  Returns (x_lo, x_hi, y_lo, y_hi).
+__device__ __forceinline__ float4 splat_cull_box(F3 Tu, F3 Tv, F3 Tw, float cx, float cy, float skip) {
+    const float inf = __builtin_inff();
+    float4 box = make_float4(-inf, inf, -inf, inf);
+    if (skip < inf) {
+        const float d = skip * (Tw.x * Tw.x + Tw.y * Tw.y) - Tw.z * Tw.z;
+        if (d < 0.0f) {
+            const float fi = 1.0f / d;
+            const float fa = skip * fi, fz = -fi;
+            const float ex_c = fa * (Tu.x * Tw.x) + fa * (Tu.y * Tw.y) + fz * (Tu.z * Tw.z);
+            const float ey_c = fa * (Tv.x * Tw.x) + fa * (Tv.y * Tw.y) + fz * (Tv.z * Tw.z);
+            const float hx = ex_c * ex_c - (fa * (Tu.x * Tu.x) + fa * (Tu.y * Tu.y) + fz * (Tu.z * Tu.z));
+            const float hy = ey_c * ey_c - (fa * (Tv.x * Tv.x) + fa * (Tv.y * Tv.y) + fz * (Tv.z * Tv.z));
+            const float ex = __builtin_sqrtf(hx > 0.0f ? hx : 0.0f) * 1.01f + 0.5f;
+            const float ey = __builtin_sqrtf(hy > 0.0f ? hy : 0.0f) * 1.01f + 0.5f;
+            const float r2 = __builtin_sqrtf(0.5f * skip) * 1.01f + 0.5f;
+            const float xl = fminf(ex_c - ex, cx - r2), xh = fmaxf(ex_c + ex, cx + r2);
+            const float yl = fminf(ey_c - ey, cy - r2), yh = fmaxf(ey_c + ey, cy + r2);
+            if (xl == xl && xh == xh && yl == yl && yh == yh && hx == hx && hy == hy) box = make_float4(xl, xh, yl, yh);
+        }
+    }
+    return box;
+}
+
 // Arithmetic policies for the per-pixel loops.
 struct ExactMath {
     static constexpr bool fast = false;

@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(
     __shared__ __attribute__((aligned(16))) float s_rgb[BATCH * 4];
     __shared__ __attribute__((aligned(16))) float s_feat[(FCH > 0 ? BATCH * FCH : 4)];
     __shared__ int s_id[BATCH];
+    __shared__ __attribute__((aligned(16))) float4 s_box[BATCH];
 
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
@@ -356,6 +357,8 @@ __global__ __launch_bounds__(256) void k_render_fwd(
 #pragma unroll
     for (int c = 0; c < (FCH > 0 ? FCH : 1); c++) E[c] = 0.0f;
     const float mscale = FAR_N / (FAR_N - NEAR_N);
+    const float bx0 = (float)(tx * TILE + (wv & 1) * 8), bx1 = bx0 + 7.0f;
+    const float by0 = (float)(ty * TILE + (wv >> 1) * 8), by1 = by0 + 7.0f;
 
     for (int64_t base = r0; base < r1; base += BATCH) {
         if (__syncthreads_and(done)) break;
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(
             s4[1] = b;                                      // Tv.yz Tw.xy
             s4[2] = make_float4(c.x, c.y, c.z, c.w);        // Tw.z cx cy nx
             s4[3] = make_float4(d.x, d.y, opa, skip);       // ny nz opa skip
+            s_box[t] = splat_cull_box(F3{a.x, a.y, a.z}, F3{a.w, b.x, b.y}, F3{b.z, b.w, c.x}, c.y, c.z, skip);
             reinterpret_cast<float4*>(s_rgb)[t] = make_float4(d.w, e.x, e.y, 0.0f);
         }
         __syncthreads();
@@ -406,9 +410,21 @@ __global__ __launch_bounds__(256) void k_render_fwd(
             }
             __syncthreads();
         }
-        // ---- walk the batch
-        for (int j = 0; !done && j < nb; j++) {
-            contributor++;
+        // ---- walk the batch: each wave visits only the splats whose cull box meets its 8x8 pixel block
+        for (int c0 = 0; c0 < nb; c0 += 64) {
+            const int jj = c0 + lane;
+            bool hit = false;
+            if (jj < nb) {
+                const float4 bb = s_box[jj];
+                hit = !(bb.x > bx1) && !(bb.y < bx0) && !(bb.z > by1) && !(bb.w < by0);
+            }
+            unsigned long long m = __ballot(hit);
+            while (m != 0ull) {
+                if (__ballot(!done) == 0ull) break;
+                const int j = c0 + __builtin_ctzll(m);
+                m &= m - 1ull;
+                if (done) continue;
+                contributor = (unsigned)(base - r0) + (unsigned)j + 1u;
             const float4 a = reinterpret_cast<const float4*>(s_rec + j * RS)[0];
             const float4 b = reinterpret_cast<const float4*>(s_rec + j * RS)[1];
             const float4 c = reinterpret_cast<const float4*>(s_rec + j * RS)[2];
@@ -465,6 +481,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(
             }
             T = test_T;
             last_contributor = contributor;
+            }
         }
     }
     if (inside) {

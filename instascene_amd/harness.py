@@ -23,7 +23,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import scenes
-from .contrastive import contrastive_loss
+from .contrastive import contrastive_loss, row_normalize
 from .dist_utils import allreduce_grads, view_for
 from .render import render
 
@@ -62,7 +62,7 @@ class SegGaussianModel:
     def get_seg_feature(self):
         if self._seg_feature is None:
             return None
-        return self._seg_feature / (torch.norm(self._seg_feature, p=2, dim=1, keepdim=True) + 1e-6)
+        return row_normalize(self._seg_feature, 1e-6)
 
 
 def gram_schmidt(vectors: torch.Tensor) -> torch.Tensor:
@@ -99,6 +99,8 @@ class SegTrainer:
         self.gen = torch.Generator(device=self.device).manual_seed(1000 + seed * 131 + rank)
         # label maps are static per view: index the labelled pixels once (the reference re-derives the
         # boolean mask every iteration, train_semantic.py:118-125)
+        self.n_labels = n_labels
+        self.vis_pool = {}        # view -> indices of visible, labelled Gaussians (geometry is frozen: static per view)
         self.valid_idx = {}
         for i, c in enumerate(self.cams):
             if c.segmap is None:
@@ -114,7 +116,7 @@ class SegTrainer:
         pix = idx_pool[pick]
         feats = seg_feature.reshape(seg_feature.shape[0], -1)[:, pix].T
         labels = segmap.reshape(-1)[pix]
-        return contrastive_loss(feats, labels, predef_u_list=predef) * self.lsv * weight
+        return contrastive_loss(feats, labels, predef_u_list=predef, num_labels=self.n_labels + 1) * self.lsv * weight
 
     def view_index(self, it):
         return view_for(it, self.rank, self.world, len(self.cams))
@@ -139,14 +141,19 @@ class SegTrainer:
             allf, alll = torch.cat(feats, dim=1), torch.cat(labs)
             pool = torch.nonzero(alll > 0).reshape(-1)
             pick = pool[torch.randint(0, pool.numel(), (self.batch,), device=self.device, generator=self.gen)]
-            loss = loss + contrastive_loss(allf[:, pick].T, alll[pick], predef_u_list=m.class_feat) * self.lmv
+            loss = loss + contrastive_loss(allf[:, pick].T, alll[pick], predef_u_list=m.class_feat,
+                                           num_labels=self.n_labels + 1) * self.lmv
         if self.l3d > 0:
-            vis_feat = m.get_seg_feature[vis]
-            vis_lab = self.labels3d[vis]
-            keep = torch.nonzero(vis_lab > 0).reshape(-1)
-            if keep.numel() > 0:
-                pick = keep[torch.randint(0, keep.numel(), (self.batch,), device=self.device, generator=self.gen)]
-                loss = loss + contrastive_loss(vis_feat[pick], vis_lab[pick], predef_u_list=m.class_feat) * self.l3d
+            # reference :175-190 materialises feature[visibility_filter] ([V,F]) and then samples; sampling the
+            # visible & labelled Gaussians first and gathering only the batch rows draws from the same distribution
+            pool = self.vis_pool.get(vi)
+            if pool is None:
+                pool = torch.nonzero(vis & (self.labels3d > 0)).reshape(-1)
+                self.vis_pool[vi] = pool
+            if pool.numel() > 0:
+                pick = pool[torch.randint(0, pool.numel(), (self.batch,), device=self.device, generator=self.gen)]
+                loss = loss + contrastive_loss(m.get_seg_feature[pick], self.labels3d[pick], predef_u_list=m.class_feat,
+                                               num_labels=self.n_labels + 1) * self.l3d
         loss.backward()
         allreduce_grads([m._seg_feature], self.world)
         self.opt.step()

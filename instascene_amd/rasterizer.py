@@ -149,7 +149,8 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, 
     L = lib()
     dev = means3D.device
     P = means3D.shape[0]
-    H, W = dL_dout_color.shape[1], dL_dout_color.shape[2]
+    _ref = next(t for t in (dL_dout_color, dL_dout_others, dL_dout_extra) if t is not None)
+    H, W = _ref.shape[1], _ref.shape[2]
     mode = _CONFIG["mode"] if mode is None else mode
     means3D = _f32c(means3D, "means3D")
     colors, scales, rotations = _f32c(colors, "colors"), _f32c(scales, "scales"), _f32c(rotations, "rotations")
@@ -159,8 +160,9 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, 
     F = extra_attrs.shape[1] if (extra_attrs is not None and extra_attrs.numel()) else 0
     extra = _f32c(extra_attrs, "extra_attrs") if F else None
     M = sh.shape[1] if (sh is not None and sh.dim() == 3) else 0
-    dC, dO = _f32c(dL_dout_color, "dL_dout_color"), _f32c(dL_dout_others, "dL_dout_others")
-    dE = _f32c(dL_dout_extra, "dL_dout_extra") if F else None
+    dC = _f32c(dL_dout_color, "dL_dout_color") if dL_dout_color is not None else None
+    dO = _f32c(dL_dout_others, "dL_dout_others") if dL_dout_others is not None else None
+    dE = _f32c(dL_dout_extra, "dL_dout_extra") if (F and dL_dout_extra is not None) else None
     if F == 0:
         grad_mask &= ~GRAD_EXTRA
     geomg = bool(grad_mask & GRAD_GEOMETRY)
@@ -258,6 +260,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, extra_attrs, sh,
                               geomBuffer, binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii, gau_related_pixels)
+        ctx.set_materialize_grads(False)     # unused outputs arrive as None (= zeros) instead of dense zero tensors
         return color, radii, depth, extra, gau_related_pixels
 
     @staticmethod
@@ -272,7 +275,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             mask |= GRAD_GEOMETRY
         if need[8] and extra_attrs.numel():
             mask |= GRAD_EXTRA
-        if mask == 0:
+        if mask == 0 or (grad_out_color is None and grad_depth is None and grad_out_extra is None):
             return (None,) * 10
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_extra_attrs) = rasterize_gaussians_backward(

@@ -9,6 +9,7 @@ import math
 
 import torch
 
+from .contrastive import row_normalize
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
@@ -85,7 +86,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     opacity = pc.get_opacity
     seg_feature = pc.get_seg_feature
     if seg_feature is not None and norm_seg_feat:
-        seg_feature = seg_feature / (seg_feature.norm(dim=-1, keepdim=True) + 1e-9)
+        seg_feature = row_normalize(seg_feature, 1e-9)      # reference :61-62
 
     scales = rotations = cov3D_precomp = None
     if getattr(pipe, "compute_cov3D_python", False):

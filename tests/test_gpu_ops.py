@@ -130,3 +130,39 @@ def test_render_returns_reference_dict_and_matches_oracle():
                                  64, 48, 1.0)
     for k, v in want.items():
         assert_close(out[k].cpu().numpy(), v.numpy(), 1e-4, k)
+
+
+@pytest.mark.parametrize("N,F,eps", [(5000, 32, 1e-6), (777, 16, 1e-9), (300, 6, 1e-6), (100, 64, 1e-9)])
+def test_row_normalize_matches_torch(N, F, eps):
+    from instascene_amd.contrastive import row_normalize
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(N, F, generator=g)
+    x[3] = 0.0                                   # zero row: subgradient 0, no NaN
+    dy = torch.randn(N, F, generator=g)
+    a = x.clone().requires_grad_(True)
+    ya = a / (a.norm(dim=-1, keepdim=True) + eps)
+    (ya * dy).sum().backward()
+    b = x.cuda().requires_grad_(True)
+    yb = row_normalize(b, eps)
+    (yb * dy.cuda()).sum().backward()
+    assert_close(yb.detach().cpu().numpy(), ya.detach().numpy(), 1e-6, "rownorm fwd")
+    assert_close(b.grad.cpu().numpy(), a.grad.numpy(), 1e-5, "rownorm bwd")
+
+
+def test_contrastive_with_label_bound_and_dropped_samples():
+    """num_labels bound larger than the labels present, unlabeled (0) samples, min_pixnum dropping small clusters."""
+    g = torch.Generator().manual_seed(5)
+    N, F = 4000, 32
+    feats = torch.randn(N, F, generator=g)
+    labels = torch.randint(0, 40, (N,), generator=g)
+    labels[labels == 7] = 0
+    labels[:3] = 55                                # a tiny cluster (3 samples) dropped by min_pixnum
+    a = feats.clone().requires_grad_(True)
+    want = torch_ops.contrastive_loss(a, labels, min_pixnum=5)
+    want.backward()
+    b = feats.cuda().requires_grad_(True)
+    got = contrastive_loss(b, labels.cuda(), min_pixnum=5, num_labels=200)
+    got.backward()
+    assert abs(float(got.detach()) - float(want.detach())) <= 1e-4 * abs(float(want.detach()))
+    assert_close(b.grad.cpu().numpy(), a.grad.numpy(), 1e-3, "grad")
+    assert float(b.grad[labels.cuda() == 0].abs().sum()) == 0.0

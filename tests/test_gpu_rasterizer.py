@@ -276,3 +276,65 @@ def test_autograd_module_matches_reference_interface():
     (out[3] * dE.cuda()).sum().backward()
     want_e = oracle.backward(st, np.zeros((3, 48, 64), np.float32), np.zeros((7, 48, 64), np.float32), dE.numpy())
     assert_close(feat.grad.cpu().numpy(), want_e["dL_dextra"], 1e-3, "feature-only grad")
+
+
+def test_backward_with_sparse_upstream_gradient():
+    """train_semantic samples a few thousand pixels: dL/dfeature is exactly zero elsewhere.  The backward skips
+    zero-gradient pixels and culls splats against the live pixels' rectangle — results must not change."""
+    sc, cams, inp = small_scene(P=2500, F=32, W=128, H=96, seed=81, mu_s=math.log(0.05))
+    cam = cams[1]
+    st = oracle_forward(inp, cam)
+    for mode in (MODE_EXACT, MODE_FAST):
+        args, out = hip_forward(inp, cam, mode=mode)
+        rng = np.random.RandomState(5)
+        dE = np.zeros_like(st["extra"])
+        pix = rng.choice(128 * 96, 40, replace=False)
+        dE.reshape(32, -1)[:, pix] = rng.randn(32, 40).astype(np.float32)
+        dC, dO = np.zeros_like(st["color"]), np.zeros_like(st["others"])
+        want = oracle.backward(st, dC, dO, dE)
+        got = hip_backward(args, out, dC, dO, dE, GRAD_EXTRA, mode)
+        assert_close(got[8].cpu().numpy(), want["dL_dextra"], 1e-3, "sparse extra-only")
+        got = hip_backward(args, out, dC, dO, dE, GRAD_EXTRA | GRAD_GEOMETRY, mode)
+        for name, t in zip(GRAD_NAMES, got):
+            assert_close(t.cpu().numpy().reshape(want[name].shape), want[name], 1e-3, "sparse:" + name)
+        # a single live pixel, and no live pixel at all
+        dE1 = np.zeros_like(dE)
+        dE1.reshape(32, -1)[:, pix[0]] = 1.0
+        want1 = oracle.backward(st, dC, dO, dE1)
+        got1 = hip_backward(args, out, dC, dO, dE1, GRAD_EXTRA, mode)
+        assert_close(got1[8].cpu().numpy(), want1["dL_dextra"], 1e-3, "one pixel")
+        got0 = hip_backward(args, out, dC, dO, np.zeros_like(dE), GRAD_EXTRA | GRAD_GEOMETRY, mode)
+        assert all(float(t.abs().sum()) == 0.0 for t in got0)
+
+
+def test_culling_survives_grazing_and_near_camera_splats():
+    """Edge-on, huge and near-plane splats: the conservative cull box must never drop a contributing pair
+    (EXACT mode stays bit-identical to the oracle, which evaluates every pair)."""
+    g = torch.Generator().manual_seed(7)
+    P = 1200
+    sc, cams, inp = small_scene(P=P, F=8, W=96, H=80, seed=91)
+    inp = dict(inp)
+    # mix: very anisotropic (edge-on slivers), very large, and some close to the camera plane
+    s = inp["scales"].clone()
+    s[:300, 0] *= 40.0
+    s[:300, 1] *= 0.02
+    s[300:500] *= 25.0
+    inp["scales"] = s
+    xyz = inp["means3D"].clone()
+    cam = cams[0]
+    center = cam.camera_center
+    fwd = -center / center.norm()
+    xyz[500:700] = center + fwd * (0.21 + 0.3 * torch.rand(200, 1, generator=g)) + 0.2 * torch.randn(200, 3, generator=g)
+    inp["means3D"] = xyz
+    op = inp["opacities"].clone()
+    op[::7] = 0.004            # barely above 1/255
+    op[1::7] = 0.0039          # below: never contributes
+    inp["opacities"] = op
+    st = oracle_forward(inp, cam, bg=(0.5, 0.5, 0.5))
+    args, out = hip_forward(inp, cam, bg=(0.5, 0.5, 0.5), mode=MODE_EXACT)
+    check_forward_exact(st, args, out)
+    dC, dO, dE = _rand_grads(st, 3)
+    want = oracle.backward(st, dC, dO, dE)
+    got = hip_backward(args, out, dC, dO, dE, GRAD_EXTRA | GRAD_GEOMETRY, MODE_EXACT)
+    for name, t in zip(GRAD_NAMES, got):
+        assert_close(t.cpu().numpy().reshape(want[name].shape), want[name], 2e-3, "grazing:" + name)
