@@ -119,9 +119,9 @@ def test_render_returns_reference_dict_and_matches_oracle():
             "rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal", "rend_depth", "rend_median_depth"}
     assert set(out.keys()) == keys
     # render() re-normalises the feature with +1e-9 (reference :61-62) before rasterising
-    # (normalised on the GPU with the same torch ops render() uses, so the oracle sees identical bits)
-    eg = inp["extra"].cuda()
-    feat = (eg / (eg.norm(dim=-1, keepdim=True) + 1e-9)).cpu()
+    # (normalised with the same HIP row-normalise op render() uses, so the oracle sees identical bits)
+    from instascene_amd.contrastive import row_normalize
+    feat = row_normalize(inp["extra"].cuda(), 1e-9).cpu()
     st = oracle_forward(dict(inp, extra=feat), cams[0])
     np.testing.assert_array_equal(out["render"].cpu().numpy(), st["color"])
     np.testing.assert_array_equal(out["seg_feature"].cpu().numpy(), st["extra"])
