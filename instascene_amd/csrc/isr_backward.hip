@@ -33,9 +33,14 @@ __host__ __device__ inline int feat_row(int ED) { return ED > 0 ? ((ED + 31) / 3
 __host__ __device__ inline int row_floats(int ED, unsigned mask) {
     return ((mask & 2u) ? GEOM_ROW : 0) + ((mask & 1u) ? feat_row(ED) : 0);
 }
+__host__ __device__ inline int n_passes(int ED, unsigned mask) { return ((mask & 1u) && ED > 32) ? (ED + 31) / 32 : 1; }
+inline size_t rows_bytes(int64_t R, int ED, unsigned mask) {
+    return align_up((size_t)(R > 0 ? R : 1) * row_floats(ED, mask) * sizeof(float), 256);
+}
+// rows[R][stride] followed by one validity byte per (pass, row): a row is written (and flagged) only when some
+// wave actually evaluated that (tile, splat) instance — everything else is skipped by the reductions.
 size_t backward_scratch_bytes(int64_t R, int ED, unsigned mask) {
-    const size_t rows = (size_t)(R > 0 ? R : 1);
-    return align_up(rows * row_floats(ED, mask) * sizeof(float), 256) + 256;
+    return rows_bytes(R, ED, mask) + align_up((size_t)(R > 0 ? R : 1) * n_passes(ED, mask), 256) + 256;
 }
 
 __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D,
@@ -66,18 +71,21 @@ __global__ __launch_bounds__(256) void k_render_bwd(
     const float* __restrict__ tm_pre, const float* __restrict__ extras, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dC,
     const float* __restrict__ dO, const float* __restrict__ dE, const uint32_t* __restrict__ point_offsets,
-    const Rect16* __restrict__ rects, float* __restrict__ partial, int row_stride, int geom_off, int feat_off,
-    int64_t capacity) {
+    const Rect16* __restrict__ rects, float* __restrict__ partial, uint8_t* __restrict__ row_flags, int row_stride,
+    int geom_off, int feat_off, int64_t capacity) {
     constexpr int RS = 16;
+    constexpr int SB = GEOM ? 64 : 128;     // instances staged per barrier round
+    constexpr int NPB = GEOM ? 1 : 2;       // partial-sum buffers (2: combine of sub-batch k overlaps phase A of k+1)
     constexpr int PART = (GEOM ? GEOM_ROW : 0) + (FEAT ? 32 : 0);   // floats per instance per wave in LDS
-    __shared__ __attribute__((aligned(16))) float s_rec[BB * RS];
-    __shared__ __attribute__((aligned(16))) float s_rgb[BB * 4];
-    __shared__ __attribute__((aligned(16))) float s_feat[QF > 0 ? BB * QF : 4];
-    __shared__ int s_id[BB];
-    __shared__ unsigned s_slot[BB];
-    __shared__ __attribute__((aligned(16))) float4 s_box[BB];
+    __shared__ __attribute__((aligned(16))) float s_rec[SB * RS];
+    __shared__ __attribute__((aligned(16))) float s_rgb[SB * 4];
+    __shared__ __attribute__((aligned(16))) float s_feat[QF > 0 ? SB * QF : 4];
+    __shared__ int s_id[SB];
+    __shared__ unsigned s_slot[SB];
+    __shared__ __attribute__((aligned(16))) float4 s_box[SB];
     __shared__ float s_W[4 * BB * WPAD];
-    __shared__ __attribute__((aligned(16))) float s_part[4 * BB * PART];
+    __shared__ __attribute__((aligned(16))) float s_part[NPB * 4 * BB * PART];
+    __shared__ unsigned s_hit[NPB * 4];
 
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
@@ -96,7 +104,6 @@ __global__ __launch_bounds__(256) void k_render_bwd(
     if (len <= 0) return;
 
     float* Ww = s_W + wv * BB * WPAD;
-    float* Pw = s_part + wv * BB * PART;
 
     const unsigned last_contributor = inside ? n_contrib[pix] : 0u;
     // ---- MFMA B operands (constant for the whole tile) -------------------------
@@ -193,17 +200,18 @@ __global__ __launch_bounds__(256) void k_render_bwd(
     float last_dL_dT = 0, last_alpha = 0, accum_q = 0, last_q = 0;
     const float bg_dot = GEOM ? (bg[0] * dpx0 + bg[1] * dpx1) + bg[2] * dpx2 : 0.0f;
 
-    // GEOM walks back to front (reference order); features-only walks front to back.
-    const int nbatch = (len + BB - 1) / BB;
-    for (int bi = 0; bi < nbatch; bi++) {
-        // batch covers list positions [lo, lo+nb) (0-based from r0)
-        int lo, nb;
-        if (GEOM) { const int hi = len - bi * BB; lo = max(0, hi - BB); nb = hi - lo; }
-        else { lo = bi * BB; nb = min(BB, len - lo); }
-        __syncthreads();   // previous batch's rows are out of s_part / s_rec
-        if (threadIdx.x < nb) {
+    // GEOM walks back to front (reference order); features-only walks front to back.  SB instances are staged
+    // per barrier round and consumed in sub-batches of BB = 32 (the MFMA M dimension).
+    const int nround = (len + SB - 1) / SB;
+    int subc = 0;
+    for (int ri = 0; ri < nround; ri++) {
+        int round_lo, nsb;
+        if (GEOM) { const int hi = len - ri * SB; round_lo = max(0, hi - SB); nsb = hi - round_lo; }
+        else { round_lo = ri * SB; nsb = min(SB, len - round_lo); }
+        __syncthreads();   // the previous round's staged data (s_slot in the last combine) is no longer needed
+        if (threadIdx.x < nsb) {
             const int t = threadIdx.x;
-            const int id = (int)point_list[r0 + lo + t];
+            const int id = (int)point_list[r0 + round_lo + t];
             s_id[t] = id;
             const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
             float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3], e = r4[4];
@@ -231,202 +239,225 @@ __global__ __launch_bounds__(256) void k_render_bwd(
         }
         __syncthreads();
         if constexpr (QF > 0) {
-            for (int e = threadIdx.x; e < nb * QF; e += 256) {
+            for (int e = threadIdx.x; e < nsb * QF; e += 256) {
                 const int inst = e / QF, c = e - inst * QF;
                 s_feat[e] = (c < ED) ? extras[(size_t)s_id[inst] * ED + c] : 0.0f;
             }
+            __syncthreads();
         }
-        // zero this wave's partial block
-        for (int e = lane; e < BB * PART; e += 64) Pw[e] = 0.0f;
-        __syncthreads();
-
-        // splats of this batch that can matter to this wave: index below the wave's deepest last contributor
-        // and cull box meeting the rectangle of the wave's live pixels
-        unsigned long long m = 0ull;
-        if (wave_live) {
-            bool hit = false;
-            if (lane < nb && (unsigned)(lo + lane) < wave_last) {
-                const float4 bb = s_box[lane];
-                hit = !(bb.x > ax1) && !(bb.y < ax0) && !(bb.z > ay1) && !(bb.w < ay0);
+        const int nsub = (nsb + BB - 1) / BB;
+        for (int si = 0; si < nsub; si++, subc++) {
+            int sub_lo, nb;
+            if (GEOM) { const int hi = nsb - si * BB; sub_lo = max(0, hi - BB); nb = hi - sub_lo; }
+            else { sub_lo = si * BB; nb = min(BB, nsb - sub_lo); }
+            const int lo = round_lo + sub_lo;                 // list position of the sub-batch's first instance
+            const int buf = NPB == 2 ? (subc & 1) : 0;
+            float* Pw = s_part + (buf * 4 + wv) * BB * PART;
+            if (NPB == 1) __syncthreads();                    // the previous combine has drained s_part
+            // splats of this sub-batch that can matter to this wave: index below the wave's deepest last
+            // contributor and cull box meeting the rectangle of the wave's live pixels
+            unsigned long long m = 0ull;
+            if (wave_live) {
+                bool hit = false;
+                if (lane < nb && (unsigned)(lo + lane) < wave_last) {
+                    const float4 bb = s_box[sub_lo + lane];
+                    hit = !(bb.x > ax1) && !(bb.y < ax0) && !(bb.z > ay1) && !(bb.w < ay0);
+                }
+                m = __ballot(hit);
             }
-            m = __ballot(hit);
-        }
-        if (m != 0ull) {
-            for (int e = lane; e < BB * WPAD; e += 64) Ww[e] = 0.0f;     // culled splats have zero weight
-            // ---- phase A: every live lane evaluates its pixel against the surviving splats ----------
-            while (m != 0ull) {
-                int j;
-                if (GEOM) { j = 63 - __builtin_clzll(m); m &= ~(1ull << j); }     // back to front
-                else { j = __builtin_ctzll(m); m &= m - 1ull; }                     // front to back
-                const unsigned contributor = (unsigned)(lo + j);     // 0-based index == reference's decremented counter
-                float w = 0.0f;
-                bool act = lane_live && contributor < last_contributor;
-                float G = 0, alpha = 0, sx = 0, sy = 0, c_d = 0, rho3d = 0, rho2d = 0, dx = 0, dy = 0;
-                F3 kk = {0, 0, 0}, ll = {0, 0, 0}, p = {0, 0, 1};
-                const float4 a = reinterpret_cast<const float4*>(s_rec + j * RS)[0];
-                const float4 b = reinterpret_cast<const float4*>(s_rec + j * RS)[1];
-                const float4 c = reinterpret_cast<const float4*>(s_rec + j * RS)[2];
-                const float4 d = reinterpret_cast<const float4*>(s_rec + j * RS)[3];
-                const F3 Tw = {b.z, b.w, c.x};
-                if (act) {
-                    const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y};
-                    kk = {Math::msub(pxf, Tw.x, Tu.x), Math::msub(pxf, Tw.y, Tu.y), Math::msub(pxf, Tw.z, Tu.z)};
-                    ll = {Math::msub(pyf, Tw.x, Tv.x), Math::msub(pyf, Tw.y, Tv.y), Math::msub(pyf, Tw.z, Tv.z)};
-                    p = {Math::msub(kk.y, ll.z, kk.z * ll.y), Math::msub(kk.z, ll.x, kk.x * ll.z),
-                         Math::msub(kk.x, ll.y, kk.y * ll.x)};
-                    dx = c.y - pxf; dy = c.z - pyf;
-                    rho2d = FILTER_INV_SQ * Math::mad(dy, dy, dx * dx);
-                    const float skip = d.w;
-                    if (rho2d > skip && Math::mad(p.y, p.y, p.x * p.x) > skip * (p.z * p.z) * 1.01f) act = false;
-                    else if (p.z == 0.0f) act = false;
-                }
-                if (act) {
-                    sx = Math::div(p.x, p.z); sy = Math::div(p.y, p.z);
-                    rho3d = Math::mad(sy, sy, sx * sx);
-                    const float rho = fminf(rho3d, rho2d);
-                    c_d = (rho3d <= rho2d) ? Math::mad(sy, Tw.y, sx * Tw.x) + Tw.z : Tw.z;
-                    const float power = -0.5f * rho;
-                    if (c_d < NEAR_N || power > 0.0f) act = false;
-                    else {
-                        G = Math::ex(power);
-                        alpha = fminf(0.99f, d.z * G);
-                        if (alpha < 1.0f / 255.0f) act = false;
-                    }
-                }
-                if (act) {
-                    if (GEOM) { T = T / (1.f - alpha); w = alpha * T; }
-                    else { w = alpha * T; T = T * (1 - alpha); }
-                }
-                Ww[j * WPAD + lane] = w;
-                if constexpr (GEOM) {
-                    float g[12];
-#pragma unroll
-                    for (int q = 0; q < 12; q++) g[q] = 0.0f;
+            if (lane == 0) s_hit[buf * 4 + wv] = (unsigned)m;
+            if (m != 0ull) {
+                for (int e = lane; e < BB * PART; e += 64) Pw[e] = 0.0f;
+                for (int e = lane; e < BB * WPAD; e += 64) Ww[e] = 0.0f;     // culled splats have zero weight
+                // ---- phase A: every live lane evaluates its pixel against the surviving splats ----------
+                while (m != 0ull) {
+                    int j;
+                    if (GEOM) { j = 63 - __builtin_clzll(m); m &= ~(1ull << j); }     // back to front
+                    else { j = __builtin_ctzll(m); m &= m - 1ull; }                     // front to back
+                    const int sj = sub_lo + j;
+                    const unsigned contributor = (unsigned)(lo + j);     // 0-based index == reference's decremented counter
+                    float w = 0.0f;
+                    bool act = lane_live && contributor < last_contributor;
+                    float G = 0, alpha = 0, sx = 0, sy = 0, c_d = 0, rho3d = 0, rho2d = 0, dx = 0, dy = 0;
+                    F3 kk = {0, 0, 0}, ll = {0, 0, 0}, p = {0, 0, 1};
+                    const float4 a = reinterpret_cast<const float4*>(s_rec + sj * RS)[0];
+                    const float4 b = reinterpret_cast<const float4*>(s_rec + sj * RS)[1];
+                    const float4 c = reinterpret_cast<const float4*>(s_rec + sj * RS)[2];
+                    const float4 d = reinterpret_cast<const float4*>(s_rec + sj * RS)[3];
+                    const F3 Tw = {b.z, b.w, c.x};
                     if (act) {
-                        const float4 col = reinterpret_cast<const float4*>(s_rgb)[j];
-                        float dL_dalpha = 0.0f;
-                        acc_r0 = last_alpha * lc0 + (1.f - last_alpha) * acc_r0; lc0 = col.x; dL_dalpha += (col.x - acc_r0) * dpx0;
-                        acc_r1 = last_alpha * lc1 + (1.f - last_alpha) * acc_r1; lc1 = col.y; dL_dalpha += (col.y - acc_r1) * dpx1;
-                        acc_r2 = last_alpha * lc2 + (1.f - last_alpha) * acc_r2; lc2 = col.z; dL_dalpha += (col.z - acc_r2) * dpx2;
-                        float dL_dz = 0.0f;
-                        const float m_d = mscale * (1 - NEAR_N / c_d);
-                        const float dmd_dd = (FAR_N * NEAR_N) / ((FAR_N - NEAR_N) * c_d * c_d);
-                        if (contributor == median_contributor - 1u) dL_dz += dL_dmedian;
-                        const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
-                        dL_dalpha += dL_dweight - last_dL_dT;
-                        last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
-                        const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
-                        dL_dz += dL_dmd * dmd_dd;
-                        accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
-                        last_depth = c_d;
-                        dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
-                        accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
-                        dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
-                        const float nx = c.w, ny = d.x, nz = d.y;
-                        an0 = last_alpha * ln0 + (1.f - last_alpha) * an0; ln0 = nx; dL_dalpha += (nx - an0) * dn0;
-                        an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = ny; dL_dalpha += (ny - an1) * dn1;
-                        an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = nz; dL_dalpha += (nz - an2) * dn2;
-                        if constexpr (QF > 0) {
-                            const float* fj = s_feat + j * QF;
-                            float q = 0.0f;
-#pragma unroll
-                            for (int ch = 0; ch < QF; ch++) q = __builtin_fmaf(fj[ch], dEp[ch], q);
-                            if (ED > QF && dE != nullptr) {     // rare: more feature channels than the register budget
-                                const float* fg = extras + (size_t)s_id[j] * ED;
-                                for (int ch = QF; ch < ED; ch++) q = __builtin_fmaf(fg[ch], dE[(size_t)ch * N + pix], q);
+                        const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y};
+                        kk = {Math::msub(pxf, Tw.x, Tu.x), Math::msub(pxf, Tw.y, Tu.y), Math::msub(pxf, Tw.z, Tu.z)};
+                        ll = {Math::msub(pyf, Tw.x, Tv.x), Math::msub(pyf, Tw.y, Tv.y), Math::msub(pyf, Tw.z, Tv.z)};
+                        p = {Math::msub(kk.y, ll.z, kk.z * ll.y), Math::msub(kk.z, ll.x, kk.x * ll.z),
+                             Math::msub(kk.x, ll.y, kk.y * ll.x)};
+                        dx = c.y - pxf; dy = c.z - pyf;
+                        rho2d = FILTER_INV_SQ * Math::mad(dy, dy, dx * dx);
+                        const float skip = d.w;
+                        if (rho2d > skip && Math::mad(p.y, p.y, p.x * p.x) > skip * (p.z * p.z) * 1.01f) act = false;
+                        else if (p.z == 0.0f) act = false;
+                    }
+                    if (act) {
+                        sx = Math::div(p.x, p.z); sy = Math::div(p.y, p.z);
+                        rho3d = Math::mad(sy, sy, sx * sx);
+                        const float rho = fminf(rho3d, rho2d);
+                        c_d = (rho3d <= rho2d) ? Math::mad(sy, Tw.y, sx * Tw.x) + Tw.z : Tw.z;
+                        const float power = -0.5f * rho;
+                        if (c_d < NEAR_N || power > 0.0f) act = false;
+                        else {
+                            G = Math::ex(power);
+                            alpha = fminf(0.99f, d.z * G);
+                            if (alpha < 1.0f / 255.0f) act = false;
+                        }
+                    }
+                    if (act) {
+                        if (GEOM) { T = T / (1.f - alpha); w = alpha * T; }
+                        else { w = alpha * T; T = T * (1 - alpha); }
+                    }
+                    Ww[j * WPAD + lane] = w;
+                    if constexpr (GEOM) {
+                        float g[12];
+    #pragma unroll
+                        for (int q = 0; q < 12; q++) g[q] = 0.0f;
+                        if (act) {
+                            const float4 col = reinterpret_cast<const float4*>(s_rgb)[sj];
+                            float dL_dalpha = 0.0f;
+                            acc_r0 = last_alpha * lc0 + (1.f - last_alpha) * acc_r0; lc0 = col.x; dL_dalpha += (col.x - acc_r0) * dpx0;
+                            acc_r1 = last_alpha * lc1 + (1.f - last_alpha) * acc_r1; lc1 = col.y; dL_dalpha += (col.y - acc_r1) * dpx1;
+                            acc_r2 = last_alpha * lc2 + (1.f - last_alpha) * acc_r2; lc2 = col.z; dL_dalpha += (col.z - acc_r2) * dpx2;
+                            float dL_dz = 0.0f;
+                            const float m_d = mscale * (1 - NEAR_N / c_d);
+                            const float dmd_dd = (FAR_N * NEAR_N) / ((FAR_N - NEAR_N) * c_d * c_d);
+                            if (contributor == median_contributor - 1u) dL_dz += dL_dmedian;
+                            const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
+                            dL_dalpha += dL_dweight - last_dL_dT;
+                            last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
+                            const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
+                            dL_dz += dL_dmd * dmd_dd;
+                            accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                            last_depth = c_d;
+                            dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
+                            accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
+                            dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
+                            const float nx = c.w, ny = d.x, nz = d.y;
+                            an0 = last_alpha * ln0 + (1.f - last_alpha) * an0; ln0 = nx; dL_dalpha += (nx - an0) * dn0;
+                            an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = ny; dL_dalpha += (ny - an1) * dn1;
+                            an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = nz; dL_dalpha += (nz - an2) * dn2;
+                            if constexpr (QF > 0) {
+                                const float* fj = s_feat + sj * QF;
+                                float q = 0.0f;
+    #pragma unroll
+                                for (int ch = 0; ch < QF; ch++) q = __builtin_fmaf(fj[ch], dEp[ch], q);
+                                if (ED > QF && dE != nullptr) {     // rare: more feature channels than the register budget
+                                    const float* fg = extras + (size_t)s_id[sj] * ED;
+                                    for (int ch = QF; ch < ED; ch++) q = __builtin_fmaf(fg[ch], dE[(size_t)ch * N + pix], q);
+                                }
+                                accum_q = last_alpha * last_q + (1.f - last_alpha) * accum_q;
+                                last_q = q;
+                                dL_dalpha += q - accum_q;
                             }
-                            accum_q = last_alpha * last_q + (1.f - last_alpha) * accum_q;
-                            last_q = q;
-                            dL_dalpha += q - accum_q;
+                            dL_dalpha *= T;
+                            last_alpha = alpha;
+                            dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                            const float dL_dG = d.z * dL_dalpha;
+                            dL_dz += alpha * T * dL_ddepth;
+                            if (rho3d <= rho2d) {
+                                const float dsx = dL_dG * -G * sx + dL_dz * Tw.x;
+                                const float dsy = dL_dG * -G * sy + dL_dz * Tw.y;
+                                const float dsx_pz = dsx / p.z, dsy_pz = dsy / p.z;
+                                const F3 dL_dp = {dsx_pz, dsy_pz, -(dsx_pz * sx + dsy_pz * sy)};
+                                const F3 dL_dk = cross3(ll, dL_dp);
+                                const F3 dL_dl = cross3(dL_dp, kk);
+                                g[0] = -dL_dk.x; g[1] = -dL_dk.y; g[2] = -dL_dk.z;
+                                g[3] = -dL_dl.x; g[4] = -dL_dl.y; g[5] = -dL_dl.z;
+                                g[6] = pxf * dL_dk.x + pyf * dL_dl.x + dL_dz * sx;
+                                g[7] = pxf * dL_dk.y + pyf * dL_dl.y + dL_dz * sy;
+                                g[8] = pxf * dL_dk.z + pyf * dL_dl.z + dL_dz * 1.0f;
+                            } else {
+                                g[9] = dL_dG * (-G * FILTER_INV_SQ * dx);
+                                g[10] = dL_dG * (-G * FILTER_INV_SQ * dy);
+                                g[8] = dL_dz;
+                            }
+                            g[11] = G * dL_dalpha;
                         }
-                        dL_dalpha *= T;
-                        last_alpha = alpha;
-                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                        const float dL_dG = d.z * dL_dalpha;
-                        dL_dz += alpha * T * dL_ddepth;
-                        if (rho3d <= rho2d) {
-                            const float dsx = dL_dG * -G * sx + dL_dz * Tw.x;
-                            const float dsy = dL_dG * -G * sy + dL_dz * Tw.y;
-                            const float dsx_pz = dsx / p.z, dsy_pz = dsy / p.z;
-                            const F3 dL_dp = {dsx_pz, dsy_pz, -(dsx_pz * sx + dsy_pz * sy)};
-                            const F3 dL_dk = cross3(ll, dL_dp);
-                            const F3 dL_dl = cross3(dL_dp, kk);
-                            g[0] = -dL_dk.x; g[1] = -dL_dk.y; g[2] = -dL_dk.z;
-                            g[3] = -dL_dl.x; g[4] = -dL_dl.y; g[5] = -dL_dl.z;
-                            g[6] = pxf * dL_dk.x + pyf * dL_dl.x + dL_dz * sx;
-                            g[7] = pxf * dL_dk.y + pyf * dL_dl.y + dL_dz * sy;
-                            g[8] = pxf * dL_dk.z + pyf * dL_dl.z + dL_dz * 1.0f;
-                        } else {
-                            g[9] = dL_dG * (-G * FILTER_INV_SQ * dx);
-                            g[10] = dL_dG * (-G * FILTER_INV_SQ * dy);
-                            g[8] = dL_dz;
+                        if (__ballot(act) != 0ull) {
+                            float sred[12];
+    #pragma unroll
+                            for (int q = 0; q < 12; q++) sred[q] = wave_sum(g[q]);
+                            if (lane == 0) {
+                                float* o = Pw + j * PART;
+    #pragma unroll
+                                for (int q = 0; q < 11; q++) o[q] = sred[q];
+                                o[14] = sred[11];
+                            }
                         }
-                        g[11] = G * dL_dalpha;
                     }
-                    if (__ballot(act) != 0ull) {
-                        float sred[12];
-#pragma unroll
-                        for (int q = 0; q < 12; q++) sred[q] = wave_sum(g[q]);
-                        if (lane == 0) {
-                            float* o = Pw + j * PART;
-#pragma unroll
-                            for (int q = 0; q < 11; q++) o[q] = sred[q];
-                            o[14] = sred[11];
+                }
+                // ---- phase M: matrix-core reduction over the wave's 64 pixels -----------
+                if constexpr (FEAT) {
+                    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    #pragma unroll
+                    for (int s = 0; s < 32; s++) {
+                        const float av = Ww[(lane & 31) * WPAD + 2 * s + (lane >> 5)];   // A[i = splat][k = pixel]
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bf[s], acc, 0, 0, 0);
+                    }
+                    // D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
+                    constexpr int FO = GEOM ? GEOM_ROW : 0;
+    #pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        Pw[row * PART + FO + (lane & 31)] = acc[r];
+                    }
+                }
+                if constexpr (GEOM) {
+    #pragma unroll
+                    for (int mt = 0; mt < 2; mt++) {
+                        f32x4 acc = {0, 0, 0, 0};
+    #pragma unroll
+                        for (int s = 0; s < 16; s++) {
+                            const float av = Ww[(mt * 16 + (lane & 15)) * WPAD + 4 * s + (lane >> 4)];
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bl[s], acc, 0, 0, 0);
+                        }
+                        // D[row = 4*(lane>>4) + r][col = lane&15]; cols 0..2 -> dL_dcolor, 3..5 -> dL_dnormal
+                        const int col = lane & 15;
+                        if (col < 6) {
+                            const int dst = col < 3 ? 15 + col : 11 + (col - 3);
+    #pragma unroll
+                            for (int r = 0; r < 4; r++) Pw[(mt * 16 + 4 * (lane >> 4) + r) * PART + dst] = acc[r];
                         }
                     }
                 }
             }
-            // ---- phase M: matrix-core reduction over the wave's 64 pixels -----------
-            if constexpr (FEAT) {
-                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int s = 0; s < 32; s++) {
-                    const float av = Ww[(lane & 31) * WPAD + 2 * s + (lane >> 5)];   // A[i = splat][k = pixel]
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bf[s], acc, 0, 0, 0);
-                }
-                // D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
-                constexpr int FO = GEOM ? GEOM_ROW : 0;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    Pw[row * PART + FO + (lane & 31)] = acc[r];
-                }
-            }
-            if constexpr (GEOM) {
-#pragma unroll
-                for (int mt = 0; mt < 2; mt++) {
-                    f32x4 acc = {0, 0, 0, 0};
-#pragma unroll
-                    for (int s = 0; s < 16; s++) {
-                        const float av = Ww[(mt * 16 + (lane & 15)) * WPAD + 4 * s + (lane >> 4)];
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bl[s], acc, 0, 0, 0);
-                    }
-                    // D[row = 4*(lane>>4) + r][col = lane&15]; cols 0..2 -> dL_dcolor, 3..5 -> dL_dnormal
-                    const int col = lane & 15;
-                    if (col < 6) {
-                        const int dst = col < 3 ? 15 + col : 11 + (col - 3);
-#pragma unroll
-                        for (int r = 0; r < 4; r++) Pw[(mt * 16 + 4 * (lane >> 4) + r) * PART + dst] = acc[r];
-                    }
+            __syncthreads();
+            // ---- combine the waves that touched an instance (fixed order) and emit its row + flag -------
+            const unsigned h0 = s_hit[buf * 4 + 0], h1 = s_hit[buf * 4 + 1], h2 = s_hit[buf * 4 + 2], h3 = s_hit[buf * 4 + 3];
+            const unsigned hany = h0 | h1 | h2 | h3;
+            if (hany != 0u) {
+                constexpr int Q4 = PART / 4;
+                const float* P0 = s_part + (buf * 4 + 0) * BB * PART;
+                const float* P1 = s_part + (buf * 4 + 1) * BB * PART;
+                const float* P2 = s_part + (buf * 4 + 2) * BB * PART;
+                const float* P3 = s_part + (buf * 4 + 3) * BB * PART;
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int e = threadIdx.x; e < nb * Q4; e += 256) {
+                    const int inst = e / Q4, q = e - inst * Q4;
+                    const unsigned bit = 1u << inst;
+                    if (!(hany & bit)) continue;
+                    // a wave that culled the whole sub-batch never zeroed its block: treat it as zero
+                    const float4 v0 = (h0 != 0u) ? reinterpret_cast<const float4*>(P0 + inst * PART)[q] : z4;
+                    const float4 v1 = (h1 != 0u) ? reinterpret_cast<const float4*>(P1 + inst * PART)[q] : z4;
+                    const float4 v2 = (h2 != 0u) ? reinterpret_cast<const float4*>(P2 + inst * PART)[q] : z4;
+                    const float4 v3 = (h3 != 0u) ? reinterpret_cast<const float4*>(P3 + inst * PART)[q] : z4;
+                    const float4 v = make_float4((v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y),
+                                                 (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w));
+                    int dst;
+                    if (GEOM && q < GEOM_ROW / 4) dst = geom_off + 4 * q;
+                    else dst = feat_off + 4 * (q - (GEOM ? GEOM_ROW / 4 : 0));
+                    const unsigned slot = s_slot[sub_lo + inst];
+                    *reinterpret_cast<float4*>(partial + (size_t)slot * row_stride + dst) = v;
+                    if (q == 0) row_flags[slot] = 1;
                 }
             }
-        }
-        __syncthreads();
-        // ---- combine the four waves in a fixed order and emit one row per instance ---
-        constexpr int Q4 = PART / 4;
-        for (int e = threadIdx.x; e < nb * Q4; e += 256) {
-            const int inst = e / Q4, q = e - inst * Q4;
-            const float4 v0 = reinterpret_cast<const float4*>(s_part + (0 * BB + inst) * PART)[q];
-            const float4 v1 = reinterpret_cast<const float4*>(s_part + (1 * BB + inst) * PART)[q];
-            const float4 v2 = reinterpret_cast<const float4*>(s_part + (2 * BB + inst) * PART)[q];
-            const float4 v3 = reinterpret_cast<const float4*>(s_part + (3 * BB + inst) * PART)[q];
-            const float4 v = make_float4((v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y),
-                                         (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w));
-            // q indexes [geom 5 float4][feat 8 float4]; map to the global row
-            int dst;
-            if (GEOM && q < GEOM_ROW / 4) dst = geom_off + 4 * q;
-            else dst = feat_off + 4 * (q - (GEOM ? GEOM_ROW / 4 : 0));
-            *reinterpret_cast<float4*>(partial + (size_t)s_slot[inst] * row_stride + dst) = v;
         }
     }
 }
@@ -435,15 +466,19 @@ __global__ __launch_bounds__(256) void k_render_bwd(
 // Row reduction: out[g, c] = sum over the Gaussian's tiles of partial[slot, src_off + c].
 __global__ __launch_bounds__(256) void k_reduce_rows(int P, int ncol, const uint32_t* __restrict__ point_offsets,
                                                      const uint32_t* __restrict__ tiles_touched,
-                                                     const float* __restrict__ partial, int row_stride, int src_off,
-                                                     float* __restrict__ out, int out_stride) {
+                                                     const float* __restrict__ partial, const uint8_t* __restrict__ row_flags,
+                                                     int64_t R, int row_stride, int src_off, float* __restrict__ out,
+                                                     int out_stride) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)P * ncol) return;
     const int g = (int)(e / ncol), c = (int)(e - (size_t)g * ncol);
     const uint32_t n = tiles_touched[g];
-    const float* src = partial + (size_t)point_offsets[g] * row_stride + src_off + c;
+    const size_t base = point_offsets[g];
+    const float* src = partial + base * row_stride + src_off + c;
+    const uint8_t* fl = row_flags + (size_t)(c >> 5) * R + base;     // pass (c / 32) wrote feature chunk (c / 32)
     float s = 0.0f;
-    for (uint32_t r = 0; r < n; r++) s += src[(size_t)r * row_stride];
+    for (uint32_t r = 0; r < n; r++)
+        if (fl[r]) s += src[(size_t)r * row_stride];
     out[(size_t)g * out_stride + c] = s;
 }
 
@@ -470,7 +505,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ tm_pre,
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos, int Wd, int Hd,
-    GeomView g, const float* __restrict__ partial, int row_stride, int geom_off, float* __restrict__ dL_dmean2D,
+    GeomView g, const float* __restrict__ partial, const uint8_t* __restrict__ row_flags, int row_stride, int geom_off,
+    float* __restrict__ dL_dmean2D,
     float* __restrict__ dL_dnormal, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
     float* __restrict__ dL_dmean3D, float* __restrict__ dL_dtransMat, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
@@ -489,7 +525,9 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     const uint32_t nt = g.tiles_touched[i];
     if (nt > 0) {
         const float* src = partial + (size_t)g.point_offsets[i] * row_stride + geom_off;
+        const uint8_t* fl = row_flags + g.point_offsets[i];
         for (uint32_t r = 0; r < nt; r++) {
+            if (!fl[r]) continue;
             const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)r * row_stride);
             const float4 a = s4[0], b = s4[1], c = s4[2], d = s4[3], e = s4[4];
             gs[0] += a.x; gs[1] += a.y; gs[2] += a.z; gs[3] += a.w; gs[4] += b.x; gs[5] += b.y; gs[6] += b.z; gs[7] += b.w;
@@ -683,8 +721,13 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
     const int stride = row_floats(ED, (geomg ? 2u : 0u) | (featg ? 1u : 0u));
     const int geom_off = 0, feat_base = geomg ? GEOM_ROW : 0;
     float* partial = (float*)scratch;
+    const unsigned eff_mask = (geomg ? 2u : 0u) | (featg ? 1u : 0u);
+    uint8_t* flags = (uint8_t*)scratch + rows_bytes(R, ED, eff_mask);
+    const int npass = n_passes(ED, eff_mask);
     if (P == 0) return 0;
     if (R > 0) {
+        if (hipMemsetAsync(flags, 0, (size_t)R * npass, s) != hipSuccess) return -2;
+        int pass = 0;
         bool first = true;
         int ch = 0;
         do {
@@ -693,7 +736,7 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
 #define ISR_GOB(GM, FT, Q)                                                                                           \
     hipLaunchKernelGGL((k_render_bwd<Math, GM, FT, Q>), dim3(T), dim3(256), 0, s, W, H, ED, ch, gx, iv.tile_offset,   \
                        bv.point_list, g.rec, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib, dC, dO, dE,      \
-                       g.point_offsets, g.rect, partial, stride, geom_off, feat_base + ch, R)
+                       g.point_offsets, g.rect, partial, flags + (size_t)pass * R, stride, geom_off, feat_base + ch, R)
             // the geometry pass needs <feature_g, dL/dfeature(pix)> over ALL channels (dL/dalpha), whatever
             // chunk of dL/dextra it emits itself
             if (do_geom && ED > 32) { if (do_feat) ISR_GOB(true, true, 64); else ISR_GOB(true, false, 64); }
@@ -704,13 +747,14 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
             ISR_CHECK_LAUNCH_B("k_render_bwd");
             first = false;
             ch += 32;
+            pass++;
         } while (featg && ch < ED);
     }
     if (featg) {
         const size_t total = (size_t)P * ED;
         ProfScope ps_("k_reduce_rows", s);
         hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P, ED, g.point_offsets,
-                           g.tiles_touched, partial, stride, feat_base, dL_dextra, ED);
+                           g.tiles_touched, partial, flags, R, stride, feat_base, dL_dextra, ED);
         ISR_CHECK_LAUNCH_B("k_reduce_rows");
     }
     if (geomg) {
@@ -718,7 +762,7 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
         const int Wd = (int)(focal_x * tan_fovx * 2), Hd = (int)(focal_y * tan_fovy * 2);   // backward.cu:633-634
         ProfScope ps_("k_preprocess_bwd", s);
         hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, shs, scales, rots,
-                           tm_pre, view, proj, campos, Wd, Hd, g, partial, stride, geom_off, dL_dmean2D, dL_dnormal,
+                           tm_pre, view, proj, campos, Wd, Hd, g, partial, flags, stride, geom_off, dL_dmean2D, dL_dnormal,
                            dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot);
         ISR_CHECK_LAUNCH_B("k_preprocess_bwd");
     }

@@ -51,18 +51,32 @@ class SegGaussianModel:
         self.active_sh_degree = 3
         self.max_sh_degree = 3
         self.class_feat = class_feat
+        self._features_cat = None
+        self._seg_cache = None
 
     get_xyz = property(lambda s: s._xyz)
     get_scaling = property(lambda s: torch.exp(s._scaling))
     get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation))
     get_opacity = property(lambda s: torch.sigmoid(s._opacity))
-    get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
+    @property
+    def get_features(self):
+        # reference: torch.cat((dc, rest), dim=1) on every call (scene/gaussian_model.py:128-131).  Both parts are
+        # frozen in this stage, so the concatenation is loop-invariant and done once.
+        if self._features_dc.requires_grad or self._features_rest.requires_grad:
+            return torch.cat((self._features_dc, self._features_rest), dim=1)
+        if self._features_cat is None:
+            self._features_cat = torch.cat((self._features_dc, self._features_rest), dim=1)
+        return self._features_cat
 
     @property
     def get_seg_feature(self):
         if self._seg_feature is None:
             return None
-        return row_normalize(self._seg_feature, 1e-6)
+        # called twice per step (render() and the 3-D loss): reuse the node while the parameter is unchanged
+        key = (self._seg_feature._version, torch.is_grad_enabled())
+        if self._seg_cache is None or self._seg_cache[0] != key:
+            self._seg_cache = (key, row_normalize(self._seg_feature, 1e-6))
+        return self._seg_cache[1]
 
 
 def gram_schmidt(vectors: torch.Tensor) -> torch.Tensor:
@@ -95,7 +109,7 @@ class SegTrainer:
         self.lsv, self.lmv, self.l3d = lambda_sv, lambda_mv, lambda_3d
         self.mv_frames, self.multiview = sample_mv_frames, multiview
         self.opt = torch.optim.Adam([{"params": [self.model._seg_feature], "lr": 0.025, "name": "seg_feature"}], lr=0.0,
-                                    eps=1e-15)
+                                    eps=1e-15, fused=self.device.type == "cuda")
         self.gen = torch.Generator(device=self.device).manual_seed(1000 + seed * 131 + rank)
         # label maps are static per view: index the labelled pixels once (the reference re-derives the
         # boolean mask every iteration, train_semantic.py:118-125)
@@ -158,4 +172,5 @@ class SegTrainer:
         allreduce_grads([m._seg_feature], self.world)
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
+        m._seg_cache = None          # the graph of this step is gone
         return loss.detach()
