@@ -50,7 +50,7 @@ static int launch_render_fwd(int tiles, hipStream_t s, int W, int H, int ED, int
 #define ISR_GO(F, B)                                                                                                 \
     hipLaunchKernelGGL((k_render_fwd<Math, F, B>), dim3(tiles), dim3(256), 0, s, W, H, ED, ch, first, gx,             \
                        iv.tile_offset, bv.point_list, rec, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,    \
-                       out_color, out_others, out_extra, tracer, tcap, tcount, capacity)
+                       out_color, out_others, out_extra, tracer, tcap, tcount, bv.box4, capacity)
         if (rem <= 0) ISR_GO(0, 256);
         else if (rem <= 8) ISR_GO(8, 256);
         else if (rem <= 16) ISR_GO(16, 256);

@@ -67,25 +67,25 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <class Math, bool GEOM, bool FEAT, int QF>
 __global__ __launch_bounds__(256) void k_render_bwd(
     int W, int H, int ED, int ch_base, int gx, const uint32_t* __restrict__ tile_offset,
-    const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ col_pre,
-    const float* __restrict__ tm_pre, const float* __restrict__ extras, const float* __restrict__ bg,
-    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dC,
-    const float* __restrict__ dO, const float* __restrict__ dE, const uint32_t* __restrict__ point_offsets,
+    const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ box4, const float* __restrict__ rec,
+    const float* __restrict__ col_pre, const float* __restrict__ tm_pre, const float* __restrict__ extras,
+    const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ dC, const float* __restrict__ dO, const float* __restrict__ dE,
+    const uint32_t* __restrict__ point_offsets,
     const Rect16* __restrict__ rects, float* __restrict__ partial, uint8_t* __restrict__ row_flags, int row_stride,
     int geom_off, int feat_off, int64_t capacity) {
     constexpr int RS = 16;
-    constexpr int SB = GEOM ? 64 : 128;     // instances staged per barrier round
-    constexpr int NPB = GEOM ? 1 : 2;       // partial-sum buffers (2: combine of sub-batch k overlaps phase A of k+1)
+    constexpr int SB = 128;                 // (id, cull box) pairs staged per barrier round: two 64-bit hit masks per wave
     constexpr int PART = (GEOM ? GEOM_ROW : 0) + (FEAT ? 32 : 0);   // floats per instance per wave in LDS
-    __shared__ __attribute__((aligned(16))) float s_rec[SB * RS];
-    __shared__ __attribute__((aligned(16))) float s_rgb[SB * 4];
-    __shared__ __attribute__((aligned(16))) float s_feat[QF > 0 ? SB * QF : 4];
+    __shared__ __attribute__((aligned(16))) float s_rec[BB * RS];      // records of the current sub-batch (hit instances only)
+    __shared__ __attribute__((aligned(16))) float s_rgb[BB * 4];
+    __shared__ __attribute__((aligned(16))) float s_feat[QF > 0 ? BB * QF : 4];
+    __shared__ unsigned s_slot[BB];
     __shared__ int s_id[SB];
-    __shared__ unsigned s_slot[SB];
-    __shared__ __attribute__((aligned(16))) float4 s_box[SB];
+    __shared__ unsigned s_box4[SB];
     __shared__ float s_W[4 * BB * WPAD];
-    __shared__ __attribute__((aligned(16))) float s_part[NPB * 4 * BB * PART];
-    __shared__ unsigned s_hit[NPB * 4];
+    __shared__ __attribute__((aligned(16))) float s_part[4 * BB * PART];
+    __shared__ unsigned s_hit[4 * (SB / 32)];      // [wave][sub-batch] 32-bit hit masks of the round
 
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
@@ -200,72 +200,84 @@ __global__ __launch_bounds__(256) void k_render_bwd(
     float last_dL_dT = 0, last_alpha = 0, accum_q = 0, last_q = 0;
     const float bg_dot = GEOM ? (bg[0] * dpx0 + bg[1] * dpx1) + bg[2] * dpx2 : 0.0f;
 
-    // GEOM walks back to front (reference order); features-only walks front to back.  SB instances are staged
-    // per barrier round and consumed in sub-batches of BB = 32 (the MFMA M dimension).
+    // GEOM walks back to front (reference order); features-only walks front to back.
+    // Per round, SB (id, packed cull box) pairs are read coalesced; every wave tests them against the rectangle of
+    // its live pixels; only instances hit by some wave are gathered (record, features, row slot) and evaluated, in
+    // sub-batches of BB = 32 (the MFMA M dimension).
+    const int tile_x0 = tx * TILE, tile_y0 = ty * TILE;
+    const int rx0 = (int)ax0 - tile_x0, rx1 = (int)ax1 - tile_x0, ry0 = (int)ay0 - tile_y0, ry1 = (int)ay1 - tile_y0;
     const int nround = (len + SB - 1) / SB;
-    int subc = 0;
+    float* Pw = s_part + wv * BB * PART;
     for (int ri = 0; ri < nround; ri++) {
         int round_lo, nsb;
         if (GEOM) { const int hi = len - ri * SB; round_lo = max(0, hi - SB); nsb = hi - round_lo; }
         else { round_lo = ri * SB; nsb = min(SB, len - round_lo); }
-        __syncthreads();   // the previous round's staged data (s_slot in the last combine) is no longer needed
+        __syncthreads();   // previous round fully consumed
         if (threadIdx.x < nsb) {
-            const int t = threadIdx.x;
-            const int id = (int)point_list[r0 + round_lo + t];
-            s_id[t] = id;
-            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
-            float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3], e = r4[4];
-            if (tm_pre != nullptr) {
-                const float* tp = tm_pre + 9 * (size_t)id;
-                a = make_float4(tp[0], tp[1], tp[2], tp[3]);
-                b = make_float4(tp[4], tp[5], tp[6], tp[7]);
-                c.x = tp[8];
-            }
-            if (col_pre != nullptr) {
-                d.w = col_pre[3 * (size_t)id]; e.x = col_pre[3 * (size_t)id + 1]; e.y = col_pre[3 * (size_t)id + 2];
-            }
-            const float opa = d.z;
-            float skip = __builtin_inff();
-            if (opa <= 1.0f) {
-                const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
-                skip = 2.0f * l * 1.01f + 0.05f;
-            }
-            float4* s4 = reinterpret_cast<float4*>(s_rec + t * RS);
-            s4[0] = a; s4[1] = b; s4[2] = c; s4[3] = make_float4(d.x, d.y, opa, skip);
-            s_box[t] = splat_cull_box(F3{a.x, a.y, a.z}, F3{a.w, b.x, b.y}, F3{b.z, b.w, c.x}, c.y, c.z, skip);
-            reinterpret_cast<float4*>(s_rgb)[t] = make_float4(d.w, e.x, e.y, 0.0f);
-            const Rect16 rc = rects[id];
-            s_slot[t] = point_offsets[id] + (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
+            s_id[threadIdx.x] = (int)point_list[r0 + round_lo + threadIdx.x];
+            s_box4[threadIdx.x] = box4[r0 + round_lo + threadIdx.x];
         }
         __syncthreads();
-        if constexpr (QF > 0) {
-            for (int e = threadIdx.x; e < nsb * QF; e += 256) {
-                const int inst = e / QF, c = e - inst * QF;
-                s_feat[e] = (c < ED) ? extras[(size_t)s_id[inst] * ED + c] : 0.0f;
+#pragma unroll
+        for (int h = 0; h < SB / 64; h++) {
+            const int t = h * 64 + lane;
+            bool hit = false;
+            if (wave_live && t < nsb && (unsigned)(round_lo + t) < wave_last) {
+                const unsigned bx = s_box4[t];
+                const int xl = (int)(signed char)(bx & 255u), xh = (int)(signed char)((bx >> 8) & 255u);
+                const int yl = (int)(signed char)((bx >> 16) & 255u), yh = (int)(signed char)(bx >> 24);
+                // saturated coordinates (+-127/128) mean "beyond": treat as unbounded
+                hit = (xl <= rx1 || xl == -128) && (xh >= rx0 || xh == 127) && (yl <= ry1 || yl == -128) && (yh >= ry0 || yh == 127);
+            }
+            const unsigned long long mm = __ballot(hit);
+            if (lane == 0) { s_hit[wv * (SB / 32) + 2 * h] = (unsigned)mm; s_hit[wv * (SB / 32) + 2 * h + 1] = (unsigned)(mm >> 32); }
+        }
+        __syncthreads();
+        const int nsub = (nsb + BB - 1) / BB;
+        for (int si = 0; si < nsub; si++) {
+            // sub-batch = staged indices [sub_lo, sub_lo + nb); aligned to 32 so that it is one s_hit word
+            int word;
+            if (GEOM) word = (nsb - 1) / BB - si; else word = si;
+            const int sub_lo = word * BB, nb = min(BB, nsb - sub_lo);
+            const int lo = round_lo + sub_lo;
+            const unsigned h0 = s_hit[0 * (SB / 32) + word], h1 = s_hit[1 * (SB / 32) + word];
+            const unsigned h2 = s_hit[2 * (SB / 32) + word], h3 = s_hit[3 * (SB / 32) + word];
+            const unsigned hany = h0 | h1 | h2 | h3;
+            if (hany == 0u) continue;                       // uniform over the workgroup
+            if (threadIdx.x < nb && ((hany >> threadIdx.x) & 1u)) {
+                const int t = threadIdx.x;
+                const int id = s_id[sub_lo + t];
+                const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
+                float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3], e = r4[4];
+                if (tm_pre != nullptr) {
+                    const float* tp = tm_pre + 9 * (size_t)id;
+                    a = make_float4(tp[0], tp[1], tp[2], tp[3]);
+                    b = make_float4(tp[4], tp[5], tp[6], tp[7]);
+                    c.x = tp[8];
+                }
+                if (col_pre != nullptr) {
+                    d.w = col_pre[3 * (size_t)id]; e.x = col_pre[3 * (size_t)id + 1]; e.y = col_pre[3 * (size_t)id + 2];
+                }
+                const float opa = d.z;
+                float skip = __builtin_inff();
+                if (opa <= 1.0f) {
+                    const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
+                    skip = 2.0f * l * 1.01f + 0.05f;
+                }
+                float4* s4 = reinterpret_cast<float4*>(s_rec + t * RS);
+                s4[0] = a; s4[1] = b; s4[2] = c; s4[3] = make_float4(d.x, d.y, opa, skip);
+                reinterpret_cast<float4*>(s_rgb)[t] = make_float4(d.w, e.x, e.y, 0.0f);
+                const Rect16 rc = rects[id];
+                s_slot[t] = point_offsets[id] + (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
+            }
+            if constexpr (QF > 0) {
+                for (int e = threadIdx.x; e < nb * QF; e += 256) {
+                    const int inst = e / QF, c = e - inst * QF;
+                    if ((hany >> inst) & 1u) s_feat[e] = (c < ED) ? extras[(size_t)s_id[sub_lo + inst] * ED + c] : 0.0f;
+                }
             }
             __syncthreads();
-        }
-        const int nsub = (nsb + BB - 1) / BB;
-        for (int si = 0; si < nsub; si++, subc++) {
-            int sub_lo, nb;
-            if (GEOM) { const int hi = nsb - si * BB; sub_lo = max(0, hi - BB); nb = hi - sub_lo; }
-            else { sub_lo = si * BB; nb = min(BB, nsb - sub_lo); }
-            const int lo = round_lo + sub_lo;                 // list position of the sub-batch's first instance
-            const int buf = NPB == 2 ? (subc & 1) : 0;
-            float* Pw = s_part + (buf * 4 + wv) * BB * PART;
-            if (NPB == 1) __syncthreads();                    // the previous combine has drained s_part
-            // splats of this sub-batch that can matter to this wave: index below the wave's deepest last
-            // contributor and cull box meeting the rectangle of the wave's live pixels
-            unsigned long long m = 0ull;
-            if (wave_live) {
-                bool hit = false;
-                if (lane < nb && (unsigned)(lo + lane) < wave_last) {
-                    const float4 bb = s_box[sub_lo + lane];
-                    hit = !(bb.x > ax1) && !(bb.y < ax0) && !(bb.z > ay1) && !(bb.w < ay0);
-                }
-                m = __ballot(hit);
-            }
-            if (lane == 0) s_hit[buf * 4 + wv] = (unsigned)m;
+            unsigned long long m = (wv == 0 ? h0 : (wv == 1 ? h1 : (wv == 2 ? h2 : h3)));
             if (m != 0ull) {
                 for (int e = lane; e < BB * PART; e += 64) Pw[e] = 0.0f;
                 for (int e = lane; e < BB * WPAD; e += 64) Ww[e] = 0.0f;     // culled splats have zero weight
@@ -274,16 +286,15 @@ __global__ __launch_bounds__(256) void k_render_bwd(
                     int j;
                     if (GEOM) { j = 63 - __builtin_clzll(m); m &= ~(1ull << j); }     // back to front
                     else { j = __builtin_ctzll(m); m &= m - 1ull; }                     // front to back
-                    const int sj = sub_lo + j;
                     const unsigned contributor = (unsigned)(lo + j);     // 0-based index == reference's decremented counter
                     float w = 0.0f;
                     bool act = lane_live && contributor < last_contributor;
                     float G = 0, alpha = 0, sx = 0, sy = 0, c_d = 0, rho3d = 0, rho2d = 0, dx = 0, dy = 0;
                     F3 kk = {0, 0, 0}, ll = {0, 0, 0}, p = {0, 0, 1};
-                    const float4 a = reinterpret_cast<const float4*>(s_rec + sj * RS)[0];
-                    const float4 b = reinterpret_cast<const float4*>(s_rec + sj * RS)[1];
-                    const float4 c = reinterpret_cast<const float4*>(s_rec + sj * RS)[2];
-                    const float4 d = reinterpret_cast<const float4*>(s_rec + sj * RS)[3];
+                    const float4 a = reinterpret_cast<const float4*>(s_rec + j * RS)[0];
+                    const float4 b = reinterpret_cast<const float4*>(s_rec + j * RS)[1];
+                    const float4 c = reinterpret_cast<const float4*>(s_rec + j * RS)[2];
+                    const float4 d = reinterpret_cast<const float4*>(s_rec + j * RS)[3];
                     const F3 Tw = {b.z, b.w, c.x};
                     if (act) {
                         const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y};
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(
     #pragma unroll
                         for (int q = 0; q < 12; q++) g[q] = 0.0f;
                         if (act) {
-                            const float4 col = reinterpret_cast<const float4*>(s_rgb)[sj];
+                            const float4 col = reinterpret_cast<const float4*>(s_rgb)[j];
                             float dL_dalpha = 0.0f;
                             acc_r0 = last_alpha * lc0 + (1.f - last_alpha) * acc_r0; lc0 = col.x; dL_dalpha += (col.x - acc_r0) * dpx0;
                             acc_r1 = last_alpha * lc1 + (1.f - last_alpha) * acc_r1; lc1 = col.y; dL_dalpha += (col.y - acc_r1) * dpx1;
@@ -344,12 +355,12 @@ __global__ __launch_bounds__(256) void k_render_bwd(
                             an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = ny; dL_dalpha += (ny - an1) * dn1;
                             an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = nz; dL_dalpha += (nz - an2) * dn2;
                             if constexpr (QF > 0) {
-                                const float* fj = s_feat + sj * QF;
+                                const float* fj = s_feat + j * QF;
                                 float q = 0.0f;
     #pragma unroll
                                 for (int ch = 0; ch < QF; ch++) q = __builtin_fmaf(fj[ch], dEp[ch], q);
                                 if (ED > QF && dE != nullptr) {     // rare: more feature channels than the register budget
-                                    const float* fg = extras + (size_t)s_id[sj] * ED;
+                                    const float* fg = extras + (size_t)s_id[sub_lo + j] * ED;
                                     for (int ch = QF; ch < ED; ch++) q = __builtin_fmaf(fg[ch], dE[(size_t)ch * N + pix], q);
                                 }
                                 accum_q = last_alpha * last_q + (1.f - last_alpha) * accum_q;
@@ -430,19 +441,16 @@ __global__ __launch_bounds__(256) void k_render_bwd(
             }
             __syncthreads();
             // ---- combine the waves that touched an instance (fixed order) and emit its row + flag -------
-            const unsigned h0 = s_hit[buf * 4 + 0], h1 = s_hit[buf * 4 + 1], h2 = s_hit[buf * 4 + 2], h3 = s_hit[buf * 4 + 3];
-            const unsigned hany = h0 | h1 | h2 | h3;
-            if (hany != 0u) {
+            {
                 constexpr int Q4 = PART / 4;
-                const float* P0 = s_part + (buf * 4 + 0) * BB * PART;
-                const float* P1 = s_part + (buf * 4 + 1) * BB * PART;
-                const float* P2 = s_part + (buf * 4 + 2) * BB * PART;
-                const float* P3 = s_part + (buf * 4 + 3) * BB * PART;
+                const float* P0 = s_part + 0 * BB * PART;
+                const float* P1 = s_part + 1 * BB * PART;
+                const float* P2 = s_part + 2 * BB * PART;
+                const float* P3 = s_part + 3 * BB * PART;
                 const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int e = threadIdx.x; e < nb * Q4; e += 256) {
                     const int inst = e / Q4, q = e - inst * Q4;
-                    const unsigned bit = 1u << inst;
-                    if (!(hany & bit)) continue;
+                    if (!((hany >> inst) & 1u)) continue;
                     // a wave that culled the whole sub-batch never zeroed its block: treat it as zero
                     const float4 v0 = (h0 != 0u) ? reinterpret_cast<const float4*>(P0 + inst * PART)[q] : z4;
                     const float4 v1 = (h1 != 0u) ? reinterpret_cast<const float4*>(P1 + inst * PART)[q] : z4;
@@ -453,11 +461,12 @@ __global__ __launch_bounds__(256) void k_render_bwd(
                     int dst;
                     if (GEOM && q < GEOM_ROW / 4) dst = geom_off + 4 * q;
                     else dst = feat_off + 4 * (q - (GEOM ? GEOM_ROW / 4 : 0));
-                    const unsigned slot = s_slot[sub_lo + inst];
+                    const unsigned slot = s_slot[inst];
                     *reinterpret_cast<float4*>(partial + (size_t)slot * row_stride + dst) = v;
                     if (q == 0) row_flags[slot] = 1;
                 }
             }
+            __syncthreads();     // s_rec / s_slot / s_part are reused by the next hit sub-batch
         }
     }
 }
@@ -469,17 +478,29 @@ __global__ __launch_bounds__(256) void k_reduce_rows(int P, int ncol, const uint
                                                      const float* __restrict__ partial, const uint8_t* __restrict__ row_flags,
                                                      int64_t R, int row_stride, int src_off, float* __restrict__ out,
                                                      int out_stride) {
+    // one thread per (Gaussian, group of 4 channels); the row bytes of a Gaussian are contiguous
+    const int q4 = (ncol + 3) >> 2;
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (size_t)P * ncol) return;
-    const int g = (int)(e / ncol), c = (int)(e - (size_t)g * ncol);
+    if (e >= (size_t)P * q4) return;
+    const int g = (int)(e / q4), q = (int)(e - (size_t)g * q4);
+    const int c = 4 * q;
     const uint32_t n = tiles_touched[g];
     const size_t base = point_offsets[g];
-    const float* src = partial + base * row_stride + src_off + c;
     const uint8_t* fl = row_flags + (size_t)(c >> 5) * R + base;     // pass (c / 32) wrote feature chunk (c / 32)
-    float s = 0.0f;
-    for (uint32_t r = 0; r < n; r++)
-        if (fl[r]) s += src[(size_t)r * row_stride];
-    out[(size_t)g * out_stride + c] = s;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t r = 0; r < n; r++) {
+        if (!fl[r]) continue;
+        const float4 v = *reinterpret_cast<const float4*>(partial + (base + r) * row_stride + src_off + c);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float* o = out + (size_t)g * out_stride + c;
+    if (c + 3 < ncol && (out_stride & 3) == 0) *reinterpret_cast<float4*>(o) = s;
+    else {
+        o[0] = s.x;
+        if (c + 1 < ncol) o[1] = s.y;
+        if (c + 2 < ncol) o[2] = s.z;
+        if (c + 3 < ncol) o[3] = s.w;
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -735,7 +756,7 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
             const bool do_geom = geomg && first, do_feat = featg;
 #define ISR_GOB(GM, FT, Q)                                                                                           \
     hipLaunchKernelGGL((k_render_bwd<Math, GM, FT, Q>), dim3(T), dim3(256), 0, s, W, H, ED, ch, gx, iv.tile_offset,   \
-                       bv.point_list, g.rec, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib, dC, dO, dE,      \
+                       bv.point_list, bv.box4, g.rec, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib, dC, dO, dE,      \
                        g.point_offsets, g.rect, partial, flags + (size_t)pass * R, stride, geom_off, feat_base + ch, R)
             // the geometry pass needs <feature_g, dL/dfeature(pix)> over ALL channels (dL/dalpha), whatever
             // chunk of dL/dextra it emits itself
@@ -751,7 +772,7 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
         } while (featg && ch < ED);
     }
     if (featg) {
-        const size_t total = (size_t)P * ED;
+        const size_t total = (size_t)P * ((ED + 3) / 4);
         ProfScope ps_("k_reduce_rows", s);
         hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P, ED, g.point_offsets,
                            g.tiles_touched, partial, flags, R, stride, feat_base, dL_dextra, ED);

@@ -46,6 +46,7 @@ struct ImageView {
 struct BinView {
     unsigned long long* keys;  // [R] (depth_bits << 32) | gaussian, bucketed by tile
     uint32_t* point_list;      // [R] sorted gaussian ids
+    uint32_t* box4;            // [R] per-instance cull box, tile-relative int8 (x_lo, x_hi, y_lo, y_hi), written by K8
 };
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -98,11 +99,12 @@ inline BinView bin_view(void* buf, int64_t R) {
     BinView b;
     b.keys = carve<unsigned long long>(p, (size_t)(R > 0 ? R : 1));
     b.point_list = carve<uint32_t>(p, (size_t)(R > 0 ? R : 1));
+    b.box4 = carve<uint32_t>(p, (size_t)(R > 0 ? R : 1));
     return b;
 }
 inline size_t bin_bytes(int64_t R) {
     BinView b = bin_view((void*)0, R);
-    return (size_t)(b.point_list + (size_t)(R > 0 ? R : 1)) + 256;
+    return (size_t)(b.box4 + (size_t)(R > 0 ? R : 1)) + 256;
 }
 
 // ---------------------------------------------------------------------------
@@ -183,6 +185,16 @@ __device__ __forceinline__ float4 splat_cull_box(F3 Tu, F3 Tv, F3 Tw, float cx, 
         }
     }
     return box;
+}
+
+// Tile-relative int8 packing of a cull box (rounded outward, saturated): the backward tests it without
+// touching the splat record.
+__device__ __forceinline__ uint32_t pack_box4(float4 box, float tile_x0, float tile_y0) {
+    const int xl = (int)fmaxf(-128.0f, fminf(127.0f, __builtin_floorf(box.x - tile_x0)));
+    const int xh = (int)fmaxf(-128.0f, fminf(127.0f, __builtin_ceilf(box.y - tile_x0)));
+    const int yl = (int)fmaxf(-128.0f, fminf(127.0f, __builtin_floorf(box.z - tile_y0)));
+    const int yh = (int)fmaxf(-128.0f, fminf(127.0f, __builtin_ceilf(box.w - tile_y0)));
+    return (uint32_t)(xl & 255) | ((uint32_t)(xh & 255) << 8) | ((uint32_t)(yl & 255) << 16) | ((uint32_t)(yh & 255) << 24);
 }
 
 // Arithmetic policies for the per-pixel loops.

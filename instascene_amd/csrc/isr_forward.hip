@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(
     const float* __restrict__ tm_pre, const float* __restrict__ extras, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_others, float* __restrict__ out_extra, int32_t* __restrict__ tracer, long long tracer_cap,
-    int32_t* __restrict__ tracer_count, int64_t capacity) {
+    int32_t* __restrict__ tracer_count, uint32_t* __restrict__ box4, int64_t capacity) {
     constexpr int RS = 16;   // staged floats per instance: Tu Tv Tw cx cy nx ny nz opa skip = 16
     __shared__ __attribute__((aligned(16))) float s_rec[BATCH * RS];
     __shared__ __attribute__((aligned(16))) float s_rgb[BATCH * 4];
@@ -390,7 +390,9 @@ __global__ __launch_bounds__(256) void k_render_fwd(
             s4[1] = b;                                      // Tv.yz Tw.xy
             s4[2] = make_float4(c.x, c.y, c.z, c.w);        // Tw.z cx cy nx
             s4[3] = make_float4(d.x, d.y, opa, skip);       // ny nz opa skip
-            s_box[t] = splat_cull_box(F3{a.x, a.y, a.z}, F3{a.w, b.x, b.y}, F3{b.z, b.w, c.x}, c.y, c.z, skip);
+            const float4 cb = splat_cull_box(F3{a.x, a.y, a.z}, F3{a.w, b.x, b.y}, F3{b.z, b.w, c.x}, c.y, c.z, skip);
+            s_box[t] = cb;
+            if (first_pass) box4[base + t] = pack_box4(cb, (float)(tx * TILE), (float)(ty * TILE));
             reinterpret_cast<float4*>(s_rgb)[t] = make_float4(d.w, e.x, e.y, 0.0f);
         }
         __syncthreads();
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(
     template __global__ void k_render_fwd<M, F, B>(int, int, int, int, int, int, const uint32_t*, const uint32_t*,     \
                                                    const float*, const float*, const float*, const float*,            \
                                                    const float*, float*, uint32_t*, float*, float*, float*, int32_t*, \
-                                                   long long, int32_t*, int64_t);
+                                                   long long, int32_t*, uint32_t*, int64_t);
 ISR_INST_FWD(ExactMath, 0, 256)
 ISR_INST_FWD(ExactMath, 8, 256)
 ISR_INST_FWD(ExactMath, 16, 256)
