@@ -192,6 +192,28 @@ __global__ __launch_bounds__(256) void k_render_bwd(
         ay0 = fminf(ay0, __shfl_xor(ay0, o)); ay1 = fmaxf(ay1, __shfl_xor(ay1, o));
         wave_last = max(wave_last, (unsigned)__shfl_xor((int)wave_last, o));
     }
+    // Sparse-wave mode (feature-only kernels): with at most 4 live pixels the splats are culled against the
+    // individual pixels and dL/dfeat[g][ch] = sum_k w(pix_k, g) * dL/dE(pix_k, ch) is four FMAs per channel
+    // lane — no weight transpose, no MFMA.
+    const unsigned long long live_mask = __ballot(lane_live);
+    const bool sparse = !GEOM && FEAT && __popcll(live_mask) <= 4;
+    int lk[4] = {-1, -1, -1, -1}, lrx[4] = {0, 0, 0, 0}, lry[4] = {0, 0, 0, 0};
+    float dEk[4] = {0.f, 0.f, 0.f, 0.f};
+    if (sparse) {
+        unsigned long long mm = live_mask;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (mm != 0ull) {
+                lk[k] = __builtin_ctzll(mm);
+                mm &= mm - 1ull;
+                const int qx = tx * TILE + (wv & 1) * 8 + (lk[k] & 7), qy = ty * TILE + (wv >> 1) * 8 + (lk[k] >> 3);
+                lrx[k] = qx - tx * TILE;
+                lry[k] = qy - ty * TILE;
+                const int ch = ch_base + (lane & 31);
+                dEk[k] = (dE != nullptr && ch < ED) ? dE[(size_t)ch * N + (size_t)W * qy + qx] : 0.0f;
+            }
+        }
+    }
     const float final_A = 1 - T_final;
     const float mscale = FAR_N / (FAR_N - NEAR_N);
     float T = GEOM ? T_final : 1.0f;
@@ -227,7 +249,13 @@ __global__ __launch_bounds__(256) void k_render_bwd(
                 const int xl = (int)(signed char)(bx & 255u), xh = (int)(signed char)((bx >> 8) & 255u);
                 const int yl = (int)(signed char)((bx >> 16) & 255u), yh = (int)(signed char)(bx >> 24);
                 // saturated coordinates (+-127/128) mean "beyond": treat as unbounded
-                hit = (xl <= rx1 || xl == -128) && (xh >= rx0 || xh == 127) && (yl <= ry1 || yl == -128) && (yh >= ry0 || yh == 127);
+                if (sparse) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        hit = hit || (lk[k] >= 0 && xl <= lrx[k] && xh >= lrx[k] && yl <= lry[k] && yh >= lry[k]);
+                } else {
+                    hit = xl <= rx1 && xh >= rx0 && yl <= ry1 && yh >= ry0;
+                }
             }
             const unsigned long long mm = __ballot(hit);
             if (lane == 0) { s_hit[wv * (SB / 32) + 2 * h] = (unsigned)mm; s_hit[wv * (SB / 32) + 2 * h + 1] = (unsigned)(mm >> 32); }
@@ -280,7 +308,8 @@ __global__ __launch_bounds__(256) void k_render_bwd(
             unsigned long long m = (wv == 0 ? h0 : (wv == 1 ? h1 : (wv == 2 ? h2 : h3)));
             if (m != 0ull) {
                 for (int e = lane; e < BB * PART; e += 64) Pw[e] = 0.0f;
-                for (int e = lane; e < BB * WPAD; e += 64) Ww[e] = 0.0f;     // culled splats have zero weight
+                if (!sparse)
+                    for (int e = lane; e < BB * WPAD; e += 64) Ww[e] = 0.0f;     // culled splats have zero weight
                 // ---- phase A: every live lane evaluates its pixel against the surviving splats ----------
                 while (m != 0ull) {
                     int j;
@@ -325,7 +354,17 @@ __global__ __launch_bounds__(256) void k_render_bwd(
                         if (GEOM) { T = T / (1.f - alpha); w = alpha * T; }
                         else { w = alpha * T; T = T * (1 - alpha); }
                     }
-                    Ww[j * WPAD + lane] = w;
+                    if (sparse) {
+                        if constexpr (FEAT && !GEOM) {
+                            float v = 0.0f;
+#pragma unroll
+                            for (int k = 0; k < 4; k++)
+                                if (lk[k] >= 0) v = __builtin_fmaf(__shfl(w, lk[k]), dEk[k], v);
+                            if (lane < 32) Pw[j * PART + lane] = v;
+                        }
+                    } else {
+                        Ww[j * WPAD + lane] = w;
+                    }
                     if constexpr (GEOM) {
                         float g[12];
     #pragma unroll
@@ -405,7 +444,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(
                     }
                 }
                 // ---- phase M: matrix-core reduction over the wave's 64 pixels -----------
-                if constexpr (FEAT) {
+                if constexpr (FEAT) if (!sparse) {
                     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     #pragma unroll
                     for (int s = 0; s < 32; s++) {

@@ -333,6 +333,11 @@ __global__ __launch_bounds__(256) void k_render_fwd(
     __shared__ __attribute__((aligned(16))) float s_feat[(FCH > 0 ? BATCH * FCH : 4)];
     __shared__ int s_id[BATCH];
     __shared__ __attribute__((aligned(16))) float4 s_box[BATCH];
+    // tracer (gaussian, pixel) pairs are collected per tile in LDS and flushed with ONE global atomic per flush
+    // (the reference does one global atomic on a single counter per hit, forward.cu:425)
+    constexpr int TCAP = 512;
+    __shared__ int s_trace[2 * TCAP];
+    __shared__ int s_tcount, s_tbase;
 
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
@@ -349,6 +354,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(
     if (r1 > capacity) r1 = capacity;
     const int nfeat = FCH > 0 ? min(FCH, ED - ch_base) : 0;
 
+    if (threadIdx.x == 0) s_tcount = 0;     // ordered before first use by the barrier at the top of the batch loop
     bool done = !inside;
     float T = 1.0f;
     unsigned contributor = 0, last_contributor = 0, median_contributor = 0;
@@ -360,8 +366,24 @@ __global__ __launch_bounds__(256) void k_render_fwd(
     const float bx0 = (float)(tx * TILE + (wv & 1) * 8), bx1 = bx0 + 7.0f;
     const float by0 = (float)(ty * TILE + (wv >> 1) * 8), by1 = by0 + 7.0f;
 
+    auto flush_trace = [&]() {      // called by all threads between two barriers
+        const int n = min(s_tcount, TCAP);
+        __syncthreads();
+        if (n > 0) {
+            if (threadIdx.x == 0) { s_tbase = atomicAdd(tracer_count, n); s_tcount = 0; }
+            __syncthreads();
+            const int gb = s_tbase;
+            for (int e = threadIdx.x; e < n; e += 256)
+                if (gb + e < tracer_cap) {
+                    tracer[2 * (size_t)(gb + e)] = s_trace[2 * e];
+                    tracer[2 * (size_t)(gb + e) + 1] = s_trace[2 * e + 1];
+                }
+            __syncthreads();
+        }
+    };
     for (int64_t base = r0; base < r1; base += BATCH) {
         if (__syncthreads_and(done)) break;
+        if (tracer != nullptr && first_pass && s_tcount > TCAP / 2) flush_trace();
         const int nb = (int)min((int64_t)BATCH, r1 - base);
         // ---- cooperative staging: one instance per thread (records), then features by float4 column
         for (int t = threadIdx.x; t < nb; t += 256) {
@@ -425,66 +447,79 @@ __global__ __launch_bounds__(256) void k_render_fwd(
                 if (__ballot(!done) == 0ull) break;
                 const int j = c0 + __builtin_ctzll(m);
                 m &= m - 1ull;
-                if (done) continue;
-                contributor = (unsigned)(base - r0) + (unsigned)j + 1u;
-            const float4 a = reinterpret_cast<const float4*>(s_rec + j * RS)[0];
-            const float4 b = reinterpret_cast<const float4*>(s_rec + j * RS)[1];
-            const float4 c = reinterpret_cast<const float4*>(s_rec + j * RS)[2];
-            const float4 d = reinterpret_cast<const float4*>(s_rec + j * RS)[3];
-            const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y}, Tw = {b.z, b.w, c.x};
-            const F3 kk = {Math::msub(pxf, Tw.x, Tu.x), Math::msub(pxf, Tw.y, Tu.y), Math::msub(pxf, Tw.z, Tu.z)};
-            const F3 ll = {Math::msub(pyf, Tw.x, Tv.x), Math::msub(pyf, Tw.y, Tv.y), Math::msub(pyf, Tw.z, Tv.z)};
-            const F3 p = {Math::msub(kk.y, ll.z, kk.z * ll.y), Math::msub(kk.z, ll.x, kk.x * ll.z),
-                          Math::msub(kk.x, ll.y, kk.y * ll.x)};
-            const float dx = c.y - pxf, dy = c.z - pyf;
-            const float rho2d = FILTER_INV_SQ * Math::mad(dy, dy, dx * dx);
-            // exact-preserving early out: both candidate rho's certainly beyond the alpha<1/255 cut
-            const float skip = d.w;
-            if (rho2d > skip && Math::mad(p.y, p.y, p.x * p.x) > skip * (p.z * p.z) * 1.01f) continue;
-            if (p.z == 0.0f) continue;
-            const float sx = Math::div(p.x, p.z), sy = Math::div(p.y, p.z);
-            const float rho3d = Math::mad(sy, sy, sx * sx);
-            const float rho = fminf(rho3d, rho2d);
-            const float depth = (rho3d <= rho2d) ? Math::mad(sy, Tw.y, sx * Tw.x) + Tw.z : Tw.z;
-            if (depth < NEAR_N) continue;
-            const float opa = d.z;
-            const float power = -0.5f * rho;
-            if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, opa * Math::ex(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            const float test_T = T * (1 - alpha);
-            if (test_T < 0.0001f) { done = true; continue; }
-            const float w = alpha * T;
-            if (first_pass) {
-                const float A = 1 - T;
-                const float m = mscale * (1 - NEAR_N / depth);
-                distortion += (Math::mad(m * m, A, M2) - 2 * m * M1) * w;
-                D = Math::mad(depth, w, D);
-                M1 = Math::mad(m, w, M1);
-                M2 = Math::mad(m * m, w, M2);
-                if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }
-                N0 = Math::mad(c.w, w, N0); N1 = Math::mad(d.x, w, N1); N2 = Math::mad(d.y, w, N2);
-                const float4 col = reinterpret_cast<const float4*>(s_rgb)[j];
-                C0 = Math::mad(col.x, w, C0); C1 = Math::mad(col.y, w, C1); C2 = Math::mad(col.z, w, C2);
-                if (tracer != nullptr && w >= 0.1f) {   // (double)w > 0.1  <=>  w >= 0.1f
-                    const int slot = atomicAdd(tracer_count, 1);
-                    if (slot < tracer_cap) { tracer[2 * (size_t)slot] = s_id[j]; tracer[2 * (size_t)slot + 1] = (int)pix; }
-                }
-            }
-            if (FCH > 0) {
-                const float* fj = s_feat + j * FCH;
-                if (Math::fast) {
+                // Flat, predicated evaluation (few exec-mask regions: the scalar unit is a co-bottleneck of this loop).
+                // A lane for which `cand`/`ok` is false computes garbage that is never used — identical results to the
+                // reference's chain of `continue`s.
+                const float4 a = reinterpret_cast<const float4*>(s_rec + j * RS)[0];
+                const float4 b = reinterpret_cast<const float4*>(s_rec + j * RS)[1];
+                const float4 c = reinterpret_cast<const float4*>(s_rec + j * RS)[2];
+                const float4 d = reinterpret_cast<const float4*>(s_rec + j * RS)[3];
+                const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y}, Tw = {b.z, b.w, c.x};
+                const F3 kk = {Math::msub(pxf, Tw.x, Tu.x), Math::msub(pxf, Tw.y, Tu.y), Math::msub(pxf, Tw.z, Tu.z)};
+                const F3 ll = {Math::msub(pyf, Tw.x, Tv.x), Math::msub(pyf, Tw.y, Tv.y), Math::msub(pyf, Tw.z, Tv.z)};
+                const F3 p = {Math::msub(kk.y, ll.z, kk.z * ll.y), Math::msub(kk.z, ll.x, kk.x * ll.z),
+                              Math::msub(kk.x, ll.y, kk.y * ll.x)};
+                const float dx = c.y - pxf, dy = c.z - pyf;
+                const float rho2d = FILTER_INV_SQ * Math::mad(dy, dy, dx * dx);
+                // exact-preserving early out: both candidate rho's certainly beyond the alpha<1/255 cut
+                const float skip = d.w;
+                const bool far = (rho2d > skip) & (Math::mad(p.y, p.y, p.x * p.x) > skip * (p.z * p.z) * 1.01f);
+                const bool cand = !done & !far & (p.z != 0.0f);
+                if (__ballot(cand) == 0ull) continue;
+                const float sx = Math::div(p.x, p.z), sy = Math::div(p.y, p.z);
+                const float rho3d = Math::mad(sy, sy, sx * sx);
+                const float rho = fminf(rho3d, rho2d);
+                const float depth = (rho3d <= rho2d) ? Math::mad(sy, Tw.y, sx * Tw.x) + Tw.z : Tw.z;
+                const float power = -0.5f * rho;
+                const float alpha = fminf(0.99f, d.z * Math::ex(power));
+                const float test_T = T * (1 - alpha);
+                const bool pass = cand & !(depth < NEAR_N) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
+                const bool stop = pass & (test_T < 0.0001f);
+                done = done | stop;
+                const bool ok = pass & !stop;
+                if (__ballot(ok) == 0ull) continue;
+                if (ok) {
+                    const float w = alpha * T;
+                    contributor = (unsigned)(base - r0) + (unsigned)j + 1u;
+                    if (first_pass) {
+                        const float A = 1 - T;
+                        const float m_ = mscale * (1 - NEAR_N / depth);
+                        distortion += (Math::mad(m_ * m_, A, M2) - 2 * m_ * M1) * w;
+                        D = Math::mad(depth, w, D);
+                        M1 = Math::mad(m_, w, M1);
+                        M2 = Math::mad(m_ * m_, w, M2);
+                        if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }
+                        N0 = Math::mad(c.w, w, N0); N1 = Math::mad(d.x, w, N1); N2 = Math::mad(d.y, w, N2);
+                        const float4 col = reinterpret_cast<const float4*>(s_rgb)[j];
+                        C0 = Math::mad(col.x, w, C0); C1 = Math::mad(col.y, w, C1); C2 = Math::mad(col.z, w, C2);
+                        if (tracer != nullptr && w >= 0.1f) {   // (double)w > 0.1  <=>  w >= 0.1f
+                            const int ls = atomicAdd(&s_tcount, 1);
+                            if (ls < TCAP) { s_trace[2 * ls] = s_id[j]; s_trace[2 * ls + 1] = (int)pix; }
+                            else {      // LDS staging full (rare): append directly
+                                const int slot = atomicAdd(tracer_count, 1);
+                                if (slot < tracer_cap) { tracer[2 * (size_t)slot] = s_id[j]; tracer[2 * (size_t)slot + 1] = (int)pix; }
+                            }
+                        }
+                    }
+                    if (FCH > 0) {
+                        const float* fj = s_feat + j * FCH;
+                        if (Math::fast) {
 #pragma unroll
-                    for (int q = 0; q < FCH; q++) E[q] = __builtin_fmaf(fj[q], w, E[q]);
-                } else {
+                            for (int q = 0; q < FCH; q++) E[q] = __builtin_fmaf(fj[q], w, E[q]);
+                        } else {
 #pragma unroll
-                    for (int q = 0; q < FCH; q++) E[q] += fj[q] * alpha * T;   // reference forward.cu:415 order
+                            for (int q = 0; q < FCH; q++) E[q] += fj[q] * alpha * T;   // reference forward.cu:415 order
+                        }
+                    }
+                    T = test_T;
+                    last_contributor = contributor;
                 }
-            }
-            T = test_T;
-            last_contributor = contributor;
             }
         }
+    }
+    if (tracer != nullptr && first_pass) {
+        __syncthreads();
+        flush_trace();
     }
     if (inside) {
         if (first_pass) {
