@@ -87,9 +87,11 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--mode", default=os.environ.get("ISR_MODE", "exact"))
+    ap.add_argument("--mode", default=os.environ.get("ISR_MODE", "fast"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tracer", type=int, default=1, help="produce gau_related_pixels each forward like the reference")
+    ap.add_argument("--async-binning", type=int, default=1,
+                    help="size the binning workspace from the previous view instead of a blocking read of R")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,6 +112,7 @@ def main():
 
     rasterizer.set_mode(args.mode)
     rasterizer.set_tracer(bool(args.tracer))
+    rasterizer.set_async_binning(bool(args.async_binning))
     scene, cams, cfg = scenes.config_scene(args.config)
     trainer = SegTrainer(scene, cams[:16], device=dev, sample_batchsize=8192, use_class_feat=True, rank=rank, world=world)
     L = lib()
@@ -177,7 +180,8 @@ def main():
                "config": {"workload": f"{args.config}: {cfg['P']} Gaussians, {cfg['W']}x{cfg['H']}, F={cfg['F']}, "
                                       f"sample batch 8192, 2 single-view + 1 3-D contrastive loss, Adam on [P,F]",
                           "parallelism": f"dp{world} (one view per rank, RCCL all-reduce of the [P,F] gradient)",
-                          "arithmetic_mode": args.mode, "tracer": bool(args.tracer)},
+                          "arithmetic_mode": args.mode, "tracer": bool(args.tracer),
+                          "async_binning": bool(args.async_binning)},
                "roofline": roof}
         if not args.no_cpu_baseline:
             try:

@@ -141,9 +141,19 @@ class SegTrainer:
         cam = self.cams[vi]
         pkg = render(cam, m, self.pipe, self.bg)
         seg_feature, vis = pkg["seg_feature"], pkg["visibility_filter"]
-        loss = self._sample_view_loss(vi, seg_feature, cam.segmap, None, 0.5)
-        if m.class_feat is not None:
-            loss = loss + self._sample_view_loss(vi, seg_feature, cam.sorted_segmap, m.class_feat, 1.0)
+        if m.class_feat is not None and self.valid_idx[vi].numel() > 0:
+            # both single-view sample sets in ONE gather (one dense dL/dfeature-map in the backward instead of two)
+            pool = self.valid_idx[vi]
+            pick = torch.randint(0, pool.numel(), (2 * self.batch,), device=self.device, generator=self.gen)
+            pix = pool[pick]
+            feats = seg_feature.reshape(seg_feature.shape[0], -1)[:, pix].T
+            la = cam.segmap.reshape(-1)[pix[:self.batch]]
+            lb = cam.sorted_segmap.reshape(-1)[pix[self.batch:]]
+            loss = contrastive_loss(feats[:self.batch], la, num_labels=self.n_labels + 1) * self.lsv * 0.5
+            loss = loss + contrastive_loss(feats[self.batch:], lb, predef_u_list=m.class_feat,
+                                           num_labels=self.n_labels + 1) * self.lsv * 1.0
+        else:
+            loss = self._sample_view_loss(vi, seg_feature, cam.segmap, None, 0.5)
         if self.multiview and self.lmv > 0 and it % 10 == 0:
             first = (vi + 1) % max(1, len(self.cams) - self.mv_frames)
             feats, labs = [], []

@@ -25,7 +25,13 @@ _CONFIG = {
     "mode": MODE_FAST if os.environ.get("ISR_MODE", "exact").lower() == "fast" else MODE_EXACT,
     # produce the (gaussian, pixel) tracer list like the reference does on every forward
     "tracer": os.environ.get("ISR_TRACER", "1") != "0",
+    # size the binning workspace from the previous view's instance count (+25 %) instead of a blocking
+    # device->host read of R in the middle of every forward (the reference always blocks, rasterizer_impl.cu:287).
+    # The true R is read back asynchronously and verified before the backward / the next forward.
+    "async_binning": os.environ.get("ISR_ASYNC_BINNING", "0") == "1",
 }
+_R_ESTIMATE = {}      # (device, P, W, H) -> last verified instance count
+_PENDING = {}         # (device, P, W, H) -> (pinned int64 tensor, event, capacity)
 
 
 LAST_NUM_RENDERED = 0   # instance count of the most recent forward (reporting only)
@@ -41,6 +47,30 @@ def get_mode() -> str:
 
 def set_tracer(enabled: bool):
     _CONFIG["tracer"] = bool(enabled)
+
+
+def set_async_binning(enabled: bool):
+    _CONFIG["async_binning"] = bool(enabled)
+
+
+class BinningOverflow(RuntimeError):
+    pass
+
+
+def _verify_pending(key):
+    """Check an asynchronously read instance count against the capacity that forward ran with."""
+    pend = _PENDING.pop(key, None)
+    if pend is None:
+        return
+    pinned, event, capacity = pend
+    event.synchronize()
+    R = int(pinned.item())
+    _R_ESTIMATE[key] = R
+    if R > capacity:
+        _CONFIG["async_binning"] = False
+        raise BinningOverflow(
+            f"rasterizer: {R} tile instances exceeded the async binning capacity {capacity}; the previous forward of "
+            "this view is invalid. async_binning has been switched off (exact, blocking sizing); re-run the step.")
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -113,14 +143,29 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
                 torch.empty((0, 2), dtype=torch.int32, device=dev), torch.full((1,), -1, dtype=torch.int32, device=dev))
     with torch.cuda.device(dev):
         st = _stream()
+        key = (dev.index, P, W, H)
+        use_async = _CONFIG["async_binning"]
+        if use_async:
+            _verify_pending(key)
+            use_async = key in _R_ESTIMATE and _CONFIG["async_binning"]
         check(L.isr_forward_prepare(P, int(degree), M, W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
                                     _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(transMat_precomp),
                                     _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
                                     int(bool(prefiltered)), _ptr(radii), _ptr(geom), _ptr(img),
-                                    ctypes.byref(num_rendered), st), "isr_forward_prepare")
-        R = int(num_rendered.value)
+                                    None if use_async else ctypes.byref(num_rendered), st), "isr_forward_prepare")
         global LAST_NUM_RENDERED
-        LAST_NUM_RENDERED = R
+        if use_async:
+            R = int(_R_ESTIMATE[key] * 1.25) + 65536            # capacity, not the count
+            pinned = torch.empty(1, dtype=torch.int64).pin_memory()
+            pinned.copy_(geom[:8].view(torch.int64), non_blocking=True)   # header[0] = R
+            ev = torch.cuda.Event()
+            ev.record()
+            _PENDING[key] = (pinned, ev, R)
+            LAST_NUM_RENDERED = _R_ESTIMATE[key]
+        else:
+            R = int(num_rendered.value)
+            _R_ESTIMATE[key] = R
+            LAST_NUM_RENDERED = R
         binning = torch.empty(L.isr_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
         if tracer:
             grp = torch.empty((H * W * 10, 2), dtype=torch.int32, device=dev)
@@ -182,6 +227,8 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, 
     ge = new(P, F) if (grad_mask & GRAD_EXTRA) else None
     if P == 0 or grad_mask == 0:
         return g2, gc, go, g3, gt, gsh, gs, gr, (ge if F else torch.empty(0, device=dev))
+    if _CONFIG["async_binning"]:
+        _verify_pending((dev.index, P, W, H))
     nbytes = L.isr_backward_scratch_bytes(int(R), F, grad_mask)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
@@ -226,6 +273,17 @@ def debug_state(P, W, H, R, geom, binning, img):
     return out
 
 
+def _attach_count(buf, last_index):
+    buf._isr_last_index = last_index
+    return buf
+
+
+def slice_tracer(buf):
+    """Valid rows of a tracer buffer returned with lazy slicing."""
+    idx = getattr(buf, "_isr_last_index", None)
+    return buf if idx is None else buf[:(idx + 1)]
+
+
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
     image_width: int
@@ -252,8 +310,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             extra_attrs, attr_degree, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
             rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
-        if gau_related_pixels.shape[0]:
+        if gau_related_pixels.shape[0] and not _CONFIG.get("lazy_tracer", False):
             gau_related_pixels = gau_related_pixels[:(gau_pixel_indices + 1)]   # same slicing as the reference (:106)
+        elif gau_related_pixels.shape[0]:
+            # render() wraps the pair in a lazily sliced dict entry: slicing needs the count on the host (a sync)
+            gau_related_pixels = _attach_count(gau_related_pixels, gau_pixel_indices)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.mode = _CONFIG["mode"]

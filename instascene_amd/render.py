@@ -10,23 +10,54 @@ import math
 import torch
 
 from .contrastive import row_normalize
+from . import rasterizer as _rz
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
-def depths_to_points(view, depthmap):
-    """utils/point_utils.py:10-27"""
-    dev = depthmap.device
+class RenderPackage(dict):
+    """The dict ``render()`` returns.  ``gau_related_pixels`` is sliced to its valid length on first access (the
+    slice needs the count on the host, i.e. a device sync — the reference pays it inside every forward, :106)."""
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if k == "gau_related_pixels" and getattr(v, "_isr_last_index", None) is not None:
+            v = _rz.slice_tracer(v)
+            dict.__setitem__(self, k, v)
+        return v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+
+_RAY_CACHE = {}
+
+
+def _camera_rays(view, device):
+    """Per-pixel ray directions and origin of utils/point_utils.py:10-27 (static per camera: cached)."""
+    key = (id(view), str(device))
+    hit = _RAY_CACHE.get(key)
+    if hit is not None and hit[0] is view.world_view_transform:
+        return hit[1], hit[2]
     c2w = (view.world_view_transform.T).inverse()
     W, H = view.image_width, view.image_height
     ndc2pix = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], dtype=torch.float32,
-                           device=dev).T
+                           device=device).T
     projection_matrix = c2w.T @ view.full_proj_transform
     intrins = (projection_matrix @ ndc2pix)[:3, :3].T
-    grid_x, grid_y = torch.meshgrid(torch.arange(W, device=dev).float(), torch.arange(H, device=dev).float(),
+    grid_x, grid_y = torch.meshgrid(torch.arange(W, device=device).float(), torch.arange(H, device=device).float(),
                                     indexing="xy")
     points = torch.stack([grid_x, grid_y, torch.ones_like(grid_x)], dim=-1).reshape(-1, 3)
     rays_d = points @ intrins.inverse().T @ c2w[:3, :3].T
     rays_o = c2w[:3, 3]
+    if len(_RAY_CACHE) > 256:
+        _RAY_CACHE.clear()
+    _RAY_CACHE[key] = (view.world_view_transform, rays_d, rays_o)
+    return rays_d, rays_o
+
+
+def depths_to_points(view, depthmap):
+    """utils/point_utils.py:10-27"""
+    rays_d, rays_o = _camera_rays(view, depthmap.device)
     return depthmap.reshape(-1, 1) * rays_d + rays_o
 
 
@@ -44,7 +75,11 @@ def post_process(viewpoint_camera, allmap, depth_ratio):
     """gaussian_renderer/__init__.py:127-167"""
     render_alpha = allmap[1:2]
     render_normal = allmap[2:5]
-    render_normal = (render_normal.permute(1, 2, 0) @ (viewpoint_camera.world_view_transform[:3, :3].T)).permute(2, 0, 1)
+    # (n.permute(1,2,0) @ R^T).permute(2,0,1) of the reference (:132), written as three broadcast FMAs — a [N,3]x[3,3]
+    # product is a poor fit for a GEMM kernel
+    Rm = viewpoint_camera.world_view_transform[:3, :3]
+    render_normal = (render_normal[0:1] * Rm[:, 0].view(3, 1, 1) + render_normal[1:2] * Rm[:, 1].view(3, 1, 1)
+                     + render_normal[2:3] * Rm[:, 2].view(3, 1, 1))
     render_depth_median = torch.nan_to_num(allmap[5:6], 0, 0)
     render_depth_expected = torch.nan_to_num(allmap[0:1] / render_alpha, 0, 0)
     render_dist = allmap[6:7]
@@ -80,6 +115,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
         sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+    _rz._CONFIG["lazy_tracer"] = True       # render() defers the tracer slice (and its host sync) to first access
 
     means3D = xyz
     means2D = screenspace_points
@@ -110,8 +146,9 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     rendered_image, radii, allmap, extra_attrs, gau_related_pixels = rasterizer(
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity, scales=scales,
         rotations=rotations, cov3D_precomp=cov3D_precomp, extra_attrs=seg_feature)
+    _rz._CONFIG["lazy_tracer"] = False
 
-    rets = {"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii,
-            "seg_feature": extra_attrs, "gau_related_pixels": gau_related_pixels}
+    rets = RenderPackage({"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0,
+                          "radii": radii, "seg_feature": extra_attrs, "gau_related_pixels": gau_related_pixels})
     rets.update(post_process(viewpoint_camera, allmap, pipe.depth_ratio))
     return rets

@@ -166,3 +166,43 @@ def test_contrastive_with_label_bound_and_dropped_samples():
     assert abs(float(got.detach()) - float(want.detach())) <= 1e-4 * abs(float(want.detach()))
     assert_close(b.grad.cpu().numpy(), a.grad.numpy(), 1e-3, "grad")
     assert float(b.grad[labels.cuda() == 0].abs().sum()) == 0.0
+
+
+def test_async_binning_and_lazy_tracer_slice():
+    """Binning workspace sized from the previous view (no blocking read of R) gives identical results; the overflow
+    check fires when the estimate is too small; the tracer list is sliced only when accessed."""
+    import copy
+    from helpers import oracle_forward
+    sc, cams, inp = small_scene(P=900, F=8, W=64, H=48, seed=77)
+    pc = _PC(inp)
+    rz.set_mode("exact")
+    rz.set_tracer(True)
+    rz._R_ESTIMATE.clear(); rz._PENDING.clear()
+    try:
+        rz.set_async_binning(True)
+        outs = []
+        for k in range(3):                       # first call sizes exactly (no estimate yet), later calls run async
+            camg = copy.deepcopy(cams[k % 2]).to("cuda")
+            outs.append(render(camg, pc, _Pipe(), torch.zeros(3, device="cuda")))
+        feat = __import__("instascene_amd.contrastive", fromlist=["row_normalize"]).row_normalize(inp["extra"].cuda(), 1e-9).cpu()
+        st0 = oracle_forward(dict(inp, extra=feat), cams[0], tracer=True)
+        np.testing.assert_array_equal(outs[2]["render"].cpu().numpy(), st0["color"])
+        np.testing.assert_array_equal(outs[2]["seg_feature"].cpu().numpy(), st0["extra"])
+        grp = outs[2]["gau_related_pixels"]       # lazily sliced here
+        assert grp.shape[0] == len(st0["tracer"])
+        assert {(int(a), int(b)) for a, b in grp.cpu().numpy()} == {(int(a), int(b)) for a, b in st0["tracer"]}
+        # force an overflow: pretend the last view had almost no instances
+        key = next(iter(rz._R_ESTIMATE))
+        rz._verify_pending(key)
+        rz._R_ESTIMATE[key] = 1
+        big = {k: (v.clone() if v is not None else None) for k, v in inp.items()}
+        big["scales"] = big["scales"] * 30.0        # far more tile instances than 1*1.25 + 65536
+        pc2 = _PC(big)
+        camg = copy.deepcopy(cams[0]).to("cuda")
+        render(camg, pc2, _Pipe(), torch.zeros(3, device="cuda"))
+        with pytest.raises(rz.BinningOverflow):
+            rz._verify_pending(key)
+        assert rz._CONFIG["async_binning"] is False
+    finally:
+        rz.set_async_binning(False)
+        rz._R_ESTIMATE.clear(); rz._PENDING.clear()
