@@ -30,6 +30,7 @@ _CONFIG = {
     # The true R is read back asynchronously and verified before the backward / the next forward.
     "async_binning": os.environ.get("ISR_ASYNC_BINNING", "0") == "1",
 }
+_ASYNC_GROWTH, _ASYNC_SLACK = 1.25, 65536
 _R_ESTIMATE = {}      # (device, P, W, H) -> last verified instance count
 _PENDING = {}         # (device, P, W, H) -> (pinned int64 tensor, event, capacity)
 
@@ -155,7 +156,7 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
                                     None if use_async else ctypes.byref(num_rendered), st), "isr_forward_prepare")
         global LAST_NUM_RENDERED
         if use_async:
-            R = int(_R_ESTIMATE[key] * 1.25) + 65536            # capacity, not the count
+            R = int(_R_ESTIMATE[key] * _ASYNC_GROWTH) + _ASYNC_SLACK            # capacity, not the count
             pinned = torch.empty(1, dtype=torch.int64).pin_memory()
             pinned.copy_(geom[:8].view(torch.int64), non_blocking=True)   # header[0] = R
             ev = torch.cuda.Event()

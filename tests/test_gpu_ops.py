@@ -195,6 +195,7 @@ def test_async_binning_and_lazy_tracer_slice():
         key = next(iter(rz._R_ESTIMATE))
         rz._verify_pending(key)
         rz._R_ESTIMATE[key] = 1
+        slack, rz._ASYNC_SLACK = rz._ASYNC_SLACK, 0
         big = {k: (v.clone() if v is not None else None) for k, v in inp.items()}
         big["scales"] = big["scales"] * 30.0        # far more tile instances than 1*1.25 + 65536
         pc2 = _PC(big)
@@ -205,4 +206,5 @@ def test_async_binning_and_lazy_tracer_slice():
         assert rz._CONFIG["async_binning"] is False
     finally:
         rz.set_async_binning(False)
+        rz._ASYNC_SLACK = 65536
         rz._R_ESTIMATE.clear(); rz._PENDING.clear()
