@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
 // pixel block (w&1, w>>1) of the tile so that a splat's footprint diverges as
 // little as possible inside a 64-lane wavefront.
 template <class Math, int FCH, int BATCH>
-__global__ __launch_bounds__(256) void k_render_fwd(
+__global__ __launch_bounds__(256, 4) void k_render_fwd(
     int W, int H, int ED, int ch_base, int first_pass, int gx, const uint32_t* __restrict__ tile_offset,
     const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ col_pre,
     const float* __restrict__ tm_pre, const float* __restrict__ extras, const float* __restrict__ bg,
@@ -381,13 +381,20 @@ __global__ __launch_bounds__(256) void k_render_fwd(
             __syncthreads();
         }
     };
+    // Staging: the ids of the NEXT batch are prefetched into a register while the current batch is blended, so a
+    // round is: records (gather, ids already known) | barrier | features (gather by float4 column) | barrier | blend.
+    // (Merging the feature gather into the record phase costs 27 more VGPRs -> 3 instead of 4 waves/SIMD: slower.)
+    constexpr int QF4 = FCH > 0 ? FCH / 4 : 1;          // float4s per feature row
+    const int my_inst = threadIdx.x & (BATCH - 1);
+    int nid = (threadIdx.x < BATCH && r0 + my_inst < r1) ? (int)point_list[r0 + my_inst] : 0;
     for (int64_t base = r0; base < r1; base += BATCH) {
         if (__syncthreads_and(done)) break;
         if (tracer != nullptr && first_pass && s_tcount > TCAP / 2) flush_trace();
         const int nb = (int)min((int64_t)BATCH, r1 - base);
-        // ---- cooperative staging: one instance per thread (records), then features by float4 column
-        for (int t = threadIdx.x; t < nb; t += 256) {
-            const int id = (int)point_list[base + t];
+        const int id = nid;
+        if (threadIdx.x < BATCH && base + BATCH + my_inst < r1) nid = (int)point_list[base + BATCH + my_inst];
+        if (threadIdx.x < nb) {
+            const int t = threadIdx.x;
             s_id[t] = id;
             const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
             float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3], e = r4[4];
@@ -420,9 +427,8 @@ __global__ __launch_bounds__(256) void k_render_fwd(
         __syncthreads();
         if (FCH > 0) {
             if ((ED & 3) == 0 && nfeat == FCH) {
-                constexpr int Q = FCH / 4;
-                for (int e = threadIdx.x; e < nb * Q; e += 256) {
-                    const int inst = e / Q, part = e - inst * Q;
+                for (int e = threadIdx.x; e < nb * QF4; e += 256) {
+                    const int inst = e / QF4, part = e - inst * QF4;
                     reinterpret_cast<float4*>(s_feat)[e] =
                         *reinterpret_cast<const float4*>(extras + (size_t)s_id[inst] * ED + ch_base + part * 4);
                 }
@@ -502,13 +508,21 @@ __global__ __launch_bounds__(256) void k_render_fwd(
                         }
                     }
                     if (FCH > 0) {
-                        const float* fj = s_feat + j * FCH;
-                        if (Math::fast) {
+                        const float4* fj = reinterpret_cast<const float4*>(s_feat + j * FCH);
 #pragma unroll
-                            for (int q = 0; q < FCH; q++) E[q] = __builtin_fmaf(fj[q], w, E[q]);
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < FCH; q++) E[q] += fj[q] * alpha * T;   // reference forward.cu:415 order
+                        for (int q4 = 0; q4 < QF4; q4++) {
+                            const float4 v = fj[q4];
+                            if (Math::fast) {
+                                E[4 * q4 + 0] = __builtin_fmaf(v.x, w, E[4 * q4 + 0]);
+                                E[4 * q4 + 1] = __builtin_fmaf(v.y, w, E[4 * q4 + 1]);
+                                E[4 * q4 + 2] = __builtin_fmaf(v.z, w, E[4 * q4 + 2]);
+                                E[4 * q4 + 3] = __builtin_fmaf(v.w, w, E[4 * q4 + 3]);
+                            } else {       // reference forward.cu:415 order: (e * alpha) * T
+                                E[4 * q4 + 0] += v.x * alpha * T;
+                                E[4 * q4 + 1] += v.y * alpha * T;
+                                E[4 * q4 + 2] += v.z * alpha * T;
+                                E[4 * q4 + 3] += v.w * alpha * T;
+                            }
                         }
                     }
                     T = test_T;
