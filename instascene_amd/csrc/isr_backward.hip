@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(
     __shared__ float s_W[4 * BB * WPAD];
     __shared__ __attribute__((aligned(16))) float s_part[4 * BB * PART];
     __shared__ unsigned s_hit[4 * (SB / 32)];      // [wave][sub-batch] 32-bit hit masks of the round
+    __shared__ unsigned s_last[4];
 
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
@@ -192,6 +193,14 @@ __global__ __launch_bounds__(256) void k_render_bwd(
         ay0 = fminf(ay0, __shfl_xor(ay0, o)); ay1 = fmaxf(ay1, __shfl_xor(ay1, o));
         wave_last = max(wave_last, (unsigned)__shfl_xor((int)wave_last, o));
     }
+    // Nothing behind the deepest last contributor of the tile's live pixels can matter: walk only that prefix of
+    // the list (a saturated pixel stops after a few dozen of the several hundred splats of its tile), and leave
+    // immediately when the tile has no live pixel at all.
+    if (lane == 0) s_last[wv] = wave_last;
+    __syncthreads();
+    const unsigned tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+    if (tile_last == 0u) return;
+    const int len_eff = min(len, (int)tile_last);
     // Sparse-wave mode (feature-only kernels): with at most 4 live pixels the splats are culled against the
     // individual pixels and dL/dfeat[g][ch] = sum_k w(pix_k, g) * dL/dE(pix_k, ch) is four FMAs per channel
     // lane — no weight transpose, no MFMA.
@@ -228,12 +237,12 @@ __global__ __launch_bounds__(256) void k_render_bwd(
     // sub-batches of BB = 32 (the MFMA M dimension).
     const int tile_x0 = tx * TILE, tile_y0 = ty * TILE;
     const int rx0 = (int)ax0 - tile_x0, rx1 = (int)ax1 - tile_x0, ry0 = (int)ay0 - tile_y0, ry1 = (int)ay1 - tile_y0;
-    const int nround = (len + SB - 1) / SB;
+    const int nround = (len_eff + SB - 1) / SB;
     float* Pw = s_part + wv * BB * PART;
     for (int ri = 0; ri < nround; ri++) {
         int round_lo, nsb;
-        if (GEOM) { const int hi = len - ri * SB; round_lo = max(0, hi - SB); nsb = hi - round_lo; }
-        else { round_lo = ri * SB; nsb = min(SB, len - round_lo); }
+        if (GEOM) { const int hi = len_eff - ri * SB; round_lo = max(0, hi - SB); nsb = hi - round_lo; }
+        else { round_lo = ri * SB; nsb = min(SB, len_eff - round_lo); }
         __syncthreads();   // previous round fully consumed
         if (threadIdx.x < nsb) {
             s_id[threadIdx.x] = (int)point_list[r0 + round_lo + threadIdx.x];
