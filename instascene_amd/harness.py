@@ -184,3 +184,64 @@ class SegTrainer:
         self.opt.zero_grad(set_to_none=True)
         m._seg_cache = None          # the graph of this step is gone
         return loss.detach()
+
+
+class RgbGaussianModel:
+    """Trainable 2DGS model for the ``train.py``-style step (scene/gaussian_model.py:109-138,206-253): six
+    parameter groups with the reference's learning rates; densification is out of scope."""
+
+    def __init__(self, scene: scenes.Scene, device):
+        s = scene.to(device)
+        mk = lambda t: nn.Parameter(t.clone().requires_grad_(True))
+        self._xyz, self._scaling, self._rotation = mk(s.xyz), mk(s.log_scale), mk(s.rot)
+        self._opacity, self._features_dc, self._features_rest = mk(s.opacity_logit), mk(s.features_dc), mk(s.features_rest)
+        self.active_sh_degree = 3
+        self.max_sh_degree = 3
+
+    get_xyz = property(lambda s: s._xyz)
+    get_scaling = property(lambda s: torch.exp(s._scaling))
+    get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation))
+    get_opacity = property(lambda s: torch.sigmoid(s._opacity))
+    get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
+    get_seg_feature = property(lambda s: None)
+
+    def param_groups(self):
+        return [{"params": [self._xyz], "lr": 0.00016, "name": "xyz"},
+                {"params": [self._features_dc], "lr": 0.0025, "name": "f_dc"},
+                {"params": [self._features_rest], "lr": 0.0025 / 20.0, "name": "f_rest"},
+                {"params": [self._opacity], "lr": 0.05, "name": "opacity"},
+                {"params": [self._scaling], "lr": 0.005, "name": "scaling"},
+                {"params": [self._rotation], "lr": 0.001, "name": "rotation"}]
+
+
+class RgbTrainer:
+    """Counterpart of train.py:57-156 without densification: render -> (1-l)*L1 + l*(1-SSIM) + lambda_dist*dist +
+    lambda_normal*(1 - <rend_normal, surf_normal>) -> backward (full geometry gradients) -> Adam."""
+
+    def __init__(self, scene, cameras, targets, device="cuda", lambda_dssim=0.2, lambda_normal=0.05, lambda_dist=0.0,
+                 rank=0, world=1):
+        from .losses import l1_loss, ssim
+        self.l1, self.ssim = l1_loss, ssim
+        self.device = torch.device(device)
+        self.model = RgbGaussianModel(scene, self.device)
+        self.cams = [c.to(self.device) for c in cameras]
+        self.targets = [t.to(self.device) for t in targets]
+        self.pipe = PipelineParams()
+        self.bg = torch.zeros(3, dtype=torch.float32, device=self.device)
+        self.ld, self.ln, self.ldist = lambda_dssim, lambda_normal, lambda_dist
+        self.rank, self.world = rank, world
+        self.opt = torch.optim.Adam(self.model.param_groups(), lr=0.0, eps=1e-15)
+
+    def step(self, it: int):
+        vi = view_for(it, self.rank, self.world, len(self.cams))
+        pkg = render(self.cams[vi], self.model, self.pipe, self.bg)
+        image, gt = pkg["render"], self.targets[vi]
+        loss = (1.0 - self.ld) * self.l1(image, gt) + self.ld * (1.0 - self.ssim(image, gt))
+        loss = loss + self.ldist * pkg["rend_dist"].mean()
+        normal_error = (1 - (pkg["rend_normal"] * pkg["surf_normal"]).sum(dim=0))[None]
+        loss = loss + self.ln * normal_error.mean()
+        loss.backward()
+        allreduce_grads([p for gr in self.opt.param_groups for p in gr["params"]], self.world)
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        return loss.detach(), pkg

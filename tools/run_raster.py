@@ -32,7 +32,9 @@ for it in range(a.iters):
     dC = torch.zeros_like(color) if not a.geom else torch.randn_like(color)
     dO = torch.zeros_like(others) if not a.geom else torch.randn_like(others)
     if F:
-        if a.sparse:
+        if a.sparse == 2:
+            dE = torch.zeros_like(extra)
+        elif a.sparse:
             dE = torch.zeros_like(extra)
             idx = torch.randint(0, W * H, (16384,), device="cuda")
             dE.view(F, -1)[:, idx] = torch.randn(F, 16384, device="cuda")
@@ -46,4 +48,11 @@ for it in range(a.iters):
                                         args[12], args[13], dC, dO, dE, args[16], 3, args[18], geom, R, binning, img,
                                         False, grad_mask=mask, mode=mode)
     torch.cuda.synchronize(); t3 = time.time()
-    print(f"iter {it}: R={R} fwd {1e3*(t1-t0):.2f} ms  bwd {1e3*(t3-t2):.2f} ms")
+    import ctypes
+    from instascene_amd._lib import lib
+    L = lib(); L.isr_profile_enable(1)
+    g = rz.rasterize_gaussians_backward(args[0], args[1], radii, e, args[4], args[5], args[8], 1.0, e, args[10], args[11],
+                                        args[12], args[13], dC, dO, dE, args[16], 3, args[18], geom, R, binning, img,
+                                        False, grad_mask=mask, mode=mode)
+    buf = ctypes.create_string_buffer(1 << 14); L.isr_profile_summary(buf, len(buf)); L.isr_profile_enable(0)
+    print(f"iter {it}: R={R} fwd {1e3*(t1-t0):.2f} ms  bwd {1e3*(t3-t2):.2f} ms | " + buf.value.decode().replace("\n", "; "))
