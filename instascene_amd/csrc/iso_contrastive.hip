@@ -47,7 +47,7 @@ inline CState cstate(void* buf, int N, int F, int K) {
     s.phi = isr::carve<float>(p, K);
     s.cnt = isr::carve<float>(p, K);
     s.G = isr::carve<float>(p, (size_t)N * K);
-    s.part = isr::carve<float>(p, (size_t)(N + 127) / 128 + 1);
+    s.part = isr::carve<float>(p, (size_t)(N + 31) / 32 + 1);
     s.dU = isr::carve<float>(p, (size_t)K * F);
     s.split = isr::carve<float>(p, (size_t)CK_NSPLIT * K * F);
     return s;
@@ -174,14 +174,21 @@ __global__ __launch_bounds__(256) void ck_phi(int N, int F, const float* __restr
     for (int ch = threadIdx.x; ch < F; ch += 256) s_u[ch] = U[(size_t)k * F + ch];
     __syncthreads();
     float d = 0.0f;
-    for (int i = threadIdx.x; i < N; i += 256) {
-        if (col[i] != k) continue;
-        float s = 0.0f;
-        for (int ch = 0; ch < F; ch++) {
-            const float t = f[(size_t)i * F + ch] - s_u[ch];
-            s += t * t;
+    for (int i0 = threadIdx.x; i0 < N; i0 += 256 * 8) {
+        int cc[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) cc[u] = (i0 + 256 * u < N) ? col[i0 + 256 * u] : -1;     // 8 loads in flight
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (cc[u] != k) continue;
+            const int i = i0 + 256 * u;
+            float s = 0.0f;
+            for (int ch = 0; ch < F; ch++) {
+                const float t = f[(size_t)i * F + ch] - s_u[ch];
+                s += t * t;
+            }
+            d += __builtin_sqrtf(s);
         }
-        d += __builtin_sqrtf(s);
     }
     const float dsum = block_sum_256(d, s_red);
     if (threadIdx.x == 0) {
@@ -195,14 +202,14 @@ __global__ __launch_bounds__(256) void ck_phi(int N, int F, const float* __restr
     }
 }
 
-// 4 waves x 32 samples per workgroup.  A[i][k] = f[row i][chan k]; B[k][j] = U[proto j][chan k].
-__global__ __launch_bounds__(256) void ck_similarity(int N, int F, int K, const float* __restrict__ f,
+// One wave (32 samples) per workgroup — N/32 small workgroups spread over all CUs instead of N/128 on a quarter of
+// them.  A[i][k] = f[row i][chan k]; B[k][j] = U[proto j][chan k].
+__global__ __launch_bounds__(64) void ck_similarity(int N, int F, int K, const float* __restrict__ f,
                                                      const float* __restrict__ U, const float* __restrict__ phi,
                                                      const float* __restrict__ cnt, const int* __restrict__ colid,
                                                      float* __restrict__ G, float* __restrict__ part) {
-    __shared__ float s_red[4];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i0 = (blockIdx.x * 4 + wv) * 32;
+    const int lane = threadIdx.x & 63;
+    const int i0 = blockIdx.x * 32;
     const int arow = i0 + (lane & 31), kk = lane >> 5;
     const int ksteps = (F + 1) / 2, ntile = (K + 31) / 32;
     float rsum[16];
@@ -249,7 +256,9 @@ __global__ __launch_bounds__(256) void ck_similarity(int N, int F, int K, const 
             }
         }
     }
-    const float tot = block_sum_256(lpart, s_red);
+    float tot = lpart;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
 
@@ -261,14 +270,14 @@ __global__ __launch_bounds__(256) void ck_loss_reduce(int nb, const float* __res
     if (threadIdx.x == 0) loss[0] = t;
 }
 
-// dF = G.(U/phi) [+ dU[y]/n_y];  dX = g * dF * inv.   4 waves x 32 samples, 32-channel tiles.
-__global__ __launch_bounds__(256) void ck_grad_f(int N, int F, int K, const float* __restrict__ G,
+// dF = G.(U/phi) [+ dU[y]/n_y];  dX = g * dF * inv.   one wave x 32 samples per workgroup, 32-channel tiles.
+__global__ __launch_bounds__(64) void ck_grad_f(int N, int F, int K, const float* __restrict__ G,
                                                  const float* __restrict__ U, const float* __restrict__ phi,
                                                  const float* __restrict__ cnt, const float* __restrict__ dU,
                                                  const int* __restrict__ colid, const float* __restrict__ inv,
                                                  const float* __restrict__ gloss, int use_mean, float* __restrict__ dX) {
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i0 = (blockIdx.x * 4 + wv) * 32;
+    const int lane = threadIdx.x & 63;
+    const int i0 = blockIdx.x * 32;
     const int arow = i0 + (lane & 31), kk = lane >> 5;
     const float g = gloss[0];
     const int ksteps = (K + 1) / 2;

@@ -306,7 +306,7 @@ int iso_contrastive_forward(int N, int F, int K, const float* features, const vo
     if (state_bytes < iso::cstate_bytes(N, F, K)) return fail(ISR_EINVAL, "contrastive state too small");
     iso::CState st = iso::cstate(state, N, F, K);
     const int shift = consider_negative ? 0 : 1;
-    const int nblk = (N + 127) / 128, nt = (N + 255) / 256;
+    const int nblk = (N + 31) / 32, nt = (N + 255) / 256;
     ISR_HIP(hipMemsetAsync(st.hist, 0, sizeof(int) * (K + 2), s));
     hipLaunchKernelGGL(iso::ck_count, dim3(nt), dim3(256), 0, s, N, K, shift, labels, labels_are_int64, st.hist);
     hipLaunchKernelGGL(iso::ck_normalize, dim3(nt), dim3(256), 0, s, N, F, K, shift, consider_negative, min_pixnum, features,
@@ -317,7 +317,7 @@ int iso_contrastive_forward(int N, int F, int K, const float* features, const vo
     hipLaunchKernelGGL(iso::ck_finish_u, dim3((K * F + 255) / 256), dim3(256), 0, s, F, K, min_pixnum, st.hist, st.split,
                        predef_u, st.U, st.cnt);
     hipLaunchKernelGGL(iso::ck_phi, dim3(K), dim3(256), 0, s, N, F, st.f, st.col, st.U, st.cnt, temp_lambda, st.phi);
-    hipLaunchKernelGGL(iso::ck_similarity, dim3(nblk), dim3(256), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, st.col, st.G, st.part);
+    hipLaunchKernelGGL(iso::ck_similarity, dim3(nblk), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, st.col, st.G, st.part);
     hipLaunchKernelGGL(iso::ck_loss_reduce, dim3(1), dim3(256), 0, s, nblk, st.part, loss);
     ISR_LAUNCH_CHECK("iso_contrastive_forward");
     return ISR_OK;
@@ -335,7 +335,7 @@ int iso_contrastive_backward(int N, int F, int K, int prototypes_predefined, con
                            st.col, st.G, st.f, st.split);
         hipLaunchKernelGGL(iso::ck_finish_du, dim3((K * F + 255) / 256), dim3(256), 0, s, F, K, st.split, st.phi, st.cnt, st.dU);
     }
-    hipLaunchKernelGGL(iso::ck_grad_f, dim3((N + 127) / 128), dim3(256), 0, s, N, F, K, st.G, st.U, st.phi, st.cnt, st.dU, st.col,
+    hipLaunchKernelGGL(iso::ck_grad_f, dim3((N + 31) / 32), dim3(64), 0, s, N, F, K, st.G, st.U, st.phi, st.cnt, st.dU, st.col,
                        st.inv, dL_dloss, use_mean, dL_dfeatures);
     ISR_LAUNCH_CHECK("iso_contrastive_backward");
     return ISR_OK;

@@ -138,7 +138,20 @@ __global__ __launch_bounds__(256) void k_preprocess(
         F3 rgb = {0.f, 0.f, 0.f};
         unsigned cm = 0;
         if (col_pre == nullptr) {
-            rgb = sh_to_rgb(D, p, F3{campos[0], campos[1], campos[2]}, shs + (size_t)i * M * 3, cm);
+            if (M == 16) {
+                // the 192-byte SH row as twelve 16-byte loads (a per-coefficient access pattern is 48 scattered dwords
+                // per lane: the texture-address unit, not HBM, was the limiter of this kernel)
+                float4 r4[12];
+                const float4* src = reinterpret_cast<const float4*>(shs + (size_t)i * 48);
+#pragma unroll
+                for (int k = 0; k < 12; k++) r4[k] = src[k];
+                float row[48];
+#pragma unroll
+                for (int k = 0; k < 12; k++) { row[4 * k] = r4[k].x; row[4 * k + 1] = r4[k].y; row[4 * k + 2] = r4[k].z; row[4 * k + 3] = r4[k].w; }
+                rgb = sh_to_rgb(D, p, F3{campos[0], campos[1], campos[2]}, row, cm);
+            } else {
+                rgb = sh_to_rgb(D, p, F3{campos[0], campos[1], campos[2]}, shs + (size_t)i * M * 3, cm);
+            }
         } else {
             rgb = {col_pre[3 * (size_t)i], col_pre[3 * (size_t)i + 1], col_pre[3 * (size_t)i + 2]};
         }
