@@ -52,10 +52,25 @@ __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __rest
     present[i] = vz > 0.2f ? 1 : 0;
 }
 
+// Sum over the 64 lanes of a wavefront with DPP adds inside each row of 16 lanes (no LDS crossbar traffic: a
+// __shfl_xor butterfly is six dependent ds_bpermute round trips per value) and four v_readlane's across the rows.
+// The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
+    return v + __int_as_float(x);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);     // row_half_mirror
+    v = dpp_add<0x140>(v);     // row_mirror: every lane now holds the sum of its row of 16
+    const int iv = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // ----------------------------------------------------------------------------
@@ -88,7 +103,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(
     __shared__ unsigned s_hit[4 * (SB / 32)];      // [wave][sub-batch] 32-bit hit masks of the round
     __shared__ unsigned s_last[4];
 
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x;       // (an XCD-contiguous tile map was measured 5 % slower: it unbalances the XCDs)
     const int tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned px = tx * TILE + (wv & 1) * 8 + (lane & 7);
