@@ -134,7 +134,7 @@ int isr_forward_prepare(int P, int D, int M, int width, int height, const float*
     if (gx > 65535 || gy > 65535) return fail(ISR_EINVAL, "image too large for 16-bit tile coordinates");
     GeomView g = geom_view(geom_buffer, P < 1 ? 1 : P);
     ImageView iv = image_view(image_buffer, width, height);
-    ISR_HIP(hipMemsetAsync(iv.tile_count, 0, sizeof(uint32_t) * T, s));
+    ISR_HIP(hipMemsetAsync(iv.tile_count, 0, sizeof(uint32_t) * (size_t)T * CNT_SUB * CNT_STRIDE, s));
     if (P > 0) {
         { ProfScope ps_("k_preprocess", s);
         hipLaunchKernelGGL(k_preprocess, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales,
@@ -149,7 +149,8 @@ int isr_forward_prepare(int P, int D, int M, int width, int height, const float*
         ISR_LAUNCH_CHECK("k_scan");
     }
     { ProfScope ps3_("k_tile_scan", s);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, iv.tile_count, iv.tile_offset, iv.tile_cursor, g.header); }
+    hipLaunchKernelGGL(k_gather_counts, dim3((T * CNT_SUB + 255) / 256), dim3(256), 0, s, T * CNT_SUB, iv.tile_count, iv.sub_offset, iv.tile_cursor);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, iv.sub_offset, iv.tile_offset, g.header); }
     ISR_LAUNCH_CHECK("k_tile_scan");
     if (num_rendered_host) return isr_read_num_rendered(geom_buffer, num_rendered_host, stream);
     return ISR_OK;
@@ -181,7 +182,7 @@ int isr_forward_render(int P, int ED, int width, int height, int mode, const flo
     if (tracer_pairs) ISR_HIP(hipMemsetAsync(tracer_count, 0, sizeof(int32_t), s));
     if (P > 0 && binning_capacity > 0) {
         { ProfScope ps_("k_scatter", s);
-        hipLaunchKernelGGL(k_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, g, iv.tile_offset, iv.tile_cursor,
+        hipLaunchKernelGGL(k_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, g, iv.sub_offset, iv.tile_cursor,
                            bv.keys, binning_capacity); }
         ISR_LAUNCH_CHECK("k_scatter");
         { ProfScope ps_("k_tile_sort", s);

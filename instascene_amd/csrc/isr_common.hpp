@@ -21,6 +21,10 @@ constexpr int REC = 20;                     // floats per splat record (80 B)
 // record layout: [0..2]=Tu [3..5]=Tv [6..8]=Tw [9..10]=centre [11..13]=normal [14]=opacity
 //                [15..17]=rgb [18]=view depth [19]=unused
 constexpr int MAX_FCHUNK = 32;              // feature channels handled per pass of the blend kernels
+// Per-tile counters are hit by R atomics per view.  Atomics on one cache line serialise in L2, so every tile gets
+// CNT_SUB sub-counters (picked by gaussian id) and every sub-counter its own 128-byte line.
+constexpr int CNT_SUB = 4;
+constexpr int CNT_STRIDE = 32;              // uint32 slots per counter (one 128-B line)
 
 struct alignas(8) Rect16 { uint16_t x0, y0, x1, y1; };
 
@@ -38,9 +42,10 @@ struct GeomView {          // carved from the caller's geometry workspace
 struct ImageView {
     float* final_T;        // [3, N]  T, M1, M2
     uint32_t* n_contrib;   // [2, N]  last contributor, median contributor
-    uint32_t* tile_count;  // [tiles]
-    uint32_t* tile_offset; // [tiles + 1] exclusive scan of tile_count (ranges[t] = off[t], off[t+1])
-    uint32_t* tile_cursor; // [tiles]
+    uint32_t* tile_count;  // [tiles * CNT_SUB * CNT_STRIDE] padded sub-counters
+    uint32_t* tile_offset; // [tiles + 1] exclusive scan of the tile totals (ranges[t] = off[t], off[t+1])
+    uint32_t* tile_cursor; // [tiles * CNT_SUB * CNT_STRIDE] padded scatter cursors
+    uint32_t* sub_offset;  // [tiles * CNT_SUB] start of every sub-bucket
 };
 
 struct BinView {
@@ -85,14 +90,15 @@ inline ImageView image_view(void* buf, int W, int H) {
     ImageView v;
     v.final_T = carve<float>(p, 3 * N);
     v.n_contrib = carve<uint32_t>(p, 2 * N);
-    v.tile_count = carve<uint32_t>(p, T);
+    v.tile_count = carve<uint32_t>(p, T * CNT_SUB * CNT_STRIDE);
     v.tile_offset = carve<uint32_t>(p, T + 1);
-    v.tile_cursor = carve<uint32_t>(p, T);
+    v.tile_cursor = carve<uint32_t>(p, T * CNT_SUB * CNT_STRIDE);
+    v.sub_offset = carve<uint32_t>(p, T * CNT_SUB);
     return v;
 }
 inline size_t image_bytes(int W, int H) {
     ImageView v = image_view((void*)0, W, H);
-    return (size_t)(v.tile_cursor + (size_t)tiles_x(W) * tiles_y(H)) + 256;
+    return (size_t)(v.sub_offset + (size_t)tiles_x(W) * tiles_y(H) * CNT_SUB) + 256;
 }
 inline BinView bin_view(void* buf, int64_t R) {
     char* p = (char*)buf;

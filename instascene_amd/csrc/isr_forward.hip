@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void k_preprocess(
         touched = (unsigned)(y1 - y0) * (unsigned)(x1 - x0);
         rc = {(uint16_t)x0, (uint16_t)y0, (uint16_t)x1, (uint16_t)y1};
         for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) atomicAdd(tile_count + (size_t)y * gx + x, 1u);
+            for (int x = x0; x < x1; x++)
+                atomicAdd(tile_count + (((size_t)y * gx + x) * CNT_SUB + (i & (CNT_SUB - 1))) * CNT_STRIDE, 1u);
     } while (false);
     radii_out[i] = radius_i;
     g.radii[i] = radius_i;
@@ -203,18 +204,28 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
     return base + x - v;
 }
 
-__global__ __launch_bounds__(1024) void k_tile_scan(int T, const uint32_t* __restrict__ count, uint32_t* __restrict__ offset,
-                                                    uint32_t* __restrict__ cursor, int64_t* header) {
+// dense copy of the padded sub-counters (and reset of the scatter cursors), then a single-workgroup scan
+__global__ __launch_bounds__(256) void k_gather_counts(int E, const uint32_t* __restrict__ count, uint32_t* __restrict__ dense,
+                                                       uint32_t* __restrict__ cursor) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= E) return;
+    dense[i] = count[(size_t)i * CNT_STRIDE];
+    cursor[(size_t)i * CNT_STRIDE] = 0u;
+}
+
+__global__ __launch_bounds__(1024) void k_tile_scan(int T, uint32_t* __restrict__ sub_offset /* in: counts, out: offsets */,
+                                                    uint32_t* __restrict__ offset, int64_t* header) {
     __shared__ uint32_t s_warp[32];
+    const int E = T * CNT_SUB;              // scan over (tile, sub-counter) in tile-major order
     uint32_t carry = 0;
-    for (int base = 0; base < T; base += 1024) {
+    for (int base = 0; base < E; base += 1024) {
         const int i = base + threadIdx.x;
-        const uint32_t v = i < T ? count[i] : 0u;
+        const uint32_t v = i < E ? sub_offset[i] : 0u;
         uint32_t total;
         const uint32_t ex = block_exclusive_scan_1024(v, s_warp, total);
-        if (i < T) {
-            offset[i] = carry + ex;
-            cursor[i] = 0u;
+        if (i < E) {
+            sub_offset[i] = carry + ex;
+            if ((i & (CNT_SUB - 1)) == 0) offset[i / CNT_SUB] = carry + ex;
         }
         carry += total;
     }
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(1024) void k_scan_add(int n, uint32_t* __restrict__
 
 // ----------------------------------------------------------------------------
 // Scatter: one (depth_bits, gaussian) key per touched tile into that tile's bucket.
-__global__ __launch_bounds__(256) void k_scatter(int P, int gx, GeomView g, const uint32_t* __restrict__ tile_offset,
+__global__ __launch_bounds__(256) void k_scatter(int P, int gx, GeomView g, const uint32_t* __restrict__ sub_offset,
                                                  uint32_t* __restrict__ tile_cursor, unsigned long long* __restrict__ keys,
                                                  int64_t capacity) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -264,9 +275,9 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, GeomView g, cons
     const unsigned long long key = ((unsigned long long)dbits << 32) | (unsigned)i;
     for (int y = rc.y0; y < rc.y1; y++)
         for (int x = rc.x0; x < rc.x1; x++) {
-            const size_t t = (size_t)y * gx + x;
-            const uint32_t pos = atomicAdd(tile_cursor + t, 1u);
-            const int64_t at = (int64_t)tile_offset[t] + pos;
+            const size_t e = ((size_t)y * gx + x) * CNT_SUB + (i & (CNT_SUB - 1));
+            const uint32_t pos = atomicAdd(tile_cursor + e * CNT_STRIDE, 1u);
+            const int64_t at = (int64_t)sub_offset[e] + pos;
             if (at < capacity) keys[at] = key;
         }
 }
