@@ -3,8 +3,6 @@ torch (conv2d plumbing) so that the RGB harness exercises the full geometry back
 reference's own outputs in tests/golden/losses.npz."""
 from __future__ import annotations
 
-from math import exp
-
 import torch
 import torch.nn.functional as F
 
@@ -19,28 +17,41 @@ def cos_loss(network_output, gt):
     return (1 - (network_output * gt).sum(dim=0)).mean()
 
 
-def _window(size: int, channel: int, device, dtype):
-    key = (size, channel, str(device), dtype)
-    w = _WINDOWS.get(key)
-    if w is None:
-        g = torch.tensor([exp(-(x - size // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(size)])
-        g = (g / g.sum()).unsqueeze(1)
-        w = (g @ g.t()).float().unsqueeze(0).unsqueeze(0).expand(channel, 1, size, size).contiguous()
-        w = w.to(device=device, dtype=dtype)
-        _WINDOWS[key] = w
-    return w
+def _taps(size: int, device, dtype):
+    """Normalised 1-D Gaussian taps (sigma 1.5).  The reference's 2-D window is the outer product of these
+    (utils/loss_utils.py:28-36), so filtering rows then columns is the same linear operator at 2*size instead of
+    size**2 multiplies per pixel."""
+    key = (size, str(device), dtype)
+    t = _WINDOWS.get(key)
+    if t is None:
+        x = torch.arange(size, dtype=torch.float64) - size // 2
+        t = torch.exp(-x * x / (2.0 * 1.5 * 1.5))
+        t = (t / t.sum()).to(device=device, dtype=dtype)
+        _WINDOWS[key] = t
+    return t
+
+
+def _blur(planes, taps):
+    """Zero-padded separable blur of every plane of a [B, C, H, W] stack (depthwise)."""
+    c, k = planes.size(1), taps.numel()
+    rows = F.conv2d(planes, taps.view(1, 1, 1, k).expand(c, 1, 1, k), padding=(0, k // 2), groups=c)
+    return F.conv2d(rows, taps.view(1, 1, k, 1).expand(c, 1, k, 1), padding=(k // 2, 0), groups=c)
 
 
 def ssim(img1, img2, window_size: int = 11, size_average: bool = True):
-    channel = img1.size(-3)
-    w = _window(window_size, channel, img1.device, img1.dtype)
-    pad = window_size // 2
-    mu1 = F.conv2d(img1, w, padding=pad, groups=channel)
-    mu2 = F.conv2d(img2, w, padding=pad, groups=channel)
-    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
-    sigma1_sq = F.conv2d(img1 * img1, w, padding=pad, groups=channel) - mu1_sq
-    sigma2_sq = F.conv2d(img2 * img2, w, padding=pad, groups=channel) - mu2_sq
-    sigma12 = F.conv2d(img1 * img2, w, padding=pad, groups=channel) - mu1_mu2
-    C1, C2 = 0.01 ** 2, 0.03 ** 2
-    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
-    return ssim_map.mean() if size_average else ssim_map.mean(1).mean(1).mean(1)
+    """Structural similarity with an 11x11 Gaussian window (utils/loss_utils.py:39-63).  The five local moments
+    (E[a], E[b], E[a^2], E[b^2], E[ab]) are filtered as one stacked depthwise pass."""
+    a = img1 if img1.dim() == 4 else img1.unsqueeze(0)
+    b = img2 if img2.dim() == 4 else img2.unsqueeze(0)
+    c = a.size(1)
+    taps = _taps(window_size, a.device, a.dtype)
+    m = _blur(torch.cat((a, b, a * a, b * b, a * b), dim=1), taps)
+    ea, eb, eaa, ebb, eab = m.split(c, dim=1)
+    k1, k2 = 0.01 ** 2, 0.03 ** 2
+    cov = eab - ea * eb
+    var_sum = (eaa - ea * ea) + (ebb - eb * eb)
+    mean_sq_sum = ea * ea + eb * eb
+    quality = (2 * ea * eb + k1) * (2 * cov + k2) / ((mean_sq_sum + k1) * (var_sum + k2))
+    if size_average:
+        return quality.mean()
+    return quality.flatten(1).mean(1)

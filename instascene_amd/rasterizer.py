@@ -94,11 +94,6 @@ def _f32c(t: Optional[torch.Tensor], name: str):
     return t.contiguous()
 
 
-class _State:
-    """Opaque forward->backward hand-off (the reference's geomBuffer/binningBuffer/imgBuffer)."""
-    __slots__ = ("geom", "binning", "image", "R", "P", "W", "H", "ED", "mode")
-
-
 def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
                         extra_attrs, attr_degree, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
                         image_width, sh, degree, campos, prefiltered, debug, *, tracer=None, mode=None):
