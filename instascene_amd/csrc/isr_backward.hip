@@ -87,8 +87,8 @@ __global__ __launch_bounds__(256) void k_render_bwd(
     const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dC, const float* __restrict__ dO, const float* __restrict__ dE,
     const uint32_t* __restrict__ point_offsets,
-    const Rect16* __restrict__ rects, float* __restrict__ partial, uint8_t* __restrict__ row_flags, int row_stride,
-    int geom_off, int feat_off, int64_t capacity) {
+    const Rect16* __restrict__ rects, float* __restrict__ partial, uint8_t* __restrict__ row_flags,
+    const uint8_t* __restrict__ tile_mode, int row_stride, int geom_off, int feat_off, int64_t capacity) {
     constexpr int RS = 16;
     constexpr int SB = 128;                 // (id, cull box) pairs staged per barrier round: two 64-bit hit masks per wave
     constexpr int PART = (GEOM ? GEOM_ROW : 0) + (FEAT ? 32 : 0);   // floats per instance per wave in LDS
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(
     __shared__ unsigned s_last[4];
 
     const int tile = blockIdx.x;       // (an XCD-contiguous tile map was measured 5 % slower: it unbalances the XCDs)
+    if (tile_mode != nullptr && tile_mode[tile] == 0) return;     // done (or empty) in k_render_bwd_sparse
     const int tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned px = tx * TILE + (wv & 1) * 8 + (lane & 7);
@@ -535,6 +536,210 @@ __global__ __launch_bounds__(256) void k_render_bwd(
 }
 
 // ----------------------------------------------------------------------------
+// K9, sparse upstream gradient (feature-only): "pixel-major" walk.
+//
+// train_semantic samples ~16k of 2M pixels per step, i.e. ~2 live pixels per tile.  For such tiles the
+// pixel-per-lane mapping of k_render_bwd leaves 62 of 64 lanes idle and pays three workgroup barriers per
+// 32 instances.  Here ONE wave walks the tile's depth-sorted list with a lane per SPLAT: 64 (id, cull box)
+// pairs are read coalesced, lanes whose box holds a live pixel gather their record, and for every live pixel
+// the transmittance in front of each lane's splat is a wave-wide multiplicative prefix scan of (1 - alpha)
+// (DPP row shifts + row broadcasts; no LDS).  Each (tile, Gaussian) instance is owned by exactly one lane, which
+// sums  w(pix_k) * dL/dE(pix_k, :)  over the live pixels in fixed order and stores the finished 32-channel row:
+// no cross-lane reduction, no barrier in the walk, deterministic.
+// Tiles with more than SPARSE_LMAX live pixels are flagged in tile_mode[] and left to k_render_bwd.
+constexpr int SPARSE_LMAX = 32;
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_fetch(float v, float fill) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), CTRL, ROWMASK, 0xF, false));
+}
+// inclusive product scan over the 64 lanes of a wavefront
+__device__ __forceinline__ float wave_scan_mul(float v) {
+    v *= dpp_fetch<0x111, 0xF>(v, 1.0f);     // row_shr:1
+    v *= dpp_fetch<0x112, 0xF>(v, 1.0f);     // row_shr:2
+    v *= dpp_fetch<0x114, 0xF>(v, 1.0f);     // row_shr:4
+    v *= dpp_fetch<0x118, 0xF>(v, 1.0f);     // row_shr:8   -> inclusive inside each row of 16
+    v *= dpp_fetch<0x142, 0xA>(v, 1.0f);     // row_bcast:15 into rows 1 and 3
+    v *= dpp_fetch<0x143, 0xC>(v, 1.0f);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// alpha of one splat at one pixel, 0 when the forward `continue`d on the pair (forward.cu:352-386)
+template <class Math>
+__device__ __forceinline__ float splat_alpha(const F3 Tu, const F3 Tv, const F3 Tw, float cx, float cy, float opa,
+                                             float skip, float pxf, float pyf) {
+    const F3 kk = {Math::msub(pxf, Tw.x, Tu.x), Math::msub(pxf, Tw.y, Tu.y), Math::msub(pxf, Tw.z, Tu.z)};
+    const F3 ll = {Math::msub(pyf, Tw.x, Tv.x), Math::msub(pyf, Tw.y, Tv.y), Math::msub(pyf, Tw.z, Tv.z)};
+    const F3 p = {Math::msub(kk.y, ll.z, kk.z * ll.y), Math::msub(kk.z, ll.x, kk.x * ll.z),
+                  Math::msub(kk.x, ll.y, kk.y * ll.x)};
+    const float dx = cx - pxf, dy = cy - pyf;
+    const float rho2d = FILTER_INV_SQ * Math::mad(dy, dy, dx * dx);
+    if (rho2d > skip && Math::mad(p.y, p.y, p.x * p.x) > skip * (p.z * p.z) * 1.01f) return 0.0f;
+    if (p.z == 0.0f) return 0.0f;
+    const float sx = Math::div(p.x, p.z), sy = Math::div(p.y, p.z);
+    const float rho3d = Math::mad(sy, sy, sx * sx);
+    const float rho = fminf(rho3d, rho2d);
+    const float c_d = (rho3d <= rho2d) ? Math::mad(sy, Tw.y, sx * Tw.x) + Tw.z : Tw.z;
+    const float power = -0.5f * rho;
+    if (c_d < NEAR_N || power > 0.0f) return 0.0f;
+    const float alpha = fminf(0.99f, opa * Math::ex(power));
+    return alpha < 1.0f / 255.0f ? 0.0f : alpha;
+}
+
+template <class Math>
+__global__ __launch_bounds__(256) void k_render_bwd_sparse(
+    int W, int H, int ED, int ch_base, int gx, const uint32_t* __restrict__ tile_offset,
+    const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ box4, const float* __restrict__ rec,
+    const float* __restrict__ tm_pre, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ dE, const uint32_t* __restrict__ point_offsets, const Rect16* __restrict__ rects,
+    float* __restrict__ partial, uint8_t* __restrict__ row_flags, uint8_t* __restrict__ tile_mode, int row_stride,
+    int feat_off, int64_t capacity) {
+    __shared__ int s_wcnt[4];
+    __shared__ unsigned s_wlast[4];
+    __shared__ int s_lxy[SPARSE_LMAX];                 // tile-relative x | y << 8 of the live pixels
+    __shared__ unsigned s_llast[SPARSE_LMAX];          // their last contributor
+    __shared__ __attribute__((aligned(16))) float s_ldE[SPARSE_LMAX * 32];
+
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lx = (wv & 1) * 8 + (lane & 7), ly = (wv >> 1) * 8 + (lane >> 3);
+    const unsigned px = tx * TILE + lx, py = ty * TILE + ly;
+    const bool inside = px < (unsigned)W && py < (unsigned)H;
+    const size_t N = (size_t)W * H;
+    const size_t pix = (size_t)W * py + px;
+
+    const int64_t r0 = tile_offset[tile];
+    int64_t r1 = tile_offset[tile + 1];
+    if (r1 > capacity) r1 = capacity;
+    const int len = (int)(r1 - r0);
+    if (len <= 0 || dE == nullptr) {
+        if (threadIdx.x == 0) tile_mode[tile] = 0;
+        return;
+    }
+    // ---- live pixels of the tile: dL/dE(pix, chunk) != 0 and something was blended there
+    const unsigned last_contributor = inside ? n_contrib[pix] : 0u;
+    bool nz = false;
+    if (inside && last_contributor > 0u) {
+        const int nch = min(32, ED - ch_base);
+        float v[32];
+#pragma unroll
+        for (int c = 0; c < 32; c++) v[c] = c < nch ? dE[(size_t)(ch_base + c) * N + pix] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 32; c++) nz = nz || (v[c] != 0.0f);
+    }
+    const unsigned long long live_mask = __ballot(nz);
+    unsigned wlast = nz ? last_contributor : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wlast = max(wlast, (unsigned)__shfl_xor((int)wlast, o));
+    if (lane == 0) { s_wcnt[wv] = __popcll(live_mask); s_wlast[wv] = wlast; }
+    __syncthreads();
+    const int nlive = (s_wcnt[0] + s_wcnt[1]) + (s_wcnt[2] + s_wcnt[3]);
+    if (nlive == 0 || nlive > SPARSE_LMAX) {
+        if (threadIdx.x == 0) tile_mode[tile] = nlive > SPARSE_LMAX ? 1 : 0;
+        return;
+    }
+    if (threadIdx.x == 0) tile_mode[tile] = 0;
+    int rank = __popcll(live_mask & ((1ull << lane) - 1ull));      // fixed order: wave-major, then lane
+    for (int w = 0; w < wv; w++) rank += s_wcnt[w];
+    if (nz) { s_lxy[rank] = lx | (ly << 8); s_llast[rank] = last_contributor; }
+    __syncthreads();
+    for (int k = threadIdx.x >> 5; k < nlive; k += 8) {
+        const int c = threadIdx.x & 31, ch = ch_base + c;
+        const int xy = s_lxy[k];
+        const size_t q = (size_t)W * (ty * TILE + (xy >> 8)) + (tx * TILE + (xy & 255));
+        s_ldE[k * 32 + c] = ch < ED ? dE[(size_t)ch * N + q] : 0.0f;
+    }
+    __syncthreads();
+    if (wv != 0) return;
+
+    const int len_eff = min(len, (int)max(max(s_wlast[0], s_wlast[1]), max(s_wlast[2], s_wlast[3])));
+    const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
+    float Tvec = 1.0f;                 // lane k: running transmittance of live pixel k
+    for (int base = 0; base < len_eff; base += 64) {
+        const int idx = base + lane;
+        unsigned hk = 0u;              // bit k: this lane's splat may touch live pixel k
+        int id = 0;
+        if (idx < len_eff) {
+            id = (int)point_list[r0 + idx];
+            const unsigned bx = box4[r0 + idx];
+            const int xl = (int)(signed char)(bx & 255u), xh = (int)(signed char)((bx >> 8) & 255u);
+            const int yl = (int)(signed char)((bx >> 16) & 255u), yh = (int)(signed char)(bx >> 24);
+            for (int k = 0; k < nlive; k++) {
+                const int xy = s_lxy[k];
+                const int x = xy & 255, y = xy >> 8;
+                if (xl <= x && xh >= x && yl <= y && yh >= y && (unsigned)idx < s_llast[k]) hk |= 1u << k;
+            }
+        }
+        // wave-uniform union of the per-lane masks
+        unsigned any = hk;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) any |= (unsigned)__shfl_xor((int)any, o);
+        any = (unsigned)__builtin_amdgcn_readfirstlane((int)any);
+        if (any == 0u) continue;
+        F3 Tu = {0, 0, 0}, Tv = {0, 0, 0}, Tw = {0, 0, 1};
+        float cx = 0, cy = 0, opa = 0, skip = 0;
+        unsigned slot = 0;
+        if (hk != 0u) {
+            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
+            float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3];
+            if (tm_pre != nullptr) {
+                const float* tp = tm_pre + 9 * (size_t)id;
+                a = make_float4(tp[0], tp[1], tp[2], tp[3]);
+                b = make_float4(tp[4], tp[5], tp[6], tp[7]);
+                c.x = tp[8];
+            }
+            const Rect16 rc = rects[id];
+            slot = point_offsets[id] + (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
+            Tu = {a.x, a.y, a.z}; Tv = {a.w, b.x, b.y}; Tw = {b.z, b.w, c.x};
+            cx = c.y; cy = c.z; opa = d.z;
+            skip = __builtin_inff();
+            if (opa <= 1.0f) {
+                const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
+                skip = 2.0f * l * 1.01f + 0.05f;
+            }
+        }
+        float acc[32];
+#pragma unroll
+        for (int c = 0; c < 32; c++) acc[c] = 0.0f;
+        bool wrote = false;
+        while (any != 0u) {
+            const int k = __builtin_ctz(any);
+            any &= any - 1u;
+            const int xy = s_lxy[k];
+            float alpha = 0.0f;
+            if ((hk >> k) & 1u)
+                alpha = splat_alpha<Math>(Tu, Tv, Tw, cx, cy, opa, skip, tile_x0 + (float)(xy & 255), tile_y0 + (float)(xy >> 8));
+            if (__ballot(alpha != 0.0f) == 0ull) continue;
+            const float incl = wave_scan_mul(1.0f - alpha);
+            const float excl = dpp_fetch<0x138, 0xF>(incl, 1.0f);        // wave_shr:1
+            const float Tk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tvec), k));
+            const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+            if (lane == k) Tvec = Tk * total;
+            const float w = alpha * (Tk * excl);
+            if (w != 0.0f) {
+                wrote = true;
+                const float4* e4 = reinterpret_cast<const float4*>(s_ldE + k * 32);
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const float4 v = e4[q];
+                    acc[4 * q + 0] = __builtin_fmaf(w, v.x, acc[4 * q + 0]);
+                    acc[4 * q + 1] = __builtin_fmaf(w, v.y, acc[4 * q + 1]);
+                    acc[4 * q + 2] = __builtin_fmaf(w, v.z, acc[4 * q + 2]);
+                    acc[4 * q + 3] = __builtin_fmaf(w, v.w, acc[4 * q + 3]);
+                }
+            }
+        }
+        if (wrote) {
+            float4* o4 = reinterpret_cast<float4*>(partial + (size_t)slot * row_stride + feat_off);
+#pragma unroll
+            for (int q = 0; q < 8; q++) o4[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            row_flags[slot] = 1;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
 // Row reduction: out[g, c] = sum over the Gaussian's tiles of partial[slot, src_off + c].
 __global__ __launch_bounds__(256) void k_reduce_rows(int P, int ncol, const uint32_t* __restrict__ point_offsets,
                                                      const uint32_t* __restrict__ tiles_touched,
@@ -551,10 +756,20 @@ __global__ __launch_bounds__(256) void k_reduce_rows(int P, int ncol, const uint
     const size_t base = point_offsets[g];
     const uint8_t* fl = row_flags + (size_t)(c >> 5) * R + base;     // pass (c / 32) wrote feature chunk (c / 32)
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t r = 0; r < n; r++) {
-        if (!fl[r]) continue;
-        const float4 v = *reinterpret_cast<const float4*>(partial + (base + r) * row_stride + src_off + c);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    // eight rows per round: flags, then the flagged rows, are independent loads in flight together (the common
+    // Gaussian touches < 8 tiles, so the whole reduction is two memory round trips); summed in row order
+    for (uint32_t r = 0; r < n; r += 8) {
+        bool f[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) f[u] = (r + u < n) && fl[r + u] != 0;
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            v[u] = f[u] ? *reinterpret_cast<const float4*>(partial + (base + r + u) * row_stride + src_off + c)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (f[u]) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
     }
     float* o = out + (size_t)g * out_stride + c;
     if (c + 3 < ncol && (out_stride & 3) == 0) *reinterpret_cast<float4*>(o) = s;
@@ -788,6 +1003,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
         if (e_ != hipSuccess) return -2;                                          \
     } while (0)
 
+// ISR_SPARSE_BWD=0 disables the pixel-major kernel (A/B measurements)
+static bool sparse_path_enabled() {
+    static const bool on = [] { const char* e = getenv("ISR_SPARSE_BWD"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 template <class Math>
 static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int H, unsigned mask, const float* bg,
                              const float* means3D, const float* shs, const float* col_pre, const float* scales,
@@ -817,10 +1038,20 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
         do {
             ProfScope ps_("k_render_bwd", s);
             const bool do_geom = geomg && first, do_feat = featg;
+            // feature-only pass: tiles with few live pixels are finished by the pixel-major kernel, the rest
+            // (flagged in tile_mode) by the dense one
+            const uint8_t* tmode = nullptr;
+            if (!do_geom && do_feat && sparse_path_enabled()) {
+                hipLaunchKernelGGL((k_render_bwd_sparse<Math>), dim3(T), dim3(256), 0, s, W, H, ED, ch, gx, iv.tile_offset,
+                                   bv.point_list, bv.box4, g.rec, tm_pre, iv.n_contrib, dE, g.point_offsets, g.rect, partial,
+                                   flags + (size_t)pass * R, iv.tile_mode, stride, feat_base + ch, R);
+                ISR_CHECK_LAUNCH_B("k_render_bwd_sparse");
+                tmode = iv.tile_mode;
+            }
 #define ISR_GOB(GM, FT, Q)                                                                                           \
     hipLaunchKernelGGL((k_render_bwd<Math, GM, FT, Q>), dim3(T), dim3(256), 0, s, W, H, ED, ch, gx, iv.tile_offset,   \
                        bv.point_list, bv.box4, g.rec, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib, dC, dO, dE,      \
-                       g.point_offsets, g.rect, partial, flags + (size_t)pass * R, stride, geom_off, feat_base + ch, R)
+                       g.point_offsets, g.rect, partial, flags + (size_t)pass * R, tmode, stride, geom_off, feat_base + ch, R)
             // the geometry pass needs <feature_g, dL/dfeature(pix)> over ALL channels (dL/dalpha), whatever
             // chunk of dL/dextra it emits itself
             if (do_geom && ED > 32) { if (do_feat) ISR_GOB(true, true, 64); else ISR_GOB(true, false, 64); }

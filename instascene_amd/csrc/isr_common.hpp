@@ -46,6 +46,7 @@ struct ImageView {
     uint32_t* tile_offset; // [tiles + 1] exclusive scan of the tile totals (ranges[t] = off[t], off[t+1])
     uint32_t* tile_cursor; // [tiles * CNT_SUB * CNT_STRIDE] padded scatter cursors
     uint32_t* sub_offset;  // [tiles * CNT_SUB] start of every sub-bucket
+    uint8_t* tile_mode;    // [tiles] backward only: 1 = tile left to the dense K9 kernel by the sparse one
 };
 
 struct BinView {
@@ -94,11 +95,12 @@ inline ImageView image_view(void* buf, int W, int H) {
     v.tile_offset = carve<uint32_t>(p, T + 1);
     v.tile_cursor = carve<uint32_t>(p, T * CNT_SUB * CNT_STRIDE);
     v.sub_offset = carve<uint32_t>(p, T * CNT_SUB);
+    v.tile_mode = carve<uint8_t>(p, T);
     return v;
 }
 inline size_t image_bytes(int W, int H) {
     ImageView v = image_view((void*)0, W, H);
-    return (size_t)(v.sub_offset + (size_t)tiles_x(W) * tiles_y(H) * CNT_SUB) + 256;
+    return (size_t)(v.tile_mode + (size_t)tiles_x(W) * tiles_y(H)) + 256;
 }
 inline BinView bin_view(void* buf, int64_t R) {
     char* p = (char*)buf;

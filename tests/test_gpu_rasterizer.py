@@ -307,6 +307,37 @@ def test_backward_with_sparse_upstream_gradient():
         assert all(float(t.abs().sum()) == 0.0 for t in got0)
 
 
+@pytest.mark.parametrize("F", [8, 32, 48])
+def test_backward_mixed_sparse_and_dense_tiles(F):
+    """Feature-only backward: tiles with <= 32 live pixels go through the pixel-major (lane per splat) kernel, denser
+    tiles through the MFMA kernel.  Cover both in one image (incl. exactly 32 / 33 live pixels in a tile), several
+    feature chunk counts, and run-to-run determinism."""
+    W, H = 112, 80
+    sc, cams, inp = small_scene(P=2200, F=F, W=W, H=H, seed=33, mu_s=math.log(0.06))
+    cam = cams[2]
+    st = oracle_forward(inp, cam)
+    rng = np.random.RandomState(11)
+    dE = np.zeros_like(st["extra"]).reshape(F, H, W)
+    dE[:, 0:16, 0:16] = rng.randn(F, 16, 16)                    # tile (0,0): fully dense
+    ys, xs = np.divmod(rng.choice(256, 32, replace=False), 16)   # tile (1,0): exactly 32 live pixels
+    dE[:, ys, 16 + xs] = rng.randn(F, 32)
+    ys, xs = np.divmod(rng.choice(256, 33, replace=False), 16)   # tile (2,0): 33 -> dense path
+    dE[:, ys, 32 + xs] = rng.randn(F, 33)
+    pix = rng.choice(W * (H - 16), 60, replace=False) + 16 * W   # the rest: scattered samples
+    dE.reshape(F, -1)[:, pix] = rng.randn(F, 60)
+    dE[1:, 40, 50] = 0.0                                         # a pixel live through a single channel
+    dE[0, 40, 50] = 0.7
+    dE = dE.astype(np.float32).reshape(st["extra"].shape)
+    dC, dO = np.zeros_like(st["color"]), np.zeros_like(st["others"])
+    want = oracle.backward(st, dC, dO, dE)
+    for mode in (MODE_EXACT, MODE_FAST):
+        args, out = hip_forward(inp, cam, mode=mode)
+        got = hip_backward(args, out, dC, dO, dE, GRAD_EXTRA, mode)[8]
+        assert_close(got.cpu().numpy(), want["dL_dextra"], 1e-3, "mixed density F=%d" % F)
+        again = hip_backward(args, out, dC, dO, dE, GRAD_EXTRA, mode)[8]
+        assert torch.equal(got, again)
+
+
 def test_culling_survives_grazing_and_near_camera_splats():
     """Edge-on, huge and near-plane splats: the conservative cull box must never drop a contributing pair
     (EXACT mode stays bit-identical to the oracle, which evaluates every pair)."""
