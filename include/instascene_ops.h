@@ -55,6 +55,13 @@ int iso_contrastive_backward(int N, int F, int K, int prototypes_predefined, con
  * backward == 0: out = y;  backward != 0: out = dL/dx given dy = dL/dy (x is the forward input). */
 int iso_rownorm(long long N, int F, float eps, int backward, const float* x, const float* dy, float* out, void* stream);
 
+/* The two chained normalisations the reference applies to the [P,F] feature every step (getter eps 1e-6, then
+ * render() eps 1e-9) as ONE pass each way; F % 4 == 0, F <= 256.
+ *   y = x/(|x|+eps1), z = y/(|y|+eps2)
+ * backward == 0: out1 = y, out2 = z.   backward != 0: out1 = dL/dx from gy = dL/dy and gz = dL/dz (either may be NULL). */
+int iso_rownorm2(long long N, int F, float eps1, float eps2, int backward, const float* x, const float* gy,
+                 const float* gz, float* out1, float* out2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

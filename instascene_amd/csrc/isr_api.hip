@@ -360,4 +360,19 @@ int iso_rownorm(long long N, int F, float eps, int backward, const float* x, con
     return ISR_OK;
 }
 
+int iso_rownorm2(long long N, int F, float eps1, float eps2, int backward, const float* x, const float* gy,
+                 const float* gz, float* out1, float* out2, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (N < 0 || F <= 0 || (F & 3) != 0 || F > 256) return fail(ISR_EINVAL, "rownorm2 needs F % 4 == 0 and F <= 256");
+    if (N > 0 && (!x || !out1 || (!backward && !out2))) return fail(ISR_EINVAL, "bad rownorm2 arguments");
+    if (N == 0) return ISR_OK;
+    int q = F >> 2, lpr = 1;
+    while (lpr < q) lpr <<= 1;
+    const unsigned blocks = (unsigned)((N * lpr + 255) / 256);
+    if (backward) hipLaunchKernelGGL(iso::rn2_kernel<true>, dim3(blocks), dim3(256), 0, s, N, F, eps1, eps2, x, gy, gz, out1, out2);
+    else hipLaunchKernelGGL(iso::rn2_kernel<false>, dim3(blocks), dim3(256), 0, s, N, F, eps1, eps2, x, gy, gz, out1, out2);
+    ISR_LAUNCH_CHECK("iso_rownorm2");
+    return ISR_OK;
+}
+
 }  // extern "C"

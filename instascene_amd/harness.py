@@ -23,7 +23,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import scenes
-from .contrastive import contrastive_loss, row_normalize
+from .contrastive import contrastive_loss, row_normalize_chain
 from .dist_utils import allreduce_grads, view_for
 from .render import render
 
@@ -75,7 +75,8 @@ class SegGaussianModel:
         # called twice per step (render() and the 3-D loss): reuse the node while the parameter is unchanged
         key = (self._seg_feature._version, torch.is_grad_enabled())
         if self._seg_cache is None or self._seg_cache[0] != key:
-            self._seg_cache = (key, row_normalize(self._seg_feature, 1e-6))
+            # eps 1e-6 here (scene/gaussian_model.py:122-125); render() re-normalises with 1e-9 — both in one pass
+            self._seg_cache = (key, row_normalize_chain(self._seg_feature, 1e-6, 1e-9))
         return self._seg_cache[1]
 
 

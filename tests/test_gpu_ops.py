@@ -149,6 +149,36 @@ def test_row_normalize_matches_torch(N, F, eps):
     assert_close(b.grad.cpu().numpy(), a.grad.numpy(), 1e-5, "rownorm bwd")
 
 
+@pytest.mark.parametrize("N,F,use", [(5000, 32, "yz"), (777, 16, "z"), (300, 64, "y"), (129, 40, "yz")])
+def test_row_normalize_chain_matches_two_passes(N, F, use):
+    """The getter + render() normalisations fused: forward bit-identical to two row_normalize passes, the second
+    row_normalize call is a lookup, backward equal to torch autograd of the chain (either upstream gradient absent)."""
+    from instascene_amd.contrastive import row_normalize, row_normalize_chain
+    g = torch.Generator().manual_seed(N + 1)
+    x = torch.randn(N, F, generator=g) * 3.0
+    x[5] = 0.0
+    gy, gz = torch.randn(N, F, generator=g), torch.randn(N, F, generator=g)
+    a = x.clone().double().requires_grad_(True)
+    ya = a / (a.norm(dim=-1, keepdim=True) + 1e-6)
+    za = ya / (ya.norm(dim=-1, keepdim=True) + 1e-9)
+    loss = 0.0
+    if "y" in use: loss = loss + (ya * gy.double()).sum()
+    if "z" in use: loss = loss + (za * gz.double()).sum()
+    loss.backward()
+    b = x.cuda().requires_grad_(True)
+    yb = row_normalize_chain(b, 1e-6, 1e-9)
+    zb = row_normalize(yb, 1e-9)                       # served from the chain
+    assert zb.grad_fn is yb.grad_fn
+    y2 = row_normalize(x.cuda(), 1e-6)
+    assert torch.equal(yb.detach(), y2) and torch.equal(zb.detach(), row_normalize(y2, 1e-9))
+    lb = 0.0
+    if "y" in use: lb = lb + (yb * gy.cuda()).sum()
+    if "z" in use: lb = lb + (zb * gz.cuda()).sum()
+    lb.backward()
+    assert_close(b.grad.cpu().numpy(), a.grad.float().numpy(), 2e-5, "rownorm chain bwd (%s)" % use)
+    assert row_normalize(yb, 1e-6) is not zb           # another eps is a fresh normalisation
+
+
 def test_contrastive_with_label_bound_and_dropped_samples():
     """num_labels bound larger than the labels present, unlabeled (0) samples, min_pixnum dropping small clusters."""
     g = torch.Generator().manual_seed(5)
