@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--tracer", type=int, default=1, help="produce gau_related_pixels each forward like the reference")
     ap.add_argument("--async-binning", type=int, default=1,
                     help="size the binning workspace from the previous view instead of a blocking read of R")
+    ap.add_argument("--lazy-maps", type=int, default=0,
+                    help="1: evaluate render()'s seven derived normal/depth maps on first access (this step never reads "
+                         "them) instead of inside render() like the reference (default 0 = reference behaviour)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,6 +133,7 @@ def main():
     rasterizer.set_async_binning(bool(args.async_binning))
     scene, cams, cfg = scenes.config_scene(args.config)
     trainer = SegTrainer(scene, cams[:16], device=dev, sample_batchsize=8192, use_class_feat=True, rank=rank, world=world)
+    trainer.pipe.lazy_maps = bool(args.lazy_maps)
     L = lib()
 
     for it in range(args.warmup):
@@ -196,7 +200,8 @@ def main():
                                       f"sample batch 8192, 2 single-view + 1 3-D contrastive loss, Adam on [P,F]",
                           "parallelism": f"dp{world} (one view per rank, RCCL all-reduce of the [P,F] gradient)",
                           "arithmetic_mode": args.mode, "tracer": bool(args.tracer),
-                          "async_binning": bool(args.async_binning)},
+                          "async_binning": bool(args.async_binning),
+                          "derived_render_maps": "on first access (never read by this step)" if args.lazy_maps else "inside render(), like the reference"},
                "roofline": roof}
         if not args.no_cpu_baseline:
             try:

@@ -53,11 +53,25 @@ class SegGaussianModel:
         self.class_feat = class_feat
         self._features_cat = None
         self._seg_cache = None
+        self._act_cache = {}
 
     get_xyz = property(lambda s: s._xyz)
-    get_scaling = property(lambda s: torch.exp(s._scaling))
-    get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation))
-    get_opacity = property(lambda s: torch.sigmoid(s._opacity))
+
+    def _frozen(self, name, src, fn):
+        """Activation of a frozen parameter: loop-invariant in this stage, evaluated once (the reference re-runs
+        exp / sigmoid / normalize on all P Gaussians every iteration, scene/gaussian_model.py:109-138)."""
+        if src.requires_grad:
+            return fn(src)
+        hit = self._act_cache.get(name)
+        if hit is None or hit[0] is not src or hit[1] != src._version:
+            hit = (src, src._version, fn(src))
+            self._act_cache[name] = hit
+        return hit[2]
+
+    get_scaling = property(lambda s: s._frozen("scaling", s._scaling, torch.exp))
+    get_rotation = property(lambda s: s._frozen("rotation", s._rotation, torch.nn.functional.normalize))
+    get_opacity = property(lambda s: s._frozen("opacity", s._opacity, torch.sigmoid))
+
     @property
     def get_features(self):
         # reference: torch.cat((dc, rest), dim=1) on every call (scene/gaussian_model.py:128-131).  Both parts are

@@ -6,6 +6,7 @@ restated here in torch (thin elementwise work)."""
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -14,11 +15,31 @@ from . import rasterizer as _rz
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
+_LAZY_KEYS = ("rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal", "rend_depth", "rend_median_depth")
+
+
 class RenderPackage(dict):
-    """The dict ``render()`` returns.  ``gau_related_pixels`` is sliced to its valid length on first access (the
-    slice needs the count on the host, i.e. a device sync — the reference pays it inside every forward, :106)."""
+    """The dict ``render()`` returns (same 13 keys as the reference).
+
+    * ``gau_related_pixels`` is sliced to its valid length on first access (the slice needs the count on the host,
+      i.e. a device sync — the reference pays it inside every forward, :106).
+    * Opt-in (``pipe.lazy_maps = True`` or ``ISR_LAZY_MAPS=1``): the seven maps derived from ``allmap`` (:127-167)
+      are evaluated on first access of any of them, under the grad mode ``render()`` was called in
+      (``train_semantic`` never reads them).  Default: inside ``render()`` like the reference."""
+
+    _pending = None
+
+    def _materialize(self):
+        job = self._pending
+        if job is not None:
+            self._pending = None
+            cam, allmap, depth_ratio, grad_mode = job
+            with torch.set_grad_enabled(grad_mode):
+                dict.update(self, post_process(cam, allmap, depth_ratio))
 
     def __getitem__(self, k):
+        if self._pending is not None and k in _LAZY_KEYS:
+            self._materialize()
         v = dict.__getitem__(self, k)
         if k == "gau_related_pixels" and getattr(v, "_isr_last_index", None) is not None:
             v = _rz.slice_tracer(v)
@@ -27,6 +48,16 @@ class RenderPackage(dict):
 
     def get(self, k, default=None):
         return self[k] if k in self else default
+
+    def __iter__(self):          # also routes dict(pkg) / {**pkg} through __getitem__
+        self._materialize()
+        return dict.__iter__(self)
+
+    def items(self):
+        return [(k, self[k]) for k in dict.keys(self)]
+
+    def values(self):
+        return [self[k] for k in dict.keys(self)]
 
 
 _RAY_CACHE = {}
@@ -150,5 +181,9 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
 
     rets = RenderPackage({"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0,
                           "radii": radii, "seg_feature": extra_attrs, "gau_related_pixels": gau_related_pixels})
-    rets.update(post_process(viewpoint_camera, allmap, pipe.depth_ratio))
+    if getattr(pipe, "lazy_maps", False) or os.environ.get("ISR_LAZY_MAPS", "0") == "1":
+        dict.update(rets, dict.fromkeys(_LAZY_KEYS))
+        rets._pending = (viewpoint_camera, allmap, pipe.depth_ratio, torch.is_grad_enabled())
+    else:
+        rets.update(post_process(viewpoint_camera, allmap, pipe.depth_ratio))
     return rets

@@ -90,3 +90,31 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_render_package_evaluates_derived_maps_on_first_access(golden_dir):
+    """The seven allmap-derived entries of render()'s dict are computed on first access, under the grad mode of the
+    render() call, and dict(pkg) / items() see real tensors."""
+    from instascene_amd import render as R
+    from instascene_amd import scenes
+    z = np.load(os.path.join(golden_dir, "render_post.npz"))
+    c = np.load(os.path.join(golden_dir, "cameras.npz"))
+    W, H = (int(v) for v in c["wh0"])
+    cam = scenes.Camera(W, H, float(c["fov0"][0]), float(c["fov0"][1]), torch.tensor(c["wvt0"]),
+                        torch.tensor(c["proj0"]), torch.tensor(c["full0"]), torch.tensor(c["center0"]))
+    allmap = torch.tensor(z["c0_r0_allmap"]).requires_grad_(True)
+    pkg = R.RenderPackage({"render": torch.zeros(3, 4, 4)})
+    dict.update(pkg, dict.fromkeys(R._LAZY_KEYS))
+    pkg._pending = (cam, allmap, 0.0, True)
+    assert set(pkg.keys()) == {"render", *R._LAZY_KEYS}
+    with torch.no_grad():                       # accessed later under no_grad: still differentiable
+        a = pkg["rend_alpha"]
+    assert pkg._pending is None and a.requires_grad
+    want = R.post_process(cam, allmap, 0.0)
+    for k in R._LAZY_KEYS:
+        assert torch.equal(pkg[k], want[k])
+    pkg2 = R.RenderPackage({"render": torch.zeros(3, 4, 4)})
+    dict.update(pkg2, dict.fromkeys(R._LAZY_KEYS))
+    pkg2._pending = (cam, allmap, 0.0, False)
+    assert all(v is not None for v in dict(pkg2).values()) and not pkg2["surf_normal"].requires_grad
+    assert all(v is not None for _, v in pkg2.items())
