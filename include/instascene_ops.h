@@ -62,6 +62,28 @@ int iso_rownorm(long long N, int F, float eps, int backward, const float* x, con
 int iso_rownorm2(long long N, int F, float eps1, float eps2, int backward, const float* x, const float* gy,
                  const float* gz, float* out1, float* out2, void* stream);
 
+/* render()'s post-processing of the rasterizer's 7-channel allmap (gaussian_renderer/__init__.py:127-167 with
+ * utils/point_utils.py:10-40) in two streaming kernels each way.  All maps are [C,H,W] row-major device arrays:
+ *   rend_alpha[1] = allmap[1]          rend_normal[3] = R_view . allmap[2:5]     rend_dist[1] = allmap[6]
+ *   rend_depth[1] = nan_to_num(allmap[0]/allmap[1])      rend_median[1] = nan_to_num(allmap[5])
+ *   surf_depth[1] = rend_depth*(1-depth_ratio) + depth_ratio*rend_median
+ *   surf_normal[3] = normalize(cross(P[y+1,x]-P[y-1,x], P[y,x+1]-P[y,x-1])) * alpha (alpha detached), 0 on the border,
+ *                    P = surf_depth * rays_d + rays_o
+ * viewmatrix: the row-major 4x4 world_view_transform of the reference camera; rays_d [H*W,3], rays_o [3]: the per-pixel
+ * ray table of utils/point_utils.py:10-27 (static per camera).
+ * backward: g_* are the upstream gradients of the seven maps (each may be NULL = zero); scratch: [6,H,W] floats, needed
+ * when g_surf_normal is given; writes all of dL_dallmap[7,H,W].  Where allmap[0]/allmap[1] is not finite the gradient
+ * is 0 (torch autograd gives NaN there). */
+int iso_render_post_forward(int W, int H, float depth_ratio, const float* allmap, const float* viewmatrix,
+                            const float* rays_d, const float* rays_o, float* rend_alpha, float* rend_normal,
+                            float* rend_dist, float* surf_depth, float* surf_normal, float* rend_depth,
+                            float* rend_median, void* stream);
+int iso_render_post_backward(int W, int H, float depth_ratio, const float* allmap, const float* viewmatrix,
+                             const float* rays_d, const float* rays_o, const float* surf_depth, const float* g_alpha,
+                             const float* g_normal, const float* g_dist, const float* g_surf_depth,
+                             const float* g_surf_normal, const float* g_depth, const float* g_median, float* scratch,
+                             float* dL_dallmap, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

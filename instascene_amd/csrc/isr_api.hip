@@ -7,6 +7,7 @@
 #include "isr_backward.hip"
 #include "iso_knn.hip"
 #include "iso_contrastive.hip"
+#include "iso_post.hip"
 #include "../../include/instascene_rasterizer.h"
 #include "../../include/instascene_ops.h"
 
@@ -357,6 +358,50 @@ int iso_rownorm(long long N, int F, float eps, int backward, const float* x, con
         hipLaunchKernelGGL(iso::rn_scalar, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, F, eps, backward, x, dy, out);
     }
     ISR_LAUNCH_CHECK("iso_rownorm");
+    return ISR_OK;
+}
+
+int iso_render_post_forward(int W, int H, float depth_ratio, const float* allmap, const float* viewmatrix,
+                            const float* rays_d, const float* rays_o, float* rend_alpha, float* rend_normal,
+                            float* rend_dist, float* surf_depth, float* surf_normal, float* rend_depth,
+                            float* rend_median, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (W <= 0 || H <= 0) return fail(ISR_EINVAL, "bad image size %dx%d", W, H);
+    if (!allmap || !viewmatrix || !rays_d || !rays_o || !rend_alpha || !rend_normal || !rend_dist || !surf_depth ||
+        !surf_normal || !rend_depth || !rend_median)
+        return fail(ISR_EINVAL, "render_post_forward: null pointer");
+    const long long N = (long long)W * H;
+    const unsigned blocks = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(iso::pp_maps, dim3(blocks), dim3(256), 0, s, N, depth_ratio, 1.0f - depth_ratio, allmap, viewmatrix,
+                       rend_alpha, rend_normal, rend_dist, surf_depth, rend_depth, rend_median);
+    ISR_LAUNCH_CHECK("pp_maps");
+    hipLaunchKernelGGL(iso::pp_surf_normal, dim3(blocks), dim3(256), 0, s, W, H, surf_depth, rend_alpha, rays_d, rays_o,
+                       surf_normal);
+    ISR_LAUNCH_CHECK("pp_surf_normal");
+    return ISR_OK;
+}
+
+int iso_render_post_backward(int W, int H, float depth_ratio, const float* allmap, const float* viewmatrix,
+                             const float* rays_d, const float* rays_o, const float* surf_depth, const float* g_alpha,
+                             const float* g_normal, const float* g_dist, const float* g_surf_depth,
+                             const float* g_surf_normal, const float* g_depth, const float* g_median, float* scratch,
+                             float* dL_dallmap, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (W <= 0 || H <= 0) return fail(ISR_EINVAL, "bad image size %dx%d", W, H);
+    if (!allmap || !viewmatrix || !rays_d || !rays_o || !surf_depth || !dL_dallmap)
+        return fail(ISR_EINVAL, "render_post_backward: null pointer");
+    if (g_surf_normal && !scratch) return fail(ISR_EINVAL, "render_post_backward: scratch [6,H,W] needed with g_surf_normal");
+    const long long N = (long long)W * H;
+    const unsigned blocks = (unsigned)((N + 255) / 256);
+    if (g_surf_normal) {
+        hipLaunchKernelGGL(iso::pp_bwd_stencil, dim3(blocks), dim3(256), 0, s, W, H, surf_depth, allmap + N, rays_d, rays_o,
+                           g_surf_normal, scratch);
+        ISR_LAUNCH_CHECK("pp_bwd_stencil");
+    }
+    hipLaunchKernelGGL(iso::pp_bwd_maps, dim3(blocks), dim3(256), 0, s, W, H, depth_ratio, 1.0f - depth_ratio, allmap,
+                       viewmatrix, rays_d, g_surf_normal ? scratch : (const float*)nullptr, g_alpha, g_normal, g_dist,
+                       g_surf_depth, g_depth, g_median, dL_dallmap);
+    ISR_LAUNCH_CHECK("pp_bwd_maps");
     return ISR_OK;
 }
 

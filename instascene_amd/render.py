@@ -5,11 +5,13 @@
 restated here in torch (thin elementwise work)."""
 from __future__ import annotations
 
+import ctypes
 import math
 import os
 
 import torch
 
+from . import _lib
 from .contrastive import row_normalize
 from . import rasterizer as _rz
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
@@ -102,8 +104,64 @@ def depth_to_normal(view, depth):
     return output
 
 
+class _RenderPost(torch.autograd.Function):
+    """The seven derived maps in two HIP kernels each way (``iso_render_post_forward/backward``)."""
+
+    @staticmethod
+    def forward(ctx, allmap, viewmatrix, rays_d, rays_o, depth_ratio):
+        L = _lib.lib()
+        am = allmap.contiguous().float()
+        _, H, W = am.shape
+        # one allocation, seven [C,H,W] views
+        alpha, normal, dist, surf, snorm, depth, median = torch.empty((11, H, W), dtype=torch.float32,
+                                                                      device=am.device).split((1, 3, 1, 1, 3, 1, 1))
+        vm = viewmatrix.contiguous().float()
+        with torch.cuda.device(am.device):
+            _lib.check(L.iso_render_post_forward(W, H, float(depth_ratio), _ptr(am), _ptr(vm), _ptr(rays_d), _ptr(rays_o),
+                                                 _ptr(alpha), _ptr(normal), _ptr(dist), _ptr(surf), _ptr(snorm),
+                                                 _ptr(depth), _ptr(median), _stream()), "iso_render_post_forward")
+        ctx.save_for_backward(am, vm, rays_d, rays_o, surf)
+        ctx.ratio = float(depth_ratio)
+        ctx.set_materialize_grads(False)
+        return alpha, normal, dist, surf, snorm, depth, median
+
+    @staticmethod
+    def backward(ctx, g_alpha, g_normal, g_dist, g_surf, g_snorm, g_depth, g_median):
+        am, vm, rays_d, rays_o, surf = ctx.saved_tensors
+        if all(g is None for g in (g_alpha, g_normal, g_dist, g_surf, g_snorm, g_depth, g_median)):
+            return None, None, None, None, None
+        L = _lib.lib()
+        _, H, W = am.shape
+        c = lambda g: None if g is None else g.contiguous().float()
+        g_alpha, g_normal, g_dist, g_surf = c(g_alpha), c(g_normal), c(g_dist), c(g_surf)
+        g_snorm, g_depth, g_median = c(g_snorm), c(g_depth), c(g_median)
+        scratch = torch.empty((6, H, W), dtype=torch.float32, device=am.device) if g_snorm is not None else None
+        out = torch.empty_like(am)
+        with torch.cuda.device(am.device):
+            _lib.check(L.iso_render_post_backward(W, H, ctx.ratio, _ptr(am), _ptr(vm), _ptr(rays_d), _ptr(rays_o), _ptr(surf),
+                                                  _ptr(g_alpha), _ptr(g_normal), _ptr(g_dist), _ptr(g_surf), _ptr(g_snorm),
+                                                  _ptr(g_depth), _ptr(g_median), _ptr(scratch), _ptr(out), _stream()),
+                       "iso_render_post_backward")
+        return out, None, None, None, None
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
 def post_process(viewpoint_camera, allmap, depth_ratio):
-    """gaussian_renderer/__init__.py:127-167"""
+    """gaussian_renderer/__init__.py:127-167.  CUDA tensors: two HIP kernels each way; the torch restatement below
+    serves host-side tensors (it is what tests/golden/render_post.npz pins)."""
+    if allmap.is_cuda:
+        rays_d, rays_o = _camera_rays(viewpoint_camera, allmap.device)
+        alpha, normal, dist, surf, snorm, depth, median = _RenderPost.apply(
+            allmap, viewpoint_camera.world_view_transform, rays_d.contiguous(), rays_o.contiguous(), float(depth_ratio))
+        return {'rend_alpha': alpha, 'rend_normal': normal, 'rend_dist': dist, 'surf_depth': surf,
+                'surf_normal': snorm, 'rend_depth': depth, 'rend_median_depth': median}
     render_alpha = allmap[1:2]
     render_normal = allmap[2:5]
     # (n.permute(1,2,0) @ R^T).permute(2,0,1) of the reference (:132), written as three broadcast FMAs — a [N,3]x[3,3]

@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""How long does the host need to ENQUEUE a train step vs how long the GPU needs to run it?
+usage: host_overhead.py [--lazy-maps 0|1] [--steps K]"""
+import argparse, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from instascene_amd import scenes, rasterizer
+from instascene_amd.harness import SegTrainer
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--lazy-maps", type=int, default=0)
+ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--delay-us", type=float, default=0.0, help="busy-wait on the host after render() returns")
+ap.add_argument("--delay-at", default="render")
+ap.add_argument("--scale", type=float, default=1.0, help="shrink the scene: the step becomes host-bound")
+a = ap.parse_args()
+rasterizer.set_mode("fast"); rasterizer.set_tracer(True); rasterizer.set_async_binning(True)
+scene, cams, cfg = scenes.config_scene("C3", a.scale)
+tr = SegTrainer(scene, cams[:16], device="cuda", sample_batchsize=8192, use_class_feat=True)
+tr.pipe.lazy_maps = bool(a.lazy_maps)
+from instascene_amd import harness as _h
+_ev = []
+def _mark(tag):
+    e = torch.cuda.Event(enable_timing=True); e.record(); _ev.append((tag, e))
+_orig_render, _orig_ar = _h.render, _h.allreduce_grads
+def _spin(us):
+    t = time.perf_counter()
+    while (time.perf_counter() - t) * 1e6 < us:
+        pass
+def _render(*x, **k):
+    if a.delay_at == "before": _spin(a.delay_us)
+    _mark("start"); r = _orig_render(*x, **k)
+    if a.delay_at == "render": _spin(a.delay_us)
+    _mark("render"); return r
+def _ar(*x, **k):
+    _mark("losses+backward"); return _orig_ar(*x, **k)
+_h.render, _h.allreduce_grads = _render, _ar
+_orig_opt = tr.opt.step
+def _opt(*x, **k):
+    if a.delay_at == "opt": _spin(a.delay_us)
+    r = _orig_opt(*x, **k); _mark("adam"); return r
+tr.opt.step = _opt
+_blocked = [0.0, 0]
+_orig_verify = rasterizer._verify_pending
+def _timed_verify(key):
+    t = time.perf_counter()
+    _orig_verify(key)
+    _blocked[0] += time.perf_counter() - t
+    _blocked[1] += 1
+rasterizer._verify_pending = _timed_verify
+for it in range(5):
+    tr.step(it)
+_blocked[0] = 0.0
+_ev.clear()
+torch.cuda.synchronize()
+ms0 = torch.cuda.memory_stats()
+t0 = time.perf_counter()
+for it in range(5, 5 + a.steps):
+    tr.step(it)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("host enqueue %.3f ms/step, total %.3f ms/step, tail after last enqueue %.3f ms" %
+      (1e3 * (t1 - t0) / a.steps, 1e3 * (t2 - t0) / a.steps, 1e3 * (t2 - t1)))
+print("host blocked on the binning-size event: %.3f ms/step" % (1e3 * _blocked[0] / a.steps))
+ms1 = torch.cuda.memory_stats()
+for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "allocation.all.allocated", "segment.all.allocated"):
+    print(k, ms1.get(k, 0) - ms0.get(k, 0))
+print("reserved GB %.2f allocated peak GB %.2f" % (ms1["reserved_bytes.all.current"] / 2**30, ms1["allocated_bytes.all.peak"] / 2**30))
+acc = {}
+for (t0_, e0), (t1_, e1) in zip(_ev[:-1], _ev[1:]):
+    key = t1_ if t1_ != "start" else "between steps"
+    acc[key] = acc.get(key, 0.0) + e0.elapsed_time(e1)
+print("GPU phases (ms/step):", {k: round(v / a.steps, 3) for k, v in acc.items()})

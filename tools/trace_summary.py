@@ -21,3 +21,14 @@ for s, e, k in sel:
     agg[k[:90]][1] += 1
 for k, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     print("%9.1f us/step  n/step %5.1f  %s" % (t / n / 1e3, c / n, k))
+# idle time on the device, attributed to the kernel that follows the gap
+gaps = collections.defaultdict(lambda: [0, 0])
+end = sel[0][1]
+for s, e, k in sel[1:]:
+    if s > end:
+        gaps[k[:70]][0] += s - end
+        gaps[k[:70]][1] += 1
+    end = max(end, e)
+print("idle before kernel (us/step, count/step):")
+for k, (t, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:25]:
+    print("%9.1f  %5.1f  %s" % (t / n / 1e3, c / n, k))
