@@ -50,8 +50,9 @@ const char* isr_last_error(void);
 int isr_version(void);
 
 /* ---- optional per-kernel timing (HIP events on the launch stream), used by bench.py.
- * isr_profile_enable(1) clears and starts recording; isr_profile_summary() synchronises and writes
- * one "kernel_name launches total_ms" line per kernel into buf (returns bytes written). */
+ * isr_profile_enable(1) clears and starts recording every kernel, (2) only the forward blend kernel (two events per
+ * step instead of ~25: the timed region of bench.py), (0) stops; isr_profile_summary() synchronises and writes one
+ * "kernel_name launches total_ms" line per kernel into buf (returns bytes written). */
 void isr_profile_enable(int on);
 size_t isr_profile_summary(char* buf, size_t len);
 

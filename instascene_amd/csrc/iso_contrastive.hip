@@ -27,7 +27,7 @@ struct CState {          // carved from the caller's state buffer
     float* f;            // [N,F] normalised features
     float* inv;          // [N]
     int* col;            // [N] column id or -1
-    int* hist;           // [K+2] raw-label histogram
+    int* hist;           // [K+4] raw-label histogram (K+2 slots) + two "last workgroup" tickets
     float* U;            // [K,F]
     float* phi;          // [K]
     float* cnt;          // [K] surviving samples per column (0 = column absent)
@@ -35,6 +35,8 @@ struct CState {          // carved from the caller's state buffer
     float* part;         // [blocks] loss partials
     float* dU;           // [K,F]
     float* split;        // [CK_NSPLIT, K, F] GEMM partials
+    float* phi_part;     // [ceil(N/256), K] per-workgroup partial sums of |f - u|
+    float* Us;           // [K,F] U / phi (0 for absent columns): B operand of the backward
 };
 inline CState cstate(void* buf, int N, int F, int K) {
     char* p = (char*)buf;
@@ -42,7 +44,7 @@ inline CState cstate(void* buf, int N, int F, int K) {
     s.f = isr::carve<float>(p, (size_t)N * F);
     s.inv = isr::carve<float>(p, N);
     s.col = isr::carve<int>(p, N);
-    s.hist = isr::carve<int>(p, K + 2);
+    s.hist = isr::carve<int>(p, K + 4);
     s.U = isr::carve<float>(p, (size_t)K * F);
     s.phi = isr::carve<float>(p, K);
     s.cnt = isr::carve<float>(p, K);
@@ -50,11 +52,13 @@ inline CState cstate(void* buf, int N, int F, int K) {
     s.part = isr::carve<float>(p, (size_t)(N + 31) / 32 + 1);
     s.dU = isr::carve<float>(p, (size_t)K * F);
     s.split = isr::carve<float>(p, (size_t)CK_NSPLIT * K * F);
+    s.phi_part = isr::carve<float>(p, (size_t)((N + 255) / 256) * K);
+    s.Us = isr::carve<float>(p, (size_t)K * F);
     return s;
 }
 inline size_t cstate_bytes(int N, int F, int K) {
     CState s = cstate((void*)0, N, F, K);
-    return (size_t)(s.split + (size_t)CK_NSPLIT * K * F) + 256;
+    return (size_t)(s.Us + (size_t)K * F) + 256;
 }
 
 __device__ __forceinline__ float block_sum_256(float v, float* s_red) {
@@ -71,31 +75,72 @@ __device__ __forceinline__ long long load_label(const void* labels, int is64, in
     return is64 ? ((const long long*)labels)[i] : (long long)((const int*)labels)[i];
 }
 
+constexpr int CK_LDS_HIST = 2048;
 __global__ __launch_bounds__(256) void ck_count(int N, int K, int shift, const void* __restrict__ labels, int is64,
                                                 int* __restrict__ hist) {
+    // per-workgroup histogram in LDS, one global atomic per non-empty bin (a few dozen labels: 8192 global atomics
+    // on ~65 addresses serialise in L2)
+    __shared__ int s_h[CK_LDS_HIST];
+    const bool lds = K + 2 <= CK_LDS_HIST;
+    if (lds) {
+        for (int b = threadIdx.x; b < K + 2; b += 256) s_h[b] = 0;
+        __syncthreads();
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const long long c = load_label(labels, is64, i) - shift;      // histogram slot c+1 (slot 0: label == shift-1, e.g. 0)
-    if (c >= -1 && c < K) atomicAdd(hist + (int)(c + 1), 1);
+    if (i < N) {
+        const long long c = load_label(labels, is64, i) - shift;      // histogram slot c+1 (slot 0: label == shift-1, e.g. 0)
+        if (c >= -1 && c < K) {
+            if (lds) atomicAdd(&s_h[(int)(c + 1)], 1);
+            else atomicAdd(hist + (int)(c + 1), 1);
+        }
+    }
+    if (lds) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < K + 2; b += 256)
+            if (s_h[b] != 0) atomicAdd(hist + b, s_h[b]);
+    }
 }
 
+// LPR lanes per sample (float4 each per step) when F % 4 == 0, one lane per sample otherwise
 __global__ __launch_bounds__(256) void ck_normalize(int N, int F, int K, int shift, int consider_negative, int min_pixnum,
                                                     const float* __restrict__ x, const void* __restrict__ labels, int is64,
                                                     const int* __restrict__ hist, float* __restrict__ f,
-                                                    float* __restrict__ inv, int* __restrict__ col) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const long long lab = load_label(labels, is64, i);
-    const long long c = lab - shift;
-    bool ok = (consider_negative || lab > 0) && c >= 0 && c < K;
-    if (ok) ok = hist[(int)c + 1] > min_pixnum;
-    col[i] = ok ? (int)c : -1;
-    const float* xi = x + (size_t)i * F;
+                                                    float* __restrict__ inv, int* __restrict__ col, int lpr) {
+    const int i = (int)(((long long)blockIdx.x * 256 + threadIdx.x) / lpr);
+    const int sub = threadIdx.x & (lpr - 1);
+    const bool ok_row = i < N;
+    const float* xi = x + (size_t)(ok_row ? i : 0) * F;
     float s = 0.0f;
-    for (int ch = 0; ch < F; ch++) s += xi[ch] * xi[ch];
+    if (lpr > 1) {
+        const int q = F >> 2;
+        for (int c = sub; c < q; c += lpr) {
+            const float4 v = ok_row ? reinterpret_cast<const float4*>(xi)[c] : make_float4(0, 0, 0, 0);
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        for (int o = lpr >> 1; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    } else if (ok_row) {
+        for (int ch = 0; ch < F; ch++) s += xi[ch] * xi[ch];
+    }
+    if (!ok_row) return;
     const float r = 1.0f / (__builtin_sqrtf(s) + 1e-9f);
-    inv[i] = r;
-    for (int ch = 0; ch < F; ch++) f[(size_t)i * F + ch] = xi[ch] * r;
+    if (sub == 0) {
+        const long long lab = load_label(labels, is64, i);
+        const long long c = lab - shift;
+        bool ok = (consider_negative || lab > 0) && c >= 0 && c < K;
+        if (ok) ok = hist[(int)c + 1] > min_pixnum;
+        col[i] = ok ? (int)c : -1;
+        inv[i] = r;
+    }
+    if (lpr > 1) {
+        const int q = F >> 2;
+        float4* fo = reinterpret_cast<float4*>(f + (size_t)i * F);
+        for (int c = sub; c < q; c += lpr) {
+            const float4 v = reinterpret_cast<const float4*>(xi)[c];
+            fo[c] = make_float4(v.x * r, v.y * r, v.z * r, v.w * r);
+        }
+    } else {
+        for (int ch = 0; ch < F; ch++) f[(size_t)i * F + ch] = xi[ch] * r;
+    }
 }
 
 // C[k][c] (partial over a slice of the samples) = sum_i A[i][k] * f[i][c]
@@ -165,33 +210,71 @@ __global__ __launch_bounds__(256) void ck_finish_du(int F, int K, const float* _
     dU[e] = cnt[k] > 0.0f ? s / phi[k] : 0.0f;
 }
 
-__global__ __launch_bounds__(256) void ck_phi(int N, int F, const float* __restrict__ f, const int* __restrict__ col,
+__device__ __forceinline__ float ld_agent(const float* p) {      // bypass the non-coherent per-CU cache
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// phi_c = clip(10 * sum_{i in c} |f_i - u_c| / (n_c log(n_c + lambda)), .5, 1)      (:60-66)
+// One thread per sample computes its distance; the workgroup sums them per column in sample order (fixed order,
+// no float atomics), and the LAST workgroup to finish adds the per-workgroup partials in workgroup order and writes
+// phi and Us = U / phi.  (The previous layout — one workgroup per column scanning all N samples — was a 35 us
+// latency chain for 8192 samples.)
+__global__ __launch_bounds__(256) void ck_phi(int N, int F, int K, const float* __restrict__ f, const int* __restrict__ col,
                                               const float* __restrict__ U, const float* __restrict__ cnt,
-                                              float temp_lambda, float* __restrict__ phi) {
-    __shared__ float s_red[4];
-    __shared__ float s_u[1024];
-    const int k = blockIdx.x;
-    for (int ch = threadIdx.x; ch < F; ch += 256) s_u[ch] = U[(size_t)k * F + ch];
-    __syncthreads();
+                                              float temp_lambda, float* __restrict__ part, int* __restrict__ ticket,
+                                              float* __restrict__ phi, float* __restrict__ Us) {
+    __shared__ __attribute__((aligned(16))) float s_d[256];
+    __shared__ __attribute__((aligned(16))) int s_c[256];
+    __shared__ int s_last;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int c = i < N ? col[i] : -1;
     float d = 0.0f;
-    for (int i0 = threadIdx.x; i0 < N; i0 += 256 * 8) {
-        int cc[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) cc[u] = (i0 + 256 * u < N) ? col[i0 + 256 * u] : -1;     // 8 loads in flight
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            if (cc[u] != k) continue;
-            const int i = i0 + 256 * u;
-            float s = 0.0f;
-            for (int ch = 0; ch < F; ch++) {
-                const float t = f[(size_t)i * F + ch] - s_u[ch];
-                s += t * t;
+    if (c >= 0) {
+        const float* fi = f + (size_t)i * F;
+        const float* uc = U + (size_t)c * F;
+        float s = 0.0f;
+        if ((F & 3) == 0) {
+            for (int q = 0; q < (F >> 2); q++) {
+                const float4 a = reinterpret_cast<const float4*>(fi)[q], b = reinterpret_cast<const float4*>(uc)[q];
+                const float t0 = a.x - b.x, t1 = a.y - b.y, t2 = a.z - b.z, t3 = a.w - b.w;
+                s += t0 * t0; s += t1 * t1; s += t2 * t2; s += t3 * t3;
             }
-            d += __builtin_sqrtf(s);
+        } else {
+            for (int ch = 0; ch < F; ch++) { const float t = fi[ch] - uc[ch]; s += t * t; }
         }
+        d = __builtin_sqrtf(s);
     }
-    const float dsum = block_sum_256(d, s_red);
-    if (threadIdx.x == 0) {
+    s_d[threadIdx.x] = d;
+    s_c[threadIdx.x] = c;
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float acc = 0.0f;
+#pragma unroll 4
+        for (int j = 0; j < 256; j += 4) {      // 128-bit LDS broadcast reads; sample order
+            const int4 cc = *reinterpret_cast<const int4*>(s_c + j);
+            const float4 dd = *reinterpret_cast<const float4*>(s_d + j);
+            if (cc.x == k) acc += dd.x;
+            if (cc.y == k) acc += dd.y;
+            if (cc.z == k) acc += dd.z;
+            if (cc.w == k) acc += dd.w;
+        }
+        part[(size_t)blockIdx.x * K + k] = acc;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float dsum = 0.0f;
+        for (unsigned b0 = 0; b0 < gridDim.x; b0 += 8) {     // eight loads in flight, added in workgroup order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = (b0 + u < gridDim.x) ? ld_agent(part + (size_t)(b0 + u) * K + k) : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; u++) dsum += v[u];
+        }
         const float n = cnt[k];
         float p = 1.0f;
         if (n > 0.0f) {
@@ -199,6 +282,13 @@ __global__ __launch_bounds__(256) void ck_phi(int N, int F, const float* __restr
             p = p < 0.5f ? 0.5f : (p > 1.0f ? 1.0f : p);
         }
         phi[k] = p;
+        s_d[k & 255] = p;        // only used when K <= 256 (below)
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * F; e += 256) {
+        const int k = e / F;
+        const float p = K <= 256 ? s_d[k] : ld_agent(phi + k);
+        Us[e] = cnt[k] > 0.0f ? U[e] / p : 0.0f;
     }
 }
 
@@ -262,6 +352,106 @@ __global__ __launch_bounds__(64) void ck_similarity(int N, int F, int K, const f
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
 
+// Fast path of ck_similarity for F <= 32 and K <= 32*NT (NT <= 3): the sample fragment (A operand) is loaded once,
+// all NT column tiles are kept in registers (one sweep instead of two), row sums use DPP adds inside a 16-lane row plus
+// one cross-row exchange, and the LAST workgroup reduces the loss partials in workgroup order (no extra launch).
+template <int CTRL>
+__device__ __forceinline__ float ck_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {     // sum over the 32 lanes of this lane's half-wave
+    v = ck_dpp_add<0xB1>(v);       // quad_perm [1,0,3,2]
+    v = ck_dpp_add<0x4E>(v);       // quad_perm [2,3,0,1]
+    v = ck_dpp_add<0x141>(v);      // row_half_mirror
+    v = ck_dpp_add<0x140>(v);      // row_mirror
+    return v + __shfl_xor(v, 16);
+}
+
+template <int NT>
+__global__ __launch_bounds__(64) void ck_similarity_small(int N, int F, int K, const float* __restrict__ f,
+                                                           const float* __restrict__ U, const float* __restrict__ phi,
+                                                           const float* __restrict__ cnt, const int* __restrict__ colid,
+                                                           float* __restrict__ G, float* __restrict__ part,
+                                                           int* __restrict__ ticket, float* __restrict__ loss) {
+    const int lane = threadIdx.x & 63;
+    const int i0 = blockIdx.x * 32;
+    const int arow = i0 + (lane & 31), kk = lane >> 5;
+    float a[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const int ch = 2 * s + kk;
+        a[s] = (arow < N && ch < F) ? f[(size_t)arow * F + ch] : 0.0f;
+    }
+    int lab[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        lab[r] = row < N ? colid[row] : -1;
+    }
+    f32x16 acc[NT];
+    bool present[NT];
+    float ph[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; jt++) {
+        const int col = jt * 32 + (lane & 31);
+        float b[16];
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const int ch = 2 * s + kk;
+            b[s] = (col < K && ch < F) ? U[(size_t)col * F + ch] : 0.0f;
+        }
+        present[jt] = col < K && cnt[col < K ? col : 0] > 0.0f;
+        ph[jt] = present[jt] ? phi[col] : 1.0f;
+        f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 16; s++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], c, 0, 0, 0);
+        acc[jt] = c;
+    }
+    float lpart = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float z[NT], e[NT], esum = 0.0f;
+#pragma unroll
+        for (int jt = 0; jt < NT; jt++) {
+            z[jt] = acc[jt][r] / ph[jt];
+            e[jt] = (present[jt] && lab[r] >= 0) ? __expf(z[jt]) : 0.0f;
+            esum += e[jt];
+        }
+        const float S = half_wave_sum(esum) + 1e-9f;
+#pragma unroll
+        for (int jt = 0; jt < NT; jt++) {
+            const int col = jt * 32 + (lane & 31);
+            if (row < N && col < K) {
+                float g = 0.0f;
+                if (lab[r] >= 0 && present[jt]) {
+                    const bool pos = (col == lab[r]);
+                    g = e[jt] / S - (pos ? 1.0f : 0.0f);
+                    if (pos) lpart += __logf(S) - z[jt];     // -log(e_pos / S)
+                }
+                G[(size_t)row * K + col] = g;
+            }
+        }
+    }
+    float tot = lpart;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
+    int last = 0;
+    if (lane == 0) {
+        part[blockIdx.x] = tot;
+        __threadfence();
+        last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+    }
+    last = __shfl(last, 0);
+    if (!last) return;
+    __threadfence();
+    float t = 0.0f;                      // fixed order: lane-strided, then the same butterfly
+    for (unsigned b = lane; b < gridDim.x; b += 64) t += ld_agent(part + b);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) loss[0] = t;
+}
+
 __global__ __launch_bounds__(256) void ck_loss_reduce(int nb, const float* __restrict__ part, float* __restrict__ loss) {
     __shared__ float s_red[4];
     float a = 0.0f;
@@ -272,7 +462,7 @@ __global__ __launch_bounds__(256) void ck_loss_reduce(int nb, const float* __res
 
 // dF = G.(U/phi) [+ dU[y]/n_y];  dX = g * dF * inv.   one wave x 32 samples per workgroup, 32-channel tiles.
 __global__ __launch_bounds__(64) void ck_grad_f(int N, int F, int K, const float* __restrict__ G,
-                                                 const float* __restrict__ U, const float* __restrict__ phi,
+                                                 const float* __restrict__ Us,
                                                  const float* __restrict__ cnt, const float* __restrict__ dU,
                                                  const int* __restrict__ colid, const float* __restrict__ inv,
                                                  const float* __restrict__ gloss, int use_mean, float* __restrict__ dX) {
@@ -280,15 +470,19 @@ __global__ __launch_bounds__(64) void ck_grad_f(int N, int F, int K, const float
     const int i0 = blockIdx.x * 32;
     const int arow = i0 + (lane & 31), kk = lane >> 5;
     const float g = gloss[0];
-    const int ksteps = (K + 1) / 2;
     for (int c0 = 0; c0 < F; c0 += 32) {
         const int ch = c0 + (lane & 31);
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int s = 0; s < ksteps; s++) {       // A[m = sample][k = cluster], B[k = cluster][n = channel]
-            const int kc = 2 * s + kk;
-            const float a = (arow < N && kc < K) ? G[(size_t)arow * K + kc] : 0.0f;
-            const float b = (kc < K && ch < F && cnt[kc] > 0.0f) ? U[(size_t)kc * F + ch] / phi[kc] : 0.0f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int k0 = 0; k0 < K; k0 += 32) {       // A[m = sample][k = cluster], B[k = cluster][n = channel]; 32 clusters
+            float a[16], b[16];                       // per round: all 32 loads are issued before the 16 MFMAs
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const int kc = k0 + 2 * s + kk;
+                a[s] = (arow < N && kc < K) ? G[(size_t)arow * K + kc] : 0.0f;
+                b[s] = (kc < K && ch < F) ? Us[(size_t)kc * F + ch] : 0.0f;      // U / phi, 0 for absent columns
+            }
+#pragma unroll
+            for (int s = 0; s < 16; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) {

@@ -32,6 +32,19 @@ static int fail(int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                             \
         if (e_ != hipSuccess) return fail(ISR_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));       \
     } while (0)
+// ISR_DEBUG_SYNC=1: synchronise after named stages and report which one faulted (debugging aid)
+static bool debug_sync() {
+    static const bool on = [] { const char* e = getenv("ISR_DEBUG_SYNC"); return e && e[0] == '1'; }();
+    return on;
+}
+#define ISR_STAGE(name, stream)                                                                             \
+    do {                                                                                                    \
+        if (debug_sync()) {                                                                                 \
+            fprintf(stderr, "[isr] stage %s\n", name);                                                      \
+            hipError_t e_ = hipStreamSynchronize(stream);                                                   \
+            if (e_ != hipSuccess) return fail(ISR_EHIP, "stage %s failed: %s", name, hipGetErrorString(e_)); \
+        }                                                                                                   \
+    } while (0)
 #define ISR_LAUNCH_CHECK(name)                                                                              \
     do {                                                                                                    \
         hipError_t e_ = hipGetLastError();                                                                  \
@@ -78,6 +91,7 @@ void isr_profile_enable(int on) {
     for (auto& r : p.recs) { p.pool.push_back(r.a); p.pool.push_back(r.b); }
     p.recs.clear();
     p.on = on != 0;
+    p.dominant_only = on == 2;
 }
 
 /* Writes "name count total_ms" lines for everything recorded since isr_profile_enable(1); synchronises
@@ -309,18 +323,37 @@ int iso_contrastive_forward(int N, int F, int K, const float* features, const vo
     iso::CState st = iso::cstate(state, N, F, K);
     const int shift = consider_negative ? 0 : 1;
     const int nblk = (N + 31) / 32, nt = (N + 255) / 256;
-    ISR_HIP(hipMemsetAsync(st.hist, 0, sizeof(int) * (K + 2), s));
+    ISR_HIP(hipMemsetAsync(st.hist, 0, sizeof(int) * (K + 4), s));       // histogram + the two tickets
+    int* ticket_phi = st.hist + K + 2;
+    int* ticket_loss = st.hist + K + 3;
     hipLaunchKernelGGL(iso::ck_count, dim3(nt), dim3(256), 0, s, N, K, shift, labels, labels_are_int64, st.hist);
-    hipLaunchKernelGGL(iso::ck_normalize, dim3(nt), dim3(256), 0, s, N, F, K, shift, consider_negative, min_pixnum, features,
-                       labels, labels_are_int64, st.hist, st.f, st.inv, st.col);
+    ISR_STAGE("ck_count", s);
+    int lpr = 1;
+    if ((F & 3) == 0) while (lpr < (F >> 2) && lpr < 64) lpr <<= 1;
+    hipLaunchKernelGGL(iso::ck_normalize, dim3((unsigned)(((long long)N * lpr + 255) / 256)), dim3(256), 0, s, N, F, K, shift,
+                       consider_negative, min_pixnum, features, labels, labels_are_int64, st.hist, st.f, st.inv, st.col, lpr);
+    ISR_STAGE("ck_normalize", s);
     if (predef_u == nullptr)
         hipLaunchKernelGGL(iso::ck_gemm_tn, dim3((K + 31) / 32, (F + 31) / 32, iso::CK_NSPLIT), dim3(256), 0, s, N, F, K, 1,
                            st.col, (const float*)nullptr, st.f, st.split);
     hipLaunchKernelGGL(iso::ck_finish_u, dim3((K * F + 255) / 256), dim3(256), 0, s, F, K, min_pixnum, st.hist, st.split,
                        predef_u, st.U, st.cnt);
-    hipLaunchKernelGGL(iso::ck_phi, dim3(K), dim3(256), 0, s, N, F, st.f, st.col, st.U, st.cnt, temp_lambda, st.phi);
-    hipLaunchKernelGGL(iso::ck_similarity, dim3(nblk), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, st.col, st.G, st.part);
-    hipLaunchKernelGGL(iso::ck_loss_reduce, dim3(1), dim3(256), 0, s, nblk, st.part, loss);
+    ISR_STAGE("ck_gemm_tn/ck_finish_u", s);
+    hipLaunchKernelGGL(iso::ck_phi, dim3(nt), dim3(256), 0, s, N, F, K, st.f, st.col, st.U, st.cnt, temp_lambda, st.phi_part,
+                       ticket_phi, st.phi, st.Us);
+    ISR_STAGE("ck_phi", s);
+    if (F <= 32 && K <= 96) {
+#define ISO_SIM(NT)                                                                                                     \
+    hipLaunchKernelGGL((iso::ck_similarity_small<NT>), dim3(nblk), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt,  \
+                       st.col, st.G, st.part, ticket_loss, loss)
+        if (K <= 32) ISO_SIM(1); else if (K <= 64) ISO_SIM(2); else ISO_SIM(3);
+#undef ISO_SIM
+    } else {
+        hipLaunchKernelGGL(iso::ck_similarity, dim3(nblk), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, st.col, st.G,
+                           st.part);
+        hipLaunchKernelGGL(iso::ck_loss_reduce, dim3(1), dim3(256), 0, s, nblk, st.part, loss);
+    }
+    ISR_STAGE("ck_similarity", s);
     ISR_LAUNCH_CHECK("iso_contrastive_forward");
     return ISR_OK;
 }
@@ -337,7 +370,7 @@ int iso_contrastive_backward(int N, int F, int K, int prototypes_predefined, con
                            st.col, st.G, st.f, st.split);
         hipLaunchKernelGGL(iso::ck_finish_du, dim3((K * F + 255) / 256), dim3(256), 0, s, F, K, st.split, st.phi, st.cnt, st.dU);
     }
-    hipLaunchKernelGGL(iso::ck_grad_f, dim3((N + 31) / 32), dim3(64), 0, s, N, F, K, st.G, st.U, st.phi, st.cnt, st.dU, st.col,
+    hipLaunchKernelGGL(iso::ck_grad_f, dim3((N + 31) / 32), dim3(64), 0, s, N, F, K, st.G, st.Us, st.cnt, st.dU, st.col,
                        st.inv, dL_dloss, use_mean, dL_dfeatures);
     ISR_LAUNCH_CHECK("iso_contrastive_backward");
     return ISR_OK;

@@ -232,6 +232,7 @@ namespace isr {
 struct ProfRec { const char* name; hipEvent_t a, b; };
 struct Prof {
     bool on = false;
+    bool dominant_only = false;     // mode 2: time only the forward blend kernel (least perturbation of the stream)
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;
     hipEvent_t get() {
@@ -242,7 +243,8 @@ struct Prof {
 inline Prof& prof() { static Prof p; return p; }
 struct ProfScope {
     hipStream_t s; ProfRec r; bool on;
-    ProfScope(const char* name, hipStream_t st) : s(st), on(prof().on) {
+    ProfScope(const char* name, hipStream_t st)
+        : s(st), on(prof().on && (!prof().dominant_only || __builtin_strcmp(name, "k_render_fwd") == 0)) {
         if (on) { r.name = name; r.a = prof().get(); r.b = prof().get(); (void)hipEventRecord(r.a, s); }
     }
     ~ProfScope() { if (on) { (void)hipEventRecord(r.b, s); prof().recs.push_back(r); } }
