@@ -2,7 +2,7 @@
 """Aggregate a rocprofv3 counter_collection.csv per kernel (mean per dispatch)."""
 import collections, csv, glob, sys
 d = sys.argv[1]
-f = glob.glob(d + "/*counter_collection.csv")[0]
+f = (glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/**/*counter_collection.csv", recursive=True))[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
