@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(
     __shared__ unsigned s_last[4];
 
     const int tile = blockIdx.x;       // (an XCD-contiguous tile map was measured 5 % slower: it unbalances the XCDs)
-    if (tile_mode != nullptr && tile_mode[tile] == 0) return;     // done (or empty) in k_render_bwd_sparse
+    if (tile_mode != nullptr && tile_mode[tile] != 255) return;   // nothing to do, or done by k_render_bwd_sparse
     const int tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned px = tx * TILE + (wv & 1) * 8 + (lane & 7);
@@ -586,83 +586,134 @@ __device__ __forceinline__ float splat_alpha(const F3 Tu, const F3 Tv, const F3 
     return alpha < 1.0f / 255.0f ? 0.0f : alpha;
 }
 
+// Step 1 — which pixels carry an upstream gradient?  A streaming pass over dL/dE: one workgroup per strip of four
+// tiles (64 x 16 pixels), a thread per 4 consecutive pixels (float4 loads: 256 contiguous bytes per row and wave;
+// the pixel-per-lane prologue of k_render_bwd reads 32-byte pieces).  Emits, per tile, the live pixels in raster
+// order: (x | y << 8, last contributor), and tile_mode = their number (0 = nothing to do, 255 = more than
+// SPARSE_LMAX: left to the dense kernel).
+constexpr int TILE_DENSE = 255;
+__global__ __launch_bounds__(256) void k_bwd_live_pixels(int W, int H, int ED, int ch_base, int gx,
+                                                         const uint32_t* __restrict__ n_contrib,
+                                                         const float* __restrict__ dE, uint32_t* __restrict__ live_list,
+                                                         uint8_t* __restrict__ tile_mode) {
+    __shared__ unsigned char s_c[4][64];
+    const int x4 = threadIdx.x & 15, y = threadIdx.x >> 4;
+    const int tl = x4 >> 2;                               // tile of the strip
+    const int tx = blockIdx.x * 4 + tl, ty = blockIdx.y;
+    const int px0 = blockIdx.x * 64 + x4 * 4, py = ty * TILE + y;
+    const size_t N = (size_t)W * H;
+    const int nch = dE != nullptr ? min(32, ED - ch_base) : 0;
+    unsigned last[4] = {0u, 0u, 0u, 0u};
+    bool nz[4] = {false, false, false, false};
+    if (py < H && px0 < W) {
+        const size_t p0 = (size_t)W * py + px0;
+        if ((W & 3) == 0) {              // px0 + 3 < W and 16-byte alignment follow
+            const uint4 lc = *reinterpret_cast<const uint4*>(n_contrib + p0);
+            last[0] = lc.x; last[1] = lc.y; last[2] = lc.z; last[3] = lc.w;
+#pragma unroll
+            for (int cb = 0; cb < 32; cb += 8) {          // eight 16-byte loads in flight per round
+                float4 v[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+                    v[c] = cb + c < nch ? *reinterpret_cast<const float4*>(dE + (size_t)(ch_base + cb + c) * N + p0)
+                                        : make_float4(0, 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    nz[0] = nz[0] || (v[c].x != 0.0f); nz[1] = nz[1] || (v[c].y != 0.0f);
+                    nz[2] = nz[2] || (v[c].z != 0.0f); nz[3] = nz[3] || (v[c].w != 0.0f);
+                }
+            }
+        } else {
+            for (int j = 0; j < 4; j++) {
+                if (px0 + j >= W) break;
+                last[j] = n_contrib[p0 + j];
+                for (int c = 0; c < nch; c++) nz[j] = nz[j] || (dE[(size_t)(ch_base + c) * N + p0 + j] != 0.0f);
+            }
+        }
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { nz[j] = nz[j] && last[j] > 0u; cnt += nz[j] ? 1 : 0; }
+    const int o = y * 4 + (x4 & 3);                       // raster order of this thread inside its tile
+    s_c[tl][o] = (unsigned char)cnt;
+    __syncthreads();
+    if (tx >= gx) return;
+    const int tile = ty * gx + tx;
+    if (o == 63) {
+        int tot = 0;
+        for (int q = 0; q < 64; q++) tot += s_c[tl][q];
+        tile_mode[tile] = (uint8_t)(tot > SPARSE_LMAX ? TILE_DENSE : tot);
+    }
+    if (cnt == 0) return;
+    int idx = 0;
+    for (int q = 0; q < o; q++) idx += s_c[tl][q];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!nz[j]) continue;
+        if (idx < SPARSE_LMAX) {
+            const int lx = (x4 & 3) * 4 + j;
+            live_list[((size_t)tile * SPARSE_LMAX + idx) * 2] = (unsigned)(lx | (y << 8));
+            live_list[((size_t)tile * SPARSE_LMAX + idx) * 2 + 1] = last[j];
+        }
+        idx++;
+    }
+}
+
+// Step 2 — one wave per tile with 1..SPARSE_LMAX live pixels.
 template <class Math>
-__global__ __launch_bounds__(256) void k_render_bwd_sparse(
+__global__ __launch_bounds__(64) void k_render_bwd_sparse(
     int W, int H, int ED, int ch_base, int gx, const uint32_t* __restrict__ tile_offset,
     const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ box4, const float* __restrict__ rec,
-    const float* __restrict__ tm_pre, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dE, const uint32_t* __restrict__ point_offsets, const Rect16* __restrict__ rects,
-    float* __restrict__ partial, uint8_t* __restrict__ row_flags, uint8_t* __restrict__ tile_mode, int row_stride,
-    int feat_off, int64_t capacity) {
-    __shared__ int s_wcnt[4];
-    __shared__ unsigned s_wlast[4];
+    const float* __restrict__ tm_pre, const float* __restrict__ dE, const uint32_t* __restrict__ point_offsets,
+    const Rect16* __restrict__ rects, float* __restrict__ partial, uint8_t* __restrict__ row_flags,
+    const uint32_t* __restrict__ live_list, const uint8_t* __restrict__ tile_mode, int row_stride, int feat_off,
+    int64_t capacity) {
     __shared__ int s_lxy[SPARSE_LMAX];                 // tile-relative x | y << 8 of the live pixels
     __shared__ unsigned s_llast[SPARSE_LMAX];          // their last contributor
     __shared__ __attribute__((aligned(16))) float s_ldE[SPARSE_LMAX * 32];
 
     const int tile = blockIdx.x;
+    const int nlive = tile_mode[tile];
+    if (nlive == 0 || nlive == TILE_DENSE) return;
     const int tx = tile % gx, ty = tile / gx;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lx = (wv & 1) * 8 + (lane & 7), ly = (wv >> 1) * 8 + (lane >> 3);
-    const unsigned px = tx * TILE + lx, py = ty * TILE + ly;
-    const bool inside = px < (unsigned)W && py < (unsigned)H;
+    const int lane = threadIdx.x;
     const size_t N = (size_t)W * H;
-    const size_t pix = (size_t)W * py + px;
-
     const int64_t r0 = tile_offset[tile];
     int64_t r1 = tile_offset[tile + 1];
     if (r1 > capacity) r1 = capacity;
     const int len = (int)(r1 - r0);
-    if (len <= 0 || dE == nullptr) {
-        if (threadIdx.x == 0) tile_mode[tile] = 0;
-        return;
+    if (len <= 0) return;
+    unsigned mylast = 0u;
+    if (lane < nlive) {
+        s_lxy[lane] = (int)live_list[((size_t)tile * SPARSE_LMAX + lane) * 2];
+        mylast = live_list[((size_t)tile * SPARSE_LMAX + lane) * 2 + 1];
+        s_llast[lane] = mylast;
     }
-    // ---- live pixels of the tile: dL/dE(pix, chunk) != 0 and something was blended there
-    const unsigned last_contributor = inside ? n_contrib[pix] : 0u;
-    bool nz = false;
-    if (inside && last_contributor > 0u) {
-        const int nch = min(32, ED - ch_base);
-        float v[32];
 #pragma unroll
-        for (int c = 0; c < 32; c++) v[c] = c < nch ? dE[(size_t)(ch_base + c) * N + pix] : 0.0f;
-#pragma unroll
-        for (int c = 0; c < 32; c++) nz = nz || (v[c] != 0.0f);
-    }
-    const unsigned long long live_mask = __ballot(nz);
-    unsigned wlast = nz ? last_contributor : 0u;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) wlast = max(wlast, (unsigned)__shfl_xor((int)wlast, o));
-    if (lane == 0) { s_wcnt[wv] = __popcll(live_mask); s_wlast[wv] = wlast; }
+    for (int o = 32; o >= 1; o >>= 1) mylast = max(mylast, (unsigned)__shfl_xor((int)mylast, o));
     __syncthreads();
-    const int nlive = (s_wcnt[0] + s_wcnt[1]) + (s_wcnt[2] + s_wcnt[3]);
-    if (nlive == 0 || nlive > SPARSE_LMAX) {
-        if (threadIdx.x == 0) tile_mode[tile] = nlive > SPARSE_LMAX ? 1 : 0;
-        return;
-    }
-    if (threadIdx.x == 0) tile_mode[tile] = 0;
-    int rank = __popcll(live_mask & ((1ull << lane) - 1ull));      // fixed order: wave-major, then lane
-    for (int w = 0; w < wv; w++) rank += s_wcnt[w];
-    if (nz) { s_lxy[rank] = lx | (ly << 8); s_llast[rank] = last_contributor; }
-    __syncthreads();
-    for (int k = threadIdx.x >> 5; k < nlive; k += 8) {
-        const int c = threadIdx.x & 31, ch = ch_base + c;
+    for (int k = lane >> 5; k < nlive; k += 2) {
+        const int c = lane & 31, ch = ch_base + c;
         const int xy = s_lxy[k];
         const size_t q = (size_t)W * (ty * TILE + (xy >> 8)) + (tx * TILE + (xy & 255));
         s_ldE[k * 32 + c] = ch < ED ? dE[(size_t)ch * N + q] : 0.0f;
     }
     __syncthreads();
-    if (wv != 0) return;
-
-    const int len_eff = min(len, (int)max(max(s_wlast[0], s_wlast[1]), max(s_wlast[2], s_wlast[3])));
+    const int len_eff = min(len, (int)mylast);
     const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
     float Tvec = 1.0f;                 // lane k: running transmittance of live pixel k
+    // (id, cull box) of the NEXT chunk are fetched while the current one is evaluated: one memory round trip per
+    // chunk on the critical path of the walk instead of two
+    int id_n = 0;
+    unsigned bx_n = 0u;
+    if (lane < len_eff) { id_n = (int)point_list[r0 + lane]; bx_n = box4[r0 + lane]; }
     for (int base = 0; base < len_eff; base += 64) {
         const int idx = base + lane;
         unsigned hk = 0u;              // bit k: this lane's splat may touch live pixel k
-        int id = 0;
+        const int id = id_n;
+        const unsigned bx = bx_n;
+        if (idx + 64 < len_eff) { id_n = (int)point_list[r0 + idx + 64]; bx_n = box4[r0 + idx + 64]; }
         if (idx < len_eff) {
-            id = (int)point_list[r0 + idx];
-            const unsigned bx = box4[r0 + idx];
             const int xl = (int)(signed char)(bx & 255u), xh = (int)(signed char)((bx >> 8) & 255u);
             const int yl = (int)(signed char)((bx >> 16) & 255u), yh = (int)(signed char)(bx >> 24);
             for (int k = 0; k < nlive; k++) {
@@ -671,12 +722,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_sparse(
                 if (xl <= x && xh >= x && yl <= y && yh >= y && (unsigned)idx < s_llast[k]) hk |= 1u << k;
             }
         }
-        // wave-uniform union of the per-lane masks
-        unsigned any = hk;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) any |= (unsigned)__shfl_xor((int)any, o);
-        any = (unsigned)__builtin_amdgcn_readfirstlane((int)any);
-        if (any == 0u) continue;
+        if (__ballot(hk != 0u) == 0ull) continue;
         F3 Tu = {0, 0, 0}, Tv = {0, 0, 0}, Tw = {0, 0, 1};
         float cx = 0, cy = 0, opa = 0, skip = 0;
         unsigned slot = 0;
@@ -703,9 +749,8 @@ __global__ __launch_bounds__(256) void k_render_bwd_sparse(
 #pragma unroll
         for (int c = 0; c < 32; c++) acc[c] = 0.0f;
         bool wrote = false;
-        while (any != 0u) {
-            const int k = __builtin_ctz(any);
-            any &= any - 1u;
+        for (int k = 0; k < nlive; k++) {
+            if (__ballot((hk >> k) & 1u) == 0ull) continue;
             const int xy = s_lxy[k];
             float alpha = 0.0f;
             if ((hk >> k) & 1u)
@@ -1042,9 +1087,12 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
             // (flagged in tile_mode) by the dense one
             const uint8_t* tmode = nullptr;
             if (!do_geom && do_feat && sparse_path_enabled()) {
-                hipLaunchKernelGGL((k_render_bwd_sparse<Math>), dim3(T), dim3(256), 0, s, W, H, ED, ch, gx, iv.tile_offset,
-                                   bv.point_list, bv.box4, g.rec, tm_pre, iv.n_contrib, dE, g.point_offsets, g.rect, partial,
-                                   flags + (size_t)pass * R, iv.tile_mode, stride, feat_base + ch, R);
+                hipLaunchKernelGGL(k_bwd_live_pixels, dim3((gx + 3) / 4, gy), dim3(256), 0, s, W, H, ED, ch, gx, iv.n_contrib, dE,
+                                   iv.live_list, iv.tile_mode);
+                ISR_CHECK_LAUNCH_B("k_bwd_live_pixels");
+                hipLaunchKernelGGL((k_render_bwd_sparse<Math>), dim3(T), dim3(64), 0, s, W, H, ED, ch, gx, iv.tile_offset,
+                                   bv.point_list, bv.box4, g.rec, tm_pre, dE, g.point_offsets, g.rect, partial,
+                                   flags + (size_t)pass * R, iv.live_list, iv.tile_mode, stride, feat_base + ch, R);
                 ISR_CHECK_LAUNCH_B("k_render_bwd_sparse");
                 tmode = iv.tile_mode;
             }

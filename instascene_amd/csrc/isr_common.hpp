@@ -46,7 +46,8 @@ struct ImageView {
     uint32_t* tile_offset; // [tiles + 1] exclusive scan of the tile totals (ranges[t] = off[t], off[t+1])
     uint32_t* tile_cursor; // [tiles * CNT_SUB * CNT_STRIDE] padded scatter cursors
     uint32_t* sub_offset;  // [tiles * CNT_SUB] start of every sub-bucket
-    uint8_t* tile_mode;    // [tiles] backward only: 1 = tile left to the dense K9 kernel by the sparse one
+    uint8_t* tile_mode;    // [tiles] backward only: live pixels of the tile (0 none, 255 = dense K9 kernel)
+    uint32_t* live_list;   // [tiles, 32, 2] backward only: (x | y << 8, last contributor) of the live pixels
 };
 
 struct BinView {
@@ -96,11 +97,12 @@ inline ImageView image_view(void* buf, int W, int H) {
     v.tile_cursor = carve<uint32_t>(p, T * CNT_SUB * CNT_STRIDE);
     v.sub_offset = carve<uint32_t>(p, T * CNT_SUB);
     v.tile_mode = carve<uint8_t>(p, T);
+    v.live_list = carve<uint32_t>(p, T * 64);
     return v;
 }
 inline size_t image_bytes(int W, int H) {
     ImageView v = image_view((void*)0, W, H);
-    return (size_t)(v.tile_mode + (size_t)tiles_x(W) * tiles_y(H)) + 256;
+    return (size_t)(v.live_list + (size_t)tiles_x(W) * tiles_y(H) * 64) + 256;
 }
 inline BinView bin_view(void* buf, int64_t R) {
     char* p = (char*)buf;
