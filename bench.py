@@ -212,7 +212,8 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{args.config}: {cfg['P']} Gaussians, {cfg['W']}x{cfg['H']}, F={cfg['F']}, "
                                       f"sample batch 8192, 2 single-view + 1 3-D contrastive loss, Adam on [P,F]",
-                          "parallelism": f"dp{world} (one view per rank, RCCL all-reduce of the [P,F] gradient)",
+                          "parallelism": f"dp{world} (one view per rank, RCCL all-reduce of the [P,F] gradient"
+                                         + (", overlapped with the next view's geometry pass)" if world > 1 else ")"),
                           "arithmetic_mode": args.mode, "tracer": bool(args.tracer),
                           "async_binning": bool(args.async_binning),
                           "derived_render_maps": "on first access (never read by this step)" if args.lazy_maps else "inside render(), like the reference"},

@@ -30,6 +30,25 @@ def allreduce_grads(params: Iterable[torch.nn.Parameter], world: int) -> None:
         dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
 
 
+def allreduce_grads_async(params: Iterable[torch.nn.Parameter], world: int):
+    """Start the gradient all-reduce and return the work handles (``[]`` for one rank): the caller overlaps it with work
+    that does not read the gradient (the next view's geometry pass) and calls :func:`wait_all` before the optimiser
+    step.  RCCL runs the collective on its own stream; ``wait()`` makes the current stream wait for it."""
+    works = []
+    if world <= 1:
+        return works
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
+    return works
+
+
+def wait_all(works) -> None:
+    for w in works:
+        w.wait()
+
+
 def replicas_in_sync(t: torch.Tensor, world: int) -> bool:
     """True iff every rank holds bit-identical ``t`` (checked with a max/min all-reduce)."""
     if world <= 1:

@@ -24,8 +24,8 @@ import torch.nn as nn
 
 from . import scenes
 from .contrastive import contrastive_loss, row_normalize_chain
-from .dist_utils import allreduce_grads, view_for
-from .render import render
+from .dist_utils import allreduce_grads, allreduce_grads_async, view_for, wait_all
+from .render import prefetch, render
 
 
 class PipelineParams:
@@ -107,9 +107,11 @@ def gram_schmidt(vectors: torch.Tensor) -> torch.Tensor:
 class SegTrainer:
     def __init__(self, scene: scenes.Scene, cameras: List[scenes.Camera], device="cuda", sample_batchsize=8192,
                  n_labels=64, lambda_sv=1e-6, lambda_mv=1e-6, lambda_3d=2.5e-6, sample_mv_frames=5, use_class_feat=False,
-                 multiview=False, seed=0, rank=0, world=1):
+                 multiview=False, seed=0, rank=0, world=1, prefetch_geometry=None):
         self.device = torch.device(device)
         self.rank, self.world = rank, world
+        # overlap of the gradient all-reduce with the next view's geometry pass (default: whenever there is one)
+        self.prefetch = (world > 1) if prefetch_geometry is None else bool(prefetch_geometry)
         F = scene.seg_feature.shape[1]
         class_feat = None
         if use_class_feat:
@@ -194,7 +196,13 @@ class SegTrainer:
                 loss = loss + contrastive_loss(m.get_seg_feature[pick], self.labels3d[pick], predef_u_list=m.class_feat,
                                                num_labels=self.n_labels + 1) * self.l3d
         loss.backward()
-        allreduce_grads([m._seg_feature], self.world)
+        if self.prefetch:
+            # the next view's geometry pass does not read the feature: it runs while RCCL sums the gradient
+            works = allreduce_grads_async([m._seg_feature], self.world)
+            prefetch(self.cams[self.view_index(it + 1)], m, self.pipe, self.bg)
+            wait_all(works)
+        else:
+            allreduce_grads([m._seg_feature], self.world)
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
         m._seg_cache = None          # the graph of this step is gone

@@ -94,6 +94,78 @@ def _f32c(t: Optional[torch.Tensor], name: str):
     return t.contiguous()
 
 
+_PREFETCHED = {}      # (device, P, W, H) -> (signature, radii, geom, img, R): a geometry pass issued ahead of its forward
+PREFETCH_HITS = 0     # forwards that found their geometry pass already issued (statistics / tests)
+
+
+def _geometry_signature(P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered, tensors):
+    """Identity of everything the geometry pass reads: scalars + (address, version) of the tensors."""
+    return (P, W, H, int(degree), M, float(scale_modifier), float(tan_fovx), float(tan_fovy), bool(prefiltered)) + tuple(
+        None if t is None else (t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+
+
+def _prepare(L, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
+             transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img):
+    """K1 + tile scan (``isr_forward_prepare``) into ``radii / geom / img``; returns the instance count R, or — with
+    async binning — the capacity the binning workspace is sized with (the true count is verified later)."""
+    global LAST_NUM_RENDERED
+    num_rendered = ctypes.c_int64(0)
+    use_async = _CONFIG["async_binning"]
+    if use_async:
+        _verify_pending(key)
+        use_async = key in _R_ESTIMATE and _CONFIG["async_binning"]
+    check(L.isr_forward_prepare(P, int(degree), M, W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
+                                _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(transMat_precomp),
+                                _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                                int(bool(prefiltered)), _ptr(radii), _ptr(geom), _ptr(img),
+                                None if use_async else ctypes.byref(num_rendered), st), "isr_forward_prepare")
+    if use_async:
+        R = int(_R_ESTIMATE[key] * _ASYNC_GROWTH) + _ASYNC_SLACK            # capacity, not the count
+        pinned = torch.empty(1, dtype=torch.int64).pin_memory()
+        pinned.copy_(geom[:8].view(torch.int64), non_blocking=True)   # header[0] = R
+        ev = torch.cuda.Event()
+        ev.record()
+        _PENDING[key] = (pinned, ev, R)
+        LAST_NUM_RENDERED = _R_ESTIMATE[key]
+    else:
+        R = int(num_rendered.value)
+        _R_ESTIMATE[key] = R
+        LAST_NUM_RENDERED = R
+    return R
+
+
+def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp, viewmatrix,
+                      projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered) -> bool:
+    """Issue the geometry pass (K1, tile counts, scan) of a view NOW, on the current stream, for a
+    ``rasterize_gaussians`` call that will follow with exactly these inputs.  It reads no feature, so a trainer can
+    overlap it with the all-reduce of the feature gradient.  Needs async binning and a known size estimate for this
+    (P, W, H); returns False (and does nothing) otherwise.  An entry that is never consumed is simply dropped."""
+    L = lib()
+    dev = means3D.device
+    P, H, W = means3D.shape[0], int(image_height), int(image_width)
+    key = (dev.index, P, W, H)
+    if P == 0 or not _CONFIG["async_binning"] or key not in _R_ESTIMATE:
+        return False
+    means3D = _f32c(means3D, "means3D")
+    colors, opacity = _f32c(colors, "colors"), _f32c(opacity, "opacity")
+    scales, rotations = _f32c(scales, "scales"), _f32c(rotations, "rotations")
+    transMat_precomp = _f32c(transMat_precomp, "transMat_precomp")
+    viewmatrix, projmatrix = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix")
+    sh, campos = _f32c(sh, "sh"), _f32c(campos, "campos")
+    M = sh.shape[1] if (sh is not None and sh.dim() == 3) else 0
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
+    img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
+    sig = _geometry_signature(P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered,
+                              (means3D, sh, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix,
+                               campos))
+    with torch.cuda.device(dev):
+        R = _prepare(L, key, _stream(), P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
+                     transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img)
+    _PREFETCHED[key] = (sig, radii, geom, img, R)
+    return True
+
+
 def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
                         extra_attrs, attr_degree, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
                         image_width, sh, degree, campos, prefiltered, debug, *, tracer=None, mode=None):
@@ -124,12 +196,11 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
     out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
     out_others = torch.empty((7, H, W), dtype=torch.float32, device=dev)
     out_extra = torch.empty((F, H, W), dtype=torch.float32, device=dev) if F > 0 else torch.empty(0, device=dev)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
-    geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
-    img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
     M = sh.shape[1] if (sh is not None and sh.dim() == 3) else 0
-    num_rendered = ctypes.c_int64(0)
     if P == 0:
+        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
+        img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
         out_color.zero_()
         out_color += bg.view(3, 1, 1)
         out_others.zero_()
@@ -140,28 +211,20 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
     with torch.cuda.device(dev):
         st = _stream()
         key = (dev.index, P, W, H)
-        use_async = _CONFIG["async_binning"]
-        if use_async:
-            _verify_pending(key)
-            use_async = key in _R_ESTIMATE and _CONFIG["async_binning"]
-        check(L.isr_forward_prepare(P, int(degree), M, W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
-                                    _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(transMat_precomp),
-                                    _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
-                                    int(bool(prefiltered)), _ptr(radii), _ptr(geom), _ptr(img),
-                                    None if use_async else ctypes.byref(num_rendered), st), "isr_forward_prepare")
-        global LAST_NUM_RENDERED
-        if use_async:
-            R = int(_R_ESTIMATE[key] * _ASYNC_GROWTH) + _ASYNC_SLACK            # capacity, not the count
-            pinned = torch.empty(1, dtype=torch.int64).pin_memory()
-            pinned.copy_(geom[:8].view(torch.int64), non_blocking=True)   # header[0] = R
-            ev = torch.cuda.Event()
-            ev.record()
-            _PENDING[key] = (pinned, ev, R)
-            LAST_NUM_RENDERED = _R_ESTIMATE[key]
+        sig = _geometry_signature(P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered,
+                                  (means3D, sh, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix,
+                                   campos))
+        ahead = _PREFETCHED.pop(key, None)
+        if ahead is not None and ahead[0] == sig:
+            radii, geom, img, R = ahead[1:]          # the geometry pass of this view was issued by prefetch_geometry()
+            global PREFETCH_HITS
+            PREFETCH_HITS += 1
         else:
-            R = int(num_rendered.value)
-            _R_ESTIMATE[key] = R
-            LAST_NUM_RENDERED = R
+            radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+            geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
+            img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
+            R = _prepare(L, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
+                         transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img)
         binning = torch.empty(L.isr_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
         if tracer:
             grp = torch.empty((H * W * 10, 2), dtype=torch.int32, device=dev)
@@ -368,6 +431,16 @@ class GaussianRasterizer(nn.Module):
         with torch.no_grad():
             rs = self.raster_settings
             return mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def prefetch(self, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                 cov3D_precomp=None) -> bool:
+        """Issue the geometry pass of the ``forward`` call that will follow with these inputs (extension; see
+        :func:`prefetch_geometry`)."""
+        rs = self.raster_settings
+        with torch.no_grad():
+            return prefetch_geometry(means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier,
+                                     cov3D_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
+                                     rs.image_width, shs, rs.sh_degree, rs.campos, rs.prefiltered)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, extra_attrs=None):

@@ -180,6 +180,45 @@ def post_process(viewpoint_camera, allmap, depth_ratio):
             'rend_median_depth': render_depth_median}
 
 
+def _geometry_inputs(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color):
+    """The rasterizer module of a view and the geometry/appearance arguments render() passes to it (:35-100)."""
+    xyz = pc.get_xyz
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
+    scales = rotations = cov3D_precomp = None
+    if getattr(pipe, "compute_cov3D_python", False):
+        splat2world = pc.get_covariance(scaling_modifier)
+        W, H = viewpoint_camera.image_width, viewpoint_camera.image_height
+        near, far = viewpoint_camera.znear, viewpoint_camera.zfar
+        ndc2pix = torch.tensor([[W / 2, 0, 0, (W - 1) / 2], [0, H / 2, 0, (H - 1) / 2], [0, 0, far - near, near],
+                                [0, 0, 0, 1]], dtype=torch.float32, device=xyz.device).T
+        world2pix = viewpoint_camera.full_proj_transform @ ndc2pix
+        cov3D_precomp = (splat2world[:, [0, 1, 3]] @ world2pix[:, [0, 1, 3]]).permute(0, 2, 1).reshape(-1, 9)
+    else:
+        scales = pc.get_scaling
+        rotations = pc.get_rotation
+    shs = colors_precomp = None
+    if override_color is None:
+        shs = pc.get_features          # the reference forces convert_SHs_python = False (:88)
+    else:
+        colors_precomp = override_color
+    return GaussianRasterizer(raster_settings=raster_settings), dict(
+        means3D=xyz, shs=shs, colors_precomp=colors_precomp, opacities=pc.get_opacity, scales=scales, rotations=rotations,
+        cov3D_precomp=cov3D_precomp)
+
+
+def prefetch(viewpoint_camera, pc, pipe, bg_color=None, scaling_modifier=1.0, override_color=None) -> bool:
+    """Issue the geometry pass (projection, tile counts, scan) of the NEXT ``render()`` of this view now (extension).
+    It depends on the Gaussians' geometry and SH only, so a data-parallel trainer runs it while the feature gradient is
+    being all-reduced; ``render()`` then starts at the key scatter.  No effect (False) without async binning."""
+    rasterizer, geo = _geometry_inputs(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color)
+    return rasterizer.prefetch(**geo)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
            norm_seg_feat=True):
     """Render the scene (reference gaussian_renderer/__init__.py:20).  ``pc`` needs the reference
@@ -196,45 +235,16 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
             screenspace_points.retain_grad()
         except Exception:
             pass
-    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
-    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
-    raster_settings = GaussianRasterizationSettings(
-        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
-        tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
-        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
-        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
-    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+    rasterizer, geo = _geometry_inputs(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color)
     _rz._CONFIG["lazy_tracer"] = True       # render() defers the tracer slice (and its host sync) to first access
 
-    means3D = xyz
     means2D = screenspace_points
-    opacity = pc.get_opacity
     seg_feature = pc.get_seg_feature
     if seg_feature is not None and norm_seg_feat:
         seg_feature = row_normalize(seg_feature, 1e-9)      # reference :61-62
 
-    scales = rotations = cov3D_precomp = None
-    if getattr(pipe, "compute_cov3D_python", False):
-        splat2world = pc.get_covariance(scaling_modifier)
-        W, H = viewpoint_camera.image_width, viewpoint_camera.image_height
-        near, far = viewpoint_camera.znear, viewpoint_camera.zfar
-        ndc2pix = torch.tensor([[W / 2, 0, 0, (W - 1) / 2], [0, H / 2, 0, (H - 1) / 2], [0, 0, far - near, near],
-                                [0, 0, 0, 1]], dtype=torch.float32, device=xyz.device).T
-        world2pix = viewpoint_camera.full_proj_transform @ ndc2pix
-        cov3D_precomp = (splat2world[:, [0, 1, 3]] @ world2pix[:, [0, 1, 3]]).permute(0, 2, 1).reshape(-1, 9)
-    else:
-        scales = pc.get_scaling
-        rotations = pc.get_rotation
-
-    shs = colors_precomp = None
-    if override_color is None:
-        shs = pc.get_features          # the reference forces convert_SHs_python = False (:88)
-    else:
-        colors_precomp = override_color
-
     rendered_image, radii, allmap, extra_attrs, gau_related_pixels = rasterizer(
-        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity, scales=scales,
-        rotations=rotations, cov3D_precomp=cov3D_precomp, extra_attrs=seg_feature)
+        means2D=means2D, extra_attrs=seg_feature, **geo)
     _rz._CONFIG["lazy_tracer"] = False
 
     rets = RenderPackage({"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0,

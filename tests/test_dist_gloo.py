@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from instascene_amd.dist_utils import allreduce_grads, replicas_in_sync, view_for
+from instascene_amd.dist_utils import allreduce_grads, allreduce_grads_async, replicas_in_sync, view_for, wait_all
 
 
 def _toy_loss(param, view):
@@ -18,7 +18,7 @@ def _toy_loss(param, view):
     return ((param * w).sum()) ** 2 * 1e-3 + (param * w).sin().sum()
 
 
-def _worker(rank, world, port, steps, n_views, out):
+def _worker(rank, world, port, steps, n_views, out, overlapped=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -30,7 +30,12 @@ def _worker(rank, world, port, steps, n_views, out):
         v = view_for(it, rank, world, n_views)
         seen.append(v)
         _toy_loss(p, v).backward()
-        allreduce_grads([p], world)
+        if overlapped:       # the trainer's overlapped form: start, do gradient-independent work, wait
+            works = allreduce_grads_async([p], world)
+            _ = torch.randn(16).sum()
+            wait_all(works)
+        else:
+            allreduce_grads([p], world)
         opt.step()
         opt.zero_grad(set_to_none=True)
         assert replicas_in_sync(p.data, world)
@@ -47,9 +52,10 @@ def _free_port():
 
 
 @pytest.mark.timeout(120)
-def test_two_rank_gradient_allreduce_equals_sum_of_view_gradients(tmp_path):
+@pytest.mark.parametrize("overlapped", [False, True])
+def test_two_rank_gradient_allreduce_equals_sum_of_view_gradients(tmp_path, overlapped):
     world, steps, n_views = 2, 4, 7
-    mp.spawn(_worker, args=(world, _free_port(), steps, n_views, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), steps, n_views, str(tmp_path), overlapped), nprocs=world, join=True)
     r0 = torch.load(tmp_path / "r0.pt")
     r1 = torch.load(tmp_path / "r1.pt")
     assert torch.equal(r0["p"], r1["p"])

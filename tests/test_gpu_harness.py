@@ -44,6 +44,32 @@ def test_seg_trainer_steps_and_is_deterministic(mode):
     rz.set_tracer(True)
 
 
+def test_prefetched_geometry_pass_changes_nothing():
+    """The data-parallel trainer issues the next view's geometry pass before the optimiser step (while RCCL sums the
+    gradient).  With one rank the same code path must reproduce the plain loop bit for bit, and every forward after
+    the first must find its geometry pass already issued."""
+    rz.set_mode("fast")
+    rz.set_tracer(False)
+    rz.set_async_binning(True)
+    try:
+        outs = []
+        for pf in (False, True):
+            sc, cams = _scene()
+            tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=2048, n_labels=12, use_class_feat=True, seed=3,
+                            prefetch_geometry=pf)
+            tr.step(0)                                   # first step: sizes the binning estimate (blocking)
+            hits0 = rz.PREFETCH_HITS
+            losses = [float(tr.step(it)) for it in range(1, 8)]
+            outs.append((losses, tr.model._seg_feature.detach().clone(), rz.PREFETCH_HITS - hits0))
+        assert outs[0][0] == outs[1][0]
+        assert torch.equal(outs[0][1], outs[1][1])
+        assert outs[0][2] == 0 and outs[1][2] == 7
+    finally:
+        rz.set_async_binning(False)
+        rz.set_mode("exact")
+        rz.set_tracer(True)
+
+
 def test_rgb_trainer_reduces_the_loss():
     rz.set_mode("fast")
     rz.set_tracer(False)
