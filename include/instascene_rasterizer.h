@@ -41,6 +41,7 @@ extern "C" {
 /* arithmetic mode of the blend kernels */
 #define ISR_MODE_EXACT 0 /* op-for-op IEEE fp32, bit-identical to oracle/surfel_oracle.cpp */
 #define ISR_MODE_FAST 1  /* explicit FMA contraction + hardware rcp/exp in the per-pixel loops */
+#define ISR_MODE_PREBINNED 0x100 /* flag for isr_forward_render: isr_forward_bin already ran on these buffers */
 
 /* which gradients isr_backward must produce (bit mask) */
 #define ISR_GRAD_EXTRA 1u    /* dL_dextra only needs the blend weights */
@@ -79,6 +80,12 @@ int isr_forward_prepare(int P, int D, int M, int width, int height,
                         int64_t* num_rendered_host, void* stream);
 
 int isr_read_num_rendered(const void* geom_buffer, int64_t* num_rendered_host, void* stream);
+
+/* ---- forward, part 2a (optional): the binning alone — key scatter into the tile buckets and the per-tile sort.
+ * Like part 1 it reads geometry only, so a caller may issue it ahead of time (e.g. while a gradient all-reduce is
+ * in flight) and then call isr_forward_render with (mode | ISR_MODE_PREBINNED). */
+int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binning_buffer, int64_t binning_capacity,
+                    void* image_buffer, void* stream);
 
 /* ---- forward, part 2: binning (K4-K7 equivalent) and the per-tile blend (K8).
  * Replaces rasterizer_impl.cu:289-351.  binning_capacity is the R the binning

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libinstascene_hip.so")
 _lib = None
 
 MODE_EXACT, MODE_FAST = 0, 1
+MODE_PREBINNED = 0x100
 GRAD_EXTRA, GRAD_GEOMETRY = 1, 2
 
 # every exported symbol and its signature (checked by tests/test_abi.py against include/*.h)
@@ -31,6 +32,7 @@ SIGNATURES = {
     "isr_forward_prepare": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
                                     c_float, c_float, c_int, _P, _P, _P, _P, _P]),
     "isr_read_num_rendered": (c_int, [_P, _P, _P]),
+    "isr_forward_bin": (c_int, [c_int, c_int, c_int, _P, _P, c_int64, _P, _P]),
     "isr_forward_render": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
                                    _P, c_int64, _P, _P]),
     "isr_backward": (c_int, [c_int, c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_uint,

@@ -179,6 +179,26 @@ int isr_read_num_rendered(const void* geom_buffer, int64_t* num_rendered_host, v
     return ISR_OK;
 }
 
+int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binning_buffer, int64_t binning_capacity,
+                    void* image_buffer, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!geom_buffer || !binning_buffer || !image_buffer) return fail(ISR_EINVAL, "null buffer");
+    const int gx = tiles_x(width), gy = tiles_y(height), T = gx * gy;
+    GeomView g = geom_view(geom_buffer, P < 1 ? 1 : P);
+    ImageView iv = image_view(image_buffer, width, height);
+    BinView bv = bin_view(binning_buffer, binning_capacity);
+    if (P > 0 && binning_capacity > 0) {
+        { ProfScope ps_("k_scatter", s);
+        hipLaunchKernelGGL(k_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, g, iv.sub_offset, iv.tile_cursor,
+                           bv.keys, binning_capacity); }
+        ISR_LAUNCH_CHECK("k_scatter");
+        { ProfScope ps_("k_tile_sort", s);
+        hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity); }
+        ISR_LAUNCH_CHECK("k_tile_sort");
+    }
+    return ISR_OK;
+}
+
 int isr_forward_render(int P, int ED, int width, int height, int mode, const float* background,
                        const float* colors_precomp, const float* transMat_precomp, const float* extra_attrs,
                        void* geom_buffer, void* binning_buffer, int64_t binning_capacity, void* image_buffer,
@@ -188,6 +208,8 @@ int isr_forward_render(int P, int ED, int width, int height, int mode, const flo
     if (!geom_buffer || !binning_buffer || !image_buffer || !out_color || !out_others || !background)
         return fail(ISR_EINVAL, "null buffer");
     if (ED < 0 || (ED > 0 && (!extra_attrs || !out_extra))) return fail(ISR_EINVAL, "extra_attrs/out_extra required when ED>0");
+    const bool prebinned = (mode & ISR_MODE_PREBINNED) != 0;
+    mode &= ~ISR_MODE_PREBINNED;
     if (mode != ISR_MODE_EXACT && mode != ISR_MODE_FAST) return fail(ISR_EINVAL, "unknown mode %d", mode);
     if (tracer_pairs && !tracer_count) return fail(ISR_EINVAL, "tracer_count required with tracer_pairs");
     const int gx = tiles_x(width), gy = tiles_y(height), T = gx * gy;
@@ -195,14 +217,9 @@ int isr_forward_render(int P, int ED, int width, int height, int mode, const flo
     ImageView iv = image_view(image_buffer, width, height);
     BinView bv = bin_view(binning_buffer, binning_capacity);
     if (tracer_pairs) ISR_HIP(hipMemsetAsync(tracer_count, 0, sizeof(int32_t), s));
-    if (P > 0 && binning_capacity > 0) {
-        { ProfScope ps_("k_scatter", s);
-        hipLaunchKernelGGL(k_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, g, iv.sub_offset, iv.tile_cursor,
-                           bv.keys, binning_capacity); }
-        ISR_LAUNCH_CHECK("k_scatter");
-        { ProfScope ps_("k_tile_sort", s);
-        hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity); }
-        ISR_LAUNCH_CHECK("k_tile_sort");
+    if (!prebinned) {
+        const int rc = isr_forward_bin(P, width, height, geom_buffer, binning_buffer, binning_capacity, image_buffer, stream);
+        if (rc != ISR_OK) return rc;
     }
     if (mode == ISR_MODE_EXACT)
         return launch_render_fwd<ExactMath>(T, s, width, height, ED, gx, iv, bv, g.rec, colors_precomp, transMat_precomp,

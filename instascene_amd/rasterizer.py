@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import GRAD_EXTRA, GRAD_GEOMETRY, MODE_EXACT, MODE_FAST, check, lib
+from ._lib import GRAD_EXTRA, GRAD_GEOMETRY, MODE_EXACT, MODE_FAST, MODE_PREBINNED, check, lib
 
 _CONFIG = {
     # arithmetic mode of the per-pixel loops: "exact" (bit-identical to the CPU oracle) or "fast"
@@ -94,7 +94,7 @@ def _f32c(t: Optional[torch.Tensor], name: str):
     return t.contiguous()
 
 
-_PREFETCHED = {}      # (device, P, W, H) -> (signature, radii, geom, img, R): a geometry pass issued ahead of its forward
+_PREFETCHED = {}      # (device, P, W, H) -> (signature, radii, geom, img, R, binning): a geometry pass + binning issued ahead of its forward
 PREFETCH_HITS = 0     # forwards that found their geometry pass already issued (statistics / tests)
 
 
@@ -136,7 +136,7 @@ def _prepare(L, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scale
 
 def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp, viewmatrix,
                       projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered) -> bool:
-    """Issue the geometry pass (K1, tile counts, scan) of a view NOW, on the current stream, for a
+    """Issue the geometry pass (K1, tile counts, scan) and the binning (key scatter, tile sort) of a view NOW, on the current stream, for a
     ``rasterize_gaussians`` call that will follow with exactly these inputs.  It reads no feature, so a trainer can
     overlap it with the all-reduce of the feature gradient.  Needs async binning and a known size estimate for this
     (P, W, H); returns False (and does nothing) otherwise.  An entry that is never consumed is simply dropped."""
@@ -160,9 +160,12 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
                               (means3D, sh, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix,
                                campos))
     with torch.cuda.device(dev):
-        R = _prepare(L, key, _stream(), P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
+        st = _stream()
+        R = _prepare(L, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
                      transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img)
-    _PREFETCHED[key] = (sig, radii, geom, img, R)
+        binning = torch.empty(L.isr_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
+        check(L.isr_forward_bin(P, W, H, _ptr(geom), _ptr(binning), R, _ptr(img), st), "isr_forward_bin")
+    _PREFETCHED[key] = (sig, radii, geom, img, R, binning)
     return True
 
 
@@ -215,8 +218,10 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
                                   (means3D, sh, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix,
                                    campos))
         ahead = _PREFETCHED.pop(key, None)
+        prebinned = 0
         if ahead is not None and ahead[0] == sig:
-            radii, geom, img, R = ahead[1:]          # the geometry pass of this view was issued by prefetch_geometry()
+            radii, geom, img, R, binning = ahead[1:]     # the geometry pass of this view was issued by prefetch_geometry()
+            prebinned = MODE_PREBINNED
             global PREFETCH_HITS
             PREFETCH_HITS += 1
         else:
@@ -225,13 +230,13 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
             img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
             R = _prepare(L, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
                          transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img)
-        binning = torch.empty(L.isr_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
+            binning = torch.empty(L.isr_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
         if tracer:
             grp = torch.empty((H * W * 10, 2), dtype=torch.int32, device=dev)
             gcount = torch.empty((1,), dtype=torch.int32, device=dev)
         else:
             grp, gcount = None, None
-        check(L.isr_forward_render(P, F, W, H, int(mode), _ptr(bg), _ptr(colors), _ptr(transMat_precomp), _ptr(extra),
+        check(L.isr_forward_render(P, F, W, H, int(mode) | prebinned, _ptr(bg), _ptr(colors), _ptr(transMat_precomp), _ptr(extra),
                                    _ptr(geom), _ptr(binning), R, _ptr(img), _ptr(out_color), _ptr(out_others),
                                    _ptr(out_extra), _ptr(grp), H * W * 10 if tracer else 0, _ptr(gcount), st),
               "isr_forward_render")

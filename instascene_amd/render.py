@@ -212,9 +212,10 @@ def _geometry_inputs(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, ove
 
 
 def prefetch(viewpoint_camera, pc, pipe, bg_color=None, scaling_modifier=1.0, override_color=None) -> bool:
-    """Issue the geometry pass (projection, tile counts, scan) of the NEXT ``render()`` of this view now (extension).
-    It depends on the Gaussians' geometry and SH only, so a data-parallel trainer runs it while the feature gradient is
-    being all-reduced; ``render()`` then starts at the key scatter.  No effect (False) without async binning."""
+    """Issue the geometry pass and binning (projection, tile counts, scan, key scatter, tile sort) of the NEXT
+    ``render()`` of this view now (extension).  They depend on the Gaussians' geometry and SH only, so a data-parallel
+    trainer runs them while the feature gradient is being all-reduced; ``render()`` then starts at the blend kernel.
+    No effect (False) without async binning."""
     rasterizer, geo = _geometry_inputs(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color)
     return rasterizer.prefetch(**geo)
 
