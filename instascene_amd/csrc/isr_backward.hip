@@ -73,6 +73,38 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// Sum TWELVE per-lane values over the wavefront at once ("packed butterfly").  A plain butterfly spends 6 exchange
+// levels on every value; here each level also halves the number of live registers, because a half-swap lets the two
+// halves of the wave finish DIFFERENT values:
+//   level 32: v_permlane32_swap(a, b) -> a' = [a.lo | b.lo], b' = [a.hi | b.hi]; a' + b' holds a's pair sums in lanes
+//             0..31 and b's in lanes 32..63                                     (12 values -> 6 registers)
+//   level 16: v_permlane16_swap on the odd/even rows of 16 lanes, same idea     (6 -> 3 registers)
+//   levels 8..1: DPP adds inside each row of 16                                 (3 registers, 12 instructions)
+// 30 instructions instead of 12 x 11.  On return every lane of row r (= lane >> 4) holds in out[i] the wave total of
+// g[4 * i + QMAP[r]] with QMAP = {0, 2, 1, 3}.
+__device__ __forceinline__ float swap_add32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);     // row_half_mirror
+    return dpp_add<0x140>(v);  // row_mirror
+}
+__device__ __forceinline__ void wave_sum12(const float (&g)[12], float (&out)[3]) {
+    float h[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) h[i] = swap_add32(g[2 * i], g[2 * i + 1]);   // lanes <32: g[2i], lanes >=32: g[2i+1]
+#pragma unroll
+    for (int i = 0; i < 3; i++) out[i] = row_sum16(swap_add16(h[2 * i], h[2 * i + 1]));
+    // rows of swap_add16(h[2i], h[2i+1]): row0 g[4i], row1 g[4i+2], row2 g[4i+1], row3 g[4i+3]
+}
+
 // ----------------------------------------------------------------------------
 // K9.  One workgroup (4 waves) per tile, wave w owns the 8x8 pixel block (w&1, w>>1).
 // GEOM: produce the 18 geometry/appearance terms.  FEAT: produce dL/dextra for the
@@ -456,14 +488,15 @@ __global__ __launch_bounds__(256) void k_render_bwd(
                             g[11] = G * dL_dalpha;
                         }
                         if (__ballot(act) != 0ull) {
-                            float sred[12];
-    #pragma unroll
-                            for (int q = 0; q < 12; q++) sred[q] = wave_sum(g[q]);
-                            if (lane == 0) {
+                            float tot[3];
+                            wave_sum12(g, tot);
+                            if ((lane & 15) == 0) {     // first lane of each row of 16 stores its three totals
+                                const int r = lane >> 4;
+                                const int q0 = (r == 0) ? 0 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
                                 float* o = Pw + j * PART;
-    #pragma unroll
-                                for (int q = 0; q < 11; q++) o[q] = sred[q];
-                                o[14] = sred[11];
+                                o[q0] = tot[0];
+                                o[4 + q0] = tot[1];
+                                o[q0 == 3 ? 14 : 8 + q0] = tot[2];      // g[11] (dL/dopacity) lives in column 14
                             }
                         }
                     }
