@@ -287,25 +287,63 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, GeomView g, cons
 // indices >= n behave as +inf without being stored.
 constexpr int SORT_LDS_KEYS = 4096;
 
+// Two network stages per pass: every thread loads the 4 keys of a group that is closed under both stages, does the
+// four compare-exchanges in registers and stores them back — half the LDS traffic and half the barriers of a
+// stage-per-pass bitonic sort (30 passes instead of 55 for 1024 keys).
+//   flip(k) + step(k/4): {b+o, b+o+k/4, b+k-1-o-k/4, b+k-1-o}, o < k/4
+//   step(j) + step(j/2): {p, p+j/2, p+j, p+3j/2}
+#define ISR_CMPX(x, y) { if ((y) < (x)) { const unsigned long long t_ = (x); (x) = (y); (y) = t_; } }
+template <typename KeyPtr>
+__device__ __forceinline__ void sort_group4(KeyPtr a, int n, int i0, int i1, int i2, int i3, bool flip_first) {
+    if (i0 >= n) return;                 // i0 is the smallest index: nothing real in the group
+    const unsigned long long INF = ~0ull;
+    unsigned long long v0 = a[i0], v1 = i1 < n ? a[i1] : INF, v2 = i2 < n ? a[i2] : INF, v3 = i3 < n ? a[i3] : INF;
+    if (flip_first) { ISR_CMPX(v0, v3); ISR_CMPX(v1, v2); ISR_CMPX(v0, v1); ISR_CMPX(v2, v3); }
+    else { ISR_CMPX(v0, v2); ISR_CMPX(v1, v3); ISR_CMPX(v0, v1); ISR_CMPX(v2, v3); }
+    a[i0] = v0;                          // +inf never moves below a real key, so slots >= n stay virtual
+    if (i1 < n) a[i1] = v1;
+    if (i2 < n) a[i2] = v2;
+    if (i3 < n) a[i3] = v3;
+}
+
 template <typename KeyPtr>
 __device__ __forceinline__ void bitonic_flip_sort(KeyPtr a, int n) {
     int npad = 1;
     while (npad < n) npad <<= 1;
-    const int half = npad >> 1;
+    const int half = npad >> 1, quarter = npad >> 2;
     for (int k = 2; k <= npad; k <<= 1) {
-        const int hk = k >> 1;
-        for (int i = threadIdx.x; i < half; i += blockDim.x) {
-            const int blk = i / hk, off = i - blk * hk;
-            const int lo = blk * k + off, hi = blk * k + k - 1 - off;
-            if (hi < n) {
-                const unsigned long long x = a[lo], y = a[hi];
-                if (y < x) { a[lo] = y; a[hi] = x; }
-            }
-        }
-        __syncthreads();
-        for (int j = k >> 2; j >= 1; j >>= 1) {
+        int j;
+        if (k == 2) {
             for (int i = threadIdx.x; i < half; i += blockDim.x) {
-                const int lo = (i / j) * 2 * j + (i % j), hi = lo + j;
+                const int lo = 2 * i, hi = lo + 1;
+                if (hi < n) {
+                    const unsigned long long x = a[lo], y = a[hi];
+                    if (y < x) { a[lo] = y; a[hi] = x; }
+                }
+            }
+            __syncthreads();
+            continue;
+        }
+        {   // flip(k) + step(k/4)
+            const int q = k >> 2;
+            for (int i = threadIdx.x; i < quarter; i += blockDim.x) {
+                const int blk = i / q, o = i - blk * q, base = blk * k;
+                sort_group4(a, n, base + o, base + o + q, base + k - 1 - o - q, base + k - 1 - o, true);
+            }
+            __syncthreads();
+            j = k >> 3;
+        }
+        for (; j >= 2; j >>= 2) {   // step(j) + step(j/2)
+            const int h = j >> 1;
+            for (int i = threadIdx.x; i < quarter; i += blockDim.x) {
+                const int p = (i / h) * 2 * j + (i % h);
+                sort_group4(a, n, p, p + h, p + j, p + j + h, false);
+            }
+            __syncthreads();
+        }
+        if (j == 1) {               // a single step(1) is left over
+            for (int i = threadIdx.x; i < half; i += blockDim.x) {
+                const int lo = 2 * i, hi = lo + 1;
                 if (hi < n) {
                     const unsigned long long x = a[lo], y = a[hi];
                     if (y < x) { a[lo] = y; a[hi] = x; }
@@ -315,6 +353,7 @@ __device__ __forceinline__ void bitonic_flip_sort(KeyPtr a, int n) {
         }
     }
 }
+#undef ISR_CMPX
 
 __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ tile_offset, unsigned long long* keys,
                                                    uint32_t* __restrict__ point_list, int64_t capacity) {
