@@ -93,7 +93,8 @@ int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binni
  * ("gau_related_pixels", forward.cu:422-428) is optional: pass NULL to skip it;
  * otherwise tracer_pairs[tracer_capacity][2] receives (gaussian, pixel) pairs
  * with blend weight > 0.1 in unspecified order and *tracer_count (device int32)
- * their number (entries beyond capacity are counted but not stored). */
+ * the index of the last pair = their number - 1 (-1 when there is none) — the reference's
+ * "gau_pixel_indices" (rasterize_points.cu:150); entries beyond capacity are counted but not stored. */
 int isr_forward_render(int P, int ED, int width, int height, int mode,
                        const float* background, const float* colors_precomp,
                        const float* transMat_precomp, const float* extra_attrs,

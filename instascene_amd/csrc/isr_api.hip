@@ -216,7 +216,7 @@ int isr_forward_render(int P, int ED, int width, int height, int mode, const flo
     GeomView g = geom_view(geom_buffer, P < 1 ? 1 : P);
     ImageView iv = image_view(image_buffer, width, height);
     BinView bv = bin_view(binning_buffer, binning_capacity);
-    if (tracer_pairs) ISR_HIP(hipMemsetAsync(tracer_count, 0, sizeof(int32_t), s));
+    if (tracer_pairs) ISR_HIP(hipMemsetAsync(tracer_count, 0xFF, sizeof(int32_t), s));     // -1: the counter ends at (pairs - 1)
     if (!prebinned) {
         const int rc = isr_forward_bin(P, width, height, geom_buffer, binning_buffer, binning_capacity, image_buffer, stream);
         if (rc != ISR_OK) return rc;

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
         const int n = min(s_tcount, TCAP);
         __syncthreads();
         if (n > 0) {
-            if (threadIdx.x == 0) { s_tbase = atomicAdd(tracer_count, n); s_tcount = 0; }
+            if (threadIdx.x == 0) { s_tbase = atomicAdd(tracer_count, n) + 1; s_tcount = 0; }   // counter starts at -1
             __syncthreads();
             const int gb = s_tbase;
             for (int e = threadIdx.x; e < n; e += 256)
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
                             const int ls = atomicAdd(&s_tcount, 1);
                             if (ls < TCAP) { s_trace[2 * ls] = s_id[j]; s_trace[2 * ls + 1] = (int)pix; }
                             else {      // LDS staging full (rare): append directly
-                                const int slot = atomicAdd(tracer_count, 1);
+                                const int slot = atomicAdd(tracer_count, 1) + 1;
                                 if (slot < tracer_cap) { tracer[2 * (size_t)slot] = s_id[j]; tracer[2 * (size_t)slot + 1] = (int)pix; }
                             }
                         }

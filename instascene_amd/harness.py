@@ -147,7 +147,7 @@ class SegTrainer:
         pix = idx_pool[pick]
         feats = seg_feature.reshape(seg_feature.shape[0], -1)[:, pix].T
         labels = segmap.reshape(-1)[pix]
-        return contrastive_loss(feats, labels, predef_u_list=predef, num_labels=self.n_labels + 1) * self.lsv * weight
+        return contrastive_loss(feats, labels, predef_u_list=predef, num_labels=self.n_labels + 1) * (self.lsv * weight)
 
     def view_index(self, it):
         return view_for(it, self.rank, self.world, len(self.cams))
@@ -164,11 +164,12 @@ class SegTrainer:
             pick = torch.randint(0, pool.numel(), (2 * self.batch,), device=self.device, generator=self.gen)
             pix = pool[pick]
             feats = seg_feature.reshape(seg_feature.shape[0], -1)[:, pix].T
+            fa, fb = feats.split(self.batch)          # one cat in the backward instead of two zero-fill + copy + add
             la = cam.segmap.reshape(-1)[pix[:self.batch]]
             lb = cam.sorted_segmap.reshape(-1)[pix[self.batch:]]
-            loss = contrastive_loss(feats[:self.batch], la, num_labels=self.n_labels + 1) * self.lsv * 0.5
-            loss = loss + contrastive_loss(feats[self.batch:], lb, predef_u_list=m.class_feat,
-                                           num_labels=self.n_labels + 1) * self.lsv * 1.0
+            loss = contrastive_loss(fa, la, num_labels=self.n_labels + 1) * (self.lsv * 0.5)
+            loss = loss + contrastive_loss(fb, lb, predef_u_list=m.class_feat,
+                                           num_labels=self.n_labels + 1) * (self.lsv * 1.0)
         else:
             loss = self._sample_view_loss(vi, seg_feature, cam.segmap, None, 0.5)
         if self.multiview and self.lmv > 0 and it % 10 == 0:

@@ -153,7 +153,7 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
     viewmatrix, projmatrix = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix")
     sh, campos = _f32c(sh, "sh"), _f32c(campos, "campos")
     M = sh.shape[1] if (sh is not None and sh.dim() == 3) else 0
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
     geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
     img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
     sig = _geometry_signature(P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered,
@@ -225,7 +225,7 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
             global PREFETCH_HITS
             PREFETCH_HITS += 1
         else:
-            radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)      # K1 writes every entry
             geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
             img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
             R = _prepare(L, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
@@ -241,7 +241,7 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
                                    _ptr(out_extra), _ptr(grp), H * W * 10 if tracer else 0, _ptr(gcount), st),
               "isr_forward_render")
     if tracer:
-        gidx = gcount - 1
+        gidx = gcount               # the library counts from -1: already the last valid index
     else:
         grp = torch.empty((0, 2), dtype=torch.int32, device=dev)
         gidx = torch.full((1,), -1, dtype=torch.int32, device=dev)

@@ -35,6 +35,21 @@ def _render(*x, **k):
 def _ar(*x, **k):
     _mark("losses+backward"); return _orig_ar(*x, **k)
 _h.render, _h.allreduce_grads = _render, _ar
+_orig_cl = _h.contrastive_loss
+_ncl = [0]
+def _cl(*x, **k):
+    r = _orig_cl(*x, **k)
+    _ncl[0] += 1
+    if _ncl[0] % 3 == 0: _mark("losses fwd")
+    return r
+_h.contrastive_loss = _cl
+_orig_rb = rasterizer.rasterize_gaussians_backward
+def _rb(*x, **k):
+    _mark("loss bwd (contrastive, gather)")
+    r = _orig_rb(*x, **k)
+    _mark("raster bwd")
+    return r
+rasterizer.rasterize_gaussians_backward = _rb
 _orig_opt = tr.opt.step
 def _opt(*x, **k):
     if a.delay_at == "opt": _spin(a.delay_us)
