@@ -134,6 +134,7 @@ def main():
     scene, cams, cfg = scenes.config_scene(args.config)
     trainer = SegTrainer(scene, cams[:16], device=dev, sample_batchsize=8192, use_class_feat=True, rank=rank, world=world)
     trainer.pipe.lazy_maps = bool(args.lazy_maps)
+    trainer.warm_view_caches()       # per-view constants (ray tables, visible pools): setup, like the label maps
     L = lib()
 
     for it in range(args.warmup):

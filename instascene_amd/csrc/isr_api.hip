@@ -422,11 +422,13 @@ int iso_render_post_forward(int W, int H, float depth_ratio, const float* allmap
         return fail(ISR_EINVAL, "render_post_forward: null pointer");
     const long long N = (long long)W * H;
     const unsigned blocks = (unsigned)((N + 255) / 256);
+    { ProfScope ps_("pp_maps", s);
     hipLaunchKernelGGL(iso::pp_maps, dim3(blocks), dim3(256), 0, s, N, depth_ratio, 1.0f - depth_ratio, allmap, viewmatrix,
-                       rend_alpha, rend_normal, rend_dist, surf_depth, rend_depth, rend_median);
+                       rend_alpha, rend_normal, rend_dist, surf_depth, rend_depth, rend_median); }
     ISR_LAUNCH_CHECK("pp_maps");
+    { ProfScope ps_("pp_surf_normal", s);
     hipLaunchKernelGGL(iso::pp_surf_normal, dim3(blocks), dim3(256), 0, s, W, H, surf_depth, rend_alpha, rays_d, rays_o,
-                       surf_normal);
+                       surf_normal); }
     ISR_LAUNCH_CHECK("pp_surf_normal");
     return ISR_OK;
 }

@@ -139,6 +139,19 @@ class SegTrainer:
                 c.sorted_segmap = c.segmap
             self.valid_idx[i] = torch.nonzero(c.segmap.reshape(-1) > 0).reshape(-1)
 
+    def warm_view_caches(self):
+        """Per-view constants that the loop otherwise builds on the first visit of a view — the camera's ray table used
+        by ``depth_to_normal`` (the reference rebuilds it on every call, utils/point_utils.py:10-27), the pool of visible
+        labelled Gaussians for the 3-D loss, the binning-size estimate — computed up front with one untrained render per
+        view, so that step times do not depend on how many views have been seen."""
+        with torch.no_grad():
+            for vi, cam in enumerate(self.cams):
+                pkg = render(cam, self.model, self.pipe, self.bg)
+                _ = pkg["surf_normal"]
+                if self.l3d > 0 and vi not in self.vis_pool:
+                    self.vis_pool[vi] = torch.nonzero(pkg["visibility_filter"] & (self.labels3d > 0)).reshape(-1)
+        self.model._seg_cache = None
+
     def _sample_view_loss(self, vi, seg_feature, segmap, predef, weight):
         idx_pool = self.valid_idx[vi]
         if idx_pool.numel() == 0:

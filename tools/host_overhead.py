@@ -18,10 +18,12 @@ rasterizer.set_mode("fast"); rasterizer.set_tracer(True); rasterizer.set_async_b
 scene, cams, cfg = scenes.config_scene("C3", a.scale)
 tr = SegTrainer(scene, cams[:16], device="cuda", sample_batchsize=8192, use_class_feat=True)
 tr.pipe.lazy_maps = bool(a.lazy_maps)
+tr.warm_view_caches()
 from instascene_amd import harness as _h
 _ev = []
+_host_t = []
 def _mark(tag):
-    e = torch.cuda.Event(enable_timing=True); e.record(); _ev.append((tag, e))
+    e = torch.cuda.Event(enable_timing=True); e.record(); _ev.append((tag, e)); _host_t.append(time.perf_counter())
 _orig_render, _orig_ar = _h.render, _h.allreduce_grads
 def _spin(us):
     t = time.perf_counter()
@@ -31,7 +33,7 @@ def _render(*x, **k):
     if a.delay_at == "before": _spin(a.delay_us)
     _mark("start"); r = _orig_render(*x, **k)
     if a.delay_at == "render": _spin(a.delay_us)
-    _mark("render"); return r
+    _mark("render: maps"); return r
 def _ar(*x, **k):
     _mark("losses+backward"); return _orig_ar(*x, **k)
 _h.render, _h.allreduce_grads = _render, _ar
@@ -50,6 +52,26 @@ def _rb(*x, **k):
     _mark("raster bwd")
     return r
 rasterizer.rasterize_gaussians_backward = _rb
+_orig_prep, _orig_rg = rasterizer._prepare, rasterizer.rasterize_gaussians
+def _prep(*x, **k):
+    _mark("render: before geometry pass (normalise, allocs)")
+    r = _orig_prep(*x, **k)
+    _mark("render: geometry pass")
+    return r
+def _rg(*x, **k):
+    r = _orig_rg(*x, **k)
+    _mark("render: binning + blend")
+    _mark("(two marks back to back)")
+    return r
+from instascene_amd import render as _rmod
+_orig_pp = _rmod.post_process
+def _pp(*x, **k):
+    _mark("render: between blend and maps (radii > 0, python)")
+    r = _orig_pp(*x, **k)
+    _mark("render: pp kernels")
+    return r
+_rmod.post_process = _pp
+rasterizer._prepare, rasterizer.rasterize_gaussians = _prep, _rg
 _orig_opt = tr.opt.step
 def _opt(*x, **k):
     if a.delay_at == "opt": _spin(a.delay_us)
@@ -66,7 +88,8 @@ rasterizer._verify_pending = _timed_verify
 for it in range(5):
     tr.step(it)
 _blocked[0] = 0.0
-_ev.clear()
+_ev.clear(); _host_t.clear()
+_e0 = torch.cuda.Event(enable_timing=True); _e0.record(); torch.cuda.synchronize(); _h0 = time.perf_counter()
 torch.cuda.synchronize()
 ms0 = torch.cuda.memory_stats()
 t0 = time.perf_counter()
@@ -87,3 +110,12 @@ for (t0_, e0), (t1_, e1) in zip(_ev[:-1], _ev[1:]):
     key = t1_ if t1_ != "start" else "between steps"
     acc[key] = acc.get(key, 0.0) + e0.elapsed_time(e1)
 print("GPU phases (ms/step):", {k: round(v / a.steps, 3) for k, v in acc.items()})
+# host lead: how long before the GPU reaches a mark was it enqueued? (one step in the middle of the run)
+starts = [i for i, (t, _) in enumerate(_ev) if t == "start"]
+lo, hi = starts[len(starts) // 2], starts[len(starts) // 2 + 1]
+print("mark                                                   host(ms)   gpu(ms)   host lead(ms)")
+for i in range(lo, hi + 1):
+    tag, e = _ev[i]
+    g = _e0.elapsed_time(e)
+    h = 1e3 * (_host_t[i] - _h0)
+    print("%-52s %9.3f %9.3f %9.3f" % (tag, h, g, g - h))
