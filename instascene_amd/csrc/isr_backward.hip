@@ -22,8 +22,6 @@
 
 namespace isr {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GEOM_ROW = 20;   // [0..8] dL_dT  [9,10] dL_dcentre  [11..13] dL_dnormal  [14] dL_dopacity  [15..17] dL_dcolor
 constexpr int BB = 32;         // instances per backward batch

@@ -118,6 +118,9 @@ inline size_t bin_bytes(int64_t R) {
 }
 
 // ---------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));     // MFMA 32x32 accumulator fragment
+typedef float f32x4 __attribute__((ext_vector_type(4)));       // MFMA 16x16 accumulator fragment
+
 struct F3 { float x, y, z; };
 __device__ __forceinline__ F3 operator+(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ F3 operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }

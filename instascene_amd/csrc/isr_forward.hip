@@ -422,9 +422,16 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
     float T = 1.0f;
     unsigned contributor = 0, last_contributor = 0, median_contributor = 0;
     float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, D = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
-    float E[FCH > 0 ? FCH : 1];
+    // FAST arithmetic, 32-channel chunk: the feature accumulation  E[pix][ch] += w(pix, splat) * feat[splat][ch]  runs on
+    // the matrix cores, two contributing splats per v_mfma_f32_32x32x2_f32 pair (one for pixels 0..31 of the wave, one
+    // for 32..63) — 16 packed FMAs + 8 LDS reads per splat leave the VALU, which is what bounds this kernel.
+    constexpr bool MF = Math::fast && FCH == 32;
+    float E[(FCH > 0 && !MF) ? FCH : 1];
 #pragma unroll
-    for (int c = 0; c < (FCH > 0 ? FCH : 1); c++) E[c] = 0.0f;
+    for (int c = 0; c < ((FCH > 0 && !MF) ? FCH : 1); c++) E[c] = 0.0f;
+    f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
+    float w_pend = 0.0f, f_pend = 0.0f;      // weight / feature fragment of a contributing splat waiting for its partner
+    bool pending = false;                    // wave-uniform
     const float mscale = FAR_N / (FAR_N - NEAR_N);
     const float bx0 = (float)(tx * TILE + (wv & 1) * 8), bx1 = bx0 + 7.0f;
     const float by0 = (float)(ty * TILE + (wv >> 1) * 8), by1 = by0 + 7.0f;
@@ -547,12 +554,14 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
                 done = done | stop;
                 const bool ok = pass & !stop;
                 if (__ballot(ok) == 0ull) continue;
+                float w_lane = 0.0f;
                 if (ok) {
                     const float w = alpha * T;
+                    w_lane = w;
                     contributor = (unsigned)(base - r0) + (unsigned)j + 1u;
                     if (first_pass) {
                         const float A = 1 - T;
-                        const float m_ = mscale * (1 - NEAR_N / depth);
+                        const float m_ = mscale * (1 - Math::div(NEAR_N, depth));
                         distortion += (Math::mad(m_ * m_, A, M2) - 2 * m_ * M1) * w;
                         D = Math::mad(depth, w, D);
                         M1 = Math::mad(m_, w, M1);
@@ -570,7 +579,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
                             }
                         }
                     }
-                    if (FCH > 0) {
+                    if (FCH > 0 && !MF) {
                         const float4* fj = reinterpret_cast<const float4*>(s_feat + j * FCH);
 #pragma unroll
                         for (int q4 = 0; q4 < QF4; q4++) {
@@ -591,7 +600,29 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
                     T = test_T;
                     last_contributor = contributor;
                 }
+                if constexpr (MF) {
+                    // A[i = channel][k = splat]: lanes 0..31 carry the pending splat's channels, 32..63 this splat's;
+                    // B[k = splat][j = pixel]: v_permlane32_swap puts the two splats' weights of one half of the pixels
+                    // into the two halves of the wave.
+                    const float f_lane = s_feat[j * FCH + (lane & 31)];
+                    if (!pending) { w_pend = w_lane; f_pend = f_lane; pending = true; }
+                    else {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(w_pend), __float_as_uint(w_lane), false, false);
+                        const float a = lane < 32 ? f_pend : f_lane;
+                        accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[0]), accA, 0, 0, 0);
+                        accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[1]), accB, 0, 0, 0);
+                        pending = false;
+                    }
+                }
             }
+        }
+    }
+    if constexpr (MF) {
+        if (pending) {          // odd number of contributing splats: pair the last one with a zero
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(w_pend), 0u, false, false);
+            const float a = lane < 32 ? f_pend : 0.0f;
+            accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[0]), accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[1]), accB, 0, 0, 0);
         }
     }
     if (tracer != nullptr && first_pass) {
@@ -616,10 +647,26 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
             out_others[5 * N + pix] = median_depth;
             out_others[6 * N + pix] = distortion;
         }
-        if (FCH > 0) {
+        if (FCH > 0 && !MF) {
 #pragma unroll
             for (int q = 0; q < FCH; q++)
                 if (q < nfeat) out_extra[(size_t)(ch_base + q) * N + pix] = E[q];
+        }
+    }
+    if constexpr (MF) {
+        // D[row = channel (r&3) + 8*(r>>2) + 4*(lane>>5)][col = pixel lane&31 of the group]
+#pragma unroll
+        for (int grp = 0; grp < 2; grp++) {
+            const int p = grp * 32 + (lane & 31);                       // pixel (wave lane numbering) held by this lane
+            const unsigned qx = tx * TILE + (wv & 1) * 8 + (p & 7), qy = ty * TILE + (wv >> 1) * 8 + (p >> 3);
+            if (qx < (unsigned)W && qy < (unsigned)H) {
+                const size_t qp = (size_t)W * qy + qx;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int ch = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (ch < nfeat) out_extra[(size_t)(ch_base + ch) * N + qp] = grp == 0 ? accA[r] : accB[r];
+                }
+            }
         }
     }
 }
