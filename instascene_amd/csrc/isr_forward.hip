@@ -419,6 +419,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
 
     if (threadIdx.x == 0) s_tcount = 0;     // ordered before first use by the barrier at the top of the batch loop
     bool done = !inside;
+    unsigned long long m_done = __ballot(!inside);      // the same predicate as a wave-uniform lane mask
     float T = 1.0f;
     unsigned contributor = 0, last_contributor = 0, median_contributor = 0;
     float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, D = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
             }
             unsigned long long m = __ballot(hit);
             while (m != 0ull) {
-                if (__ballot(!done) == 0ull) break;
+                if (m_done == ~0ull) break;
                 const int j = c0 + __builtin_ctzll(m);
                 m &= m - 1ull;
                 // Flat, predicated evaluation (few exec-mask regions: the scalar unit is a co-bottleneck of this loop).
@@ -539,9 +540,13 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
                 const float rho2d = FILTER_INV_SQ * Math::mad(dy, dy, dx * dx);
                 // exact-preserving early out: both candidate rho's certainly beyond the alpha<1/255 cut
                 const float skip = d.w;
-                const bool far = (rho2d > skip) & (Math::mad(p.y, p.y, p.x * p.x) > skip * (p.z * p.z) * 1.01f);
-                const bool cand = !done & !far & (p.z != 0.0f);
-                if (__ballot(cand) == 0ull) continue;
+                // Wave-uniform masks are built from ballots of the individual compares and combined on the scalar unit
+                // (a ballot of an already combined predicate costs two more vector instructions).
+                const bool far_a = rho2d > skip, far_b = Math::mad(p.y, p.y, p.x * p.x) > skip * (p.z * p.z) * 1.01f;
+                const bool nz = p.z != 0.0f;
+                const unsigned long long m_cand = ~m_done & ~(__ballot(far_a) & __ballot(far_b)) & __ballot(nz);
+                if (m_cand == 0ull) continue;
+                const bool cand = !done & !(far_a & far_b) & nz;
                 const float sx = Math::div(p.x, p.z), sy = Math::div(p.y, p.z);
                 const float rho3d = Math::mad(sy, sy, sx * sx);
                 const float rho = fminf(rho3d, rho2d);
@@ -549,11 +554,16 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
                 const float power = -0.5f * rho;
                 const float alpha = fminf(0.99f, d.z * Math::ex(power));
                 const float test_T = T * (1 - alpha);
-                const bool pass = cand & !(depth < NEAR_N) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
-                const bool stop = pass & (test_T < 0.0001f);
+                const bool t_near = !(depth < NEAR_N), t_pow = !(power > 0.0f), t_alpha = !(alpha < 1.0f / 255.0f);
+                const bool t_stop = test_T < 0.0001f;
+                const unsigned long long m_pass = m_cand & __ballot(t_near) & __ballot(t_pow) & __ballot(t_alpha);
+                const unsigned long long m_stop = m_pass & __ballot(t_stop);
+                m_done |= m_stop;
+                const bool pass = cand & t_near & t_pow & t_alpha;
+                const bool stop = pass & t_stop;
                 done = done | stop;
                 const bool ok = pass & !stop;
-                if (__ballot(ok) == 0ull) continue;
+                if ((m_pass & ~m_stop) == 0ull) continue;
                 float w_lane = 0.0f;
                 if (ok) {
                     const float w = alpha * T;
