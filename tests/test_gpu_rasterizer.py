@@ -338,6 +338,26 @@ def test_backward_mixed_sparse_and_dense_tiles(F):
         assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("W,H,F", [(90, 70, 8), (101, 67, 32), (130, 50, 20)])
+def test_sparse_backward_on_ragged_image_sizes(W, H, F):
+    """Widths that are not multiples of 4 (scalar path of the live-pixel scan), of the 16-pixel tile or of the 4-tile
+    strip, and a feature width that is not a multiple of 32: sampled dL/dfeature incl. the last row / column."""
+    sc, cams, inp = small_scene(P=1800, F=F, W=W, H=H, seed=57, mu_s=math.log(0.06))
+    cam = cams[1]
+    st = oracle_forward(inp, cam)
+    rng = np.random.RandomState(W)
+    dE = np.zeros_like(st["extra"]).reshape(F, -1)
+    pix = np.concatenate([rng.choice(W * H, 50, replace=False), [W - 1, W * H - 1, W * (H - 1), 0]])
+    dE[:, pix] = rng.randn(F, pix.size)
+    dE = dE.astype(np.float32).reshape(st["extra"].shape)
+    dC, dO = np.zeros_like(st["color"]), np.zeros_like(st["others"])
+    want = oracle.backward(st, dC, dO, dE)
+    for mode in (MODE_EXACT, MODE_FAST):
+        args, out = hip_forward(inp, cam, mode=mode)
+        got = hip_backward(args, out, dC, dO, dE, GRAD_EXTRA, mode)[8]
+        assert_close(got.cpu().numpy(), want["dL_dextra"], 1e-3, "ragged %dx%d F=%d" % (W, H, F))
+
+
 def test_culling_survives_grazing_and_near_camera_splats():
     """Edge-on, huge and near-plane splats: the conservative cull box must never drop a contributing pair
     (EXACT mode stays bit-identical to the oracle, which evaluates every pair)."""
