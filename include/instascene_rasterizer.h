@@ -69,7 +69,12 @@ size_t isr_backward_scratch_bytes(int64_t num_rendered, int ED, unsigned grad_ma
  * Replaces rasterizer_impl.cu:233-287.  Writes radii[P].  If num_rendered_host is
  * non-NULL the call synchronises the stream and stores R there (the reference
  * always does this blocking read, rasterizer_impl.cu:287); pass NULL to stay
- * asynchronous and read R later with isr_read_num_rendered(). */
+ * asynchronous and read R later with isr_read_num_rendered().
+ * `prefiltered`: bit 0 is the reference's flag (unused there too); ISR_PREPARE_TIGHT_RECTS drops from every splat's
+ * tile rectangle the tiles in which its alpha is certainly below 1/255 (the reference bins the square of the larger
+ * 3-sigma extent) — same images and gradients, fewer tile instances; the tile lists then differ from the reference's,
+ * so the bit-exact mode does not use it. */
+#define ISR_PREPARE_TIGHT_RECTS 0x100
 int isr_forward_prepare(int P, int D, int M, int width, int height,
                         const float* means3D, const float* shs, const float* colors_precomp,
                         const float* opacities, const float* scales, float scale_modifier,

@@ -131,8 +131,8 @@ size_t isr_backward_scratch_bytes(int64_t num_rendered, int ED, unsigned grad_ma
 int isr_forward_prepare(int P, int D, int M, int width, int height, const float* means3D, const float* shs,
                         const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
                         const float* rotations, const float* transMat_precomp, const float* viewmatrix,
-                        const float* projmatrix, const float* cam_pos, float, float, int, int* radii, void* geom_buffer,
-                        void* image_buffer, int64_t* num_rendered_host, void* stream) {
+                        const float* projmatrix, const float* cam_pos, float, float, int prefiltered, int* radii,
+                        void* geom_buffer, void* image_buffer, int64_t* num_rendered_host, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (P < 0 || width <= 0 || height <= 0) return fail(ISR_EINVAL, "bad sizes P=%d W=%d H=%d", P, width, height);
     if (!geom_buffer || !image_buffer || (P > 0 && !radii)) return fail(ISR_EINVAL, "null workspace/radii");
@@ -154,7 +154,8 @@ int isr_forward_prepare(int P, int D, int M, int width, int height, const float*
         { ProfScope ps_("k_preprocess", s);
         hipLaunchKernelGGL(k_preprocess, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales,
                            scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, viewmatrix,
-                           projmatrix, cam_pos, width, height, gx, gy, radii, g, iv.tile_count); }
+                           projmatrix, cam_pos, width, height, gx, gy, radii, g, iv.tile_count,
+                           (prefiltered & ISR_PREPARE_TIGHT_RECTS) ? 1 : 0); }
         ISR_LAUNCH_CHECK("k_preprocess");
         const int nb = (P + 1023) / 1024;
         ProfScope ps2_("k_scan_gaussians", s);

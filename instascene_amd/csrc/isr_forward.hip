@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_preprocess(
     const float* __restrict__ rots, const float* __restrict__ opacities, const float* __restrict__ shs,
     const float* __restrict__ tm_pre, const float* __restrict__ col_pre, const float* __restrict__ view,
     const float* __restrict__ proj, const float* __restrict__ campos, int W, int H, int gx, int gy,
-    int* __restrict__ radii_out, GeomView g, uint32_t* __restrict__ tile_count) {
+    int* __restrict__ radii_out, GeomView g, uint32_t* __restrict__ tile_count, int tight_rects) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     int radius_i = 0;
@@ -133,6 +133,28 @@ __global__ __launch_bounds__(256) void k_preprocess(
         int x0, y0, x1, y1;
         tile_rect(cx, cy, sat_i32(radius), gx, gy, x0, y0, x1, y1);
         if ((unsigned)(x1 - x0) * (unsigned)(y1 - y0) == 0u) break;
+        bool nowhere = false;
+        if (tight_rects) {
+            // The reference bins a splat into the SQUARE of its larger 3-sigma extent.  Outside the box below
+            // alpha < 1/255 is certain (the blend loops skip such pairs anyway), so tiles the box does not reach are
+            // dropped from the splat's rectangle: fewer instances to count, scatter, sort and stage.  `radii` is not
+            // changed.  Not used in the EXACT mode, whose tile lists are the reference's bit for bit.
+            const float opa = opacities[i];
+            float skip = __builtin_inff();
+            if (opa <= 1.0f) {
+                const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
+                skip = 2.0f * l * 1.01f + 0.05f;
+            }
+            const float4 cb = splat_cull_box(Tu, Tv, Tw, cx, cy, skip);
+            if (cb.x > -1e30f && cb.y < 1e30f && cb.z > -1e30f && cb.w < 1e30f) {
+                const int bx0 = (int)fmaxf(0.0f, __builtin_floorf(cb.x * (1.0f / TILE)));
+                const int bx1 = (int)fminf((float)gx, __builtin_floorf(cb.y * (1.0f / TILE)) + 1.0f);
+                const int by0 = (int)fmaxf(0.0f, __builtin_floorf(cb.z * (1.0f / TILE)));
+                const int by1 = (int)fminf((float)gy, __builtin_floorf(cb.w * (1.0f / TILE)) + 1.0f);
+                x0 = max(x0, bx0); x1 = min(x1, bx1); y0 = max(y0, by0); y1 = min(y1, by1);
+                if (x1 <= x0 || y1 <= y0) { x1 = x0; y1 = y0; nowhere = true; }
+            }
+        }
 
         float* rec = g.rec + (size_t)i * REC;
         F3 rgb = {0.f, 0.f, 0.f};

@@ -94,17 +94,19 @@ def _f32c(t: Optional[torch.Tensor], name: str):
     return t.contiguous()
 
 
+_TIGHT_RECTS = 0x100   # ISR_PREPARE_TIGHT_RECTS: FAST mode bins a splat only into tiles it can reach
 _PREFETCHED = {}      # (device, P, W, H) -> (signature, radii, geom, img, R, binning): a geometry pass + binning issued ahead of its forward
 PREFETCH_HITS = 0     # forwards that found their geometry pass already issued (statistics / tests)
 
 
-def _geometry_signature(P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered, tensors):
+def _geometry_signature(mode, P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered, tensors):
     """Identity of everything the geometry pass reads: scalars + (address, version) of the tensors."""
-    return (P, W, H, int(degree), M, float(scale_modifier), float(tan_fovx), float(tan_fovy), bool(prefiltered)) + tuple(
+    return (int(mode), P, W, H, int(degree), M, float(scale_modifier), float(tan_fovx), float(tan_fovy),
+            bool(prefiltered)) + tuple(
         None if t is None else (t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
 
 
-def _prepare(L, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
+def _prepare(L, mode, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
              transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img):
     """K1 + tile scan (``isr_forward_prepare``) into ``radii / geom / img``; returns the instance count R, or — with
     async binning — the capacity the binning workspace is sized with (the true count is verified later)."""
@@ -117,7 +119,8 @@ def _prepare(L, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scale
     check(L.isr_forward_prepare(P, int(degree), M, W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
                                 _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(transMat_precomp),
                                 _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
-                                int(bool(prefiltered)), _ptr(radii), _ptr(geom), _ptr(img),
+                                int(bool(prefiltered)) | (_TIGHT_RECTS if mode == MODE_FAST else 0), _ptr(radii),
+                                _ptr(geom), _ptr(img),
                                 None if use_async else ctypes.byref(num_rendered), st), "isr_forward_prepare")
     if use_async:
         R = int(_R_ESTIMATE[key] * _ASYNC_GROWTH) + _ASYNC_SLACK            # capacity, not the count
@@ -156,12 +159,13 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
     geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
     img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
-    sig = _geometry_signature(P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered,
+    mode = _CONFIG["mode"]
+    sig = _geometry_signature(mode, P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered,
                               (means3D, sh, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix,
                                campos))
     with torch.cuda.device(dev):
         st = _stream()
-        R = _prepare(L, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
+        R = _prepare(L, mode, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
                      transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img)
         binning = torch.empty(L.isr_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
         check(L.isr_forward_bin(P, W, H, _ptr(geom), _ptr(binning), R, _ptr(img), st), "isr_forward_bin")
@@ -214,7 +218,7 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
     with torch.cuda.device(dev):
         st = _stream()
         key = (dev.index, P, W, H)
-        sig = _geometry_signature(P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered,
+        sig = _geometry_signature(mode, P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered,
                                   (means3D, sh, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix,
                                    campos))
         ahead = _PREFETCHED.pop(key, None)
@@ -228,7 +232,7 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
             radii = torch.empty((P,), dtype=torch.int32, device=dev)      # K1 writes every entry
             geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
             img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
-            R = _prepare(L, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
+            R = _prepare(L, mode, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
                          transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img)
             binning = torch.empty(L.isr_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
         if tracer:

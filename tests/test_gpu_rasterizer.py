@@ -220,10 +220,17 @@ def test_fast_mode_forward_within_tolerance(P, F, W, H, seed):
     st = oracle_forward(inp, cams[0], bg=(0.1, 0.2, 0.3))
     args, out = hip_forward(inp, cams[0], bg=(0.1, 0.2, 0.3), mode=MODE_FAST)
     R, color, others, radii, extra = out[:5]
-    assert R == st["R"]
+    # FAST mode bins a splat only into the tiles it can reach (alpha >= 1/255 somewhere): every tile list is a
+    # subsequence, in the same order, of the reference's list; radii are untouched
+    assert 0 < R <= st["R"]
     np.testing.assert_array_equal(radii.cpu().numpy(), st["radii"])
     dbg = rz.debug_state(P, W, H, R, out[5], out[6], out[7])
-    np.testing.assert_array_equal(dbg["point_list"], st["point_list"])      # binning is mode-independent
+    ref_ranges = np.asarray(st["ranges"]).reshape(-1, 2)
+    got_ranges = np.asarray(dbg["ranges"]).reshape(-1, 2)
+    assert got_ranges.shape == ref_ranges.shape
+    for (a0, a1), (b0, b1) in zip(got_ranges, ref_ranges):
+        it = iter(st["point_list"][b0:b1])
+        assert all(any(g == r for r in it) for g in dbg["point_list"][a0:a1])
     for name, got, want in [("color", color, st["color"]), ("extra", extra, st["extra"]),
                             ("alpha", others[1], st["others"][1]), ("depth", others[0], st["others"][0])]:
         got = got.cpu().numpy()
