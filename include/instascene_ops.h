@@ -84,6 +84,17 @@ int iso_render_post_backward(int W, int H, float depth_ratio, const float* allma
                              const float* g_surf_normal, const float* g_depth, const float* g_median, float* scratch,
                              float* dL_dallmap, void* stream);
 
+/* Mean structural similarity of two [C,H,W] images (utils/loss_utils.py:39-63: 11x11 Gaussian window, sigma 1.5, zero
+ * padding, size_average=True) and its gradient with respect to img1.  The window is applied separably through LDS
+ * (the reference issues five depthwise conv2d's and their transposes).  dmaps [3,C,H,W] (optional in forward, required
+ * by backward): the three partial derivatives of the SSIM map that the backward blurs.  g_mean: device scalar
+ * dL/d(ssim_mean).  scratch: iso_ssim_scratch_bytes. */
+size_t iso_ssim_scratch_bytes(int C, int H, int W);
+int iso_ssim_forward(int C, int H, int W, const float* img1, const float* img2, float* ssim_mean, float* dmaps,
+                     void* scratch, size_t scratch_bytes, void* stream);
+int iso_ssim_backward(int C, int H, int W, const float* img1, const float* img2, const float* dmaps, const float* g_mean,
+                      float* dL_dimg1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,147 @@
+// Structural similarity (reference utils/loss_utils.py:39-63: 11x11 Gaussian window, sigma 1.5, zero padding,
+// C1 = 0.01^2, C2 = 0.03^2) for the train.py photometric loss, forward and backward with respect to the first image.
+// The reference runs five depthwise conv2d's forward and their transposes backward (MIOpen: ~9 ms per 1080p step
+// here); the window is separable, so one workgroup blurs a 32x8 output tile of all five moment maps through LDS
+// (rows, then columns), evaluates the SSIM map and its three partial derivatives in registers, and reduces the map
+// in fixed order.  Backward: the three derivative maps are blurred the same way (the zero-padded blur is symmetric).
+#include "isr_common.hpp"
+
+namespace iso {
+
+constexpr int SS_R = 5;                      // window radius (11 taps)
+constexpr int SS_TW = 32, SS_TH = 8;         // output tile: one pixel per thread of a 256-thread workgroup
+constexpr int SS_IW = SS_TW + 2 * SS_R;      // 42 input columns
+constexpr int SS_IH = SS_TH + 2 * SS_R;      // 18 input rows
+struct SsimTaps { float w[2 * SS_R + 1]; };
+static_assert(SS_TW * SS_TH == 256, "one output pixel per thread");
+
+// Horizontal then vertical blur of NM maps held in LDS as in[m][SS_IH][SS_IW]; the thread (tx, ty) of the 32x8 tile
+// receives the blurred values of its pixel in out[NM] (256 threads = 32 x 8 pixels).  hbuf[m][SS_IH][SS_TW] is scratch.
+template <int NM>
+__device__ __forceinline__ void tile_blur(const float* __restrict__ in, float* __restrict__ hbuf, const SsimTaps& tp,
+                                          float (&out)[NM]) {
+    const int tid = threadIdx.x;
+    // rows: SS_IH x SS_TW outputs per map
+    for (int e = tid; e < NM * SS_IH * SS_TW; e += 256) {
+        const int m = e / (SS_IH * SS_TW), r = (e / SS_TW) % SS_IH, c = e % SS_TW;
+        const float* src = in + (m * SS_IH + r) * SS_IW + c;
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k <= 2 * SS_R; k++) acc = __builtin_fmaf(tp.w[k], src[k], acc);
+        hbuf[e] = acc;
+    }
+    __syncthreads();
+    const int tx = tid & (SS_TW - 1), ty = tid >> 5;
+#pragma unroll
+    for (int m = 0; m < NM; m++) {
+        const float* src = hbuf + (m * SS_IH + ty) * SS_TW + tx;
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k <= 2 * SS_R; k++) acc = __builtin_fmaf(tp.w[k], src[k * SS_TW], acc);
+        out[m] = acc;
+    }
+}
+
+// grid (ceil(W/32), ceil(H/8), C).  map_part[block] = sum of the SSIM map over the block's pixels.
+// dmaps (optional) [3][C][H][W]: d map / d mu1, d map / d E[a^2], d map / d E[ab].
+__global__ __launch_bounds__(256) void ssim_fwd(int C, int H, int W, SsimTaps tp, const float* __restrict__ img1,
+                                                const float* __restrict__ img2, float* __restrict__ map_part,
+                                                float* __restrict__ dmaps) {
+    __shared__ float s_in[5 * SS_IH * SS_IW];      // a, b, a*a, b*b, a*b  (15.1 KB)
+    __shared__ float s_h[5 * SS_IH * SS_TW];       // (11.5 KB)
+    __shared__ float s_red[4];
+    const int ch = blockIdx.z;
+    const int x0 = blockIdx.x * SS_TW - SS_R, y0 = blockIdx.y * SS_TH - SS_R;
+    const size_t plane = (size_t)H * W;
+    for (int e = threadIdx.x; e < SS_IH * SS_IW; e += 256) {
+        const int r = e / SS_IW, c = e - r * SS_IW;
+        const int x = x0 + c, y = y0 + r;
+        float a = 0.0f, b = 0.0f;
+        if (x >= 0 && x < W && y >= 0 && y < H) {
+            a = img1[ch * plane + (size_t)y * W + x];
+            b = img2[ch * plane + (size_t)y * W + x];
+        }
+        s_in[e] = a; s_in[SS_IH * SS_IW + e] = b; s_in[2 * SS_IH * SS_IW + e] = a * a;
+        s_in[3 * SS_IH * SS_IW + e] = b * b; s_in[4 * SS_IH * SS_IW + e] = a * b;
+    }
+    __syncthreads();
+    float m[5];
+    tile_blur<5>(s_in, s_h, tp, m);
+    const int tx = threadIdx.x & (SS_TW - 1), ty = threadIdx.x >> 5;
+    const int x = blockIdx.x * SS_TW + tx, y = blockIdx.y * SS_TH + ty;
+    float val = 0.0f;
+    if (x < W && y < H) {
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float mu1 = m[0], mu2 = m[1];
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = m[2] - mu1_sq, s2 = m[3] - mu2_sq, s12 = m[4] - mu12;
+        const float n1 = 2.0f * mu12 + C1, n2 = 2.0f * s12 + C2;
+        const float d1 = mu1_sq + mu2_sq + C1, d2 = s1 + s2 + C2;
+        const float inv = 1.0f / (d1 * d2);
+        val = n1 * n2 * inv;
+        if (dmaps != nullptr) {
+            // map = n1 n2 / (d1 d2) with  s1 = Eaa - mu1^2, s12 = Eab - mu1 mu2
+            //   d/dEaa = -map / d2;   d/dEab = 2 n1 / (d1 d2)
+            //   d/dmu1 = 2 mu2 (n2 - n1) / (d1 d2) - map * 2 mu1 (1/d1 - 1/d2)
+            const size_t o = ch * plane + (size_t)y * W + x;
+            const size_t cp = (size_t)C * plane;
+            dmaps[o] = 2.0f * mu2 * (n2 - n1) * inv - val * 2.0f * mu1 * (1.0f / d1 - 1.0f / d2);
+            dmaps[cp + o] = -val / d2;
+            dmaps[2 * cp + o] = 2.0f * n1 * inv;
+        }
+    }
+    // fixed-order block sum
+    float v = val;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        map_part[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__global__ __launch_bounds__(256) void ssim_sum_parts(int n, const float* __restrict__ part, float inv_count,
+                                                      float* __restrict__ out) {
+    __shared__ float s_red[4];
+    float a = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * inv_count;
+}
+
+// dL/dimg1 = g * ( blur(dm1) + 2 a blur(dm2) + b blur(dm3) ),  g = dL/d(mean) / (C H W)
+__global__ __launch_bounds__(256) void ssim_bwd(int C, int H, int W, SsimTaps tp, const float* __restrict__ img1,
+                                                const float* __restrict__ img2, const float* __restrict__ dmaps,
+                                                const float* __restrict__ g_mean, float inv_count,
+                                                float* __restrict__ dimg1) {
+    __shared__ float s_in[3 * SS_IH * SS_IW];
+    __shared__ float s_h[3 * SS_IH * SS_TW];
+    const int ch = blockIdx.z;
+    const int x0 = blockIdx.x * SS_TW - SS_R, y0 = blockIdx.y * SS_TH - SS_R;
+    const size_t plane = (size_t)H * W, cp = (size_t)C * plane;
+    for (int e = threadIdx.x; e < SS_IH * SS_IW; e += 256) {
+        const int r = e / SS_IW, c = e - r * SS_IW;
+        const int x = x0 + c, y = y0 + r;
+        float d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
+        if (x >= 0 && x < W && y >= 0 && y < H) {
+            const size_t o = ch * plane + (size_t)y * W + x;
+            d1 = dmaps[o]; d2 = dmaps[cp + o]; d3 = dmaps[2 * cp + o];
+        }
+        s_in[e] = d1; s_in[SS_IH * SS_IW + e] = d2; s_in[2 * SS_IH * SS_IW + e] = d3;
+    }
+    __syncthreads();
+    float m[3];
+    tile_blur<3>(s_in, s_h, tp, m);
+    const int tx = threadIdx.x & (SS_TW - 1), ty = threadIdx.x >> 5;
+    const int x = blockIdx.x * SS_TW + tx, y = blockIdx.y * SS_TH + ty;
+    if (x < W && y < H) {
+        const size_t o = ch * plane + (size_t)y * W + x;
+        const float a = img1[o], b = img2[o];
+        dimg1[o] = (g_mean[0] * inv_count) * (m[0] + 2.0f * a * m[1] + b * m[2]);
+    }
+}
+
+}  // namespace iso

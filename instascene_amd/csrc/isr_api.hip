@@ -8,9 +8,11 @@
 #include "iso_knn.hip"
 #include "iso_contrastive.hip"
 #include "iso_post.hip"
+#include "iso_ssim.hip"
 #include "../../include/instascene_rasterizer.h"
 #include "../../include/instascene_ops.h"
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -455,6 +457,46 @@ int iso_render_post_backward(int W, int H, float depth_ratio, const float* allma
                        viewmatrix, rays_d, g_surf_normal ? scratch : (const float*)nullptr, g_alpha, g_normal, g_dist,
                        g_surf_depth, g_depth, g_median, dL_dallmap);
     ISR_LAUNCH_CHECK("pp_bwd_maps");
+    return ISR_OK;
+}
+
+static iso::SsimTaps ssim_taps() {
+    iso::SsimTaps t;
+    double g[11], sum = 0.0;
+    for (int i = 0; i < 11; i++) { g[i] = exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); sum += g[i]; }
+    for (int i = 0; i < 11; i++) t.w[i] = (float)(g[i] / sum);
+    return t;
+}
+
+size_t iso_ssim_scratch_bytes(int C, int H, int W) {
+    const size_t nb = (size_t)((W + iso::SS_TW - 1) / iso::SS_TW) * ((H + iso::SS_TH - 1) / iso::SS_TH) * (size_t)(C > 0 ? C : 1);
+    return nb * sizeof(float) + 256;
+}
+
+int iso_ssim_forward(int C, int H, int W, const float* img1, const float* img2, float* ssim_mean, float* dmaps,
+                     void* scratch, size_t scratch_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !ssim_mean || !scratch) return fail(ISR_EINVAL, "bad ssim arguments");
+    if (scratch_bytes < iso_ssim_scratch_bytes(C, H, W)) return fail(ISR_EINVAL, "ssim scratch too small");
+    const dim3 grid((W + iso::SS_TW - 1) / iso::SS_TW, (H + iso::SS_TH - 1) / iso::SS_TH, C);
+    const int nb = (int)(grid.x * grid.y * grid.z);
+    { ProfScope ps_("ssim_fwd", s);
+    hipLaunchKernelGGL(iso::ssim_fwd, grid, dim3(256), 0, s, C, H, W, ssim_taps(), img1, img2, (float*)scratch, dmaps); }
+    hipLaunchKernelGGL(iso::ssim_sum_parts, dim3(1), dim3(256), 0, s, nb, (const float*)scratch,
+                       (float)(1.0 / ((double)C * H * W)), ssim_mean);
+    ISR_LAUNCH_CHECK("iso_ssim_forward");
+    return ISR_OK;
+}
+
+int iso_ssim_backward(int C, int H, int W, const float* img1, const float* img2, const float* dmaps, const float* g_mean,
+                      float* dL_dimg1, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dmaps || !g_mean || !dL_dimg1) return fail(ISR_EINVAL, "bad ssim arguments");
+    const dim3 grid((W + iso::SS_TW - 1) / iso::SS_TW, (H + iso::SS_TH - 1) / iso::SS_TH, C);
+    { ProfScope ps_("ssim_bwd", s);
+    hipLaunchKernelGGL(iso::ssim_bwd, grid, dim3(256), 0, s, C, H, W, ssim_taps(), img1, img2, dmaps, g_mean,
+                       (float)(1.0 / ((double)C * H * W)), dL_dimg1); }
+    ISR_LAUNCH_CHECK("iso_ssim_backward");
     return ISR_OK;
 }
 
