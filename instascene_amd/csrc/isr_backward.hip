@@ -110,7 +110,7 @@ __device__ __forceinline__ void wave_sum12(const float (&g)[12], float (&out)[3]
 // QF: feature channels whose dL/dfeature(pixel) is kept in registers for the q-dot of the geometry pass
 //     (channels beyond QF are read from global memory; QF = 0 when there is no geometry pass or no feature).
 template <class Math, bool GEOM, bool FEAT, int QF>
-__global__ __launch_bounds__(256) void k_render_bwd(
+__global__ __launch_bounds__(256, 2) void k_render_bwd(
     int W, int H, int ED, int ch_base, int gx, const uint32_t* __restrict__ tile_offset,
     const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ box4, const float* __restrict__ rec,
     const float* __restrict__ col_pre, const float* __restrict__ tm_pre, const float* __restrict__ extras,
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(
                         }
                     }
                     if (act) {
-                        if (GEOM) { T = T / (1.f - alpha); w = alpha * T; }
+                        if (GEOM) { T = Math::div(T, 1.f - alpha); w = alpha * T; }
                         else { w = alpha * T; T = T * (1 - alpha); }
                     }
                     if (sparse) {
@@ -431,8 +431,8 @@ __global__ __launch_bounds__(256) void k_render_bwd(
                             acc_r1 = last_alpha * lc1 + (1.f - last_alpha) * acc_r1; lc1 = col.y; dL_dalpha += (col.y - acc_r1) * dpx1;
                             acc_r2 = last_alpha * lc2 + (1.f - last_alpha) * acc_r2; lc2 = col.z; dL_dalpha += (col.z - acc_r2) * dpx2;
                             float dL_dz = 0.0f;
-                            const float m_d = mscale * (1 - NEAR_N / c_d);
-                            const float dmd_dd = (FAR_N * NEAR_N) / ((FAR_N - NEAR_N) * c_d * c_d);
+                            const float m_d = mscale * (1 - Math::div(NEAR_N, c_d));
+                            const float dmd_dd = Math::div(FAR_N * NEAR_N, (FAR_N - NEAR_N) * c_d * c_d);
                             if (contributor == median_contributor - 1u) dL_dz += dL_dmedian;
                             const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
                             dL_dalpha += dL_dweight - last_dL_dT;
@@ -463,13 +463,13 @@ __global__ __launch_bounds__(256) void k_render_bwd(
                             }
                             dL_dalpha *= T;
                             last_alpha = alpha;
-                            dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                            dL_dalpha += Math::div(-T_final, 1.f - alpha) * bg_dot;
                             const float dL_dG = d.z * dL_dalpha;
                             dL_dz += alpha * T * dL_ddepth;
                             if (rho3d <= rho2d) {
                                 const float dsx = dL_dG * -G * sx + dL_dz * Tw.x;
                                 const float dsy = dL_dG * -G * sy + dL_dz * Tw.y;
-                                const float dsx_pz = dsx / p.z, dsy_pz = dsy / p.z;
+                                const float dsx_pz = Math::div(dsx, p.z), dsy_pz = Math::div(dsy, p.z);
                                 const F3 dL_dp = {dsx_pz, dsy_pz, -(dsx_pz * sx + dsy_pz * sy)};
                                 const F3 dL_dk = cross3(ll, dL_dp);
                                 const F3 dL_dl = cross3(dL_dp, kk);

@@ -133,7 +133,6 @@ __global__ __launch_bounds__(256) void k_preprocess(
         int x0, y0, x1, y1;
         tile_rect(cx, cy, sat_i32(radius), gx, gy, x0, y0, x1, y1);
         if ((unsigned)(x1 - x0) * (unsigned)(y1 - y0) == 0u) break;
-        bool nowhere = false;
         if (tight_rects) {
             // The reference bins a splat into the SQUARE of its larger 3-sigma extent.  Outside the box below
             // alpha < 1/255 is certain (the blend loops skip such pairs anyway), so tiles the box does not reach are
@@ -152,7 +151,7 @@ __global__ __launch_bounds__(256) void k_preprocess(
                 const int by0 = (int)fmaxf(0.0f, __builtin_floorf(cb.z * (1.0f / TILE)));
                 const int by1 = (int)fminf((float)gy, __builtin_floorf(cb.w * (1.0f / TILE)) + 1.0f);
                 x0 = max(x0, bx0); x1 = min(x1, bx1); y0 = max(y0, by0); y1 = min(y1, by1);
-                if (x1 <= x0 || y1 <= y0) { x1 = x0; y1 = y0; nowhere = true; }
+                if (x1 <= x0 || y1 <= y0) { x1 = x0; y1 = y0; }      // reaches no tile: zero instances, radius kept
             }
         }
 
