@@ -417,11 +417,13 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
     __shared__ __attribute__((aligned(16))) float s_feat[(FCH > 0 ? BATCH * FCH : 4)];
     __shared__ int s_id[BATCH];
     __shared__ __attribute__((aligned(16))) float4 s_box[BATCH];
-    // tracer (gaussian, pixel) pairs are collected per tile in LDS and flushed with ONE global atomic per flush
-    // (the reference does one global atomic on a single counter per hit, forward.cu:425)
-    constexpr int TCAP = 512;
-    __shared__ int s_trace[2 * TCAP];
-    __shared__ int s_tcount, s_tbase;
+    // tracer (gaussian, pixel) pairs: every wave stages its pairs in its OWN LDS region and keeps the fill count in a
+    // wave-uniform register, so an append is a ballot + popcount (no LDS atomic, no workgroup barrier); a region that
+    // is nearly full is flushed by its wave alone with ONE global atomic (the reference does a global atomic on a
+    // single counter per hit, forward.cu:425).
+    constexpr int WCAP = 128;               // pairs per wave region; flushed when fewer than 64 slots are left
+    __shared__ int s_trace[4 * 2 * WCAP];
+    int wcnt = 0;
 
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
@@ -438,7 +440,6 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
     if (r1 > capacity) r1 = capacity;
     const int nfeat = FCH > 0 ? min(FCH, ED - ch_base) : 0;
 
-    if (threadIdx.x == 0) s_tcount = 0;     // ordered before first use by the barrier at the top of the batch loop
     bool done = !inside;
     unsigned long long m_done = __ballot(!inside);      // the same predicate as a wave-uniform lane mask
     float T = 1.0f;
@@ -458,19 +459,20 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
     const float bx0 = (float)(tx * TILE + (wv & 1) * 8), bx1 = bx0 + 7.0f;
     const float by0 = (float)(ty * TILE + (wv >> 1) * 8), by1 = by0 + 7.0f;
 
-    auto flush_trace = [&]() {      // called by all threads between two barriers
-        const int n = min(s_tcount, TCAP);
-        __syncthreads();
+    auto flush_trace = [&]() {      // one wave, its own region: no workgroup barrier
+        const int n = wcnt;
         if (n > 0) {
-            if (threadIdx.x == 0) { s_tbase = atomicAdd(tracer_count, n) + 1; s_tcount = 0; }   // counter starts at -1
-            __syncthreads();
-            const int gb = s_tbase;
-            for (int e = threadIdx.x; e < n; e += 256)
-                if (gb + e < tracer_cap) {
-                    tracer[2 * (size_t)(gb + e)] = s_trace[2 * e];
-                    tracer[2 * (size_t)(gb + e) + 1] = s_trace[2 * e + 1];
-                }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the lanes' LDS writes before the lanes' reads
+            __builtin_amdgcn_wave_barrier();
+            int gb = 0;
+            if (lane == 0) gb = atomicAdd(tracer_count, n) + 1;        // counter starts at -1
+            gb = __builtin_amdgcn_readfirstlane(gb);
+            const int* src = s_trace + wv * 2 * WCAP;
+            for (int e = lane; e < n; e += 64)
+                if (gb + e < tracer_cap)
+                    *reinterpret_cast<int2*>(tracer + 2 * (size_t)(gb + e)) = make_int2(src[2 * e], src[2 * e + 1]);
+            __builtin_amdgcn_wave_barrier();
+            wcnt = 0;
         }
     };
     // Staging: the ids of the NEXT batch are prefetched into a register while the current batch is blended, so a
@@ -481,7 +483,6 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
     int nid = (threadIdx.x < BATCH && r0 + my_inst < r1) ? (int)point_list[r0 + my_inst] : 0;
     for (int64_t base = r0; base < r1; base += BATCH) {
         if (__syncthreads_and(done)) break;
-        if (tracer != nullptr && first_pass && s_tcount > TCAP / 2) flush_trace();
         const int nb = (int)min((int64_t)BATCH, r1 - base);
         const int id = nid;
         if (threadIdx.x < BATCH && base + BATCH + my_inst < r1) nid = (int)point_list[base + BATCH + my_inst];
@@ -601,14 +602,6 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
                         N0 = Math::mad(c.w, w, N0); N1 = Math::mad(d.x, w, N1); N2 = Math::mad(d.y, w, N2);
                         const float4 col = reinterpret_cast<const float4*>(s_rgb)[j];
                         C0 = Math::mad(col.x, w, C0); C1 = Math::mad(col.y, w, C1); C2 = Math::mad(col.z, w, C2);
-                        if (tracer != nullptr && w >= 0.1f) {   // (double)w > 0.1  <=>  w >= 0.1f
-                            const int ls = atomicAdd(&s_tcount, 1);
-                            if (ls < TCAP) { s_trace[2 * ls] = s_id[j]; s_trace[2 * ls + 1] = (int)pix; }
-                            else {      // LDS staging full (rare): append directly
-                                const int slot = atomicAdd(tracer_count, 1) + 1;
-                                if (slot < tracer_cap) { tracer[2 * (size_t)slot] = s_id[j]; tracer[2 * (size_t)slot + 1] = (int)pix; }
-                            }
-                        }
                     }
                     if (FCH > 0 && !MF) {
                         const float4* fj = reinterpret_cast<const float4*>(s_feat + j * FCH);
@@ -630,6 +623,20 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
                     }
                     T = test_T;
                     last_contributor = contributor;
+                }
+                if (tracer != nullptr && first_pass) {
+                    const unsigned long long m_tr = __ballot(w_lane >= 0.1f);     // (double)w > 0.1  <=>  w >= 0.1f
+                    if (m_tr != 0ull) {
+                        if (w_lane >= 0.1f) {
+                            const int slot = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_tr >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((unsigned)m_tr, 0u));
+                            int* dst = s_trace + wv * 2 * WCAP + 2 * slot;
+                            dst[0] = s_id[j];
+                            dst[1] = (int)pix;
+                        }
+                        wcnt += __popcll(m_tr);
+                        if (wcnt > WCAP - 64) flush_trace();
+                    }
                 }
                 if constexpr (MF) {
                     // A[i = channel][k = splat]: lanes 0..31 carry the pending splat's channels, 32..63 this splat's;
@@ -656,10 +663,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
             accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[1]), accB, 0, 0, 0);
         }
     }
-    if (tracer != nullptr && first_pass) {
-        __syncthreads();
-        flush_trace();
-    }
+    if (tracer != nullptr && first_pass) flush_trace();
     if (inside) {
         if (first_pass) {
             final_T[pix] = T;
