@@ -107,6 +107,10 @@ def main():
     ap.add_argument("--tracer", type=int, default=1, help="produce gau_related_pixels each forward like the reference")
     ap.add_argument("--async-binning", type=int, default=1,
                     help="size the binning workspace from the previous view instead of a blocking read of R")
+    ap.add_argument("--view-cache-gb", type=float, default=0.0,
+                    help="opt-in exploration, NOT the headline configuration: keep each view's geometry pass + binning "
+                         "while the geometry is frozen (rasterizer.set_view_cache); 0 = recompute every step like the "
+                         "reference")
     ap.add_argument("--lazy-maps", type=int, default=0,
                     help="1: evaluate render()'s seven derived normal/depth maps on first access (this step never reads "
                          "them) instead of inside render() like the reference (default 0 = reference behaviour)")
@@ -131,6 +135,7 @@ def main():
     rasterizer.set_mode(args.mode)
     rasterizer.set_tracer(bool(args.tracer))
     rasterizer.set_async_binning(bool(args.async_binning))
+    rasterizer.set_view_cache(args.view_cache_gb)
     scene, cams, cfg = scenes.config_scene(args.config)
     trainer = SegTrainer(scene, cams[:16], device=dev, sample_batchsize=8192, use_class_feat=True, rank=rank, world=world)
     trainer.pipe.lazy_maps = bool(args.lazy_maps)
@@ -216,7 +221,7 @@ def main():
                           "parallelism": f"dp{world} (one view per rank, RCCL all-reduce of the [P,F] gradient"
                                          + (", overlapped with the next view's geometry pass)" if world > 1 else ")"),
                           "arithmetic_mode": args.mode, "tracer": bool(args.tracer),
-                          "async_binning": bool(args.async_binning),
+                          "async_binning": bool(args.async_binning), "view_cache_gb": args.view_cache_gb,
                           "derived_render_maps": "on first access (never read by this step)" if args.lazy_maps else "inside render(), like the reference"},
                "roofline": roof}
         if not args.no_cpu_baseline:

@@ -10,7 +10,9 @@ plumbing; all arithmetic happens in ``libinstascene_hip.so``.
 """
 from __future__ import annotations
 
+import collections
 import ctypes
+import weakref
 import os
 from typing import NamedTuple, Optional
 
@@ -52,6 +54,46 @@ def set_tracer(enabled: bool):
 
 def set_async_binning(enabled: bool):
     _CONFIG["async_binning"] = bool(enabled)
+
+
+class _ViewState:
+    """Geometry pass + binning of one view, kept for the next render of the same view with the same inputs."""
+    __slots__ = ("radii", "geom", "img", "R", "binning", "nbytes", "busy", "__weakref__")
+
+    def __init__(self, radii, geom, img, R, binning):
+        self.radii, self.geom, self.img, self.R, self.binning = radii, geom, img, R, binning
+        self.nbytes = sum(t.numel() * t.element_size() for t in (radii, geom, img, binning))
+        self.busy = 0           # forwards whose backward has not run yet: they still need this img / binning state
+
+    def release(self):
+        self.busy = max(0, self.busy - 1)
+
+
+_VIEW_CACHE = collections.OrderedDict()       # geometry signature -> _ViewState (LRU)
+VIEW_CACHE_HITS = 0
+
+
+def set_view_cache(gigabytes: float):
+    """Opt-in (default 0 = off).  While the geometry, SH and camera tensors of a render are unchanged (same storage, same
+    version counters — e.g. the frozen-geometry feature training of train_semantic.py), the projection, the tile lists
+    and their depth order are the same every time that view comes round.  With a budget, the forward keeps that state
+    (~35 bytes per Gaussian + 16 per tile instance + 20 per pixel; 0.2 GB per 1080p view of a 1.5 M scene — a few hundred
+    views fit the 288 GB of an MI355X) and the next render of the view starts at the blend kernel.  An entry is not reused
+    while a backward that needs it is outstanding; any in-place update of an input invalidates it."""
+    _CONFIG["view_cache_bytes"] = int(max(0.0, float(gigabytes)) * (1 << 30))
+    if _CONFIG["view_cache_bytes"] == 0:
+        _VIEW_CACHE.clear()
+
+
+def _view_cache_put(sig, state):
+    _VIEW_CACHE[sig] = state
+    total = sum(v.nbytes for v in _VIEW_CACHE.values())
+    for k in list(_VIEW_CACHE.keys()):
+        if total <= _CONFIG["view_cache_bytes"] or k == sig:
+            continue
+        if _VIEW_CACHE[k].busy:
+            continue
+        total -= _VIEW_CACHE.pop(k).nbytes
 
 
 class BinningOverflow(RuntimeError):
@@ -156,13 +198,16 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
     viewmatrix, projmatrix = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix")
     sh, campos = _f32c(sh, "sh"), _f32c(campos, "campos")
     M = sh.shape[1] if (sh is not None and sh.dim() == 3) else 0
-    radii = torch.empty((P,), dtype=torch.int32, device=dev)
-    geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
-    img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
     mode = _CONFIG["mode"]
     sig = _geometry_signature(mode, P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered,
                               (means3D, sh, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix,
                                campos))
+    kept = _VIEW_CACHE.get(sig) if _CONFIG.get("view_cache_bytes", 0) > 0 else None
+    if kept is not None and kept.busy == 0:
+        return False                      # the view cache already holds this view's state
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
+    img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         st = _stream()
         R = _prepare(L, mode, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
@@ -175,7 +220,7 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
 
 def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
                         extra_attrs, attr_degree, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
-                        image_width, sh, degree, campos, prefiltered, debug, *, tracer=None, mode=None):
+                        image_width, sh, degree, campos, prefiltered, debug, *, tracer=None, mode=None, _state_out=None):
     """Equivalent of ``_C.rasterize_gaussians`` (rasterize_points.cu:39-151).
 
     Returns ``(num_rendered, out_color, out_others, radii, out_extra, geomBuffer, binningBuffer, imgBuffer,
@@ -223,7 +268,16 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
                                    campos))
         ahead = _PREFETCHED.pop(key, None)
         prebinned = 0
-        if ahead is not None and ahead[0] == sig:
+        kept = _VIEW_CACHE.get(sig) if _CONFIG.get("view_cache_bytes", 0) > 0 else None
+        if kept is not None and kept.busy == 0:
+            radii, geom, img, R, binning = kept.radii, kept.geom, kept.img, kept.R, kept.binning
+            prebinned = MODE_PREBINNED
+            _VIEW_CACHE.move_to_end(sig)
+            global VIEW_CACHE_HITS
+            VIEW_CACHE_HITS += 1
+            if _state_out is not None:
+                _state_out.append(kept)
+        elif ahead is not None and ahead[0] == sig:
             radii, geom, img, R, binning = ahead[1:]     # the geometry pass of this view was issued by prefetch_geometry()
             prebinned = MODE_PREBINNED
             global PREFETCH_HITS
@@ -244,6 +298,11 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
                                    _ptr(geom), _ptr(binning), R, _ptr(img), _ptr(out_color), _ptr(out_others),
                                    _ptr(out_extra), _ptr(grp), H * W * 10 if tracer else 0, _ptr(gcount), st),
               "isr_forward_render")
+    if _CONFIG.get("view_cache_bytes", 0) > 0 and kept is None and _state_out is not None:
+        st_new = _ViewState(radii, geom, img, R, binning)
+        if st_new.nbytes <= _CONFIG["view_cache_bytes"]:
+            _view_cache_put(sig, st_new)
+            _state_out.append(st_new)
     if tracer:
         gidx = gcount               # the library counts from -1: already the last valid index
     else:
@@ -367,17 +426,28 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+class _Token:
+    """Dies with the autograd context that holds it (see weakref.finalize in _RasterizeGaussians.forward)."""
+    __slots__ = ("__weakref__",)
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, extra_attrs,
                 raster_settings):
         rs = raster_settings
         attr_degree = extra_attrs.shape[1] if extra_attrs.shape[0] != 0 else 0
+        kept_state = []
         (num_rendered, color, depth, radii, extra, geomBuffer, binningBuffer, imgBuffer, gau_related_pixels,
          gau_pixel_indices) = rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             extra_attrs, attr_degree, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
-            rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+            rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, _state_out=kept_state)
+        if kept_state and any(ctx.needs_input_grad):
+            # the cached view state now backs a pending backward: not reusable until that has run (or the graph is freed)
+            kept_state[0].busy += 1
+            ctx.view_token = _Token()
+            weakref.finalize(ctx.view_token, kept_state[0].release)
         if gau_related_pixels.shape[0] and not _CONFIG.get("lazy_tracer", False):
             gau_related_pixels = gau_related_pixels[:(gau_pixel_indices + 1)]   # same slicing as the reference (:106)
         elif gau_related_pixels.shape[0]:

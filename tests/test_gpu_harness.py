@@ -70,6 +70,43 @@ def test_prefetched_geometry_pass_changes_nothing():
         rz.set_tracer(True)
 
 
+def test_view_cache_reproduces_the_plain_loop():
+    """Opt-in cache of the per-view geometry pass + binning (frozen geometry): same losses and parameters bit for bit,
+    every revisit of a view is a hit, and a second forward of a view whose backward is still outstanding bypasses it."""
+    rz.set_mode("fast")
+    rz.set_tracer(False)
+    try:
+        outs = []
+        for gb in (0.0, 1.0):
+            rz.set_view_cache(gb)
+            sc, cams = _scene()
+            tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=2048, n_labels=12, use_class_feat=True, seed=3)
+            hits0 = rz.VIEW_CACHE_HITS
+            losses = [float(tr.step(it)) for it in range(14)]          # 6 views: 2 full cycles + 2
+            outs.append((losses, tr.model._seg_feature.detach().clone(), rz.VIEW_CACHE_HITS - hits0))
+        assert outs[0][0] == outs[1][0]
+        assert torch.equal(outs[0][1], outs[1][1])
+        assert outs[0][2] == 0 and outs[1][2] == 8
+        # two forwards of one view before either backward: the second must not reuse (and overwrite) the first one's state
+        m, cam = tr.model, tr.cams[0]
+        a = render(cam, m, tr.pipe, tr.bg)["seg_feature"]
+        h = rz.VIEW_CACHE_HITS
+        b = render(cam, m, tr.pipe, tr.bg)["seg_feature"]
+        assert rz.VIEW_CACHE_HITS in (h, h + 1)
+        (a.sum() + 2.0 * b.sum()).backward()
+        g_two = m._seg_feature.grad.clone(); m._seg_feature.grad = None
+        rz.set_view_cache(0.0)
+        m._seg_cache = None
+        a = render(cam, m, tr.pipe, tr.bg)["seg_feature"]
+        b = render(cam, m, tr.pipe, tr.bg)["seg_feature"]
+        (a.sum() + 2.0 * b.sum()).backward()
+        assert torch.equal(g_two, m._seg_feature.grad)
+    finally:
+        rz.set_view_cache(0.0)
+        rz.set_mode("exact")
+        rz.set_tracer(True)
+
+
 def test_rgb_trainer_reduces_the_loss():
     rz.set_mode("fast")
     rz.set_tracer(False)
