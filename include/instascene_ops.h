@@ -95,6 +95,12 @@ int iso_ssim_forward(int C, int H, int W, const float* img1, const float* img2, 
 int iso_ssim_backward(int C, int H, int W, const float* img1, const float* img2, const float* dmaps, const float* g_mean,
                       float* dL_dimg1, void* stream);
 
+/* Densification statistics of one iteration (train.py:140-142; scene/gaussian_model.py:601-604): for every Gaussian i
+ * with visible[i] != 0:  grad_accum[i] += |viewspace_grad[i, 0:C]|_2,  denom[i] += 1,
+ * max_radii[i] = max(max_radii[i], radii[i]). */
+int iso_densify_stats(int P, int C, const float* viewspace_grad, const unsigned char* visible, const int* radii,
+                      float* grad_accum, float* denom, float* max_radii, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -151,4 +151,19 @@ __global__ __launch_bounds__(256) void pp_bwd_maps(int W, int H, float ratio, fl
     out[6 * N + i] = g_dist ? g_dist[i] : 0.0f;
 }
 
+// Densification statistics of one training iteration (train.py:140-142, scene/gaussian_model.py:601-604): for every visible
+// Gaussian  accum += |dL/dmean2D|,  denom += 1,  max_radii = max(max_radii, radii)  — one pass over the P rows.
+__global__ __launch_bounds__(256) void densify_stats(int P, int C, const float* __restrict__ grad,
+                                                     const uint8_t* __restrict__ visible, const int* __restrict__ radii,
+                                                     float* __restrict__ accum, float* __restrict__ denom,
+                                                     float* __restrict__ max_radii) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P || !visible[i]) return;
+    float s = 0.0f;
+    for (int c = 0; c < C; c++) { const float g = grad[(size_t)i * C + c]; s += g * g; }
+    accum[i] += __builtin_sqrtf(s);
+    denom[i] += 1.0f;
+    max_radii[i] = fmaxf(max_radii[i], (float)radii[i]);
+}
+
 }  // namespace iso

@@ -500,6 +500,18 @@ int iso_ssim_backward(int C, int H, int W, const float* img1, const float* img2,
     return ISR_OK;
 }
 
+int iso_densify_stats(int P, int C, const float* viewspace_grad, const unsigned char* visible, const int* radii,
+                      float* grad_accum, float* denom, float* max_radii, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || C <= 0) return fail(ISR_EINVAL, "bad densify_stats sizes");
+    if (P == 0) return ISR_OK;
+    if (!viewspace_grad || !visible || !radii || !grad_accum || !denom || !max_radii) return fail(ISR_EINVAL, "densify_stats: null pointer");
+    hipLaunchKernelGGL(iso::densify_stats, dim3((P + 255) / 256), dim3(256), 0, s, P, C, viewspace_grad, visible, radii,
+                       grad_accum, denom, max_radii);
+    ISR_LAUNCH_CHECK("iso_densify_stats");
+    return ISR_OK;
+}
+
 int iso_rownorm2(long long N, int F, float eps1, float eps2, int backward, const float* x, const float* gy,
                  const float* gz, float* out1, float* out2, void* stream) {
     hipStream_t s = (hipStream_t)stream;

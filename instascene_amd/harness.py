@@ -256,7 +256,10 @@ class RgbTrainer:
     lambda_normal*(1 - <rend_normal, surf_normal>) -> backward (full geometry gradients) -> Adam."""
 
     def __init__(self, scene, cameras, targets, device="cuda", lambda_dssim=0.2, lambda_normal=0.05, lambda_dist=0.0,
-                 rank=0, world=1):
+                 rank=0, world=1, densify=None, scene_extent=None):
+        """``densify``: None (off) or a dict overriding the reference's schedule (arguments/__init__.py:106-125):
+        ``from_iter=500, until_iter=15000, interval=100, opacity_reset_interval=3000, grad_threshold=0.0002,
+        opacity_cull=0.05, percent_dense=0.01``; ``scene_extent`` = the reference's ``cameras_extent``."""
         from .losses import l1_loss, ssim
         self.l1, self.ssim = l1_loss, ssim
         self.device = torch.device(device)
@@ -268,6 +271,35 @@ class RgbTrainer:
         self.ld, self.ln, self.ldist = lambda_dssim, lambda_normal, lambda_dist
         self.rank, self.world = rank, world
         self.opt = torch.optim.Adam(self.model.param_groups(), lr=0.0, eps=1e-15)
+        self.densify_cfg = None
+        if densify is not None:
+            from .densify import Densifier
+            self.densify_cfg = dict(from_iter=500, until_iter=15_000, interval=100, opacity_reset_interval=3000,
+                                    grad_threshold=0.0002, opacity_cull=0.05, percent_dense=0.01)
+            self.densify_cfg.update(densify)
+            self.densifier = Densifier(self.model, self.opt, self.densify_cfg["percent_dense"])
+            if scene_extent is None:      # radius of the camera ring around its centroid, x1.1 (scene/dataset_readers.py)
+                centers = torch.stack([c.camera_center for c in self.cams])
+                scene_extent = float((centers - centers.mean(dim=0)).norm(dim=1).max()) * 1.1
+            self.scene_extent = float(scene_extent)
+
+    def _density_control(self, iteration: int, pkg) -> None:
+        """train.py:138-151, between backward and the optimiser step; with several ranks the statistics are summed /
+        maxed first and the split draws from an identically seeded stream, so every replica edits the same rows."""
+        cfg, d = self.densify_cfg, self.densifier
+        if iteration >= cfg["until_iter"]:
+            return
+        d.accumulate(pkg["viewspace_points"].grad, pkg["visibility_filter"], pkg["radii"])
+        if iteration > cfg["from_iter"] and iteration % cfg["interval"] == 0:
+            if self.world > 1:
+                dist.all_reduce(d.xyz_gradient_accum, op=dist.ReduceOp.SUM)
+                dist.all_reduce(d.denom, op=dist.ReduceOp.SUM)
+                dist.all_reduce(d.max_radii2D, op=dist.ReduceOp.MAX)
+                torch.manual_seed(977 + iteration)
+            size_threshold = 20 if iteration > cfg["opacity_reset_interval"] else None
+            d.densify_and_prune(cfg["grad_threshold"], cfg["opacity_cull"], self.scene_extent, size_threshold)
+        if iteration % cfg["opacity_reset_interval"] == 0:
+            d.reset_opacity()
 
     def step(self, it: int):
         vi = view_for(it, self.rank, self.world, len(self.cams))
@@ -279,6 +311,8 @@ class RgbTrainer:
         loss = loss + self.ln * normal_error.mean()
         loss.backward()
         allreduce_grads([p for gr in self.opt.param_groups for p in gr["params"]], self.world)
+        if self.densify_cfg is not None:
+            self._density_control(it + 1, pkg)          # the reference counts iterations from 1
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
         return loss.detach(), pkg

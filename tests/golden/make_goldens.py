@@ -281,3 +281,66 @@ with CpuMode():
              seg_rand=seg0, masks=masks)
     except Exception as e:  # pragma: no cover
         print("gram-schmidt golden skipped:", repr(e))
+
+    # ------------------------------------------------------------------ densification (train.py:138-151)
+    try:
+        class _Args:
+            percent_dense = 0.01
+            position_lr_init = 0.00016
+            position_lr_final = 0.0000016
+            position_lr_delay_mult = 0.01
+            position_lr_max_steps = 30_000
+            feature_lr = 0.0025
+            opacity_lr = 0.05
+            scaling_lr = 0.005
+            rotation_lr = 0.001
+            seg_feature_lr = 0.025
+
+        gen = torch.Generator().manual_seed(4242)
+        P = 600
+        gm = GaussianModel(3)
+        gm.spatial_lr_scale = 1.0
+        mk = lambda t: torch.nn.Parameter(t.requires_grad_(True))
+        init = dict(xyz=torch.randn(P, 3, generator=gen), f_dc=torch.randn(P, 1, 3, generator=gen),
+                    f_rest=0.1 * torch.randn(P, 15, 3, generator=gen), opacity=1.5 * torch.randn(P, 1, generator=gen),
+                    scaling=math.log(0.03) + 0.8 * torch.randn(P, 2, generator=gen), rotation=torch.randn(P, 4, generator=gen))
+        gm._xyz, gm._features_dc, gm._features_rest = mk(init["xyz"].clone()), mk(init["f_dc"].clone()), mk(init["f_rest"].clone())
+        gm._opacity, gm._scaling, gm._rotation = mk(init["opacity"].clone()), mk(init["scaling"].clone()), mk(init["rotation"].clone())
+        gm.max_radii2D = torch.zeros(P)
+        gm.training_setup(_Args())
+        out = {"init_" + k: v for k, v in init.items()}
+        # two optimiser steps with seeded gradients (non-trivial Adam moments), three rounds of statistics
+        names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+        params = [gm._xyz, gm._features_dc, gm._features_rest, gm._opacity, gm._scaling, gm._rotation]
+        for s in range(2):
+            for n, p_ in zip(names, params):
+                p_.grad = 0.01 * torch.randn(p_.shape, generator=gen)
+                out[f"grad{s}_{n}"] = p_.grad.clone()
+            gm.optimizer.step()
+            gm.optimizer.zero_grad(set_to_none=True)
+        for s in range(3):
+            vs = torch.zeros(P, 3, requires_grad=True)
+            vs.grad = torch.cat([0.0008 * torch.rand(P, 2, generator=gen), torch.zeros(P, 1)], dim=1)
+            vis = torch.rand(P, generator=gen) > 0.3
+            radii = torch.randint(0, 40, (P,), generator=gen).int()
+            gm.max_radii2D[vis] = torch.max(gm.max_radii2D[vis], radii[vis])
+            gm.add_densification_stats(vs, vis)
+            out[f"vsgrad{s}"], out[f"vis{s}"], out[f"radii{s}"] = vs.grad.clone(), vis, radii
+        out["stats_accum"], out["stats_denom"], out["stats_max_radii"] = gm.xyz_gradient_accum.clone(), gm.denom.clone(), gm.max_radii2D.clone()
+        torch.manual_seed(31337)
+        gm.densify_and_prune(0.0002, 0.05, 2.5, 20)
+        for n, attr in zip(names, ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]):
+            p_ = getattr(gm, attr)
+            st = gm.optimizer.state[p_]
+            out[f"after_{n}"], out[f"after_m_{n}"], out[f"after_v_{n}"] = p_.detach(), st["exp_avg"], st["exp_avg_sq"]
+        out["after_accum"], out["after_denom"], out["after_max_radii"] = gm.xyz_gradient_accum, gm.denom, gm.max_radii2D
+        gm.reset_opacity()
+        st = gm.optimizer.state[gm._opacity]
+        out["reset_opacity"], out["reset_m"], out["reset_v"] = gm._opacity.detach(), st["exp_avg"], st["exp_avg_sq"]
+        out["params"] = np.array([0.0002, 0.05, 2.5, 20, 0.01])     # max_grad, min_opacity, extent, max_screen_size, percent_dense
+        out["seed"] = np.array(31337)
+        save("densify.npz", **out)
+    except Exception as e:  # pragma: no cover
+        import traceback
+        traceback.print_exc()
+        print("densification golden skipped:", repr(e))

@@ -160,3 +160,38 @@ def test_segmap_gaussians_from_rendered_tracer():
     for m in want:
         assert set(got[m].tolist()) == want[m]
     assert set(frame.tolist()) == set(grp[:, 0].tolist())
+
+
+def test_rgb_trainer_with_density_control():
+    """train.py's loop incl. densification on a short schedule: the Gaussian count changes, parameters / Adam state /
+    statistics stay consistent, the loss keeps going down and the rasterizer follows the new P."""
+    rz.set_mode("fast")
+    rz.set_tracer(False)
+    try:
+        sc, cams = _scene(P=1500, F=0, W=96, H=64, seed=11)
+        ref = copy.deepcopy(sc)
+        tr0 = RgbTrainer(ref, cams, [torch.zeros(3, 64, 96)] * len(cams), device="cuda")
+        with torch.no_grad():
+            targets = [render(c, tr0.model, tr0.pipe, tr0.bg)["render"].clone() for c in tr0.cams]
+        g = torch.Generator().manual_seed(2)
+        sc.xyz = sc.xyz + 0.02 * torch.randn(sc.xyz.shape, generator=g)
+        sc.features_dc = sc.features_dc + 0.3 * torch.randn(sc.features_dc.shape, generator=g)
+        tr = RgbTrainer(sc, cams, targets, device="cuda",
+                        densify=dict(from_iter=3, until_iter=40, interval=4, opacity_reset_interval=16, grad_threshold=1e-5))
+        counts, losses = [], []
+        for it in range(24):
+            loss, _ = tr.step(it)
+            losses.append(float(loss))
+            counts.append(tr.model._xyz.shape[0])
+        assert len(set(counts)) > 1, "densification never changed the number of Gaussians"
+        P = tr.model._xyz.shape[0]
+        for grp in tr.opt.param_groups:
+            p = grp["params"][0]
+            assert p.shape[0] == P and p.requires_grad
+            st = tr.opt.state.get(p)
+            assert st is None or st["exp_avg"].shape == p.shape
+        assert tr.densifier.denom.shape[0] == P and tr.densifier.max_radii2D.shape[0] == P
+        assert all(np.isfinite(losses))
+    finally:
+        rz.set_mode("exact")
+        rz.set_tracer(True)
