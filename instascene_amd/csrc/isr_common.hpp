@@ -200,6 +200,34 @@ __device__ __forceinline__ float4 splat_cull_box(F3 Tu, F3 Tv, F3 Tw, float cx, 
     return box;
 }
 
+// The same bound along the two diagonals (u1 = x + y, u2 = x - y): with the axis-aligned box this is the bounding
+// octagon of the alpha >= 1/255 region, which is what an elongated splat at 45 degrees needs (its box is mostly empty).
+// The extent of the rho3d <= skip conic along a direction  alpha x + beta y  is the box formula with  alpha Tu + beta Tv
+// in place of Tu.  Returns (u1_lo, u1_hi, u2_lo, u2_hi); infinite whenever splat_cull_box would be.
+__device__ __forceinline__ float4 splat_cull_diag(F3 Tu, F3 Tv, F3 Tw, float cx, float cy, float skip) {
+    const float inf = __builtin_inff();
+    float4 box = make_float4(-inf, inf, -inf, inf);
+    if (skip < inf) {
+        const float d = skip * (Tw.x * Tw.x + Tw.y * Tw.y) - Tw.z * Tw.z;
+        if (d < 0.0f) {
+            const float fi = 1.0f / d;
+            const float fa = skip * fi, fz = -fi;
+            const F3 P = {Tu.x + Tv.x, Tu.y + Tv.y, Tu.z + Tv.z}, M = {Tu.x - Tv.x, Tu.y - Tv.y, Tu.z - Tv.z};
+            const float c1 = fa * (P.x * Tw.x) + fa * (P.y * Tw.y) + fz * (P.z * Tw.z);
+            const float c2 = fa * (M.x * Tw.x) + fa * (M.y * Tw.y) + fz * (M.z * Tw.z);
+            const float h1 = c1 * c1 - (fa * (P.x * P.x) + fa * (P.y * P.y) + fz * (P.z * P.z));
+            const float h2 = c2 * c2 - (fa * (M.x * M.x) + fa * (M.y * M.y) + fz * (M.z * M.z));
+            const float e1 = __builtin_sqrtf(h1 > 0.0f ? h1 : 0.0f) * 1.01f + 1.0f;       // 0.5 px on both axes
+            const float e2 = __builtin_sqrtf(h2 > 0.0f ? h2 : 0.0f) * 1.01f + 1.0f;
+            const float r2 = (__builtin_sqrtf(0.5f * skip) * 1.01f + 0.5f) * 1.41421357f + 0.01f;
+            const float lo1 = fminf(c1 - e1, (cx + cy) - r2), hi1 = fmaxf(c1 + e1, (cx + cy) + r2);
+            const float lo2 = fminf(c2 - e2, (cx - cy) - r2), hi2 = fmaxf(c2 + e2, (cx - cy) + r2);
+            if (lo1 == lo1 && hi1 == hi1 && lo2 == lo2 && hi2 == hi2 && h1 == h1 && h2 == h2) box = make_float4(lo1, hi1, lo2, hi2);
+        }
+    }
+    return box;
+}
+
 // Tile-relative int8 packing of a cull box (rounded outward, saturated): the backward tests it without
 // touching the splat record.
 __device__ __forceinline__ uint32_t pack_box4(float4 box, float tile_x0, float tile_y0) {

@@ -417,6 +417,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
     __shared__ __attribute__((aligned(16))) float s_feat[(FCH > 0 ? BATCH * FCH : 4)];
     __shared__ int s_id[BATCH];
     __shared__ __attribute__((aligned(16))) float4 s_box[BATCH];
+    __shared__ __attribute__((aligned(16))) float4 s_diag[BATCH];     // the same bound along x + y and x - y
     // tracer (gaussian, pixel) pairs: every wave stages its pairs in its OWN LDS region and keeps the fill count in a
     // wave-uniform register, so an append is a ballot + popcount (no LDS atomic, no workgroup barrier); a region that
     // is nearly full is flushed by its wave alone with ONE global atomic (the reference does a global atomic on a
@@ -514,6 +515,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
             s4[3] = make_float4(d.x, d.y, opa, skip);       // ny nz opa skip
             const float4 cb = splat_cull_box(F3{a.x, a.y, a.z}, F3{a.w, b.x, b.y}, F3{b.z, b.w, c.x}, c.y, c.z, skip);
             s_box[t] = cb;
+            s_diag[t] = splat_cull_diag(F3{a.x, a.y, a.z}, F3{a.w, b.x, b.y}, F3{b.z, b.w, c.x}, c.y, c.z, skip);
             if (first_pass) box4[base + t] = pack_box4(cb, (float)(tx * TILE), (float)(ty * TILE));
             reinterpret_cast<float4*>(s_rgb)[t] = make_float4(d.w, e.x, e.y, 0.0f);
         }
@@ -538,8 +540,9 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
             const int jj = c0 + lane;
             bool hit = false;
             if (jj < nb) {
-                const float4 bb = s_box[jj];
-                hit = !(bb.x > bx1) && !(bb.y < bx0) && !(bb.z > by1) && !(bb.w < by0);
+                const float4 bb = s_box[jj], dg = s_diag[jj];
+                hit = !(bb.x > bx1) && !(bb.y < bx0) && !(bb.z > by1) && !(bb.w < by0) &&
+                      !(dg.x > bx1 + by1) && !(dg.y < bx0 + by0) && !(dg.z > bx1 - by0) && !(dg.w < bx0 - by1);
             }
             unsigned long long m = __ballot(hit);
             while (m != 0ull) {
