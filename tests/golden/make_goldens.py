@@ -344,3 +344,66 @@ with CpuMode():
         import traceback
         traceback.print_exc()
         print("densification golden skipped:", repr(e))
+
+    # ------------------------------------------------------------------ COLMAP sparse model
+    try:
+        import tempfile
+        sys.path.insert(0, os.path.join(os.path.dirname(OUT), ".."))
+        from instascene_amd import colmap_io as cio          # only its WRITERS are used here, to make the input files
+        from scene import colmap_loader as ref_cl
+        from scene.dataset_readers import getNerfppNorm
+        from utils.graphics_utils import focal2fov
+
+        rng = np.random.RandomState(21)
+        intr = {1: cio.Intrinsics(1, "PINHOLE", 640, 480, np.array([520.5, 515.25, 320.0, 240.0])),
+                7: cio.Intrinsics(7, "SIMPLE_PINHOLE", 800, 600, np.array([700.0, 400.0, 300.0])),
+                3: cio.Intrinsics(3, "OPENCV", 320, 200, np.array([250.0, 260.0, 160.0, 100.0, 0.01, -0.02, 0.0, 0.0]))}
+        poses, obs = {}, {}
+        for k, iid in enumerate([4, 9, 2, 11, 6]):
+            q = rng.randn(4); q /= np.linalg.norm(q)
+            poses[iid] = cio.Pose(iid, q, rng.randn(3) * 2.0, [1, 7, 3, 1, 7][k], f"sub/frame_{20 - k:03d}.jpg")
+            obs[iid] = np.concatenate([rng.rand(k * 3, 2) * 100, rng.randint(-1, 50, (k * 3, 1))], axis=1)
+        n = 40
+        xyz, rgb, err = rng.randn(n, 3), rng.randint(0, 256, (n, 3)).astype(np.uint8), rng.rand(n)
+        tracks = [np.stack([rng.randint(1, 12, t), rng.randint(0, 30, t)], axis=1) for t in rng.randint(0, 6, n)]
+        with tempfile.TemporaryDirectory() as td:
+            cio.write_cameras_bin(os.path.join(td, "cameras.bin"), intr)
+            cio.write_images_bin(os.path.join(td, "images.bin"), poses, obs)
+            cio.write_points3d_bin(os.path.join(td, "points3D.bin"), xyz, rgb, err, tracks)
+            files = {k: np.frombuffer(open(os.path.join(td, k + ".bin"), "rb").read(), dtype=np.uint8) for k in ("cameras", "images", "points3D")}
+            r_ext = ref_cl.read_extrinsics_binary(os.path.join(td, "images.bin"))
+            r_int = ref_cl.read_intrinsics_binary(os.path.join(td, "cameras.bin"))
+            r_xyz, r_rgb, r_err = ref_cl.read_points3D_binary(os.path.join(td, "points3D.bin"))
+        out = {"file_" + k: v for k, v in files.items()}
+        infos = []
+
+        class _CI:
+            pass
+
+        for key in r_ext:
+            e = r_ext[key]
+            i_ = r_int[e.camera_id]
+            ci = _CI()
+            ci.R, ci.T = np.transpose(ref_cl.qvec2rotmat(e.qvec)), np.array(e.tvec)
+            fy = i_.params[0] if i_.model in ("SIMPLE_PINHOLE", "SIMPLE_RADIAL") else i_.params[1]
+            ci.FovY, ci.FovX = focal2fov(fy, i_.height), focal2fov(i_.params[0], i_.width)
+            ci.name, ci.uid, ci.width, ci.height = os.path.basename(e.name).split(".")[0], i_.id, i_.width, i_.height
+            infos.append(ci)
+        infos.sort(key=lambda c: c.name)
+        norm = getNerfppNorm(infos)
+        out.update(names=np.array([c.name for c in infos]), uid=np.array([c.uid for c in infos]),
+                   R=np.stack([c.R for c in infos]), T=np.stack([c.T for c in infos]),
+                   fov=np.array([[c.FovX, c.FovY] for c in infos]), wh=np.array([[c.width, c.height] for c in infos]),
+                   xyz=r_xyz, rgb=r_rgb, err=r_err, norm_translate=norm["translate"], norm_radius=np.array(norm["radius"]))
+        mats = []
+        for j, c in enumerate(infos):
+            cam = Camera(colmap_id=c.uid, R=c.R, T=c.T, FoVx=c.FovX, FoVy=c.FovY, image=torch.zeros(3, c.height, c.width),
+                         image_name=c.name, uid=j, data_device="cpu")
+            mats.append(torch.stack([cam.world_view_transform, cam.full_proj_transform]))
+            out[f"center{j}"] = cam.camera_center
+        out["matrices"] = torch.stack(mats)
+        save("colmap.npz", **out)
+    except Exception as e:  # pragma: no cover
+        import traceback
+        traceback.print_exc()
+        print("colmap golden skipped:", repr(e))
