@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Randomised parity sweep (development aid): EXACT-mode forward must stay bit-identical to the CPU oracle and both
+modes' gradients within 1e-3 over scenes with extreme anisotropy, size and opacity.  usage: fuzz_parity.py [n_cases] [seed0]"""
+import math, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle
+from helpers import small_scene, oracle_forward
+import test_gpu_rasterizer as T
+
+n, seed0 = (int(sys.argv[1]) if len(sys.argv) > 1 else 20), (int(sys.argv[2]) if len(sys.argv) > 2 else 1000)
+bad = 0
+for case in range(n):
+    rng = np.random.RandomState(seed0 + case)
+    P = int(rng.choice([300, 1200, 3000]))
+    W, H = [(64, 48), (100, 70), (130, 90), (48, 112)][rng.randint(4)]
+    F = int(rng.choice([0, 8, 20, 32]))
+    mu = math.log(float(rng.choice([0.01, 0.04, 0.12, 0.4])))
+    sc, cams, inp = small_scene(P=P, F=F, W=W, H=H, seed=seed0 + case, mu_s=mu)
+    inp = dict(inp)
+    s = inp["scales"].clone()
+    k = P // 3
+    s[:k, 0] *= float(rng.choice([1, 20, 60])); s[:k, 1] *= float(rng.choice([1, 0.05, 0.01]))
+    inp["scales"] = s
+    op = inp["opacities"].clone()
+    op[::5] = float(rng.choice([0.004, 0.0039, 0.02, 0.999]))
+    inp["opacities"] = op
+    cam = cams[rng.randint(len(cams))]
+    st = oracle_forward(inp, cam)
+    try:
+        args, out = T.hip_forward(inp, cam, mode=T.MODE_EXACT)
+        T.check_forward_exact(st, args, out)
+        dC, dO, dE = T._rand_grads(st, case)
+        want = oracle.backward(st, dC, dO, dE)
+        for mode in (T.MODE_EXACT, T.MODE_FAST):
+            a2, o2 = T.hip_forward(inp, cam, mode=mode)
+            got = T.hip_backward(a2, o2, dC, dO, dE, T.GRAD_EXTRA | T.GRAD_GEOMETRY if F else T.GRAD_GEOMETRY, mode)
+            for name, t in zip(T.GRAD_NAMES, got):
+                if t is None or name not in want or want[name].size == 0:
+                    continue
+                T.assert_close(t.cpu().numpy().reshape(want[name].shape), want[name], 1e-3, f"case {case} mode {mode} {name}")
+        print("case", case, "ok", (P, W, H, F, round(mu, 2)), "R", st["R"], flush=True)
+    except AssertionError as e:
+        bad += 1
+        print("case", case, "FAILED", (P, W, H, F, round(mu, 2)), str(e)[:300], flush=True)
+        if "mode 1" in str(e):       # FAST: is it a handful of threshold flips or a systematic error?
+            ge = T.hip_backward(*T.hip_forward(inp, cam, mode=T.MODE_EXACT), dC, dO, dE, T.GRAD_EXTRA | T.GRAD_GEOMETRY if F else T.GRAD_GEOMETRY, T.MODE_EXACT)
+            gf = T.hip_backward(*T.hip_forward(inp, cam, mode=T.MODE_FAST), dC, dO, dE, T.GRAD_EXTRA | T.GRAD_GEOMETRY if F else T.GRAD_GEOMETRY, T.MODE_FAST)
+            d = (ge[0] - gf[0]).abs().max(dim=1).values
+            big = (d > 1e-4 * ge[0].abs().max()).sum().item()
+            print("     exact-vs-fast dL_dmeans2D: rows above 1e-4 of max:", big, "of", d.numel(), " top:", d.topk(3).values.tolist(), flush=True)
+print("failures:", bad)
