@@ -136,7 +136,8 @@ def _f32c(t: Optional[torch.Tensor], name: str):
     return t.contiguous()
 
 
-_TIGHT_RECTS = 0x100   # ISR_PREPARE_TIGHT_RECTS: FAST mode bins a splat only into tiles it can reach
+# ISR_PREPARE_TIGHT_RECTS: FAST mode bins a splat only into tiles it can reach (ISR_TIGHT_RECTS=0 turns it off: A/B, debugging)
+_TIGHT_RECTS = 0x100 if os.environ.get("ISR_TIGHT_RECTS", "1") != "0" else 0
 _PREFETCHED = {}      # (device, P, W, H) -> (signature, radii, geom, img, R, binning): a geometry pass + binning issued ahead of its forward
 PREFETCH_HITS = 0     # forwards that found their geometry pass already issued (statistics / tests)
 

@@ -48,6 +48,9 @@ for case in range(n):
         if "mode 1" in str(e):       # FAST: is it a handful of threshold flips or a systematic error?
             ge = T.hip_backward(*T.hip_forward(inp, cam, mode=T.MODE_EXACT), dC, dO, dE, T.GRAD_EXTRA | T.GRAD_GEOMETRY if F else T.GRAD_GEOMETRY, T.MODE_EXACT)
             gf = T.hip_backward(*T.hip_forward(inp, cam, mode=T.MODE_FAST), dC, dO, dE, T.GRAD_EXTRA | T.GRAD_GEOMETRY if F else T.GRAD_GEOMETRY, T.MODE_FAST)
+            af, of_ = T.hip_forward(inp, cam, mode=T.MODE_FAST)
+            dcol = (of_[1].cpu().numpy() - st["color"])
+            print("     FAST forward vs oracle: pixels off by > 1e-4:", int((np.abs(dcol).max(axis=0) > 1e-4).sum()), "max", float(np.abs(dcol).max()), flush=True)
             d = (ge[0] - gf[0]).abs().max(dim=1).values
             big = (d > 1e-4 * ge[0].abs().max()).sum().item()
             print("     exact-vs-fast dL_dmeans2D: rows above 1e-4 of max:", big, "of", d.numel(), " top:", d.topk(3).values.tolist(), flush=True)
