@@ -101,6 +101,14 @@ int iso_ssim_backward(int C, int H, int W, const float* img1, const float* img2,
 int iso_densify_stats(int P, int C, const float* viewspace_grad, const unsigned char* visible, const int* radii,
                       float* grad_accum, float* denom, float* max_radii, void* stream);
 
+/* Adam update of a [N,F] parameter (torch.optim.Adam arithmetic: no weight decay, no amsgrad; `step` counts from 1;
+ * scene/gaussian_model.py:249 with the group's lr and eps) fused with the two chained row normalisations of the updated
+ * rows (iso_rownorm2 forward): param / exp_avg / exp_avg_sq are updated in place, y and z receive the normalised rows the
+ * next forward needs.  F % 4 == 0, F <= 256. */
+int iso_adam_rownorm2(long long N, int F, double lr, double beta1, double beta2, double eps, long long step, float eps1,
+                      float eps2, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* y, float* z,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

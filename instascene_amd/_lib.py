@@ -55,6 +55,9 @@ SIGNATURES = {
     "iso_ssim_forward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "iso_ssim_backward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "iso_densify_stats": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "iso_adam_rownorm2": (c_int, [ctypes.c_longlong, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                  ctypes.c_longlong, c_float,
+                                  c_float, _P, _P, _P, _P, _P, _P, _P]),
     "iso_rownorm2": (c_int, [ctypes.c_longlong, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P]),
 }
 

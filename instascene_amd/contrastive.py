@@ -130,6 +130,79 @@ class _RowNorm2(torch.autograd.Function):
         return out, None, None
 
 
+class _RowNorm2Given(torch.autograd.Function):
+    """``y, z`` of :class:`_RowNorm2` when they were already produced (by the fused optimiser pass): the forward only
+    attaches them to the graph, the backward is the same single kernel."""
+
+    @staticmethod
+    def forward(ctx, x, y, z, eps1, eps2):
+        ctx.save_for_backward(x.detach())
+        ctx.eps = (float(eps1), float(eps2))
+        ctx.set_materialize_grads(False)
+        return y.view_as(y), z.view_as(z)
+
+    @staticmethod
+    def backward(ctx, gy, gz):
+        g = _RowNorm2.backward(ctx, gy, gz)
+        return g[0], None, None, None, None
+
+
+class FeatureAdam:
+    """Adam on ONE ``[P,F]`` parameter with the arithmetic of ``torch.optim.Adam(lr, betas, eps)`` (the reference's
+    optimiser for ``_seg_feature``, scene/gaussian_model.py:223-249), whose step also emits the parameter's two chained
+    row normalisations (``iso_adam_rownorm2``) so that the next forward does not re-read it.  ``state_dict`` /
+    ``load_state_dict`` use torch's key names."""
+
+    def __init__(self, param: torch.nn.Parameter, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, norm_eps=(1e-6, 1e-9)):
+        if not param.is_cuda or param.dim() != 2 or (param.shape[1] & 3) or param.shape[1] > 256:
+            raise ValueError("FeatureAdam needs a CUDA [P,F] parameter with F % 4 == 0 and F <= 256")
+        self.param, self.lr, self.betas, self.eps, self.norm_eps = param, float(lr), betas, float(eps), norm_eps
+        self.exp_avg = torch.zeros_like(param, memory_format=torch.contiguous_format)
+        self.exp_avg_sq = torch.zeros_like(param, memory_format=torch.contiguous_format)
+        self.step_count = 0
+        self.normalized = None          # (version of param, y, z) written by the last step
+
+    def step(self):
+        p = self.param
+        if p.grad is None:
+            return
+        L = lib()
+        g = p.grad.contiguous().float()
+        y, z = torch.empty_like(p.data), torch.empty_like(p.data)
+        self.step_count += 1
+        with torch.cuda.device(p.device):
+            check(L.iso_adam_rownorm2(p.shape[0], p.shape[1], self.lr, float(self.betas[0]), float(self.betas[1]), self.eps,
+                                      self.step_count, float(self.norm_eps[0]), float(self.norm_eps[1]), _p(p.data), _p(g),
+                                      _p(self.exp_avg), _p(self.exp_avg_sq), _p(y), _p(z), _stream()), "iso_adam_rownorm2")
+        torch.autograd.graph.increment_version(p)       # the kernel wrote through the raw pointer: tell autograd
+        self.normalized = (p._version, y, z)
+
+    def zero_grad(self, set_to_none: bool = True):
+        if set_to_none:
+            self.param.grad = None
+        elif self.param.grad is not None:
+            self.param.grad.zero_()
+
+    def normalized_chain(self):
+        """``row_normalize_chain(param, *norm_eps)`` — from the last step's output when the parameter is unchanged since."""
+        p = self.param
+        if self.normalized is not None and self.normalized[0] == p._version:
+            y, z = _RowNorm2Given.apply(p, self.normalized[1], self.normalized[2], *self.norm_eps)
+            setattr(y, _MEMO_ATTR, (float(self.norm_eps[1]), z, y._version))
+            return y
+        return row_normalize_chain(p, *self.norm_eps)
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr,
+                "betas": self.betas, "eps": self.eps}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.normalized = None
+
+
 _MEMO_ATTR = "_isr_renormalized"
 
 

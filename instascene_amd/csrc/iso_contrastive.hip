@@ -605,6 +605,50 @@ __global__ __launch_bounds__(256) void rn2_kernel(long long N, int F, float eps1
     }
 }
 
+// Adam step on a [N,F] parameter fused with the two chained row normalisations of the updated rows (F % 4 == 0,
+// F <= 256; one float4 per lane): the optimiser pass (4 streams in, 3 out) already has every new row in registers, so the
+// next forward's y = p/(|p|+eps1), z = y/(|y|+eps2) cost two more streams out instead of a separate 1-in 2-out pass.
+// Arithmetic of torch.optim.Adam (no weight decay, no amsgrad):
+//   m = m + (1-b1)(g - m);  v = b2 v + (1-b2) g^2;  p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_rn2_kernel(long long N, int F, float lr_over_bc1, float om1, float beta2, float om2,
+                                                       float inv_sqrt_bc2, float eps, float eps1, float eps2,
+                                                       float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v,
+                                                       float* __restrict__ y, float* __restrict__ z) {
+    const int q = F >> 2;
+    int lpr = 1;
+    while (lpr < q) lpr <<= 1;
+    const int sub = (threadIdx.x & 63) & (lpr - 1);
+    const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) / lpr;
+    const bool ok = row < N && sub < q;
+    const size_t off = (size_t)(row < N ? row : 0) * F + 4 * sub;
+    float4 np4 = make_float4(0, 0, 0, 0);
+    if (ok) {
+        const float4 p4 = *reinterpret_cast<const float4*>(p + off), g4 = *reinterpret_cast<const float4*>(g + off);
+        float4 m4 = *reinterpret_cast<const float4*>(m + off), v4 = *reinterpret_cast<const float4*>(v + off);
+#define ISO_ADAM1(c)                                                                   \
+        m4.c = m4.c + om1 * (g4.c - m4.c);                                             \
+        v4.c = beta2 * v4.c + om2 * (g4.c * g4.c);                                     \
+        np4.c = p4.c - lr_over_bc1 * (m4.c / (__builtin_sqrtf(v4.c) * inv_sqrt_bc2 + eps));
+        ISO_ADAM1(x) ISO_ADAM1(y) ISO_ADAM1(z) ISO_ADAM1(w)
+#undef ISO_ADAM1
+        *reinterpret_cast<float4*>(m + off) = m4;
+        *reinterpret_cast<float4*>(v + off) = v4;
+        *reinterpret_cast<float4*>(p + off) = np4;
+    }
+    float ss = np4.x * np4.x + np4.y * np4.y + np4.z * np4.z + np4.w * np4.w;
+    for (int o = lpr >> 1; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+    const float r1 = 1.0f / (__builtin_sqrtf(ss) + eps1);
+    const float4 y4 = make_float4(np4.x * r1, np4.y * r1, np4.z * r1, np4.w * r1);
+    float s2 = y4.x * y4.x + y4.y * y4.y + y4.z * y4.z + y4.w * y4.w;
+    for (int o = lpr >> 1; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
+    const float r2 = 1.0f / (__builtin_sqrtf(s2) + eps2);
+    if (ok) {
+        *reinterpret_cast<float4*>(y + off) = y4;
+        *reinterpret_cast<float4*>(z + off) = make_float4(y4.x * r2, y4.y * r2, y4.z * r2, y4.w * r2);
+    }
+}
+
 __global__ __launch_bounds__(256) void rn_scalar(long long N, int F, float eps, int bwd, const float* __restrict__ x,
                                                  const float* __restrict__ dy, float* __restrict__ out) {
     const long long row = (long long)blockIdx.x * 256 + threadIdx.x;

@@ -512,6 +512,26 @@ int iso_densify_stats(int P, int C, const float* viewspace_grad, const unsigned 
     return ISR_OK;
 }
 
+int iso_adam_rownorm2(long long N, int F, double lr, double beta1, double beta2, double eps, long long step, float eps1,
+                      float eps2, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* y, float* z,
+                      void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (N < 0 || F <= 0 || (F & 3) != 0 || F > 256) return fail(ISR_EINVAL, "adam_rownorm2 needs F % 4 == 0 and F <= 256");
+    if (step < 1) return fail(ISR_EINVAL, "adam_rownorm2: step counts from 1");
+    if (N > 0 && (!param || !grad || !exp_avg || !exp_avg_sq || !y || !z)) return fail(ISR_EINVAL, "adam_rownorm2: null pointer");
+    if (N == 0) return ISR_OK;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    int q = F >> 2, lpr = 1;
+    while (lpr < q) lpr <<= 1;
+    const unsigned blocks = (unsigned)((N * lpr + 255) / 256);
+    // hyper-parameters are doubles like torch's: 1 - 0.999f would be off by 5e-5 relative
+    hipLaunchKernelGGL(iso::adam_rn2_kernel, dim3(blocks), dim3(256), 0, s, N, F, (float)(lr / bc1), (float)(1.0 - beta1),
+                       (float)beta2, (float)(1.0 - beta2), (float)(1.0 / sqrt(bc2)), (float)eps, eps1, eps2, param, grad,
+                       exp_avg, exp_avg_sq, y, z);
+    ISR_LAUNCH_CHECK("iso_adam_rownorm2");
+    return ISR_OK;
+}
+
 int iso_rownorm2(long long N, int F, float eps1, float eps2, int backward, const float* x, const float* gy,
                  const float* gz, float* out1, float* out2, void* stream) {
     hipStream_t s = (hipStream_t)stream;

@@ -89,8 +89,11 @@ class SegGaussianModel:
         # called twice per step (render() and the 3-D loss): reuse the node while the parameter is unchanged
         key = (self._seg_feature._version, torch.is_grad_enabled())
         if self._seg_cache is None or self._seg_cache[0] != key:
-            # eps 1e-6 here (scene/gaussian_model.py:122-125); render() re-normalises with 1e-9 — both in one pass
-            self._seg_cache = (key, row_normalize_chain(self._seg_feature, 1e-6, 1e-9))
+            # eps 1e-6 here (scene/gaussian_model.py:122-125); render() re-normalises with 1e-9 — both in one pass, which
+            # the fused optimiser step has already made when the parameter has not been touched since
+            opt = getattr(self, "feature_optimizer", None)
+            chain = opt.normalized_chain() if opt is not None else row_normalize_chain(self._seg_feature, 1e-6, 1e-9)
+            self._seg_cache = (key, chain)
         return self._seg_cache[1]
 
 
@@ -107,7 +110,7 @@ def gram_schmidt(vectors: torch.Tensor) -> torch.Tensor:
 class SegTrainer:
     def __init__(self, scene: scenes.Scene, cameras: List[scenes.Camera], device="cuda", sample_batchsize=8192,
                  n_labels=64, lambda_sv=1e-6, lambda_mv=1e-6, lambda_3d=2.5e-6, sample_mv_frames=5, use_class_feat=False,
-                 multiview=False, seed=0, rank=0, world=1, prefetch_geometry=None):
+                 multiview=False, seed=0, rank=0, world=1, prefetch_geometry=None, fused_update=None):
         self.device = torch.device(device)
         self.rank, self.world = rank, world
         # overlap of the gradient all-reduce with the next view's geometry pass (default: whenever there is one)
@@ -125,8 +128,16 @@ class SegTrainer:
         self.batch = sample_batchsize
         self.lsv, self.lmv, self.l3d = lambda_sv, lambda_mv, lambda_3d
         self.mv_frames, self.multiview = sample_mv_frames, multiview
-        self.opt = torch.optim.Adam([{"params": [self.model._seg_feature], "lr": 0.025, "name": "seg_feature"}], lr=0.0,
-                                    eps=1e-15, fused=self.device.type == "cuda")
+        F_ = self.model._seg_feature.shape[1]
+        if fused_update is None:
+            fused_update = self.device.type == "cuda" and F_ % 4 == 0 and F_ <= 256
+        if fused_update:       # Adam + the next forward's normalisation chain in one pass over [P,F]
+            from .contrastive import FeatureAdam
+            self.opt = FeatureAdam(self.model._seg_feature, lr=0.025, eps=1e-15, norm_eps=(1e-6, 1e-9))
+            self.model.feature_optimizer = self.opt
+        else:
+            self.opt = torch.optim.Adam([{"params": [self.model._seg_feature], "lr": 0.025, "name": "seg_feature"}], lr=0.0,
+                                        eps=1e-15, fused=self.device.type == "cuda")
         self.gen = torch.Generator(device=self.device).manual_seed(1000 + seed * 131 + rank)
         # label maps are static per view: index the labelled pixels once (the reference re-derives the
         # boolean mask every iteration, train_semantic.py:118-125)

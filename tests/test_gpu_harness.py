@@ -195,3 +195,23 @@ def test_rgb_trainer_with_density_control():
     finally:
         rz.set_mode("exact")
         rz.set_tracer(True)
+
+
+def test_fused_feature_update_tracks_torch_adam():
+    """SegTrainer with the fused Adam + normalisation pass vs torch.optim.Adam followed by the separate normalisation."""
+    rz.set_mode("fast")
+    rz.set_tracer(False)
+    try:
+        res = []
+        for fused in (False, True):
+            sc, cams = _scene()
+            tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=2048, n_labels=12, use_class_feat=True, seed=3,
+                            fused_update=fused)
+            losses = [float(tr.step(it)) for it in range(8)]
+            res.append((losses, tr.model._seg_feature.detach().clone()))
+        np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-4)
+        d = (res[0][1] - res[1][1]).abs().max().item()
+        assert d <= 2e-4 * res[0][1].abs().max().item(), d
+    finally:
+        rz.set_mode("exact")
+        rz.set_tracer(True)

@@ -319,3 +319,41 @@ def test_hip_ssim_matches_torch_restatement_and_golden(golden_dir, C, H, W):
     assert abs(float(ss.detach()) - float(z["ssim"])) < 1e-5
     (0.8 * l1 + 0.2 * (1.0 - ss)).backward()
     assert_close(img.grad.cpu().numpy(), z["grad"], 1e-4, "loss grad vs reference")
+
+
+def test_feature_adam_matches_torch_adam_and_emits_the_normalisation_chain():
+    """iso_adam_rownorm2: parameters / moments like torch.optim.Adam(lr .025, eps 1e-15) over several steps, and the
+    emitted (y, z) bit-identical to row_normalize_chain of the updated parameter; the chain stays differentiable."""
+    from instascene_amd.contrastive import FeatureAdam, row_normalize, row_normalize_chain
+    g = torch.Generator().manual_seed(12)
+    x0 = torch.randn(3001, 32, generator=g)
+    a = torch.nn.Parameter(x0.clone().cuda())
+    b = torch.nn.Parameter(x0.clone().cuda())
+    ref = torch.optim.Adam([a], lr=0.025, eps=1e-15)
+    opt = FeatureAdam(b, lr=0.025, eps=1e-15, norm_eps=(1e-6, 1e-9))
+    for it in range(6):
+        gr = (torch.randn(3001, 32, generator=g) * (10.0 ** (-it))).cuda()
+        gr[7] = 0.0
+        a.grad, b.grad = gr.clone(), gr.clone()
+        ref.step(); opt.step()
+        assert_close(b.detach().cpu().numpy(), a.detach().cpu().numpy(), 2e-6, "adam param step %d" % it)
+        st = ref.state[a]
+        assert_close(opt.exp_avg.cpu().numpy(), st["exp_avg"].cpu().numpy(), 2e-6, "exp_avg")
+        assert_close(opt.exp_avg_sq.cpu().numpy(), st["exp_avg_sq"].cpu().numpy(), 2e-6, "exp_avg_sq")
+        y = opt.normalized_chain()
+        y2 = row_normalize_chain(b.detach(), 1e-6, 1e-9)
+        assert torch.equal(y.detach(), y2) and torch.equal(row_normalize(y, 1e-9).detach(), row_normalize(y2, 1e-9))
+    # gradient through the given chain == gradient through the computed chain
+    w = torch.randn(3001, 32, generator=g).cuda()
+    b.grad = None
+    y = opt.normalized_chain()
+    ((y * w).sum() + (row_normalize(y, 1e-9) * w.flip(0)).sum()).backward()
+    g_given = b.grad.clone(); b.grad = None
+    yc = row_normalize_chain(b, 1e-6, 1e-9)
+    ((yc * w).sum() + (row_normalize(yc, 1e-9) * w.flip(0)).sum()).backward()
+    assert torch.equal(g_given, b.grad)
+    # an in-place change of the parameter invalidates the emitted chain
+    with torch.no_grad():
+        b.mul_(2.0)
+    y3 = opt.normalized_chain()
+    assert torch.equal(y3.detach(), row_normalize_chain(b.detach(), 1e-6, 1e-9))
