@@ -128,6 +128,19 @@ int isr_backward(int P, int D, int M, int64_t num_rendered, int ED, int width, i
                  float* dL_dextra /*[P,ED]*/,
                  void* scratch, size_t scratch_bytes, void* stream);
 
+/* ---- extension: the feature map is only read at n sampled pixels (train_semantic.py:118-129 picks 8192 pixels per
+ * loss).  isr_sample_extra gathers sampled[i, :] = out_extra[:, pixels[i]] (pixels = y*W + x, int64, may repeat);
+ * isr_backward_sampled turns dL/dsampled [n, ED] into dL_dextra [P, ED] (added to its content when accumulate != 0)
+ * without ever materialising the dense [ED, H, W] gradient: the samples are binned per tile and each tile's list is
+ * walked once with a lane per splat.  Same forward state (geom / binning / image buffers) as isr_backward. */
+size_t isr_backward_sampled_scratch_bytes(int64_t num_rendered, int ED, int n_samples, int width, int height);
+int isr_sample_extra(int ED, int width, int height, int n_samples, const float* out_extra, const long long* pixels,
+                     float* sampled, void* stream);
+int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int height, int mode, int n_samples,
+                         const long long* pixels, const float* dL_dsampled, const float* transMat_precomp,
+                         const void* geom_buffer, const void* binning_buffer, const void* image_buffer, float* dL_dextra,
+                         int accumulate, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- rasterizer_impl.cu:141-153 */
 int isr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);

@@ -40,6 +40,10 @@ SIGNATURES = {
                              _P, _P, _P, _P, _P, _P,
                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                              _P, c_size_t, _P]),
+    "isr_backward_sampled_scratch_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
+    "isr_sample_extra": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "isr_backward_sampled": (c_int, [c_int, c_int64, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P,
+                                     c_size_t, _P]),
     "isr_mark_visible": (c_int, [c_int, _P, _P, _P, _P, _P]),
     "isr_debug_state": (c_int, [c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     # include/instascene_ops.h

@@ -262,6 +262,36 @@ int isr_backward(int P, int D, int M, int64_t num_rendered, int ED, int width, i
     return ISR_OK;
 }
 
+size_t isr_backward_sampled_scratch_bytes(int64_t num_rendered, int ED, int n_samples, int width, int height) {
+    return backward_sampled_scratch_bytes(num_rendered, ED, n_samples, width, height);
+}
+
+int isr_sample_extra(int ED, int width, int height, int n_samples, const float* out_extra, const long long* pixels,
+                     float* sampled, void* stream) {
+    if (ED < 0 || width <= 0 || height <= 0 || n_samples < 0) return fail(ISR_EINVAL, "bad sample_extra sizes");
+    if (n_samples > 0 && ED > 0 && (!out_extra || !pixels || !sampled)) return fail(ISR_EINVAL, "sample_extra: null pointer");
+    if (launch_sample_gather(n_samples, ED, (long long)width * height, out_extra, pixels, sampled, (hipStream_t)stream) != 0)
+        return fail(ISR_EHIP, "sample_extra launch failed");
+    return ISR_OK;
+}
+
+int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int height, int mode, int n_samples,
+                         const long long* pixels, const float* dL_dsampled, const float* transMat_precomp,
+                         const void* geom_buffer, const void* binning_buffer, const void* image_buffer, float* dL_dextra,
+                         int accumulate, void* scratch, size_t scratch_bytes, void* stream) {
+    if (P < 0 || ED <= 0 || width <= 0 || height <= 0 || n_samples < 0) return fail(ISR_EINVAL, "bad backward_sampled sizes");
+    if (mode != ISR_MODE_EXACT && mode != ISR_MODE_FAST) return fail(ISR_EINVAL, "unknown mode %d", mode);
+    if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dextra || !scratch) return fail(ISR_EINVAL, "null buffer");
+    if (n_samples > 0 && (!pixels || !dL_dsampled)) return fail(ISR_EINVAL, "backward_sampled: pixels / dL_dsampled required");
+    if (scratch_bytes < backward_sampled_scratch_bytes(num_rendered, ED, n_samples, width, height))
+        return fail(ISR_EINVAL, "backward_sampled scratch too small");
+    const int rc = launch_backward_sampled(P, num_rendered, ED, width, height, mode, n_samples, pixels, dL_dsampled,
+                                           transMat_precomp, geom_buffer, binning_buffer, image_buffer, dL_dextra, accumulate,
+                                           scratch, (hipStream_t)stream);
+    if (rc != 0) return fail(ISR_EHIP, "backward_sampled launch failed (%d)", rc);
+    return ISR_OK;
+}
+
 int isr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float*, uint8_t* present, void* stream) {
     if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return fail(ISR_EINVAL, "null argument");
     if (P == 0) return ISR_OK;

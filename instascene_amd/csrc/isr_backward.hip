@@ -691,43 +691,89 @@ __global__ __launch_bounds__(256) void k_bwd_live_pixels(int W, int H, int ED, i
 }
 
 // Step 2 — one wave per tile with 1..SPARSE_LMAX live pixels.
-template <class Math>
+// SAMPLED = false: live pixels come from k_bwd_live_pixels (dense dL/dE map, at most SPARSE_LMAX per tile).
+// SAMPLED = true : the upstream gradient is given for n SAMPLES, dL/dE(pix[i], :) = sample_rows[i, :] (the map was
+//                  only read at those pixels: render(..., sample_pixels=)); seg_off / seg_idx list the samples of every
+//                  tile.  A tile's samples are walked in groups of SPARSE_LMAX; from the second group on the lane adds to
+//                  the row it wrote before (always the same lane of the same wave: no race).  A pixel sampled twice is
+//                  two list entries — no merging needed.  Summation order is fixed (sample index) as long as a tile
+//                  has at most 1024 samples; beyond that only the order between blocks of 1024 is the fill kernel's.
+template <class Math, bool SAMPLED>
 __global__ __launch_bounds__(64) void k_render_bwd_sparse(
     int W, int H, int ED, int ch_base, int gx, const uint32_t* __restrict__ tile_offset,
     const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ box4, const float* __restrict__ rec,
     const float* __restrict__ tm_pre, const float* __restrict__ dE, const uint32_t* __restrict__ point_offsets,
     const Rect16* __restrict__ rects, float* __restrict__ partial, uint8_t* __restrict__ row_flags,
     const uint32_t* __restrict__ live_list, const uint8_t* __restrict__ tile_mode, int row_stride, int feat_off,
-    int64_t capacity) {
+    int64_t capacity, const uint32_t* __restrict__ n_contrib, const long long* __restrict__ sample_pix,
+    const float* __restrict__ sample_rows, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_idx) {
     __shared__ int s_lxy[SPARSE_LMAX];                 // tile-relative x | y << 8 of the live pixels
     __shared__ unsigned s_llast[SPARSE_LMAX];          // their last contributor
+    __shared__ unsigned s_sample[SPARSE_LMAX];
     __shared__ __attribute__((aligned(16))) float s_ldE[SPARSE_LMAX * 32];
+    constexpr int SEG_SORT = SAMPLED ? 1024 : 1;       // samples of a tile put in index order (fixed summation order)
+    __shared__ unsigned s_seg_in[SEG_SORT], s_seg[SEG_SORT];
 
     const int tile = blockIdx.x;
-    const int nlive = tile_mode[tile];
-    if (nlive == 0 || nlive == TILE_DENSE) return;
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
     const size_t N = (size_t)W * H;
+    int ntotal, seg0 = 0;
+    if constexpr (SAMPLED) { seg0 = (int)seg_off[tile]; ntotal = (int)seg_off[tile + 1] - seg0; }
+    else { ntotal = tile_mode[tile]; if (ntotal == TILE_DENSE) return; }
+    if (ntotal == 0) return;
     const int64_t r0 = tile_offset[tile];
     int64_t r1 = tile_offset[tile + 1];
     if (r1 > capacity) r1 = capacity;
     const int len = (int)(r1 - r0);
     if (len <= 0) return;
+  for (int g0 = 0; g0 < ntotal; g0 += SPARSE_LMAX) {
+    const int nlive = min(SPARSE_LMAX, ntotal - g0);
     unsigned mylast = 0u;
-    if (lane < nlive) {
-        s_lxy[lane] = (int)live_list[((size_t)tile * SPARSE_LMAX + lane) * 2];
-        mylast = live_list[((size_t)tile * SPARSE_LMAX + lane) * 2 + 1];
-        s_llast[lane] = mylast;
+    if constexpr (SAMPLED) {
+        __syncthreads();                                   // the previous group is done with the LDS lists
+        if ((g0 % SEG_SORT) == 0) {
+            // the fill kernel placed the tile's samples in the order of its atomics: rank-sort the next (up to) 1024 of
+            // them by sample index, so that the groups and the order inside them do not depend on that race
+            const int nseg = min(SEG_SORT, ntotal - g0);
+            for (int e = lane; e < nseg; e += 64) s_seg_in[e] = seg_idx[seg0 + g0 + e];
+            __syncthreads();
+            for (int e = lane; e < nseg; e += 64) {
+                const unsigned mine = s_seg_in[e];
+                int rank = 0;
+                for (int j = 0; j < nseg; j++) rank += (s_seg_in[j] < mine) ? 1 : 0;
+                s_seg[rank] = mine;
+            }
+            __syncthreads();
+        }
+        if (lane < nlive) {
+            const unsigned mine = s_seg[(g0 % SEG_SORT) + lane];
+            const long long q = sample_pix[mine];
+            const int qx = (int)(q % W), qy = (int)(q / W);
+            mylast = n_contrib[q];
+            s_lxy[lane] = (qx - tx * TILE) | ((qy - ty * TILE) << 8);
+            s_llast[lane] = mylast;
+            s_sample[lane] = mine;
+        }
+    } else {
+        if (lane < nlive) {
+            s_lxy[lane] = (int)live_list[((size_t)tile * SPARSE_LMAX + lane) * 2];
+            mylast = live_list[((size_t)tile * SPARSE_LMAX + lane) * 2 + 1];
+            s_llast[lane] = mylast;
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mylast = max(mylast, (unsigned)__shfl_xor((int)mylast, o));
     __syncthreads();
     for (int k = lane >> 5; k < nlive; k += 2) {
         const int c = lane & 31, ch = ch_base + c;
-        const int xy = s_lxy[k];
-        const size_t q = (size_t)W * (ty * TILE + (xy >> 8)) + (tx * TILE + (xy & 255));
-        s_ldE[k * 32 + c] = ch < ED ? dE[(size_t)ch * N + q] : 0.0f;
+        if constexpr (SAMPLED) {
+            s_ldE[k * 32 + c] = ch < ED ? sample_rows[(size_t)s_sample[k] * ED + ch] : 0.0f;
+        } else {
+            const int xy = s_lxy[k];
+            const size_t q = (size_t)W * (ty * TILE + (xy >> 8)) + (tx * TILE + (xy & 255));
+            s_ldE[k * 32 + c] = ch < ED ? dE[(size_t)ch * N + q] : 0.0f;
+        }
     }
     __syncthreads();
     const int len_eff = min(len, (int)mylast);
@@ -808,11 +854,63 @@ __global__ __launch_bounds__(64) void k_render_bwd_sparse(
         }
         if (wrote) {
             float4* o4 = reinterpret_cast<float4*>(partial + (size_t)slot * row_stride + feat_off);
+            if (SAMPLED && g0 > 0 && row_flags[slot]) {      // an earlier group of this tile's samples reached the splat too
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const float4 o = o4[q];
+                    acc[4 * q] += o.x; acc[4 * q + 1] += o.y; acc[4 * q + 2] += o.z; acc[4 * q + 3] += o.w;
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 8; q++) o4[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
             row_flags[slot] = 1;
         }
     }
+  }
+}
+
+// Samples -> per-tile segments: count, (single-workgroup) scan, fill.  The order inside a segment is the order of the
+// cursor atomics; k_render_bwd_sparse re-orders every group of SPARSE_LMAX by sample index.
+__global__ __launch_bounds__(256) void k_sample_count(int n, int W, int H, int gx, const long long* __restrict__ pix,
+                                                      uint32_t* __restrict__ cnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long q = pix[i];
+    if (q < 0 || q >= (long long)W * H) return;
+    atomicAdd(cnt + ((int)(q / W) / TILE) * gx + ((int)(q % W) / TILE), 1u);
+}
+__global__ __launch_bounds__(1024) void k_sample_scan(int T, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off,
+                                                      uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t s_warp[32];
+    uint32_t carry = 0;
+    for (int base = 0; base < T; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < T ? cnt[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan_1024(v, s_warp, total);
+        if (i < T) { off[i] = carry + ex; cursor[i] = 0u; }
+        carry += total;
+    }
+    if (threadIdx.x == 0) off[T] = carry;
+}
+__global__ __launch_bounds__(256) void k_sample_fill(int n, int W, int H, int gx, const long long* __restrict__ pix,
+                                                     const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor,
+                                                     uint32_t* __restrict__ seg_idx) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long q = pix[i];
+    if (q < 0 || q >= (long long)W * H) return;
+    const int t = ((int)(q / W) / TILE) * gx + ((int)(q % W) / TILE);
+    seg_idx[off[t] + atomicAdd(cursor + t, 1u)] = (uint32_t)i;
+}
+// out[i, :] = map[:, pix[i]]  (the forward half of the sampled path)
+__global__ __launch_bounds__(256) void k_sample_gather(int n, int F, long long N, const float* __restrict__ map,
+                                                       const long long* __restrict__ pix, float* __restrict__ out) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)n * F) return;
+    const int i = (int)(e / F), c = (int)(e - (long long)i * F);
+    const long long q = pix[i];
+    out[e] = (q >= 0 && q < N) ? map[(size_t)c * N + q] : 0.0f;
 }
 
 // ----------------------------------------------------------------------------
@@ -821,7 +919,7 @@ __global__ __launch_bounds__(256) void k_reduce_rows(int P, int ncol, const uint
                                                      const uint32_t* __restrict__ tiles_touched,
                                                      const float* __restrict__ partial, const uint8_t* __restrict__ row_flags,
                                                      int64_t R, int row_stride, int src_off, float* __restrict__ out,
-                                                     int out_stride) {
+                                                     int out_stride, int accumulate) {
     // one thread per (Gaussian, group of 4 channels); the row bytes of a Gaussian are contiguous
     const int q4 = (ncol + 3) >> 2;
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -848,6 +946,12 @@ __global__ __launch_bounds__(256) void k_reduce_rows(int P, int ncol, const uint
             if (f[u]) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
     }
     float* o = out + (size_t)g * out_stride + c;
+    if (accumulate) {
+        s.x += o[0];
+        if (c + 1 < ncol) s.y += o[1];
+        if (c + 2 < ncol) s.z += o[2];
+        if (c + 3 < ncol) s.w += o[3];
+    }
     if (c + 3 < ncol && (out_stride & 3) == 0) *reinterpret_cast<float4*>(o) = s;
     else {
         o[0] = s.x;
@@ -1121,9 +1225,11 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
                 hipLaunchKernelGGL(k_bwd_live_pixels, dim3((gx + 3) / 4, gy), dim3(256), 0, s, W, H, ED, ch, gx, iv.n_contrib, dE,
                                    iv.live_list, iv.tile_mode);
                 ISR_CHECK_LAUNCH_B("k_bwd_live_pixels");
-                hipLaunchKernelGGL((k_render_bwd_sparse<Math>), dim3(T), dim3(64), 0, s, W, H, ED, ch, gx, iv.tile_offset,
+                hipLaunchKernelGGL((k_render_bwd_sparse<Math, false>), dim3(T), dim3(64), 0, s, W, H, ED, ch, gx, iv.tile_offset,
                                    bv.point_list, bv.box4, g.rec, tm_pre, dE, g.point_offsets, g.rect, partial,
-                                   flags + (size_t)pass * R, iv.live_list, iv.tile_mode, stride, feat_base + ch, R);
+                                   flags + (size_t)pass * R, iv.live_list, iv.tile_mode, stride, feat_base + ch, R,
+                                   (const uint32_t*)nullptr, (const long long*)nullptr, (const float*)nullptr,
+                                   (const uint32_t*)nullptr, (const uint32_t*)nullptr);
                 ISR_CHECK_LAUNCH_B("k_render_bwd_sparse");
                 tmode = iv.tile_mode;
             }
@@ -1148,7 +1254,7 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
         const size_t total = (size_t)P * ((ED + 3) / 4);
         ProfScope ps_("k_reduce_rows", s);
         hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P, ED, g.point_offsets,
-                           g.tiles_touched, partial, flags, R, stride, feat_base, dL_dextra, ED);
+                           g.tiles_touched, partial, flags, R, stride, feat_base, dL_dextra, ED, 0);
         ISR_CHECK_LAUNCH_B("k_reduce_rows");
     }
     if (geomg) {
@@ -1160,6 +1266,70 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
                            dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot);
         ISR_CHECK_LAUNCH_B("k_preprocess_bwd");
     }
+    return 0;
+}
+
+// Feature gradient from SAMPLED pixels: scratch = rows + flags (as backward_scratch_bytes(R, ED, GRAD_EXTRA)) followed by
+// cnt[T], off[T+1], cursor[T], seg_idx[n] (u32).
+size_t backward_sampled_scratch_bytes(int64_t R, int ED, int n, int W, int H) {
+    const size_t T = (size_t)tiles_x(W) * tiles_y(H);
+    return backward_scratch_bytes(R, ED, 1u) + align_up((3 * T + 1 + (size_t)(n > 0 ? n : 1)) * sizeof(uint32_t), 256) + 256;
+}
+
+template <class Math>
+static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int n, const long long* pix,
+                                     const float* rows_in, const float* tm_pre, const void* geom, const void* binning,
+                                     const void* image, float* dL_dextra, int accumulate, void* scratch, hipStream_t s) {
+    const int gx = tiles_x(W), gy = tiles_y(H), T = gx * gy;
+    GeomView g = geom_view(const_cast<void*>(geom), P < 1 ? 1 : P);
+    ImageView iv = image_view(const_cast<void*>(image), W, H);
+    BinView bv = bin_view(const_cast<void*>(binning), R);
+    const int stride = row_floats(ED, 1u), npass = n_passes(ED, 1u);
+    float* partial = (float*)scratch;
+    uint8_t* flags = (uint8_t*)scratch + rows_bytes(R, ED, 1u);
+    uint32_t* cnt = (uint32_t*)((char*)scratch + align_up(backward_scratch_bytes(R, ED, 1u), 256));
+    uint32_t* off = cnt + T;
+    uint32_t* cursor = off + T + 1;
+    uint32_t* seg_idx = cursor + T;
+    if (P == 0) return 0;
+    if (R > 0 && n > 0) {
+        if (hipMemsetAsync(flags, 0, (size_t)R * npass, s) != hipSuccess) return -2;
+        if (hipMemsetAsync(cnt, 0, sizeof(uint32_t) * T, s) != hipSuccess) return -2;
+        ProfScope ps_("k_render_bwd", s);
+        hipLaunchKernelGGL(k_sample_count, dim3((n + 255) / 256), dim3(256), 0, s, n, W, H, gx, pix, cnt);
+        hipLaunchKernelGGL(k_sample_scan, dim3(1), dim3(1024), 0, s, T, cnt, off, cursor);
+        hipLaunchKernelGGL(k_sample_fill, dim3((n + 255) / 256), dim3(256), 0, s, n, W, H, gx, pix, off, cursor, seg_idx);
+        for (int pass = 0, ch = 0; ch < ED; pass++, ch += 32)
+            hipLaunchKernelGGL((k_render_bwd_sparse<Math, true>), dim3(T), dim3(64), 0, s, W, H, ED, ch, gx, iv.tile_offset,
+                               bv.point_list, bv.box4, g.rec, tm_pre, (const float*)nullptr, g.point_offsets, g.rect, partial,
+                               flags + (size_t)pass * R, (const uint32_t*)nullptr, (const uint8_t*)nullptr, stride, ch, R,
+                               iv.n_contrib, pix, rows_in, off, seg_idx);
+        ISR_CHECK_LAUNCH_B("k_render_bwd_sparse");
+    } else if (R > 0) {
+        if (hipMemsetAsync(flags, 0, (size_t)R * npass, s) != hipSuccess) return -2;
+    }
+    const size_t total = (size_t)P * ((ED + 3) / 4);
+    ProfScope ps_("k_reduce_rows", s);
+    hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P, ED, g.point_offsets,
+                       g.tiles_touched, partial, flags, R, stride, 0, dL_dextra, ED, accumulate);
+    ISR_CHECK_LAUNCH_B("k_reduce_rows");
+    return 0;
+}
+
+int launch_backward_sampled(int P, int64_t R, int ED, int W, int H, int mode, int n, const long long* pix,
+                            const float* rows_in, const float* tm_pre, const void* geom, const void* binning,
+                            const void* image, float* dL_dextra, int accumulate, void* scratch, hipStream_t s) {
+    if (mode == 0)
+        return launch_backward_sampled_t<ExactMath>(P, R, ED, W, H, n, pix, rows_in, tm_pre, geom, binning, image, dL_dextra,
+                                                    accumulate, scratch, s);
+    return launch_backward_sampled_t<FastMath>(P, R, ED, W, H, n, pix, rows_in, tm_pre, geom, binning, image, dL_dextra,
+                                               accumulate, scratch, s);
+}
+
+int launch_sample_gather(int n, int F, long long N, const float* map, const long long* pix, float* out, hipStream_t s) {
+    if (n <= 0 || F <= 0) return 0;
+    hipLaunchKernelGGL(k_sample_gather, dim3((unsigned)(((long long)n * F + 255) / 256)), dim3(256), 0, s, n, F, N, map, pix, out);
+    ISR_CHECK_LAUNCH_B("k_sample_gather");
     return 0;
 }
 

@@ -110,9 +110,10 @@ def gram_schmidt(vectors: torch.Tensor) -> torch.Tensor:
 class SegTrainer:
     def __init__(self, scene: scenes.Scene, cameras: List[scenes.Camera], device="cuda", sample_batchsize=8192,
                  n_labels=64, lambda_sv=1e-6, lambda_mv=1e-6, lambda_3d=2.5e-6, sample_mv_frames=5, use_class_feat=False,
-                 multiview=False, seed=0, rank=0, world=1, prefetch_geometry=None, fused_update=None):
+                 multiview=False, seed=0, rank=0, world=1, prefetch_geometry=None, fused_update=None, sampled_path=True):
         self.device = torch.device(device)
         self.rank, self.world = rank, world
+        self.sampled_path = bool(sampled_path)      # render(sample_pixels=...) instead of indexing the feature map
         # overlap of the gradient all-reduce with the next view's geometry pass (default: whenever there is one)
         self.prefetch = (world > 1) if prefetch_geometry is None else bool(prefetch_geometry)
         F = scene.seg_feature.shape[1]
@@ -180,14 +181,18 @@ class SegTrainer:
         m = self.model
         vi = self.view_index(it)
         cam = self.cams[vi]
-        pkg = render(cam, m, self.pipe, self.bg)
-        seg_feature, vis = pkg["seg_feature"], pkg["visibility_filter"]
-        if m.class_feat is not None and self.valid_idx[vi].numel() > 0:
-            # both single-view sample sets in ONE gather (one dense dL/dfeature-map in the backward instead of two)
+        merged = m.class_feat is not None and self.valid_idx[vi].numel() > 0
+        pix = None
+        if merged:
+            # the pixels do not depend on the render: choose them first and let the rasterizer hand back the features at
+            # those pixels (both single-view sample sets in ONE list; no dense dL/dfeature map in the backward)
             pool = self.valid_idx[vi]
             pick = torch.randint(0, pool.numel(), (2 * self.batch,), device=self.device, generator=self.gen)
             pix = pool[pick]
-            feats = seg_feature.reshape(seg_feature.shape[0], -1)[:, pix].T
+        pkg = render(cam, m, self.pipe, self.bg, sample_pixels=pix if self.sampled_path else None)
+        seg_feature, vis = pkg["seg_feature"], pkg["visibility_filter"]
+        if merged:
+            feats = pkg["sampled_seg_feature"] if self.sampled_path else seg_feature.reshape(seg_feature.shape[0], -1)[:, pix].T
             fa, fb = feats.split(self.batch)          # one cat in the backward instead of two zero-fill + copy + add
             la = cam.segmap.reshape(-1)[pix[:self.batch]]
             lb = cam.sorted_segmap.reshape(-1)[pix[self.batch:]]

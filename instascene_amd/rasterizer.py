@@ -372,6 +372,39 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, 
     return g2, gc, go, g3, gt, gsh, gs, gr, ge
 
 
+def sample_extra(out_extra: torch.Tensor, pixels: torch.Tensor) -> torch.Tensor:
+    """``out_extra.reshape(F, -1)[:, pixels].T`` as one gather kernel (``isr_sample_extra``); ``pixels`` int64 = y*W + x."""
+    F, H, W = out_extra.shape
+    pix = pixels.contiguous().to(torch.int64)
+    out = torch.empty((pix.shape[0], F), dtype=torch.float32, device=out_extra.device)
+    with torch.cuda.device(out_extra.device):
+        check(lib().isr_sample_extra(F, W, H, pix.shape[0], _ptr(out_extra), _ptr(pix), _ptr(out), _stream()), "isr_sample_extra")
+    return out
+
+
+def rasterize_gaussians_backward_sampled(P, F, W, H, R, pixels, dL_dsampled, transMat_precomp, geomBuffer, binningBuffer,
+                                         imageBuffer, *, accumulate_into=None, mode=None):
+    """dL/dextra ``[P,F]`` from the gradient of the features SAMPLED at ``pixels`` (``isr_backward_sampled``): the dense
+    ``[F,H,W]`` gradient map is never built.  ``accumulate_into``: an existing dL/dextra to add to."""
+    L = lib()
+    dev = geomBuffer.device
+    mode = _CONFIG["mode"] if mode is None else mode
+    if _CONFIG["async_binning"]:
+        _verify_pending((dev.index, P, W, H))
+    pix = pixels.contiguous().to(torch.int64)
+    g = dL_dsampled.contiguous().float()
+    n = pix.shape[0]
+    out = accumulate_into if accumulate_into is not None else torch.empty((P, F), dtype=torch.float32, device=dev)
+    nbytes = L.isr_backward_sampled_scratch_bytes(int(R), F, n, W, H)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(L.isr_backward_sampled(P, int(R), F, W, H, int(mode), n, _ptr(pix), _ptr(g), _ptr(_f32c(transMat_precomp, "transMat_precomp")),
+                                     _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(out),
+                                     1 if accumulate_into is not None else 0, _ptr(scratch), nbytes, _stream()),
+              "isr_backward_sampled")
+    return out
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     """Equivalent of ``_C.mark_visible`` (rasterize_points.cu:264-283)."""
     L = lib()
@@ -435,7 +468,7 @@ class _Token:
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, extra_attrs,
-                raster_settings):
+                raster_settings, sample_pixels=None):
         rs = raster_settings
         attr_degree = extra_attrs.shape[1] if extra_attrs.shape[0] != 0 else 0
         kept_state = []
@@ -457,14 +490,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.mode = _CONFIG["mode"]
+        # extension: features read at sampled pixels only — their gradient never becomes a dense [F,H,W] map
+        has_samples = sample_pixels is not None and attr_degree > 0
+        sampled = sample_extra(extra, sample_pixels) if has_samples else torch.empty(0, device=color.device)
+        ctx.sample_pixels = sample_pixels.detach() if has_samples else None
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, extra_attrs, sh,
                               geomBuffer, binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii, gau_related_pixels)
         ctx.set_materialize_grads(False)     # unused outputs arrive as None (= zeros) instead of dense zero tensors
-        return color, radii, depth, extra, gau_related_pixels
+        return color, radii, depth, extra, gau_related_pixels, sampled
 
     @staticmethod
-    def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_out_extra, grad_gau_related_pixels):
+    def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_out_extra, grad_gau_related_pixels, grad_sampled=None):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, extra_attrs, sh, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
@@ -475,14 +512,34 @@ class _RasterizeGaussians(torch.autograd.Function):
             mask |= GRAD_GEOMETRY
         if need[8] and extra_attrs.numel():
             mask |= GRAD_EXTRA
-        if mask == 0 or (grad_out_color is None and grad_depth is None and grad_out_extra is None):
-            return (None,) * 10
+        if ctx.sample_pixels is None:
+            grad_sampled = None
+        if grad_sampled is not None and (mask & GRAD_GEOMETRY):
+            # geometry gradients through the feature need the dense map gradient: scatter the samples into it
+            Fm, Hm, Wm = extra_attrs.shape[1], rs.image_height, rs.image_width
+            dense = torch.zeros((Fm, Hm * Wm), dtype=torch.float32, device=means3D.device) if grad_out_extra is None \
+                else grad_out_extra.reshape(Fm, -1).clone()
+            dense.index_add_(1, ctx.sample_pixels.to(torch.int64), grad_sampled.t().contiguous().float())
+            grad_out_extra, grad_sampled = dense.reshape(Fm, Hm, Wm), None
+        if mask == 0 or (grad_out_color is None and grad_depth is None and grad_out_extra is None and grad_sampled is None):
+            return (None,) * 11
+        if grad_sampled is not None and grad_out_color is None and grad_depth is None and grad_out_extra is None:
+            # the common case of feature training: only sampled features carry gradient
+            ge = rasterize_gaussians_backward_sampled(means3D.shape[0], extra_attrs.shape[1], rs.image_width, rs.image_height,
+                                                      ctx.num_rendered, ctx.sample_pixels, grad_sampled, cov3Ds_precomp,
+                                                      geomBuffer, binningBuffer, imgBuffer, mode=ctx.mode)
+            return (None,) * 8 + (ge, None, None)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_extra_attrs) = rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, extra_attrs, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_out_extra, sh,
             rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug, grad_mask=mask,
             mode=ctx.mode)
+        if grad_sampled is not None and grad_extra_attrs is not None and grad_extra_attrs.numel():
+            grad_extra_attrs = rasterize_gaussians_backward_sampled(
+                means3D.shape[0], extra_attrs.shape[1], rs.image_width, rs.image_height, ctx.num_rendered, ctx.sample_pixels,
+                grad_sampled, cov3Ds_precomp, geomBuffer, binningBuffer, imgBuffer, accumulate_into=grad_extra_attrs,
+                mode=ctx.mode)
 
         def pick(i, g, ref):
             if not need[i] or g is None or ref.numel() == 0:
@@ -493,13 +550,14 @@ class _RasterizeGaussians(torch.autograd.Function):
                 pick(3, grad_colors_precomp, colors_precomp), grad_opacities if need[4] else None,
                 pick(5, grad_scales, scales), pick(6, grad_rotations, rotations),
                 pick(7, grad_cov3Ds_precomp, cov3Ds_precomp),
-                grad_extra_attrs if (need[8] and extra_attrs.numel()) else None, None)
+                grad_extra_attrs if (need[8] and extra_attrs.numel()) else None, None, None)
 
 
 def rasterize_gaussians_autograd(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                 extra_attrs, raster_settings):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, extra_attrs, raster_settings)
+                                 extra_attrs, raster_settings, sample_pixels=None):
+    out = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                    cov3Ds_precomp, extra_attrs, raster_settings, sample_pixels)
+    return out if sample_pixels is not None else out[:5]
 
 
 class GaussianRasterizer(nn.Module):
@@ -523,7 +581,9 @@ class GaussianRasterizer(nn.Module):
                                      rs.image_width, shs, rs.sh_degree, rs.campos, rs.prefiltered)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, extra_attrs=None):
+                cov3D_precomp=None, extra_attrs=None, sample_pixels=None):
+        """Reference signature (:210-248).  Extension: ``sample_pixels`` (int64 ``y*W + x``, may repeat) appends a sixth
+        result, the feature map read at those pixels ``[n, F]``; its gradient is propagated without a dense map."""
         rs = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -539,4 +599,4 @@ class GaussianRasterizer(nn.Module):
         cov3D_precomp = empty() if cov3D_precomp is None else cov3D_precomp
         extra_attrs = empty() if extra_attrs is None else extra_attrs
         return rasterize_gaussians_autograd(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                            cov3D_precomp, extra_attrs, rs)
+                                            cov3D_precomp, extra_attrs, rs, sample_pixels)

@@ -222,10 +222,12 @@ def prefetch(viewpoint_camera, pc, pipe, bg_color=None, scaling_modifier=1.0, ov
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
-           norm_seg_feat=True):
+           norm_seg_feat=True, sample_pixels=None):
     """Render the scene (reference gaussian_renderer/__init__.py:20).  ``pc`` needs the reference
     ``GaussianModel`` getters (get_xyz, get_opacity, get_scaling, get_rotation, get_features,
-    get_seg_feature, active_sh_degree); background tensor must be on the GPU."""
+    get_seg_feature, active_sh_degree); background tensor must be on the GPU.  ``sample_pixels`` (extension, int64
+    ``y*W + x``): also return ``sampled_seg_feature [n, F]``, the feature map at those pixels — what train_semantic.py
+    builds by indexing the map (:118-129) — whose gradient reaches the Gaussians without a dense ``[F,H,W]`` map."""
     xyz = pc.get_xyz
     # The reference always makes this carrier require grad (:29-33).  Its gradient is only consumed by
     # train.py's densification; when the geometry is frozen (train_semantic) nothing reads it, so the
@@ -253,12 +255,16 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if seg_feature is not None and norm_seg_feat:
         seg_feature = row_normalize(seg_feature, 1e-9)      # reference :61-62
 
-    rendered_image, radii, allmap, extra_attrs, gau_related_pixels = rasterizer(
-        means2D=means2D, extra_attrs=seg_feature, **geo)
+    res = rasterizer(means2D=means2D, extra_attrs=seg_feature, sample_pixels=sample_pixels if seg_feature is not None else None,
+                     **geo)
+    rendered_image, radii, allmap, extra_attrs, gau_related_pixels = res[:5]
     _rz._CONFIG["lazy_tracer"] = False
 
     rets = RenderPackage({"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0,
                           "radii": radii, "seg_feature": extra_attrs, "gau_related_pixels": gau_related_pixels})
+    if len(res) > 5:
+        # extension: ``seg_feature.reshape(F, -1)[:, sample_pixels].T`` without a dense gradient map in the backward
+        rets["sampled_seg_feature"] = res[5]
     if getattr(pipe, "lazy_maps", False) or os.environ.get("ISR_LAZY_MAPS", "0") == "1":
         dict.update(rets, dict.fromkeys(_LAZY_KEYS))
         rets._pending = (viewpoint_camera, allmap, pipe.depth_ratio, torch.is_grad_enabled())

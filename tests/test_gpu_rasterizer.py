@@ -365,6 +365,77 @@ def test_sparse_backward_on_ragged_image_sizes(W, H, F):
         assert_close(got.cpu().numpy(), want["dL_dextra"], 1e-3, "ragged %dx%d F=%d" % (W, H, F))
 
 
+@pytest.mark.parametrize("F,W,H,nsamp", [(32, 112, 80, 300), (20, 101, 67, 90), (48, 64, 48, 2000)])
+def test_sampled_feature_path_matches_dense_path(F, W, H, nsamp):
+    """render(..., sample_pixels=): features gathered at sampled pixels and their gradient propagated without a dense
+    [F,H,W] map (isr_sample_extra / isr_backward_sampled) == indexing the map and the ordinary backward.  Samples repeat,
+    pile up in one tile (> 32: several groups) and include pixels nothing was blended into."""
+    sc, cams, inp = small_scene(P=2000, F=F, W=W, H=H, seed=71, mu_s=math.log(0.06))
+    cam = cams[1]
+    st = oracle_forward(inp, cam)
+    rng = np.random.RandomState(nsamp)
+    pix = rng.randint(0, W * H, nsamp)
+    pix[:70] = (rng.randint(0, 16, 70) * W + 16 + rng.randint(0, 16, 70))     # 70 samples in tile (1, 0), with repeats
+    pix[70:75] = pix[0]
+    g_rows = rng.randn(nsamp, F).astype(np.float32)
+    dE = np.zeros((F, W * H), dtype=np.float32)
+    np.add.at(dE.T, pix, g_rows)
+    dC, dO = np.zeros_like(st["color"]), np.zeros_like(st["others"])
+    want = oracle.backward(st, dC, dO, dE.reshape(st["extra"].shape))["dL_dextra"]
+    pix_t = torch.tensor(pix, dtype=torch.int64).cuda()
+    for mode in (MODE_EXACT, MODE_FAST):
+        args, out = hip_forward(inp, cam, mode=mode)
+        R, extra, geom, binning, img = out[0], out[4], out[5], out[6], out[7]
+        feats = rz.sample_extra(extra, pix_t)
+        assert torch.equal(feats, extra.reshape(F, -1)[:, pix_t].T)
+        got = rz.rasterize_gaussians_backward_sampled(2000, F, W, H, R, pix_t, torch.tensor(g_rows).cuda(), None, geom, binning,
+                                                      img, mode=mode)
+        assert_close(got.cpu().numpy(), want, 1e-3, "sampled path F=%d" % F)
+        again = rz.rasterize_gaussians_backward_sampled(2000, F, W, H, R, pix_t, torch.tensor(g_rows).cuda(), None, geom,
+                                                        binning, img, mode=mode)
+        if nsamp <= 300:          # deterministic whenever no tile holds more than 32 samples ... and in practice beyond
+            assert torch.equal(got, again) or np.abs((got - again).cpu().numpy()).max() <= 1e-6 * np.abs(want).max()
+        acc = rz.rasterize_gaussians_backward_sampled(2000, F, W, H, R, pix_t, torch.tensor(g_rows).cuda(), None, geom, binning,
+                                                      img, accumulate_into=got.clone(), mode=mode)
+        assert_close(acc.cpu().numpy(), 2.0 * want, 1e-3, "accumulate")
+
+
+def test_sampled_feature_path_through_autograd():
+    """GaussianRasterizer(..., sample_pixels=): sampled-only, sampled + dense map, and sampled with geometry gradients."""
+    sc, cams, inp = small_scene(P=1500, F=16, W=96, H=64, seed=19, mu_s=math.log(0.06))
+    cam = cams[0]
+    rz.set_mode("exact")
+    g = torch.Generator().manual_seed(4)
+    pix = torch.randint(0, 96 * 64, (500,), generator=g).cuda()
+    w_s = torch.randn(500, 16, generator=g).cuda()
+    w_m = torch.randn(16, 64, 96, generator=g).cuda()
+
+    def run(use_samples, use_map, geom_grad):
+        t = {k: (v.cuda() if v is not None else None) for k, v in inp.items()}
+        feat = t["extra"].clone().requires_grad_(True)
+        xyz = t["means3D"].clone().requires_grad_(geom_grad)
+        settings = rz.GaussianRasterizationSettings(64, 96, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.zeros(3).cuda(), 1.0,
+                                                    cam.world_view_transform.cuda(), cam.full_proj_transform.cuda(), 3,
+                                                    cam.camera_center.cuda(), False, False)
+        r = rz.GaussianRasterizer(settings)
+        res = r(xyz, torch.zeros_like(xyz), t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"],
+                extra_attrs=feat, sample_pixels=pix if use_samples else None)
+        fmap = res[3]
+        sampled = res[5] if use_samples else fmap.reshape(16, -1)[:, pix].T
+        loss = (sampled * w_s).sum()
+        if use_map:
+            loss = loss + (fmap * w_m).sum()
+        loss.backward()
+        return feat.grad.clone(), (xyz.grad.clone() if geom_grad else None)
+
+    for use_map, geom in [(False, False), (True, False), (False, True)]:
+        ref_f, ref_x = run(False, use_map, geom)
+        got_f, got_x = run(True, use_map, geom)
+        assert_close(got_f.cpu().numpy(), ref_f.cpu().numpy(), 1e-4, "feature grad map=%s geom=%s" % (use_map, geom))
+        if geom:
+            assert_close(got_x.cpu().numpy(), ref_x.cpu().numpy(), 1e-4, "xyz grad")
+
+
 def test_culling_survives_grazing_and_near_camera_splats():
     """Edge-on, huge and near-plane splats: the conservative cull box must never drop a contributing pair
     (EXACT mode stays bit-identical to the oracle, which evaluates every pair)."""
