@@ -215,3 +215,22 @@ def test_fused_feature_update_tracks_torch_adam():
     finally:
         rz.set_mode("exact")
         rz.set_tracer(True)
+
+
+def test_sampled_path_matches_dense_path():
+    """SegTrainer reads the rendered feature only at its sampled pixels.  With ``sampled_path`` the rasterizer gathers
+    them itself and takes the [n, F] gradient back; without it the reference's formulation (index the dense map, dense
+    gradient map in the backward) runs.  Same samples, same losses, the same parameters to rounding of the summation order."""
+    rz.set_mode("exact")
+    rz.set_tracer(False)
+    outs = []
+    for sp in (False, True):
+        sc, cams = _scene()
+        tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=2048, n_labels=12, use_class_feat=True, multiview=True,
+                        sample_mv_frames=2, seed=3, sampled_path=sp)
+        losses = [float(tr.step(it)) for it in range(11)]
+        outs.append((losses, tr.model._seg_feature.detach().clone()))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-5)
+    d = (outs[0][1] - outs[1][1]).abs().max().item()
+    assert d <= 2e-4 * outs[0][1].abs().max().item(), d
+    rz.set_tracer(True)
