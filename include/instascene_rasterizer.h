@@ -130,8 +130,8 @@ int isr_backward(int P, int D, int M, int64_t num_rendered, int ED, int width, i
 
 /* ---- extension: the feature map is only read at n sampled pixels (train_semantic.py:118-129 picks 8192 pixels per
  * loss).  isr_sample_extra gathers sampled[i, :] = out_extra[:, pixels[i]] (pixels = y*W + x, int64, may repeat);
- * isr_backward_sampled turns dL/dsampled [n, ED] into dL_dextra [P, ED] (added to its content when accumulate != 0)
- * without ever materialising the dense [ED, H, W] gradient: the samples are binned per tile and each tile's list is
+ * isr_backward_sampled turns dL/dsampled [n, ED] into dL_dextra [P, ED] (added to its content when accumulate != 0;
+ * NULL = stop before the per-Gaussian reduction, see isr_feature_rows_step) without ever materialising the dense [ED, H, W] gradient: the samples are binned per tile and each tile's list is
  * walked once with a lane per splat.  Same forward state (geom / binning / image buffers) as isr_backward. */
 size_t isr_backward_sampled_scratch_bytes(int64_t num_rendered, int ED, int n_samples, int width, int height);
 int isr_sample_extra(int ED, int width, int height, int n_samples, const float* out_extra, const long long* pixels,
@@ -140,6 +140,20 @@ int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int hei
                          const long long* pixels, const float* dL_dsampled, const float* transMat_precomp,
                          const void* geom_buffer, const void* binning_buffer, const void* image_buffer, float* dL_dextra,
                          int accumulate, void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---- extension: the per-Gaussian tail of a feature-training step in one pass over [P, ED] (ED % 4 == 0, ED <= 256).
+ * isr_backward_sampled called with dL_dextra == NULL leaves the per-(tile, Gaussian) partial rows in its scratch
+ * ("rows_scratch" here, NULL = no rows).  This entry then, for every Gaussian row:
+ *   dL/dz  = sum of its flagged partial rows (+ gz_dense[P, ED] if not NULL)
+ *   dL/dx  = chain of dL/dz and gy (dL/dy, [P, ED] or NULL) through  y = x/(|x|+eps1), z = y/(|y|+eps2)
+ *            (scene/gaussian_model.py:122-125 and gaussian_renderer/__init__.py:61-62)
+ *   grad_out != NULL:  grad_out = dL/dx, nothing else is written (a data-parallel caller all-reduces it);
+ *   grad_out == NULL:  torch.optim.Adam step (lr, betas, eps, step counted from 1; scene/gaussian_model.py:249) on
+ *                      x / exp_avg / exp_avg_sq in place, and y, z of the UPDATED rows are written for the next forward. */
+int isr_feature_rows_step(int P, int64_t num_rendered, int ED, const void* geom_buffer, const void* rows_scratch,
+                          const float* gz_dense, const float* gy, float eps1, float eps2, float* x, float* grad_out,
+                          double lr, double beta1, double beta2, double eps, long long step, float* exp_avg,
+                          float* exp_avg_sq, float* y, float* z, void* stream);
 
 /* ---- rasterizer_impl.cu:141-153 */
 int isr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

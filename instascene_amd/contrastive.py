@@ -161,6 +161,10 @@ class FeatureAdam:
         self.exp_avg_sq = torch.zeros_like(param, memory_format=torch.contiguous_format)
         self.step_count = 0
         self.normalized = None          # (version of param, y, z) written by the last step
+        # leaf mode (``step_rows``): normalized_chain() hands out y and z as LEAVES; the caller finishes the chain rule,
+        # the optimiser step and the next normalisation in one pass over the rows (isr_feature_rows_step)
+        self.leaf_mode = False
+        self.leaves = None
 
     def step(self):
         p = self.param
@@ -177,6 +181,43 @@ class FeatureAdam:
         torch.autograd.graph.increment_version(p)       # the kernel wrote through the raw pointer: tell autograd
         self.normalized = (p._version, y, z)
 
+    def step_rows(self, rows=None, grad_only: bool = False):
+        """Leaf mode: finish the step from the gradients that reached the leaves of ``normalized_chain()`` — ``y.grad``
+        (3-D loss), ``z.grad`` (any dense rasterizer gradient) — and the partial rows ``rows`` a
+        ``rasterizer.DeferredFeatureRows`` block collected: reduction, chain rule through both normalisations, Adam and
+        the next normalisations in ONE kernel (``isr_feature_rows_step``).  ``grad_only``: stop at ``param.grad`` (for an
+        all-reduce; ``step()`` then completes)."""
+        p = self.param
+        if self.leaves is None:
+            raise RuntimeError("step_rows: normalized_chain() was not called in leaf mode")
+        y_leaf, z_leaf = self.leaves
+        gy = None if y_leaf.grad is None else y_leaf.grad.contiguous().float()
+        gz = None if z_leaf.grad is None else z_leaf.grad.contiguous().float()
+        self.leaves = None
+        if rows is None and gy is None and gz is None:
+            return
+        if rows is not None and (rows.P != p.shape[0] or rows.F != p.shape[1]):
+            raise ValueError("step_rows: rows of a different model")
+        L = lib()
+        P, F = p.shape
+        grad_out = torch.empty_like(p.data) if grad_only else None
+        y = z = None
+        if not grad_only:
+            y, z = torch.empty_like(p.data), torch.empty_like(p.data)
+            self.step_count += 1
+        with torch.cuda.device(p.device):
+            check(L.isr_feature_rows_step(P, rows.R if rows is not None else 0, F, _p(rows.geom) if rows is not None else None,
+                                          _p(rows.scratch) if rows is not None else None, _p(gz), _p(gy),
+                                          float(self.norm_eps[0]), float(self.norm_eps[1]), _p(p.data), _p(grad_out), self.lr,
+                                          float(self.betas[0]), float(self.betas[1]), self.eps, max(1, self.step_count),
+                                          _p(self.exp_avg), _p(self.exp_avg_sq), _p(y), _p(z), _stream()),
+                  "isr_feature_rows_step")
+        if grad_only:
+            p.grad = grad_out
+            return
+        torch.autograd.graph.increment_version(p)
+        self.normalized = (p._version, y, z)
+
     def zero_grad(self, set_to_none: bool = True):
         if set_to_none:
             self.param.grad = None
@@ -186,6 +227,16 @@ class FeatureAdam:
     def normalized_chain(self):
         """``row_normalize_chain(param, *norm_eps)`` — from the last step's output when the parameter is unchanged since."""
         p = self.param
+        if self.leaf_mode and torch.is_grad_enabled():
+            if self.normalized is None or self.normalized[0] != p._version:
+                with torch.no_grad():
+                    y0, z0 = _RowNorm2.apply(p.detach(), *self.norm_eps)
+                self.normalized = (p._version, y0, z0)
+            y = self.normalized[1].detach().requires_grad_(True)
+            z = self.normalized[2].detach().requires_grad_(True)
+            setattr(y, _MEMO_ATTR, (float(self.norm_eps[1]), z, y._version))
+            self.leaves = (y, z)
+            return y
         if self.normalized is not None and self.normalized[0] == p._version:
             y, z = _RowNorm2Given.apply(p, self.normalized[1], self.normalized[2], *self.norm_eps)
             setattr(y, _MEMO_ATTR, (float(self.norm_eps[1]), z, y._version))

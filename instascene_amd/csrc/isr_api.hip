@@ -281,7 +281,7 @@ int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int hei
                          int accumulate, void* scratch, size_t scratch_bytes, void* stream) {
     if (P < 0 || ED <= 0 || width <= 0 || height <= 0 || n_samples < 0) return fail(ISR_EINVAL, "bad backward_sampled sizes");
     if (mode != ISR_MODE_EXACT && mode != ISR_MODE_FAST) return fail(ISR_EINVAL, "unknown mode %d", mode);
-    if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dextra || !scratch) return fail(ISR_EINVAL, "null buffer");
+    if (!geom_buffer || !binning_buffer || !image_buffer || !scratch) return fail(ISR_EINVAL, "null buffer");
     if (n_samples > 0 && (!pixels || !dL_dsampled)) return fail(ISR_EINVAL, "backward_sampled: pixels / dL_dsampled required");
     if (scratch_bytes < backward_sampled_scratch_bytes(num_rendered, ED, n_samples, width, height))
         return fail(ISR_EINVAL, "backward_sampled scratch too small");
@@ -289,6 +289,28 @@ int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int hei
                                            transMat_precomp, geom_buffer, binning_buffer, image_buffer, dL_dextra, accumulate,
                                            scratch, (hipStream_t)stream);
     if (rc != 0) return fail(ISR_EHIP, "backward_sampled launch failed (%d)", rc);
+    return ISR_OK;
+}
+
+int isr_feature_rows_step(int P, int64_t num_rendered, int ED, const void* geom_buffer, const void* rows_scratch,
+                          const float* gz_dense, const float* gy, float eps1, float eps2, float* x, float* grad_out,
+                          double lr, double beta1, double beta2, double eps, long long step, float* exp_avg,
+                          float* exp_avg_sq, float* y, float* z, void* stream) {
+    if (P < 0 || ED <= 0 || (ED & 3) != 0 || ED > 256) return fail(ISR_EINVAL, "feature_rows_step needs ED % 4 == 0 and ED <= 256");
+    if (P == 0) return ISR_OK;
+    if (!x || (rows_scratch && !geom_buffer)) return fail(ISR_EINVAL, "feature_rows_step: null pointer");
+    float lr_over_bc1 = 0.f, inv_sqrt_bc2 = 0.f;
+    if (grad_out == nullptr) {
+        if (!exp_avg || !exp_avg_sq || !y || !z) return fail(ISR_EINVAL, "feature_rows_step: Adam state / outputs required");
+        if (step < 1) return fail(ISR_EINVAL, "feature_rows_step: step counts from 1");
+        const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+        lr_over_bc1 = (float)(lr / bc1);
+        inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    }
+    const int rc = launch_feature_rows_step(P, num_rendered, ED, geom_buffer, rows_scratch, gz_dense, gy, eps1, eps2, x,
+                                            grad_out, lr_over_bc1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                                            inv_sqrt_bc2, (float)eps, exp_avg, exp_avg_sq, y, z, (hipStream_t)stream);
+    if (rc != 0) return fail(ISR_EHIP, "feature_rows_step launch failed (%d)", rc);
     return ISR_OK;
 }
 

@@ -706,7 +706,8 @@ __global__ __launch_bounds__(64) void k_render_bwd_sparse(
     const Rect16* __restrict__ rects, float* __restrict__ partial, uint8_t* __restrict__ row_flags,
     const uint32_t* __restrict__ live_list, const uint8_t* __restrict__ tile_mode, int row_stride, int feat_off,
     int64_t capacity, const uint32_t* __restrict__ n_contrib, const long long* __restrict__ sample_pix,
-    const float* __restrict__ sample_rows, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_idx) {
+    const float* __restrict__ sample_rows, const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_idx,
+    unsigned long long* __restrict__ row_mask) {
     __shared__ int s_lxy[SPARSE_LMAX];                 // tile-relative x | y << 8 of the live pixels
     __shared__ unsigned s_llast[SPARSE_LMAX];          // their last contributor
     __shared__ unsigned s_sample[SPARSE_LMAX];
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_sparse(
         if (__ballot(hk != 0u) == 0ull) continue;
         F3 Tu = {0, 0, 0}, Tv = {0, 0, 0}, Tw = {0, 0, 1};
         float cx = 0, cy = 0, opa = 0, skip = 0;
-        unsigned slot = 0;
+        unsigned slot = 0, ordinal = 0;
         if (hk != 0u) {
             const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
             float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3];
@@ -813,7 +814,8 @@ __global__ __launch_bounds__(64) void k_render_bwd_sparse(
                 c.x = tp[8];
             }
             const Rect16 rc = rects[id];
-            slot = point_offsets[id] + (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
+            ordinal = (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
+            slot = point_offsets[id] + ordinal;
             Tu = {a.x, a.y, a.z}; Tv = {a.w, b.x, b.y}; Tw = {b.z, b.w, c.x};
             cx = c.y; cy = c.z; opa = d.z;
             skip = __builtin_inff();
@@ -864,6 +866,9 @@ __global__ __launch_bounds__(64) void k_render_bwd_sparse(
 #pragma unroll
             for (int q = 0; q < 8; q++) o4[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
             row_flags[slot] = 1;
+            // per-Gaussian summary of the flags (an OR: order-independent), so that the per-Gaussian pass finds the rows
+            // of a Gaussian with one load instead of one per tile instance
+            if (row_mask != nullptr) atomicOr(row_mask + id, 1ull << (ordinal < 63u ? ordinal : 63u));
         }
     }
   }
@@ -958,6 +963,125 @@ __global__ __launch_bounds__(256) void k_reduce_rows(int P, int ncol, const uint
         if (c + 1 < ncol) o[1] = s.y;
         if (c + 2 < ncol) o[2] = s.z;
         if (c + 3 < ncol) o[3] = s.w;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// Feature training: the whole per-Gaussian tail of a step in ONE pass over the [P,F] rows.
+//
+// After the sampled backward the step still has to (1) sum each Gaussian's per-tile partial rows (k_reduce_rows),
+// (2) chain that gradient through the two row normalisations y = x/(|x|+eps1), z = y/(|y|+eps2) together with the 3-D
+// loss' gradient on y (rn2_kernel<true>), (3) apply Adam and (4) emit the next forward's y and z (adam_rn2_kernel):
+// three streaming kernels with 2 + 4 + 9 passes over [P,F].  A row needs nothing from any other row, so here the lanes
+// that own a row (one float4 each) do all of it with the row in registers: in  x, m, v, gy (+ the flagged partial rows),
+// out  x, m, v, y, z.  ADAM = false stops after (2) and writes dL/dx (the multi-GPU trainer all-reduces it first).
+// Same expressions as the three kernels it replaces (bit-identical results).
+template <bool ADAM>
+__global__ __launch_bounds__(256) void k_feature_rows_step(
+    int P, int F, const uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ tiles_touched,
+    const unsigned long long* __restrict__ row_mask, const float* __restrict__ partial,
+    const uint8_t* __restrict__ row_flags, int64_t R, int row_stride,
+    const float* __restrict__ gz_dense, const float* __restrict__ gy, float eps1, float eps2, float* __restrict__ x,
+    float* __restrict__ grad_out, float lr_over_bc1, float om1, float beta2, float om2, float inv_sqrt_bc2, float eps,
+    float* __restrict__ m, float* __restrict__ v, float* __restrict__ y, float* __restrict__ z) {
+    const int q = F >> 2;
+    int lpr = 1;
+    while (lpr < q) lpr <<= 1;
+    const int sub = (threadIdx.x & 63) & (lpr - 1);
+    const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) / lpr;
+    const bool ok = row < P && sub < q;
+    const int c = 4 * sub;
+    const size_t off = (size_t)(row < P ? row : 0) * F + c;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the row's streams are requested first: they are in flight while the partial rows are chased (flag, then row)
+    const float4 xv = ok ? *reinterpret_cast<const float4*>(x + off) : z4;
+    const float4 a = (ok && gy != nullptr) ? *reinterpret_cast<const float4*>(gy + off) : z4;
+    float4 m4 = z4, v4 = z4;
+    if (ADAM && ok) { m4 = *reinterpret_cast<const float4*>(m + off); v4 = *reinterpret_cast<const float4*>(v + off); }
+    // (1) dL/dz row: flagged per-tile partial rows in row order (+ a dense contribution, if any)
+    const float4 bd = ok && gz_dense != nullptr ? *reinterpret_cast<const float4*>(gz_dense + off) : z4;
+    float4 b = z4;
+    if (ok && partial != nullptr) {
+        // which of the Gaussian's tile instances hold a row: one 64-bit word (k_render_bwd_sparse) — two dependent memory
+        // round trips (mask, rows) instead of three (instance count, byte flags, rows), and nothing at all for the ~70 % of
+        // Gaussians no sampled pixel reached
+        const unsigned long long mk = row_mask[row];
+        if (mk != 0ull) {
+            const size_t base = point_offsets[row];
+            unsigned long long bits = mk & ~(1ull << 63);
+            while (bits != 0ull) {                       // ascending instance order = the order of k_reduce_rows
+                int idx[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    idx[u] = bits != 0ull ? __builtin_ctzll(bits) : -1;
+                    bits &= bits - 1ull;
+                }
+                float4 pv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    pv[u] = idx[u] >= 0 ? *reinterpret_cast<const float4*>(partial + (base + idx[u]) * row_stride + c) : z4;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (idx[u] >= 0) { b.x += pv[u].x; b.y += pv[u].y; b.z += pv[u].z; b.w += pv[u].w; }
+            }
+            if (mk >> 63) {                              // a Gaussian spread over more than 63 tiles: byte flags from there on
+                const uint32_t n = tiles_touched[row];
+                const uint8_t* fl = row_flags + (size_t)(c >> 5) * R + base;
+                for (uint32_t r = 63; r < n; r++)
+                    if (fl[r] != 0) {
+                        const float4 pv = *reinterpret_cast<const float4*>(partial + (base + r) * row_stride + c);
+                        b.x += pv.x; b.y += pv.y; b.z += pv.z; b.w += pv.w;
+                    }
+            }
+        }
+    }
+    if (gz_dense != nullptr) { b.x += bd.x; b.y += bd.y; b.z += bd.z; b.w += bd.w; }
+    // (2) through z = y/(|y|+eps2), y = x/(|x|+eps1)   (rn2_kernel<true>)
+    float ss = xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
+    float sa = xv.x * a.x + xv.y * a.y + xv.z * a.z + xv.w * a.w;
+    float sb = xv.x * b.x + xv.y * b.y + xv.z * b.z + xv.w * b.w;
+    for (int o = lpr >> 1; o >= 1; o >>= 1) {
+        ss += __shfl_xor(ss, o); sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o);
+    }
+    const float nx = __builtin_sqrtf(ss), r1 = 1.0f / (nx + eps1);
+    const float ny = nx * r1, r2 = 1.0f / (ny + eps2);
+    const float k2 = ny > 0.0f ? r2 * r2 * (r1 * sb) / ny : 0.0f;
+    const float sxu = sa + r2 * sb - k2 * r1 * ss;
+    const float k1 = nx > 0.0f ? r1 * r1 * sxu / nx : 0.0f;
+    const float cy = k2 * r1;
+    float4 g4;
+    g4.x = r1 * (a.x + r2 * b.x - cy * xv.x) - k1 * xv.x;
+    g4.y = r1 * (a.y + r2 * b.y - cy * xv.y) - k1 * xv.y;
+    g4.z = r1 * (a.z + r2 * b.z - cy * xv.z) - k1 * xv.z;
+    g4.w = r1 * (a.w + r2 * b.w - cy * xv.w) - k1 * xv.w;
+    if constexpr (!ADAM) {
+        if (ok) *reinterpret_cast<float4*>(grad_out + off) = g4;
+    } else {
+        // (3) torch.optim.Adam arithmetic (adam_rn2_kernel)
+        float4 np4 = z4;
+        if (ok) {
+#define ISR_ADAM1(e)                                                                    \
+            m4.e = m4.e + om1 * (g4.e - m4.e);                                          \
+            v4.e = beta2 * v4.e + om2 * (g4.e * g4.e);                                  \
+            np4.e = xv.e - lr_over_bc1 * (m4.e / (__builtin_sqrtf(v4.e) * inv_sqrt_bc2 + eps));
+            ISR_ADAM1(x) ISR_ADAM1(y) ISR_ADAM1(z) ISR_ADAM1(w)
+#undef ISR_ADAM1
+            *reinterpret_cast<float4*>(m + off) = m4;
+            *reinterpret_cast<float4*>(v + off) = v4;
+            *reinterpret_cast<float4*>(x + off) = np4;
+        }
+        // (4) the next forward's normalisations of the updated row
+        float s1 = np4.x * np4.x + np4.y * np4.y + np4.z * np4.z + np4.w * np4.w;
+        for (int o = lpr >> 1; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o);
+        const float q1 = 1.0f / (__builtin_sqrtf(s1) + eps1);
+        const float4 y4 = make_float4(np4.x * q1, np4.y * q1, np4.z * q1, np4.w * q1);
+        float s2 = y4.x * y4.x + y4.y * y4.y + y4.z * y4.z + y4.w * y4.w;
+        for (int o = lpr >> 1; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
+        const float q2 = 1.0f / (__builtin_sqrtf(s2) + eps2);
+        if (ok) {
+            *reinterpret_cast<float4*>(y + off) = y4;
+            *reinterpret_cast<float4*>(z + off) = make_float4(y4.x * q2, y4.y * q2, y4.z * q2, y4.w * q2);
+        }
     }
 }
 
@@ -1229,7 +1353,7 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
                                    bv.point_list, bv.box4, g.rec, tm_pre, dE, g.point_offsets, g.rect, partial,
                                    flags + (size_t)pass * R, iv.live_list, iv.tile_mode, stride, feat_base + ch, R,
                                    (const uint32_t*)nullptr, (const long long*)nullptr, (const float*)nullptr,
-                                   (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                                   (const uint32_t*)nullptr, (const uint32_t*)nullptr, (unsigned long long*)nullptr);
                 ISR_CHECK_LAUNCH_B("k_render_bwd_sparse");
                 tmode = iv.tile_mode;
             }
@@ -1292,6 +1416,9 @@ static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int
     uint32_t* cursor = off + T + 1;
     uint32_t* seg_idx = cursor + T;
     if (P == 0) return 0;
+    // rows only (the caller finishes them with launch_feature_rows_step): also keep a per-Gaussian mask of flagged instances
+    unsigned long long* row_mask = dL_dextra == nullptr ? g.row_mask : nullptr;
+    if (row_mask != nullptr && hipMemsetAsync(row_mask, 0, sizeof(unsigned long long) * (size_t)P, s) != hipSuccess) return -2;
     if (R > 0 && n > 0) {
         if (hipMemsetAsync(flags, 0, (size_t)R * npass, s) != hipSuccess) return -2;
         if (hipMemsetAsync(cnt, 0, sizeof(uint32_t) * T, s) != hipSuccess) return -2;
@@ -1303,16 +1430,42 @@ static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int
             hipLaunchKernelGGL((k_render_bwd_sparse<Math, true>), dim3(T), dim3(64), 0, s, W, H, ED, ch, gx, iv.tile_offset,
                                bv.point_list, bv.box4, g.rec, tm_pre, (const float*)nullptr, g.point_offsets, g.rect, partial,
                                flags + (size_t)pass * R, (const uint32_t*)nullptr, (const uint8_t*)nullptr, stride, ch, R,
-                               iv.n_contrib, pix, rows_in, off, seg_idx);
+                               iv.n_contrib, pix, rows_in, off, seg_idx, pass == 0 ? row_mask : (unsigned long long*)nullptr);
         ISR_CHECK_LAUNCH_B("k_render_bwd_sparse");
     } else if (R > 0) {
         if (hipMemsetAsync(flags, 0, (size_t)R * npass, s) != hipSuccess) return -2;
     }
+    if (dL_dextra == nullptr) return 0;
     const size_t total = (size_t)P * ((ED + 3) / 4);
     ProfScope ps_("k_reduce_rows", s);
     hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P, ED, g.point_offsets,
                        g.tiles_touched, partial, flags, R, stride, 0, dL_dextra, ED, accumulate);
     ISR_CHECK_LAUNCH_B("k_reduce_rows");
+    return 0;
+}
+
+int launch_feature_rows_step(int P, int64_t R, int F, const void* geom, const void* rows_scratch, const float* gz_dense,
+                             const float* gy, float eps1, float eps2, float* x, float* grad_out, float lr_over_bc1,
+                             float om1, float beta2, float om2, float inv_sqrt_bc2, float eps, float* m, float* v, float* y,
+                             float* z, hipStream_t s) {
+    if (P <= 0) return 0;
+    GeomView g = geom_view(const_cast<void*>(geom), P);
+    const float* partial = (const float*)rows_scratch;
+    const uint8_t* flags = rows_scratch ? (const uint8_t*)rows_scratch + rows_bytes(R, F, 1u) : nullptr;
+    const int stride = row_floats(F, 1u);
+    int q = F >> 2, lpr = 1;
+    while (lpr < q) lpr <<= 1;
+    const unsigned blocks = (unsigned)(((long long)P * lpr + 255) / 256);
+    ProfScope ps_("k_feature_rows_step", s);
+    if (grad_out != nullptr)
+        hipLaunchKernelGGL(k_feature_rows_step<false>, dim3(blocks), dim3(256), 0, s, P, F, g.point_offsets, g.tiles_touched,
+                           g.row_mask, partial, flags, R, stride, gz_dense, gy, eps1, eps2, x, grad_out, lr_over_bc1, om1, beta2, om2,
+                           inv_sqrt_bc2, eps, m, v, y, z);
+    else
+        hipLaunchKernelGGL(k_feature_rows_step<true>, dim3(blocks), dim3(256), 0, s, P, F, g.point_offsets, g.tiles_touched,
+                           g.row_mask, partial, flags, R, stride, gz_dense, gy, eps1, eps2, x, grad_out, lr_over_bc1, om1, beta2, om2,
+                           inv_sqrt_bc2, eps, m, v, y, z);
+    ISR_CHECK_LAUNCH_B("k_feature_rows_step");
     return 0;
 }
 

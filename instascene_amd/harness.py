@@ -25,6 +25,7 @@ import torch.nn as nn
 from . import scenes
 from .contrastive import contrastive_loss, row_normalize_chain
 from .dist_utils import allreduce_grads, allreduce_grads_async, view_for, wait_all
+from .rasterizer import DeferredFeatureRows
 from .render import prefetch, render
 
 
@@ -110,7 +111,8 @@ def gram_schmidt(vectors: torch.Tensor) -> torch.Tensor:
 class SegTrainer:
     def __init__(self, scene: scenes.Scene, cameras: List[scenes.Camera], device="cuda", sample_batchsize=8192,
                  n_labels=64, lambda_sv=1e-6, lambda_mv=1e-6, lambda_3d=2.5e-6, sample_mv_frames=5, use_class_feat=False,
-                 multiview=False, seed=0, rank=0, world=1, prefetch_geometry=None, fused_update=None, sampled_path=True):
+                 multiview=False, seed=0, rank=0, world=1, prefetch_geometry=None, fused_update=None, sampled_path=True,
+                 fused_tail=None):
         self.device = torch.device(device)
         self.rank, self.world = rank, world
         self.sampled_path = bool(sampled_path)      # render(sample_pixels=...) instead of indexing the feature map
@@ -139,6 +141,11 @@ class SegTrainer:
         else:
             self.opt = torch.optim.Adam([{"params": [self.model._seg_feature], "lr": 0.025, "name": "seg_feature"}], lr=0.0,
                                         eps=1e-15, fused=self.device.type == "cuda")
+        # everything between the blend backward and the next forward in one pass over the [P,F] rows: row reduction,
+        # chain rule through both normalisations, Adam, next normalisations (FeatureAdam.step_rows)
+        self.fused_tail = bool(fused_update and self.sampled_path) if fused_tail is None else bool(fused_tail)
+        if self.fused_tail and not (fused_update and self.sampled_path):
+            raise ValueError("fused_tail needs fused_update and sampled_path")
         self.gen = torch.Generator(device=self.device).manual_seed(1000 + seed * 131 + rank)
         # label maps are static per view: index the labelled pixels once (the reference re-derives the
         # boolean mask every iteration, train_semantic.py:118-125)
@@ -178,6 +185,20 @@ class SegTrainer:
         return view_for(it, self.rank, self.world, len(self.cams))
 
     def step(self, it: int):
+        if not self.fused_tail:
+            return self._step(it)
+        # inside the step the normalised feature is a pair of autograd LEAVES (FeatureAdam.leaf_mode); outside it the
+        # model differentiates down to the parameter as usual
+        self.model._seg_cache = None
+        self.opt.leaf_mode = True
+        try:
+            return self._step(it)
+        finally:
+            self.opt.leaf_mode = False
+            self.opt.leaves = None
+            self.model._seg_cache = None
+
+    def _step(self, it: int):
         m = self.model
         vi = self.view_index(it)
         cam = self.cams[vi]
@@ -225,7 +246,17 @@ class SegTrainer:
                 pick = pool[torch.randint(0, pool.numel(), (self.batch,), device=self.device, generator=self.gen)]
                 loss = loss + contrastive_loss(m.get_seg_feature[pick], self.labels3d[pick], predef_u_list=m.class_feat,
                                                num_labels=self.n_labels + 1) * self.l3d
-        loss.backward()
+        if self.fused_tail:
+            with DeferredFeatureRows() as sink:
+                loss.backward()
+            if self.world == 1 and not self.prefetch:
+                self.opt.step_rows(sink.rows)
+                m._seg_cache = None
+                return loss.detach()
+            self.opt.step_rows(sink.rows, grad_only=True)       # dL/dparam; Adam after the all-reduce
+            del sink
+        else:
+            loss.backward()
         if self.prefetch:
             # the next view's geometry pass does not read the feature: it runs while RCCL sums the gradient
             works = allreduce_grads_async([m._seg_feature], self.world)

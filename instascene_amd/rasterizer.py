@@ -382,10 +382,42 @@ def sample_extra(out_extra: torch.Tensor, pixels: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class FeatureRows:
+    """Per-(tile, Gaussian) partial rows of dL/dextra left by a sampled backward that stopped before the per-Gaussian
+    reduction; finished by ``isr_feature_rows_step`` (``contrastive.FeatureAdam.step_rows``)."""
+
+    def __init__(self, scratch, geom, R, P, F):
+        self.scratch, self.geom, self.R, self.P, self.F = scratch, geom, int(R), int(P), int(F)
+
+
+class DeferredFeatureRows:
+    """``with DeferredFeatureRows() as sink: loss.backward()`` — the first backward of a render whose only gradient is the
+    one of its sampled features hands over its :class:`FeatureRows` in ``sink.rows`` and reports NO gradient for
+    ``extra_attrs`` (the caller owns the rest of the chain); any further such backward inside the block takes the normal
+    path and its dense ``[P,F]`` gradient reaches ``extra_attrs`` through autograd as usual."""
+
+    def __init__(self):
+        self.rows: Optional[FeatureRows] = None
+
+    def __enter__(self):
+        global _ROWS_SINK
+        self._prev, _ROWS_SINK = _ROWS_SINK, self
+        return self
+
+    def __exit__(self, *exc):
+        global _ROWS_SINK
+        _ROWS_SINK = self._prev
+        return False
+
+
+_ROWS_SINK: Optional[DeferredFeatureRows] = None
+
+
 def rasterize_gaussians_backward_sampled(P, F, W, H, R, pixels, dL_dsampled, transMat_precomp, geomBuffer, binningBuffer,
-                                         imageBuffer, *, accumulate_into=None, mode=None):
+                                         imageBuffer, *, accumulate_into=None, mode=None, rows_only=False):
     """dL/dextra ``[P,F]`` from the gradient of the features SAMPLED at ``pixels`` (``isr_backward_sampled``): the dense
-    ``[F,H,W]`` gradient map is never built.  ``accumulate_into``: an existing dL/dextra to add to."""
+    ``[F,H,W]`` gradient map is never built.  ``accumulate_into``: an existing dL/dextra to add to.  ``rows_only``: stop
+    before the per-Gaussian reduction and return the :class:`FeatureRows`."""
     L = lib()
     dev = geomBuffer.device
     mode = _CONFIG["mode"] if mode is None else mode
@@ -394,7 +426,10 @@ def rasterize_gaussians_backward_sampled(P, F, W, H, R, pixels, dL_dsampled, tra
     pix = pixels.contiguous().to(torch.int64)
     g = dL_dsampled.contiguous().float()
     n = pix.shape[0]
-    out = accumulate_into if accumulate_into is not None else torch.empty((P, F), dtype=torch.float32, device=dev)
+    if rows_only:
+        out = None
+    else:
+        out = accumulate_into if accumulate_into is not None else torch.empty((P, F), dtype=torch.float32, device=dev)
     nbytes = L.isr_backward_sampled_scratch_bytes(int(R), F, n, W, H)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
@@ -402,6 +437,8 @@ def rasterize_gaussians_backward_sampled(P, F, W, H, R, pixels, dL_dsampled, tra
                                      _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(out),
                                      1 if accumulate_into is not None else 0, _ptr(scratch), nbytes, _stream()),
               "isr_backward_sampled")
+    if rows_only:
+        return FeatureRows(scratch, geomBuffer, R, P, F)
     return out
 
 
@@ -525,6 +562,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             return (None,) * 11
         if grad_sampled is not None and grad_out_color is None and grad_depth is None and grad_out_extra is None:
             # the common case of feature training: only sampled features carry gradient
+            sink = _ROWS_SINK
+            if sink is not None and sink.rows is None and extra_attrs.shape[1] % 4 == 0 and extra_attrs.shape[1] <= 256:
+                sink.rows = rasterize_gaussians_backward_sampled(
+                    means3D.shape[0], extra_attrs.shape[1], rs.image_width, rs.image_height, ctx.num_rendered,
+                    ctx.sample_pixels, grad_sampled, cov3Ds_precomp, geomBuffer, binningBuffer, imgBuffer, mode=ctx.mode,
+                    rows_only=True)
+                return (None,) * 11
             ge = rasterize_gaussians_backward_sampled(means3D.shape[0], extra_attrs.shape[1], rs.image_width, rs.image_height,
                                                       ctx.num_rendered, ctx.sample_pixels, grad_sampled, cov3Ds_precomp,
                                                       geomBuffer, binningBuffer, imgBuffer, mode=ctx.mode)

@@ -234,3 +234,24 @@ def test_sampled_path_matches_dense_path():
     d = (outs[0][1] - outs[1][1]).abs().max().item()
     assert d <= 2e-4 * outs[0][1].abs().max().item(), d
     rz.set_tracer(True)
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_fused_tail_reproduces_the_separate_kernels(mode):
+    """SegTrainer(fused_tail=True): everything between the blend backward and the next forward is one pass over the [P,F]
+    rows (isr_feature_rows_step).  Same arithmetic as reduction + rownorm2 backward + FeatureAdam: identical parameters,
+    including the iterations whose multi-view branch sends a dense gradient to the same leaves."""
+    rz.set_mode(mode)
+    rz.set_tracer(False)
+    outs = []
+    for ft in (False, True):
+        sc, cams = _scene()
+        tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=2048, n_labels=12, use_class_feat=True, multiview=True,
+                        sample_mv_frames=2, seed=3, fused_tail=ft)
+        assert tr.fused_tail == ft
+        losses = [float(tr.step(it)) for it in range(12)]
+        outs.append((losses, tr.model._seg_feature.detach().clone(), tr.opt.exp_avg.clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    rz.set_mode("exact")
+    rz.set_tracer(True)

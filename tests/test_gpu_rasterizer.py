@@ -400,6 +400,66 @@ def test_sampled_feature_path_matches_dense_path(F, W, H, nsamp):
         assert_close(acc.cpu().numpy(), 2.0 * want, 1e-3, "accumulate")
 
 
+@pytest.mark.parametrize("F", [32, 20, 64])
+def test_feature_rows_step_equals_the_three_passes(F):
+    """isr_feature_rows_step (row reduction + chain rule through both normalisations + Adam + next normalisations in one
+    pass) == isr_backward_sampled's reduction, then iso_rownorm2 backward, then iso_adam_rownorm2 — bit for bit; both the
+    gradient-only form (multi-GPU) and the Adam form, with and without dL/dy and a dense dL/dz."""
+    from instascene_amd.contrastive import FeatureAdam, _RowNorm2
+    P, W, H, n = 2000, 112, 80, 700
+    sc, cams, inp = small_scene(P=P, F=F, W=W, H=H, seed=23, mu_s=math.log(0.06))
+    cam = cams[2]
+    rng = np.random.RandomState(F)
+    pix_t = torch.tensor(rng.randint(0, W * H, n), dtype=torch.int64).cuda()
+    g_rows = torch.tensor(rng.randn(n, F).astype(np.float32)).cuda()
+    x0 = torch.tensor(rng.randn(P, F).astype(np.float32)).cuda()
+    x0[5] = 0.0                                                   # a zero row: the sub-gradient branch
+    gy = torch.zeros(P, F).cuda()
+    gy[rng.randint(0, P, 300)] = torch.tensor(rng.randn(300, F).astype(np.float32)).cuda()
+    gzd = torch.tensor(rng.randn(P, F).astype(np.float32)).cuda() * 0.1
+    for mode in (MODE_EXACT, MODE_FAST):
+        args, out = hip_forward(inp, cam, mode=mode)
+        R, geom, binning, img = out[0], out[5], out[6], out[7]
+        ge = rz.rasterize_gaussians_backward_sampled(P, F, W, H, R, pix_t, g_rows, None, geom, binning, img, mode=mode)
+        rows = rz.rasterize_gaussians_backward_sampled(P, F, W, H, R, pix_t, g_rows, None, geom, binning, img, mode=mode,
+                                                       rows_only=True)
+        for use_gy, use_gz, use_rows in [(True, False, True), (False, True, True), (True, True, False), (False, False, True)]:
+            def make():
+                p = torch.nn.Parameter(x0.clone())
+                opt = FeatureAdam(p, lr=0.025, eps=1e-15)
+                opt.exp_avg.copy_(torch.tensor(rng.randn(P, F).astype(np.float32)) * 0.01)
+                opt.exp_avg_sq.copy_(torch.tensor(rng.rand(P, F).astype(np.float32)) * 1e-4)
+                opt.step_count = 6
+                return p, opt
+            st = rng.get_state()
+            p_a, opt_a = make()
+            rng.set_state(st)
+            p_b, opt_b = make()
+            # reference: three passes
+            y, z = _RowNorm2.apply(p_a, 1e-6, 1e-9)
+            gz_total = (ge if use_rows else torch.zeros_like(ge)) + (gzd if use_gz else 0.0)
+            torch.autograd.backward([y, z], [gy if use_gy else torch.zeros_like(gy), gz_total])
+            want_grad = p_a.grad.clone()
+            opt_a.step()
+            # fused
+            opt_b.leaf_mode = True
+            for grad_only in (True, False):
+                yl = opt_b.normalized_chain()
+                zl = opt_b.leaves[1]
+                if use_gy:
+                    yl.grad = gy.clone()
+                if use_gz:
+                    zl.grad = gzd.clone()
+                opt_b.step_rows(rows if use_rows else None, grad_only=grad_only)
+                if grad_only:
+                    assert torch.equal(p_b.grad, want_grad), (mode, use_gy, use_gz, use_rows)
+                    p_b.grad = None
+            assert torch.equal(p_b.data, p_a.data)
+            assert torch.equal(opt_b.exp_avg, opt_a.exp_avg) and torch.equal(opt_b.exp_avg_sq, opt_a.exp_avg_sq)
+            assert torch.equal(opt_b.normalized[1], opt_a.normalized[1]) and torch.equal(opt_b.normalized[2], opt_a.normalized[2])
+            assert opt_b.step_count == opt_a.step_count == 7
+
+
 def test_sampled_feature_path_through_autograd():
     """GaussianRasterizer(..., sample_pixels=): sampled-only, sampled + dense map, and sampled with geometry gradients."""
     sc, cams, inp = small_scene(P=1500, F=16, W=96, H=64, seed=19, mu_s=math.log(0.06))
