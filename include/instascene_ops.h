@@ -109,6 +109,14 @@ int iso_adam_rownorm2(long long N, int F, double lr, double beta1, double beta2,
                       float eps2, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* y, float* z,
                       void* stream);
 
+/* Gradient of a row gather  rows = table[idx]  (table [P,F]; train_semantic.py:183-190 samples the visible Gaussians'
+ * features with replacement) kept sparse: slot[P] (int32) is set to -1, then for every distinct valid idx[i] the FIRST
+ * position i becomes slot[idx[i]] = i and merged[i, :] = sum of vals[j, :] over all j with idx[j] == idx[i], ascending j
+ * (the order of index_put_(accumulate=True)).  Rows of `merged` that are not a slot target are not written.
+ * n <= 16384.  Consumed by isr_feature_rows_step(gy_slot, gy_merged). */
+int iso_rows_compact(int n, int F, long long P, const long long* idx, const float* vals, int* slot /*[P]*/,
+                     float* merged /*[n,F]*/, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,7 +44,7 @@ SIGNATURES = {
     "isr_sample_extra": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "isr_backward_sampled": (c_int, [c_int, c_int64, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P,
                                      c_size_t, _P]),
-    "isr_feature_rows_step": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, ctypes.c_double,
+    "isr_feature_rows_step": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_longlong, _P, _P, _P, _P,
                                       _P]),
     "isr_mark_visible": (c_int, [c_int, _P, _P, _P, _P, _P]),
@@ -62,6 +62,7 @@ SIGNATURES = {
     "iso_ssim_forward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "iso_ssim_backward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "iso_densify_stats": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "iso_rows_compact": (c_int, [c_int, c_int, ctypes.c_longlong, _P, _P, _P, _P, _P]),
     "iso_adam_rownorm2": (c_int, [ctypes.c_longlong, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                   ctypes.c_longlong, c_float,
                                   c_float, _P, _P, _P, _P, _P, _P, _P]),

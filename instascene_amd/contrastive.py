@@ -147,6 +147,35 @@ class _RowNorm2Given(torch.autograd.Function):
         return g[0], None, None, None, None
 
 
+class _GatherRows(torch.autograd.Function):
+    """``table[idx]``; inside a ``rasterizer.DeferredFeatureRows`` block the first backward keeps its gradient sparse
+    (``sink.row_grads``) instead of building a dense ``[P,F]`` tensor by sort + scatter."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        ctx.save_for_backward(idx)
+        ctx.shape = table.shape
+        return table.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import rasterizer as _rz
+        (idx,) = ctx.saved_tensors
+        sink = _rz._ROWS_SINK
+        n = idx.shape[0]
+        if sink is not None and sink.row_grads is None and g.is_cuda and n <= 16384:
+            sink.row_grads = (idx, g.contiguous().float())
+            return None, None
+        dense = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        dense.index_put_((idx,), g, accumulate=True)
+        return dense, None
+
+
+def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """``table[idx]`` for a ``[P,F]`` table and int64 row indices (train_semantic.py:183-190)."""
+    return _GatherRows.apply(table, idx)
+
+
 class FeatureAdam:
     """Adam on ONE ``[P,F]`` parameter with the arithmetic of ``torch.optim.Adam(lr, betas, eps)`` (the reference's
     optimiser for ``_seg_feature``, scene/gaussian_model.py:223-249), whose step also emits the parameter's two chained
@@ -165,6 +194,7 @@ class FeatureAdam:
         # the optimiser step and the next normalisation in one pass over the rows (isr_feature_rows_step)
         self.leaf_mode = False
         self.leaves = None
+        self._slot = None
 
     def step(self):
         p = self.param
@@ -181,12 +211,13 @@ class FeatureAdam:
         torch.autograd.graph.increment_version(p)       # the kernel wrote through the raw pointer: tell autograd
         self.normalized = (p._version, y, z)
 
-    def step_rows(self, rows=None, grad_only: bool = False):
+    def step_rows(self, rows=None, grad_only: bool = False, row_grads=None):
         """Leaf mode: finish the step from the gradients that reached the leaves of ``normalized_chain()`` — ``y.grad``
         (3-D loss), ``z.grad`` (any dense rasterizer gradient) — and the partial rows ``rows`` a
         ``rasterizer.DeferredFeatureRows`` block collected: reduction, chain rule through both normalisations, Adam and
         the next normalisations in ONE kernel (``isr_feature_rows_step``).  ``grad_only``: stop at ``param.grad`` (for an
-        all-reduce; ``step()`` then completes)."""
+        all-reduce; ``step()`` then completes).  ``row_grads``: ``(idx, [n,F])`` sparse gradient on ``y`` rows
+        (``gather_rows``), merged per row by ``iso_rows_compact``."""
         p = self.param
         if self.leaves is None:
             raise RuntimeError("step_rows: normalized_chain() was not called in leaf mode")
@@ -194,7 +225,7 @@ class FeatureAdam:
         gy = None if y_leaf.grad is None else y_leaf.grad.contiguous().float()
         gz = None if z_leaf.grad is None else z_leaf.grad.contiguous().float()
         self.leaves = None
-        if rows is None and gy is None and gz is None:
+        if rows is None and gy is None and gz is None and row_grads is None:
             return
         if rows is not None and (rows.P != p.shape[0] or rows.F != p.shape[1]):
             raise ValueError("step_rows: rows of a different model")
@@ -205,9 +236,19 @@ class FeatureAdam:
         if not grad_only:
             y, z = torch.empty_like(p.data), torch.empty_like(p.data)
             self.step_count += 1
+        slot = merged = None
         with torch.cuda.device(p.device):
+            if row_grads is not None:
+                idx, vals = row_grads
+                idx = idx.contiguous().to(torch.int64)
+                vals = vals.contiguous().float()
+                if self._slot is None or self._slot.shape[0] != P:
+                    self._slot = torch.empty(P, dtype=torch.int32, device=p.device)
+                slot, merged = self._slot, torch.empty_like(vals)
+                check(L.iso_rows_compact(idx.shape[0], F, P, _p(idx), _p(vals), _p(slot), _p(merged), _stream()),
+                      "iso_rows_compact")
             check(L.isr_feature_rows_step(P, rows.R if rows is not None else 0, F, _p(rows.geom) if rows is not None else None,
-                                          _p(rows.scratch) if rows is not None else None, _p(gz), _p(gy),
+                                          _p(rows.scratch) if rows is not None else None, _p(gz), _p(gy), _p(slot), _p(merged),
                                           float(self.norm_eps[0]), float(self.norm_eps[1]), _p(p.data), _p(grad_out), self.lr,
                                           float(self.betas[0]), float(self.betas[1]), self.eps, max(1, self.step_count),
                                           _p(self.exp_avg), _p(self.exp_avg_sq), _p(y), _p(z), _stream()),

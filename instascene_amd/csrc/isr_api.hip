@@ -293,12 +293,13 @@ int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int hei
 }
 
 int isr_feature_rows_step(int P, int64_t num_rendered, int ED, const void* geom_buffer, const void* rows_scratch,
-                          const float* gz_dense, const float* gy, float eps1, float eps2, float* x, float* grad_out,
-                          double lr, double beta1, double beta2, double eps, long long step, float* exp_avg,
-                          float* exp_avg_sq, float* y, float* z, void* stream) {
+                          const float* gz_dense, const float* gy, const int* gy_slot, const float* gy_merged, float eps1,
+                          float eps2, float* x, float* grad_out, double lr, double beta1, double beta2, double eps,
+                          long long step, float* exp_avg, float* exp_avg_sq, float* y, float* z, void* stream) {
     if (P < 0 || ED <= 0 || (ED & 3) != 0 || ED > 256) return fail(ISR_EINVAL, "feature_rows_step needs ED % 4 == 0 and ED <= 256");
     if (P == 0) return ISR_OK;
-    if (!x || (rows_scratch && !geom_buffer)) return fail(ISR_EINVAL, "feature_rows_step: null pointer");
+    if (!x || (rows_scratch && !geom_buffer) || ((gy_slot != nullptr) != (gy_merged != nullptr)))
+        return fail(ISR_EINVAL, "feature_rows_step: null pointer");
     float lr_over_bc1 = 0.f, inv_sqrt_bc2 = 0.f;
     if (grad_out == nullptr) {
         if (!exp_avg || !exp_avg_sq || !y || !z) return fail(ISR_EINVAL, "feature_rows_step: Adam state / outputs required");
@@ -307,8 +308,8 @@ int isr_feature_rows_step(int P, int64_t num_rendered, int ED, const void* geom_
         lr_over_bc1 = (float)(lr / bc1);
         inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     }
-    const int rc = launch_feature_rows_step(P, num_rendered, ED, geom_buffer, rows_scratch, gz_dense, gy, eps1, eps2, x,
-                                            grad_out, lr_over_bc1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+    const int rc = launch_feature_rows_step(P, num_rendered, ED, geom_buffer, rows_scratch, gz_dense, gy, gy_slot, gy_merged, eps1,
+                                            eps2, x, grad_out, lr_over_bc1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
                                             inv_sqrt_bc2, (float)eps, exp_avg, exp_avg_sq, y, z, (hipStream_t)stream);
     if (rc != 0) return fail(ISR_EHIP, "feature_rows_step launch failed (%d)", rc);
     return ISR_OK;
@@ -581,6 +582,20 @@ int iso_adam_rownorm2(long long N, int F, double lr, double beta1, double beta2,
                        (float)beta2, (float)(1.0 - beta2), (float)(1.0 / sqrt(bc2)), (float)eps, eps1, eps2, param, grad,
                        exp_avg, exp_avg_sq, y, z);
     ISR_LAUNCH_CHECK("iso_adam_rownorm2");
+    return ISR_OK;
+}
+
+int iso_rows_compact(int n, int F, long long P, const long long* idx, const float* vals, int* slot, float* merged,
+                     void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (n < 0 || F <= 0 || P < 0) return fail(ISR_EINVAL, "rows_compact: bad sizes");
+    if (P > 0 && !slot) return fail(ISR_EINVAL, "rows_compact: null slot table");
+    if (n > 0 && (!idx || !vals || !merged)) return fail(ISR_EINVAL, "rows_compact: null pointer");
+    if (P > 0 && hipMemsetAsync(slot, 0xFF, sizeof(int) * (size_t)P, s) != hipSuccess) return fail(ISR_EHIP, "rows_compact: memset failed");
+    if (n == 0 || P == 0) return ISR_OK;
+    if (n > iso::ROWS_COMPACT_MAX) return fail(ISR_EINVAL, "rows_compact: at most %d rows", iso::ROWS_COMPACT_MAX);
+    hipLaunchKernelGGL(iso::rows_compact_kernel, dim3((n + 63) / 64), dim3(256), 0, s, n, F, P, idx, vals, slot, merged);
+    ISR_LAUNCH_CHECK("iso_rows_compact");
     return ISR_OK;
 }
 

@@ -981,7 +981,8 @@ __global__ __launch_bounds__(256) void k_feature_rows_step(
     int P, int F, const uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ tiles_touched,
     const unsigned long long* __restrict__ row_mask, const float* __restrict__ partial,
     const uint8_t* __restrict__ row_flags, int64_t R, int row_stride,
-    const float* __restrict__ gz_dense, const float* __restrict__ gy, float eps1, float eps2, float* __restrict__ x,
+    const float* __restrict__ gz_dense, const float* __restrict__ gy, const int* __restrict__ gy_slot,
+    const float* __restrict__ gy_merged, float eps1, float eps2, float* __restrict__ x,
     float* __restrict__ grad_out, float lr_over_bc1, float om1, float beta2, float om2, float inv_sqrt_bc2, float eps,
     float* __restrict__ m, float* __restrict__ v, float* __restrict__ y, float* __restrict__ z) {
     const int q = F >> 2;
@@ -995,7 +996,8 @@ __global__ __launch_bounds__(256) void k_feature_rows_step(
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // the row's streams are requested first: they are in flight while the partial rows are chased (flag, then row)
     const float4 xv = ok ? *reinterpret_cast<const float4*>(x + off) : z4;
-    const float4 a = (ok && gy != nullptr) ? *reinterpret_cast<const float4*>(gy + off) : z4;
+    float4 a = (ok && gy != nullptr) ? *reinterpret_cast<const float4*>(gy + off) : z4;
+    const int gslot = (ok && gy_slot != nullptr) ? gy_slot[row] : -1;       // dL/dy as (row -> merged entry), iso_rows_compact
     float4 m4 = z4, v4 = z4;
     if (ADAM && ok) { m4 = *reinterpret_cast<const float4*>(m + off); v4 = *reinterpret_cast<const float4*>(v + off); }
     // (1) dL/dz row: flagged per-tile partial rows in row order (+ a dense contribution, if any)
@@ -1036,6 +1038,10 @@ __global__ __launch_bounds__(256) void k_feature_rows_step(
         }
     }
     if (gz_dense != nullptr) { b.x += bd.x; b.y += bd.y; b.z += bd.z; b.w += bd.w; }
+    if (gslot >= 0) {
+        const float4 e = *reinterpret_cast<const float4*>(gy_merged + (size_t)gslot * F + c);
+        a.x += e.x; a.y += e.y; a.z += e.z; a.w += e.w;
+    }
     // (2) through z = y/(|y|+eps2), y = x/(|x|+eps1)   (rn2_kernel<true>)
     float ss = xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
     float sa = xv.x * a.x + xv.y * a.y + xv.z * a.z + xv.w * a.w;
@@ -1445,7 +1451,7 @@ static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int
 }
 
 int launch_feature_rows_step(int P, int64_t R, int F, const void* geom, const void* rows_scratch, const float* gz_dense,
-                             const float* gy, float eps1, float eps2, float* x, float* grad_out, float lr_over_bc1,
+                             const float* gy, const int* gy_slot, const float* gy_merged, float eps1, float eps2, float* x, float* grad_out, float lr_over_bc1,
                              float om1, float beta2, float om2, float inv_sqrt_bc2, float eps, float* m, float* v, float* y,
                              float* z, hipStream_t s) {
     if (P <= 0) return 0;
@@ -1459,11 +1465,11 @@ int launch_feature_rows_step(int P, int64_t R, int F, const void* geom, const vo
     ProfScope ps_("k_feature_rows_step", s);
     if (grad_out != nullptr)
         hipLaunchKernelGGL(k_feature_rows_step<false>, dim3(blocks), dim3(256), 0, s, P, F, g.point_offsets, g.tiles_touched,
-                           g.row_mask, partial, flags, R, stride, gz_dense, gy, eps1, eps2, x, grad_out, lr_over_bc1, om1, beta2, om2,
+                           g.row_mask, partial, flags, R, stride, gz_dense, gy, gy_slot, gy_merged, eps1, eps2, x, grad_out, lr_over_bc1, om1, beta2, om2,
                            inv_sqrt_bc2, eps, m, v, y, z);
     else
         hipLaunchKernelGGL(k_feature_rows_step<true>, dim3(blocks), dim3(256), 0, s, P, F, g.point_offsets, g.tiles_touched,
-                           g.row_mask, partial, flags, R, stride, gz_dense, gy, eps1, eps2, x, grad_out, lr_over_bc1, om1, beta2, om2,
+                           g.row_mask, partial, flags, R, stride, gz_dense, gy, gy_slot, gy_merged, eps1, eps2, x, grad_out, lr_over_bc1, om1, beta2, om2,
                            inv_sqrt_bc2, eps, m, v, y, z);
     ISR_CHECK_LAUNCH_B("k_feature_rows_step");
     return 0;

@@ -23,7 +23,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import scenes
-from .contrastive import contrastive_loss, row_normalize_chain
+from .contrastive import contrastive_loss, gather_rows, row_normalize_chain
 from .dist_utils import allreduce_grads, allreduce_grads_async, view_for, wait_all
 from .rasterizer import DeferredFeatureRows
 from .render import prefetch, render
@@ -244,16 +244,17 @@ class SegTrainer:
                 self.vis_pool[vi] = pool
             if pool.numel() > 0:
                 pick = pool[torch.randint(0, pool.numel(), (self.batch,), device=self.device, generator=self.gen)]
-                loss = loss + contrastive_loss(m.get_seg_feature[pick], self.labels3d[pick], predef_u_list=m.class_feat,
+                rows3d = gather_rows(m.get_seg_feature, pick) if self.fused_tail else m.get_seg_feature[pick]
+                loss = loss + contrastive_loss(rows3d, self.labels3d[pick], predef_u_list=m.class_feat,
                                                num_labels=self.n_labels + 1) * self.l3d
         if self.fused_tail:
             with DeferredFeatureRows() as sink:
                 loss.backward()
             if self.world == 1 and not self.prefetch:
-                self.opt.step_rows(sink.rows)
+                self.opt.step_rows(sink.rows, row_grads=sink.row_grads)
                 m._seg_cache = None
                 return loss.detach()
-            self.opt.step_rows(sink.rows, grad_only=True)       # dL/dparam; Adam after the all-reduce
+            self.opt.step_rows(sink.rows, grad_only=True, row_grads=sink.row_grads)     # dL/dparam; Adam after the all-reduce
             del sink
         else:
             loss.backward()

@@ -394,10 +394,13 @@ class DeferredFeatureRows:
     """``with DeferredFeatureRows() as sink: loss.backward()`` — the first backward of a render whose only gradient is the
     one of its sampled features hands over its :class:`FeatureRows` in ``sink.rows`` and reports NO gradient for
     ``extra_attrs`` (the caller owns the rest of the chain); any further such backward inside the block takes the normal
-    path and its dense ``[P,F]`` gradient reaches ``extra_attrs`` through autograd as usual."""
+    path and its dense ``[P,F]`` gradient reaches ``extra_attrs`` through autograd as usual.  Likewise the first backward
+    of a ``contrastive.gather_rows`` leaves its sparse gradient in ``sink.row_grads`` instead of scattering it into a dense
+    ``[P,F]`` tensor."""
 
     def __init__(self):
         self.rows: Optional[FeatureRows] = None
+        self.row_grads = None          # (indices, [n,F] gradient) of the first contrastive.gather_rows backward
 
     def __enter__(self):
         global _ROWS_SINK

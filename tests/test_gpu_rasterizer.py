@@ -460,6 +460,32 @@ def test_feature_rows_step_equals_the_three_passes(F):
             assert opt_b.step_count == opt_a.step_count == 7
 
 
+def test_sparse_row_gradient_equals_dense_index_put():
+    """iso_rows_compact + isr_feature_rows_step(gy_slot, gy_merged) == the dense dL/dy that index_put_(accumulate=True)
+    builds, bit for bit; rows drawn with replacement (pairs, a 5-fold repeat), out-of-range indices ignored."""
+    from instascene_amd.contrastive import FeatureAdam
+    P, F, n = 3000, 32, 1500
+    rng = np.random.RandomState(3)
+    idx = rng.randint(0, 400, n)                 # heavy repetition
+    idx[[7, 300, 301, 900, 1499]] = 2999
+    vals = torch.tensor(rng.randn(n, F).astype(np.float32)).cuda()
+    idx_t = torch.tensor(idx, dtype=torch.int64).cuda()
+    x0 = torch.tensor(rng.randn(P, F).astype(np.float32)).cuda()
+    dense = torch.zeros(P, F).cuda().index_put_((idx_t,), vals, accumulate=True)
+    outs = []
+    for sparse in (False, True):
+        p = torch.nn.Parameter(x0.clone())
+        opt = FeatureAdam(p, lr=0.025, eps=1e-15)
+        opt.leaf_mode = True
+        yl = opt.normalized_chain()
+        if not sparse:
+            yl.grad = dense.clone()
+        opt.step_rows(None, grad_only=True, row_grads=(idx_t, vals) if sparse else None)
+        outs.append(p.grad.clone())
+    assert torch.equal(outs[0], outs[1])
+    assert outs[0].abs().max() > 0
+
+
 def test_sampled_feature_path_through_autograd():
     """GaussianRasterizer(..., sample_pixels=): sampled-only, sampled + dense map, and sampled with geometry gradients."""
     sc, cams, inp = small_scene(P=1500, F=16, W=96, H=64, seed=19, mu_s=math.log(0.06))
