@@ -51,6 +51,20 @@ int iso_contrastive_forward(int N, int F, int K, const float* features /*[N,F]*/
 int iso_contrastive_backward(int N, int F, int K, int prototypes_predefined, const float* dL_dloss /*[1]*/,
                              float* dL_dfeatures /*[N,F]*/, void* state, size_t state_bytes, void* stream);
 
+/* nb (1..4) losses of the same shape (N, F, K, flags) in one sequence of launches — train_semantic.py:118-190 evaluates
+ * two single-view losses and the 3-D loss per iteration, each a handful of microsecond-sized kernels.  features / labels /
+ * predef_u / dL_dfeatures are HOST arrays of nb device pointers (predef_u may be NULL or hold NULL entries = cluster
+ * means); state holds nb consecutive blocks of iso_contrastive_scratch_bytes(N, F, K).  loss[b] = weights[b] * loss_b;
+ * loss_total (may be NULL) = their sum in problem order.  The backward multiplies dL_dloss by weights[b]. */
+int iso_contrastive_forward_batch(int nb, int N, int F, int K, const float* const* features, const void* const* labels,
+                                  int labels_are_int64, const float* const* predef_u, int consider_negative, int min_pixnum,
+                                  float temp_lambda, const float* weights /*host [nb] or NULL = 1*/, float* loss /*[nb]*/,
+                                  float* loss_total /*[1] or NULL*/, void* state, size_t state_bytes, void* stream);
+int iso_contrastive_backward_batch(int nb, int N, int F, int K, const int* prototypes_predefined /*host [nb]*/,
+                                   const float* dL_dloss /*[1]*/, const float* weights /*host [nb] or NULL*/,
+                                   float* const* dL_dfeatures /*host [nb] of [N,F]*/, void* state, size_t state_bytes,
+                                   void* stream);
+
 /* Row normalisation y = x / (|x|_2 + eps) on [N,F] (scene/gaussian_model.py:122-125, gaussian_renderer/__init__.py:61-62):
  * backward == 0: out = y;  backward != 0: out = dL/dx given dy = dL/dy (x is the forward input). */
 int iso_rownorm(long long N, int F, float eps, int backward, const float* x, const float* dy, float* out, void* stream);

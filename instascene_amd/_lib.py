@@ -55,6 +55,9 @@ SIGNATURES = {
     "iso_contrastive_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "iso_contrastive_forward": (c_int, [c_int, c_int, c_int, _P, _P, c_int, _P, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
     "iso_contrastive_backward": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "iso_contrastive_forward_batch": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, c_int, c_float, _P, _P, _P,
+                                              _P, c_size_t, _P]),
+    "iso_contrastive_backward_batch": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "iso_rownorm": (c_int, [ctypes.c_longlong, c_int, c_float, c_int, _P, _P, _P, _P]),
     "iso_render_post_forward": (c_int, [c_int, c_int, c_float] + [_P] * 11 + [_P]),
     "iso_render_post_backward": (c_int, [c_int, c_int, c_float] + [_P] * 14 + [_P]),

@@ -76,6 +76,71 @@ def contrastive_loss(features, masks, predef_u_list=None, min_pixnum=0, temp_lam
     return _ProtoNCE.apply(features, masks, predef_u_list, K, float(temp_lambda), bool(consider_negative), int(min_pixnum))
 
 
+class _ProtoNCEBatch(torch.autograd.Function):
+    """``sum_b weights[b] * contrastive_loss(features[b], labels[b], predefs[b])`` for up to four problems of the same
+    shape, evaluated by ONE sequence of launches (``iso_contrastive_forward_batch``)."""
+
+    @staticmethod
+    def forward(ctx, K, temp_lambda, consider_negative, min_pixnum, weights, labels, predefs, *features):
+        L = lib()
+        nb = len(features)
+        feats = [f.contiguous().float() for f in features]
+        N, F = feats[0].shape
+        labs = [l.contiguous() if l.dtype == torch.int64 else l.to(torch.int64).contiguous() for l in labels]
+        pres = [p.contiguous().float() if p is not None else None for p in predefs]
+        dev = feats[0].device
+        one = L.iso_contrastive_scratch_bytes(N, F, K)
+        state = torch.empty(one * nb, dtype=torch.uint8, device=dev)
+        loss = torch.empty(nb + 1, dtype=torch.float32, device=dev)
+        ptrs = lambda ts: (ctypes.c_void_p * nb)(*[None if t is None else t.data_ptr() for t in ts])
+        w = (ctypes.c_float * nb)(*[float(x) for x in weights])
+        with torch.cuda.device(dev):
+            check(L.iso_contrastive_forward_batch(nb, N, F, K, ptrs(feats), ptrs(labs), 1, ptrs(pres),
+                                                  int(bool(consider_negative)), int(min_pixnum), float(temp_lambda), w,
+                                                  _p(loss), ctypes.c_void_p(loss.data_ptr() + 4 * nb), _p(state), one * nb,
+                                                  _stream()), "iso_contrastive_forward_batch")
+        ctx.save_for_backward(state)
+        ctx.dims = (nb, N, F, K, one * nb, [p is not None for p in pres], [float(x) for x in weights])
+        ctx.mark_non_differentiable(loss)
+        return loss[nb], loss
+
+    @staticmethod
+    def backward(ctx, grad_total, _grad_parts):
+        L = lib()
+        (state,) = ctx.saved_tensors
+        nb, N, F, K, nbytes, has_pre, weights = ctx.dims
+        g = grad_total.reshape(1).contiguous().float()
+        outs = [torch.empty((N, F), dtype=torch.float32, device=state.device) for _ in range(nb)]
+        flags = (ctypes.c_int * nb)(*[int(h) for h in has_pre])
+        w = (ctypes.c_float * nb)(*weights)
+        optr = (ctypes.c_void_p * nb)(*[o.data_ptr() for o in outs])
+        with torch.cuda.device(state.device):
+            check(L.iso_contrastive_backward_batch(nb, N, F, K, flags, _p(g), w, optr, _p(state), nbytes, _stream()),
+                  "iso_contrastive_backward_batch")
+        return (None,) * 7 + tuple(outs)
+
+
+def contrastive_loss_batch(features, masks, predef_u_lists, weights, num_labels, min_pixnum=0, temp_lambda=1000,
+                           consider_negative=False):
+    """``sum_b weights[b] * contrastive_loss(features[b], masks[b], predef_u_lists[b], num_labels=num_labels)`` (weighted
+    losses added in order) for 1..4 problems whose ``[N,F]`` shapes agree and whose prototypes, where predefined, have
+    ``num_labels`` rows; one sequence of launches instead of one per loss.  Returns ``(total, weighted_parts[nb+1])``."""
+    nb = len(features)
+    if not (1 <= nb <= 4) or len(masks) != nb or len(predef_u_lists) != nb or len(weights) != nb:
+        raise ValueError("contrastive_loss_batch: 1..4 problems, one mask / prototype entry / weight each")
+    shape = features[0].shape
+    K = max(int(num_labels), 1)
+    for f, p in zip(features, predef_u_lists):
+        if not f.is_cuda:
+            raise RuntimeError("contrastive_loss_batch: features must be CUDA tensors (the HIP library is the only backend)")
+        if f.shape != shape or shape[0] == 0:
+            raise ValueError("contrastive_loss_batch: all problems need the same non-empty [N,F] shape")
+        if p is not None and int(p.shape[0]) != K:
+            raise ValueError("contrastive_loss_batch: predefined prototypes must have num_labels rows")
+    return _ProtoNCEBatch.apply(K, float(temp_lambda), bool(consider_negative), int(min_pixnum), tuple(weights),
+                                tuple(masks), tuple(predef_u_lists), *features)
+
+
 class _RowNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, eps):

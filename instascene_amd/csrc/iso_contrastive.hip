@@ -27,7 +27,7 @@ struct CState {          // carved from the caller's state buffer
     float* f;            // [N,F] normalised features
     float* inv;          // [N]
     int* col;            // [N] column id or -1
-    int* hist;           // [K+4] raw-label histogram (K+2 slots) + two "last workgroup" tickets
+    int* hist;           // [K+6] raw-label histogram (K+2 slots) + tickets: phi, loss, batch total (problem 0's)
     float* U;            // [K,F]
     float* phi;          // [K]
     float* cnt;          // [K] surviving samples per column (0 = column absent)
@@ -44,7 +44,7 @@ inline CState cstate(void* buf, int N, int F, int K) {
     s.f = isr::carve<float>(p, (size_t)N * F);
     s.inv = isr::carve<float>(p, N);
     s.col = isr::carve<int>(p, N);
-    s.hist = isr::carve<int>(p, K + 4);
+    s.hist = isr::carve<int>(p, K + 6);
     s.U = isr::carve<float>(p, (size_t)K * F);
     s.phi = isr::carve<float>(p, K);
     s.cnt = isr::carve<float>(p, K);
@@ -59,6 +59,25 @@ inline CState cstate(void* buf, int N, int F, int K) {
 inline size_t cstate_bytes(int N, int F, int K) {
     CState s = cstate((void*)0, N, F, K);
     return (size_t)(s.Us + (size_t)K * F) + 256;
+}
+
+// Several losses of identical shape (N, F, K and flags) in ONE sequence of launches: every kernel takes the problem
+// index from a spare grid dimension; the problems' state blocks are `stride` bytes apart, their inputs / outputs are
+// separate tensors.  A single loss is a batch of one.
+constexpr int CK_MAXB = 4;
+struct CKBatch {
+    long long stride;                   // bytes between consecutive problems' state blocks
+    const float* x[CK_MAXB];            // features [N,F]
+    const void* labels[CK_MAXB];        // [N] int64 / int32
+    const float* predef[CK_MAXB];       // [K,F] predefined prototypes, or NULL (cluster means)
+    float* dX[CK_MAXB];                 // backward: dL/dfeatures [N,F]
+    float w[CK_MAXB];                   // loss weights
+};
+#define CK_AT(ptr, pb) ptr = (decltype(ptr))((const char*)(ptr) + (size_t)(pb) * (size_t)bt.stride)
+
+__global__ __launch_bounds__(256) void ck_zero(int n, int* __restrict__ hist, CKBatch bt) {
+    CK_AT(hist, blockIdx.y);
+    for (int e = threadIdx.x; e < n; e += 256) hist[e] = 0;
 }
 
 __device__ __forceinline__ float block_sum_256(float v, float* s_red) {
@@ -76,8 +95,9 @@ __device__ __forceinline__ long long load_label(const void* labels, int is64, in
 }
 
 constexpr int CK_LDS_HIST = 2048;
-__global__ __launch_bounds__(256) void ck_count(int N, int K, int shift, const void* __restrict__ labels, int is64,
-                                                int* __restrict__ hist) {
+__global__ __launch_bounds__(256) void ck_count(int N, int K, int shift, int is64, int* __restrict__ hist, CKBatch bt) {
+    const void* labels = bt.labels[blockIdx.y];
+    CK_AT(hist, blockIdx.y);
     // per-workgroup histogram in LDS, one global atomic per non-empty bin (a few dozen labels: 8192 global atomics
     // on ~65 addresses serialise in L2)
     __shared__ int s_h[CK_LDS_HIST];
@@ -103,9 +123,11 @@ __global__ __launch_bounds__(256) void ck_count(int N, int K, int shift, const v
 
 // LPR lanes per sample (float4 each per step) when F % 4 == 0, one lane per sample otherwise
 __global__ __launch_bounds__(256) void ck_normalize(int N, int F, int K, int shift, int consider_negative, int min_pixnum,
-                                                    const float* __restrict__ x, const void* __restrict__ labels, int is64,
-                                                    const int* __restrict__ hist, float* __restrict__ f,
-                                                    float* __restrict__ inv, int* __restrict__ col, int lpr) {
+                                                    int is64, const int* __restrict__ hist, float* __restrict__ f,
+                                                    float* __restrict__ inv, int* __restrict__ col, int lpr, CKBatch bt) {
+    const float* x = bt.x[blockIdx.y];
+    const void* labels = bt.labels[blockIdx.y];
+    CK_AT(hist, blockIdx.y); CK_AT(f, blockIdx.y); CK_AT(inv, blockIdx.y); CK_AT(col, blockIdx.y);
     const int i = (int)(((long long)blockIdx.x * 256 + threadIdx.x) / lpr);
     const int sub = threadIdx.x & (lpr - 1);
     const bool ok_row = i < N;
@@ -149,13 +171,16 @@ __global__ __launch_bounds__(256) void ck_normalize(int N, int F, int K, int shi
 // grid (ceil(K/32), ceil(F/32), CK_NSPLIT); the block's 4 waves stripe its slice; fixed-order combine.
 __global__ __launch_bounds__(256) void ck_gemm_tn(int N, int F, int K, int onehot, const int* __restrict__ col,
                                                   const float* __restrict__ G, const float* __restrict__ f,
-                                                  float* __restrict__ split) {
+                                                  float* __restrict__ split, CKBatch bt) {
+    const int pb = blockIdx.z / CK_NSPLIT, zs = blockIdx.z - pb * CK_NSPLIT;
+    if (bt.predef[pb] != nullptr) return;           // predefined prototypes: no cluster sums, no prototype gradient
+    CK_AT(col, pb); CK_AT(G, pb); CK_AT(f, pb); CK_AT(split, pb);
     __shared__ float s_acc[4][32][33];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int kidx = k0 + (lane & 31), cidx = c0 + (lane & 31), kk = lane >> 5;
     const int chunk = (N + CK_NSPLIT - 1) / CK_NSPLIT;
-    const int i_lo = blockIdx.z * chunk, i_hi = min(N, i_lo + chunk);
+    const int i_lo = zs * chunk, i_hi = min(N, i_lo + chunk);
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = i_lo + 2 * wv; i < i_hi; i += 8) {       // A[m = cluster][k = sample], B[k = sample][n = channel]
         const int smp = i + kk;
@@ -172,15 +197,17 @@ __global__ __launch_bounds__(256) void ck_gemm_tn(int N, int F, int K, int oneho
     for (int e = threadIdx.x; e < 1024; e += 256) {
         const int m = e >> 5, c = e & 31;
         if (k0 + m < K && c0 + c < F)
-            split[((size_t)blockIdx.z * K + k0 + m) * F + c0 + c] =
+            split[((size_t)zs * K + k0 + m) * F + c0 + c] =
                 (s_acc[0][m][c] + s_acc[1][m][c]) + (s_acc[2][m][c] + s_acc[3][m][c]);
     }
 }
 
 // U = cluster mean (or predefined prototype), cnt = surviving samples per column
 __global__ __launch_bounds__(256) void ck_finish_u(int F, int K, int min_pixnum, const int* __restrict__ hist,
-                                                   const float* __restrict__ split, const float* __restrict__ predef,
-                                                   float* __restrict__ U, float* __restrict__ cnt) {
+                                                   const float* __restrict__ split, float* __restrict__ U,
+                                                   float* __restrict__ cnt, CKBatch bt) {
+    const float* predef = bt.predef[blockIdx.y];
+    CK_AT(hist, blockIdx.y); CK_AT(split, blockIdx.y); CK_AT(U, blockIdx.y); CK_AT(cnt, blockIdx.y);
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= K * F) return;
     const int k = e / F;
@@ -201,7 +228,9 @@ __global__ __launch_bounds__(256) void ck_finish_u(int F, int K, int min_pixnum,
 
 __global__ __launch_bounds__(256) void ck_finish_du(int F, int K, const float* __restrict__ split,
                                                     const float* __restrict__ phi, const float* __restrict__ cnt,
-                                                    float* __restrict__ dU) {
+                                                    float* __restrict__ dU, CKBatch bt) {
+    if (bt.predef[blockIdx.y] != nullptr) return;
+    CK_AT(split, blockIdx.y); CK_AT(phi, blockIdx.y); CK_AT(cnt, blockIdx.y); CK_AT(dU, blockIdx.y);
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= K * F) return;
     const int k = e / F;
@@ -222,7 +251,9 @@ __device__ __forceinline__ float ld_agent(const float* p) {      // bypass the n
 __global__ __launch_bounds__(256) void ck_phi(int N, int F, int K, const float* __restrict__ f, const int* __restrict__ col,
                                               const float* __restrict__ U, const float* __restrict__ cnt,
                                               float temp_lambda, float* __restrict__ part, int* __restrict__ ticket,
-                                              float* __restrict__ phi, float* __restrict__ Us) {
+                                              float* __restrict__ phi, float* __restrict__ Us, CKBatch bt) {
+    CK_AT(f, blockIdx.y); CK_AT(col, blockIdx.y); CK_AT(U, blockIdx.y); CK_AT(cnt, blockIdx.y); CK_AT(part, blockIdx.y);
+    CK_AT(ticket, blockIdx.y); CK_AT(phi, blockIdx.y); CK_AT(Us, blockIdx.y);
     __shared__ __attribute__((aligned(16))) float s_d[256];
     __shared__ __attribute__((aligned(16))) int s_c[256];
     __shared__ int s_last;
@@ -297,7 +328,9 @@ __global__ __launch_bounds__(256) void ck_phi(int N, int F, int K, const float* 
 __global__ __launch_bounds__(64) void ck_similarity(int N, int F, int K, const float* __restrict__ f,
                                                      const float* __restrict__ U, const float* __restrict__ phi,
                                                      const float* __restrict__ cnt, const int* __restrict__ colid,
-                                                     float* __restrict__ G, float* __restrict__ part) {
+                                                     float* __restrict__ G, float* __restrict__ part, CKBatch bt) {
+    CK_AT(f, blockIdx.y); CK_AT(U, blockIdx.y); CK_AT(phi, blockIdx.y); CK_AT(cnt, blockIdx.y); CK_AT(colid, blockIdx.y);
+    CK_AT(G, blockIdx.y); CK_AT(part, blockIdx.y);
     const int lane = threadIdx.x & 63;
     const int i0 = blockIdx.x * 32;
     const int arow = i0 + (lane & 31), kk = lane >> 5;
@@ -367,12 +400,29 @@ __device__ __forceinline__ float half_wave_sum(float v) {     // sum over the 32
     return v + __shfl_xor(v, 16);
 }
 
+// A problem's loss is final: weight it, and let the LAST problem of the batch add the weighted losses in problem order.
+__device__ __forceinline__ void ck_publish_loss(float t, int pb, int nb, float w, float* __restrict__ loss,
+                                                float* __restrict__ loss_total, int* __restrict__ ticket_total) {
+    loss[pb] = t * w;
+    if (loss_total == nullptr) return;
+    __threadfence();
+    if (atomicAdd(ticket_total, 1) != nb - 1) return;
+    __threadfence();
+    float tot = ld_agent(loss);
+    for (int p = 1; p < nb; p++) tot += ld_agent(loss + p);
+    loss_total[0] = tot;
+}
+
 template <int NT>
 __global__ __launch_bounds__(64) void ck_similarity_small(int N, int F, int K, const float* __restrict__ f,
                                                            const float* __restrict__ U, const float* __restrict__ phi,
                                                            const float* __restrict__ cnt, const int* __restrict__ colid,
                                                            float* __restrict__ G, float* __restrict__ part,
-                                                           int* __restrict__ ticket, float* __restrict__ loss) {
+                                                           int* __restrict__ ticket, float* __restrict__ loss,
+                                                           float* __restrict__ loss_total, int* __restrict__ ticket_total,
+                                                           CKBatch bt) {
+    CK_AT(f, blockIdx.y); CK_AT(U, blockIdx.y); CK_AT(phi, blockIdx.y); CK_AT(cnt, blockIdx.y); CK_AT(colid, blockIdx.y);
+    CK_AT(G, blockIdx.y); CK_AT(part, blockIdx.y); CK_AT(ticket, blockIdx.y);
     const int lane = threadIdx.x & 63;
     const int i0 = blockIdx.x * 32;
     const int arow = i0 + (lane & 31), kk = lane >> 5;
@@ -449,15 +499,18 @@ __global__ __launch_bounds__(64) void ck_similarity_small(int N, int F, int K, c
     for (unsigned b = lane; b < gridDim.x; b += 64) t += ld_agent(part + b);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
-    if (lane == 0) loss[0] = t;
+    if (lane == 0) ck_publish_loss(t, blockIdx.y, gridDim.y, bt.w[blockIdx.y], loss, loss_total, ticket_total);
 }
 
-__global__ __launch_bounds__(256) void ck_loss_reduce(int nb, const float* __restrict__ part, float* __restrict__ loss) {
+__global__ __launch_bounds__(256) void ck_loss_reduce(int nblk, const float* __restrict__ part, float* __restrict__ loss,
+                                                      float* __restrict__ loss_total, int* __restrict__ ticket_total,
+                                                      CKBatch bt) {
+    CK_AT(part, blockIdx.y);
     __shared__ float s_red[4];
     float a = 0.0f;
-    for (int i = threadIdx.x; i < nb; i += 256) a += part[i];
+    for (int i = threadIdx.x; i < nblk; i += 256) a += part[i];
     const float t = block_sum_256(a, s_red);
-    if (threadIdx.x == 0) loss[0] = t;
+    if (threadIdx.x == 0) ck_publish_loss(t, blockIdx.y, gridDim.y, bt.w[blockIdx.y], loss, loss_total, ticket_total);
 }
 
 // dF = G.(U/phi) [+ dU[y]/n_y];  dX = g * dF * inv.   one wave x 32 samples per workgroup, 32-channel tiles.
@@ -465,11 +518,15 @@ __global__ __launch_bounds__(64) void ck_grad_f(int N, int F, int K, const float
                                                  const float* __restrict__ Us,
                                                  const float* __restrict__ cnt, const float* __restrict__ dU,
                                                  const int* __restrict__ colid, const float* __restrict__ inv,
-                                                 const float* __restrict__ gloss, int use_mean, float* __restrict__ dX) {
+                                                 const float* __restrict__ gloss, CKBatch bt) {
+    CK_AT(G, blockIdx.y); CK_AT(Us, blockIdx.y); CK_AT(cnt, blockIdx.y); CK_AT(dU, blockIdx.y); CK_AT(colid, blockIdx.y);
+    CK_AT(inv, blockIdx.y);
+    float* dX = bt.dX[blockIdx.y];
+    const bool use_mean = bt.predef[blockIdx.y] == nullptr;
     const int lane = threadIdx.x & 63;
     const int i0 = blockIdx.x * 32;
     const int arow = i0 + (lane & 31), kk = lane >> 5;
-    const float g = gloss[0];
+    const float g = gloss[0] * bt.w[blockIdx.y];
     for (int c0 = 0; c0 < F; c0 += 32) {
         const int ch = c0 + (lane & 31);
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -386,67 +386,122 @@ int iso_dist2_3nn(int P, const float* points, float* mean_dist2, void* scratch, 
 
 size_t iso_contrastive_scratch_bytes(int N, int F, int K) { return iso::cstate_bytes(N < 1 ? 1 : N, F < 1 ? 1 : F, K < 1 ? 1 : K); }
 
-int iso_contrastive_forward(int N, int F, int K, const float* features, const void* labels, int labels_are_int64,
-                            const float* predef_u, int consider_negative, int min_pixnum, float temp_lambda, float* loss,
-                            void* state, size_t state_bytes, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
+static int contrastive_forward_impl(int nb, int N, int F, int K, const float* const* features, const void* const* labels,
+                                    int labels_are_int64, const float* const* predef_u, int consider_negative,
+                                    int min_pixnum, float temp_lambda, const float* weights, float* loss,
+                                    float* loss_total, void* state, size_t state_bytes, hipStream_t s) {
+    if (nb < 1 || nb > iso::CK_MAXB) return fail(ISR_EINVAL, "contrastive batch of %d (1..%d supported)", nb, iso::CK_MAXB);
     if (N <= 0 || F <= 0 || K <= 0 || !features || !labels || !loss || !state) return fail(ISR_EINVAL, "bad contrastive arguments");
     if (F > 1024) return fail(ISR_EINVAL, "feature dimension %d > 1024 unsupported", F);
-    if (state_bytes < iso::cstate_bytes(N, F, K)) return fail(ISR_EINVAL, "contrastive state too small");
+    const size_t one = iso::cstate_bytes(N, F, K);
+    if (state_bytes < one * (size_t)nb) return fail(ISR_EINVAL, "contrastive state too small");
+    iso::CKBatch bt = {};
+    bt.stride = (long long)one;
+    for (int b = 0; b < nb; b++) {
+        if (!features[b] || !labels[b]) return fail(ISR_EINVAL, "bad contrastive arguments (problem %d)", b);
+        bt.x[b] = features[b];
+        bt.labels[b] = labels[b];
+        bt.predef[b] = predef_u ? predef_u[b] : nullptr;
+        bt.w[b] = weights ? weights[b] : 1.0f;
+    }
     iso::CState st = iso::cstate(state, N, F, K);
     const int shift = consider_negative ? 0 : 1;
     const int nblk = (N + 31) / 32, nt = (N + 255) / 256;
-    ISR_HIP(hipMemsetAsync(st.hist, 0, sizeof(int) * (K + 4), s));       // histogram + the two tickets
     int* ticket_phi = st.hist + K + 2;
     int* ticket_loss = st.hist + K + 3;
-    hipLaunchKernelGGL(iso::ck_count, dim3(nt), dim3(256), 0, s, N, K, shift, labels, labels_are_int64, st.hist);
+    int* ticket_total = st.hist + K + 4;          // problem 0's
+    bool any_mean = false;
+    for (int b = 0; b < nb; b++) any_mean = any_mean || bt.predef[b] == nullptr;
+    hipLaunchKernelGGL(iso::ck_zero, dim3(1, nb), dim3(256), 0, s, K + 6, st.hist, bt);       // histogram + tickets
+    hipLaunchKernelGGL(iso::ck_count, dim3(nt, nb), dim3(256), 0, s, N, K, shift, labels_are_int64, st.hist, bt);
     ISR_STAGE("ck_count", s);
     int lpr = 1;
     if ((F & 3) == 0) while (lpr < (F >> 2) && lpr < 64) lpr <<= 1;
-    hipLaunchKernelGGL(iso::ck_normalize, dim3((unsigned)(((long long)N * lpr + 255) / 256)), dim3(256), 0, s, N, F, K, shift,
-                       consider_negative, min_pixnum, features, labels, labels_are_int64, st.hist, st.f, st.inv, st.col, lpr);
+    hipLaunchKernelGGL(iso::ck_normalize, dim3((unsigned)(((long long)N * lpr + 255) / 256), nb), dim3(256), 0, s, N, F, K, shift,
+                       consider_negative, min_pixnum, labels_are_int64, st.hist, st.f, st.inv, st.col, lpr, bt);
     ISR_STAGE("ck_normalize", s);
-    if (predef_u == nullptr)
-        hipLaunchKernelGGL(iso::ck_gemm_tn, dim3((K + 31) / 32, (F + 31) / 32, iso::CK_NSPLIT), dim3(256), 0, s, N, F, K, 1,
-                           st.col, (const float*)nullptr, st.f, st.split);
-    hipLaunchKernelGGL(iso::ck_finish_u, dim3((K * F + 255) / 256), dim3(256), 0, s, F, K, min_pixnum, st.hist, st.split,
-                       predef_u, st.U, st.cnt);
+    if (any_mean)
+        hipLaunchKernelGGL(iso::ck_gemm_tn, dim3((K + 31) / 32, (F + 31) / 32, iso::CK_NSPLIT * nb), dim3(256), 0, s, N, F, K, 1,
+                           st.col, (const float*)nullptr, st.f, st.split, bt);
+    hipLaunchKernelGGL(iso::ck_finish_u, dim3((K * F + 255) / 256, nb), dim3(256), 0, s, F, K, min_pixnum, st.hist, st.split,
+                       st.U, st.cnt, bt);
     ISR_STAGE("ck_gemm_tn/ck_finish_u", s);
-    hipLaunchKernelGGL(iso::ck_phi, dim3(nt), dim3(256), 0, s, N, F, K, st.f, st.col, st.U, st.cnt, temp_lambda, st.phi_part,
-                       ticket_phi, st.phi, st.Us);
+    hipLaunchKernelGGL(iso::ck_phi, dim3(nt, nb), dim3(256), 0, s, N, F, K, st.f, st.col, st.U, st.cnt, temp_lambda, st.phi_part,
+                       ticket_phi, st.phi, st.Us, bt);
     ISR_STAGE("ck_phi", s);
     if (F <= 32 && K <= 96) {
-#define ISO_SIM(NT)                                                                                                     \
-    hipLaunchKernelGGL((iso::ck_similarity_small<NT>), dim3(nblk), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt,  \
-                       st.col, st.G, st.part, ticket_loss, loss)
+#define ISO_SIM(NT)                                                                                                       \
+    hipLaunchKernelGGL((iso::ck_similarity_small<NT>), dim3(nblk, nb), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, \
+                       st.col, st.G, st.part, ticket_loss, loss, loss_total, ticket_total, bt)
         if (K <= 32) ISO_SIM(1); else if (K <= 64) ISO_SIM(2); else ISO_SIM(3);
 #undef ISO_SIM
     } else {
-        hipLaunchKernelGGL(iso::ck_similarity, dim3(nblk), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, st.col, st.G,
-                           st.part);
-        hipLaunchKernelGGL(iso::ck_loss_reduce, dim3(1), dim3(256), 0, s, nblk, st.part, loss);
+        hipLaunchKernelGGL(iso::ck_similarity, dim3(nblk, nb), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, st.col, st.G,
+                           st.part, bt);
+        hipLaunchKernelGGL(iso::ck_loss_reduce, dim3(1, nb), dim3(256), 0, s, nblk, st.part, loss, loss_total, ticket_total, bt);
     }
     ISR_STAGE("ck_similarity", s);
     ISR_LAUNCH_CHECK("iso_contrastive_forward");
     return ISR_OK;
 }
 
-int iso_contrastive_backward(int N, int F, int K, int prototypes_predefined, const float* dL_dloss, float* dL_dfeatures,
-                             void* state, size_t state_bytes, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    if (N <= 0 || F <= 0 || K <= 0 || !dL_dloss || !dL_dfeatures || !state) return fail(ISR_EINVAL, "bad contrastive arguments");
-    if (state_bytes < iso::cstate_bytes(N, F, K)) return fail(ISR_EINVAL, "contrastive state too small");
-    iso::CState st = iso::cstate(state, N, F, K);
-    const int use_mean = prototypes_predefined ? 0 : 1;
-    if (use_mean) {
-        hipLaunchKernelGGL(iso::ck_gemm_tn, dim3((K + 31) / 32, (F + 31) / 32, iso::CK_NSPLIT), dim3(256), 0, s, N, F, K, 0,
-                           st.col, st.G, st.f, st.split);
-        hipLaunchKernelGGL(iso::ck_finish_du, dim3((K * F + 255) / 256), dim3(256), 0, s, F, K, st.split, st.phi, st.cnt, st.dU);
+static int contrastive_backward_impl(int nb, int N, int F, int K, const int* prototypes_predefined, const float* dL_dloss,
+                                     const float* weights, float* const* dL_dfeatures, void* state, size_t state_bytes,
+                                     hipStream_t s) {
+    if (nb < 1 || nb > iso::CK_MAXB) return fail(ISR_EINVAL, "contrastive batch of %d (1..%d supported)", nb, iso::CK_MAXB);
+    if (N <= 0 || F <= 0 || K <= 0 || !dL_dloss || !dL_dfeatures || !state || !prototypes_predefined)
+        return fail(ISR_EINVAL, "bad contrastive arguments");
+    const size_t one = iso::cstate_bytes(N, F, K);
+    if (state_bytes < one * (size_t)nb) return fail(ISR_EINVAL, "contrastive state too small");
+    iso::CKBatch bt = {};
+    bt.stride = (long long)one;
+    bool any_mean = false;
+    for (int b = 0; b < nb; b++) {
+        if (!dL_dfeatures[b]) return fail(ISR_EINVAL, "bad contrastive arguments (problem %d)", b);
+        bt.dX[b] = dL_dfeatures[b];
+        bt.predef[b] = prototypes_predefined[b] ? reinterpret_cast<const float*>(state) : nullptr;   // only its null-ness is read
+        bt.w[b] = weights ? weights[b] : 1.0f;
+        any_mean = any_mean || !prototypes_predefined[b];
     }
-    hipLaunchKernelGGL(iso::ck_grad_f, dim3((N + 31) / 32), dim3(64), 0, s, N, F, K, st.G, st.Us, st.cnt, st.dU, st.col,
-                       st.inv, dL_dloss, use_mean, dL_dfeatures);
+    iso::CState st = iso::cstate(state, N, F, K);
+    if (any_mean) {
+        hipLaunchKernelGGL(iso::ck_gemm_tn, dim3((K + 31) / 32, (F + 31) / 32, iso::CK_NSPLIT * nb), dim3(256), 0, s, N, F, K, 0,
+                           st.col, st.G, st.f, st.split, bt);
+        hipLaunchKernelGGL(iso::ck_finish_du, dim3((K * F + 255) / 256, nb), dim3(256), 0, s, F, K, st.split, st.phi, st.cnt,
+                           st.dU, bt);
+    }
+    hipLaunchKernelGGL(iso::ck_grad_f, dim3((N + 31) / 32, nb), dim3(64), 0, s, N, F, K, st.G, st.Us, st.cnt, st.dU, st.col,
+                       st.inv, dL_dloss, bt);
     ISR_LAUNCH_CHECK("iso_contrastive_backward");
     return ISR_OK;
+}
+
+int iso_contrastive_forward(int N, int F, int K, const float* features, const void* labels, int labels_are_int64,
+                            const float* predef_u, int consider_negative, int min_pixnum, float temp_lambda, float* loss,
+                            void* state, size_t state_bytes, void* stream) {
+    return contrastive_forward_impl(1, N, F, K, &features, &labels, labels_are_int64, &predef_u, consider_negative, min_pixnum,
+                                    temp_lambda, nullptr, loss, nullptr, state, state_bytes, (hipStream_t)stream);
+}
+
+int iso_contrastive_backward(int N, int F, int K, int prototypes_predefined, const float* dL_dloss, float* dL_dfeatures,
+                             void* state, size_t state_bytes, void* stream) {
+    return contrastive_backward_impl(1, N, F, K, &prototypes_predefined, dL_dloss, nullptr, &dL_dfeatures, state, state_bytes,
+                                     (hipStream_t)stream);
+}
+
+int iso_contrastive_forward_batch(int nb, int N, int F, int K, const float* const* features, const void* const* labels,
+                                  int labels_are_int64, const float* const* predef_u, int consider_negative, int min_pixnum,
+                                  float temp_lambda, const float* weights, float* loss, float* loss_total, void* state,
+                                  size_t state_bytes, void* stream) {
+    return contrastive_forward_impl(nb, N, F, K, features, labels, labels_are_int64, predef_u, consider_negative, min_pixnum,
+                                    temp_lambda, weights, loss, loss_total, state, state_bytes, (hipStream_t)stream);
+}
+
+int iso_contrastive_backward_batch(int nb, int N, int F, int K, const int* prototypes_predefined, const float* dL_dloss,
+                                   const float* weights, float* const* dL_dfeatures, void* state, size_t state_bytes,
+                                   void* stream) {
+    return contrastive_backward_impl(nb, N, F, K, prototypes_predefined, dL_dloss, weights, dL_dfeatures, state, state_bytes,
+                                     (hipStream_t)stream);
 }
 
 int iso_rownorm(long long N, int F, float eps, int backward, const float* x, const float* dy, float* out, void* stream) {

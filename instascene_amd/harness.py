@@ -23,7 +23,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import scenes
-from .contrastive import contrastive_loss, gather_rows, row_normalize_chain
+from .contrastive import contrastive_loss, contrastive_loss_batch, gather_rows, row_normalize_chain
 from .dist_utils import allreduce_grads, allreduce_grads_async, view_for, wait_all
 from .rasterizer import DeferredFeatureRows
 from .render import prefetch, render
@@ -112,10 +112,11 @@ class SegTrainer:
     def __init__(self, scene: scenes.Scene, cameras: List[scenes.Camera], device="cuda", sample_batchsize=8192,
                  n_labels=64, lambda_sv=1e-6, lambda_mv=1e-6, lambda_3d=2.5e-6, sample_mv_frames=5, use_class_feat=False,
                  multiview=False, seed=0, rank=0, world=1, prefetch_geometry=None, fused_update=None, sampled_path=True,
-                 fused_tail=None):
+                 fused_tail=None, batched_losses=None):
         self.device = torch.device(device)
         self.rank, self.world = rank, world
         self.sampled_path = bool(sampled_path)      # render(sample_pixels=...) instead of indexing the feature map
+        self.batched_losses = (self.device.type == "cuda") if batched_losses is None else bool(batched_losses)
         # overlap of the gradient all-reduce with the next view's geometry pass (default: whenever there is one)
         self.prefetch = (world > 1) if prefetch_geometry is None else bool(prefetch_geometry)
         F = scene.seg_feature.shape[1]
@@ -212,16 +213,42 @@ class SegTrainer:
             pix = pool[pick]
         pkg = render(cam, m, self.pipe, self.bg, sample_pixels=pix if self.sampled_path else None)
         seg_feature, vis = pkg["seg_feature"], pkg["visibility_filter"]
+        # the step's prototype-contrastive losses, as (features, labels, predefined prototypes, weight)
+        problems = []
         if merged:
             feats = pkg["sampled_seg_feature"] if self.sampled_path else seg_feature.reshape(seg_feature.shape[0], -1)[:, pix].T
             fa, fb = feats.split(self.batch)          # one cat in the backward instead of two zero-fill + copy + add
             la = cam.segmap.reshape(-1)[pix[:self.batch]]
             lb = cam.sorted_segmap.reshape(-1)[pix[self.batch:]]
-            loss = contrastive_loss(fa, la, num_labels=self.n_labels + 1) * (self.lsv * 0.5)
-            loss = loss + contrastive_loss(fb, lb, predef_u_list=m.class_feat,
-                                           num_labels=self.n_labels + 1) * (self.lsv * 1.0)
+            problems.append((fa, la, None, self.lsv * 0.5))
+            problems.append((fb, lb, m.class_feat, self.lsv * 1.0))
+            loss = None
         else:
             loss = self._sample_view_loss(vi, seg_feature, cam.segmap, None, 0.5)
+        if self.l3d > 0:
+            # reference :175-190 materialises feature[visibility_filter] ([V,F]) and then samples; sampling the
+            # visible & labelled Gaussians first and gathering only the batch rows draws from the same distribution
+            pool = self.vis_pool.get(vi)
+            if pool is None:
+                pool = torch.nonzero(vis & (self.labels3d > 0)).reshape(-1)
+                self.vis_pool[vi] = pool
+            if pool.numel() > 0:
+                pick = pool[torch.randint(0, pool.numel(), (self.batch,), device=self.device, generator=self.gen)]
+                rows3d = gather_rows(m.get_seg_feature, pick) if self.fused_tail else m.get_seg_feature[pick]
+                problems.append((rows3d, self.labels3d[pick], m.class_feat, self.l3d))
+        if problems:
+            K = self.n_labels + 1
+            same = all(f.shape == problems[0][0].shape and (u is None or u.shape[0] == K) for f, _, u, _ in problems)
+            if self.batched_losses and len(problems) > 1 and same:
+                # one sequence of launches for all of them (iso_contrastive_forward_batch): each loss is ~8 kernels of a
+                # few microseconds, i.e. launch-bound
+                part = contrastive_loss_batch([q[0] for q in problems], [q[1] for q in problems], [q[2] for q in problems],
+                                              [q[3] for q in problems], num_labels=K)[0]
+                loss = part if loss is None else loss + part
+            else:
+                for f, l, u, w in problems:
+                    term = contrastive_loss(f, l, predef_u_list=u, num_labels=K) * w
+                    loss = term if loss is None else loss + term
         if self.multiview and self.lmv > 0 and it % 10 == 0:
             first = (vi + 1) % max(1, len(self.cams) - self.mv_frames)
             feats, labs = [], []
@@ -235,18 +262,6 @@ class SegTrainer:
             pick = pool[torch.randint(0, pool.numel(), (self.batch,), device=self.device, generator=self.gen)]
             loss = loss + contrastive_loss(allf[:, pick].T, alll[pick], predef_u_list=m.class_feat,
                                            num_labels=self.n_labels + 1) * self.lmv
-        if self.l3d > 0:
-            # reference :175-190 materialises feature[visibility_filter] ([V,F]) and then samples; sampling the
-            # visible & labelled Gaussians first and gathering only the batch rows draws from the same distribution
-            pool = self.vis_pool.get(vi)
-            if pool is None:
-                pool = torch.nonzero(vis & (self.labels3d > 0)).reshape(-1)
-                self.vis_pool[vi] = pool
-            if pool.numel() > 0:
-                pick = pool[torch.randint(0, pool.numel(), (self.batch,), device=self.device, generator=self.gen)]
-                rows3d = gather_rows(m.get_seg_feature, pick) if self.fused_tail else m.get_seg_feature[pick]
-                loss = loss + contrastive_loss(rows3d, self.labels3d[pick], predef_u_list=m.class_feat,
-                                               num_labels=self.n_labels + 1) * self.l3d
         if self.fused_tail:
             with DeferredFeatureRows() as sink:
                 loss.backward()

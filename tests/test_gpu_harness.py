@@ -255,3 +255,20 @@ def test_fused_tail_reproduces_the_separate_kernels(mode):
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
     rz.set_mode("exact")
     rz.set_tracer(True)
+
+
+def test_batched_losses_change_nothing():
+    """SegTrainer(batched_losses=True) evaluates the step's three contrastive losses with one sequence of launches:
+    same losses, same parameters as one call per loss."""
+    rz.set_mode("exact")
+    rz.set_tracer(False)
+    outs = []
+    for bl in (False, True):
+        sc, cams = _scene()
+        tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=2048, n_labels=12, use_class_feat=True, multiview=True,
+                        sample_mv_frames=2, seed=3, batched_losses=bl)
+        losses = [float(tr.step(it)) for it in range(11)]
+        outs.append((losses, tr.model._seg_feature.detach().clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
+    rz.set_tracer(True)

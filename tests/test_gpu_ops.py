@@ -179,6 +179,38 @@ def test_row_normalize_chain_matches_two_passes(N, F, use):
     assert row_normalize(yb, 1e-6) is not zb           # another eps is a fresh normalisation
 
 
+@pytest.mark.parametrize("N,F,K", [(4096, 32, 65), (1000, 16, 13), (700, 48, 130)])
+def test_contrastive_batch_equals_separate_losses(N, F, K):
+    """iso_contrastive_forward/backward_batch: three losses (cluster-mean prototypes, predefined, predefined with unlabeled
+    samples) in one sequence of launches == the three single calls, weighted and added in order — bit for bit, values
+    and gradients (the small-K MFMA path and the general path)."""
+    from instascene_amd.contrastive import contrastive_loss_batch
+    g = torch.Generator().manual_seed(N + K)
+    feats = [torch.randn(N, F, generator=g).cuda() for _ in range(3)]
+    labels = [torch.randint(1, K, (N,), generator=g).cuda() for _ in range(3)]
+    labels[2][::7] = 0
+    pre = torch.nn.functional.normalize(torch.randn(K, F, generator=g), dim=1).cuda()
+    predefs = [None, pre, pre]
+    w = [5e-7, 1e-6, 2.5e-6]
+    singles = [f.clone().requires_grad_(True) for f in feats]
+    want = None
+    for f, l, u, wi in zip(singles, labels, predefs, w):
+        term = contrastive_loss(f, l, predef_u_list=u, num_labels=K) * wi
+        want = term if want is None else want + term
+    want.backward()
+    batched = [f.clone().requires_grad_(True) for f in feats]
+    got, parts = contrastive_loss_batch(batched, labels, predefs, w, num_labels=K)
+    got.backward()
+    assert float(got.detach()) == float(want.detach())
+    assert float(parts[3]) == float(got.detach())
+    for a, b in zip(batched, singles):
+        assert torch.equal(a.grad, b.grad)
+    # a batch of one is the plain loss
+    one = feats[1].clone().requires_grad_(True)
+    l1, _ = contrastive_loss_batch([one], [labels[1]], [pre], [1.0], num_labels=K)
+    assert float(l1.detach()) == float(contrastive_loss(feats[1], labels[1], predef_u_list=pre, num_labels=K))
+
+
 def test_contrastive_with_label_bound_and_dropped_samples():
     """num_labels bound larger than the labels present, unlabeled (0) samples, min_pixnum dropping small clusters."""
     g = torch.Generator().manual_seed(5)
