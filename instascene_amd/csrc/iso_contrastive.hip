@@ -710,35 +710,41 @@ __global__ __launch_bounds__(256) void adam_rn2_kernel(long long N, int F, float
 // (the backward of a row gather; indices repeat when rows were drawn with replacement).  The first occurrence of a row
 // ("head") receives the sum of all its occurrences, in ascending i — the order of index_put_(accumulate=True) — and
 // slot[row] = i points at merged[i, :].  n is a few thousand, so instead of sorting the index list every workgroup keeps
-// all of it in LDS and its 64 samples are compared against everything: the four waves scan a quarter each (one
+// all of it in LDS and its 64 samples are compared against everything: the sixteen waves scan a sixteenth each (one
 // broadcast LDS read + one compare per candidate, a scalar branch skips the rest when no lane matches) and combine
 // "smallest matching position" / "number of matches" with integer LDS atomics (order-independent).
 constexpr int ROWS_COMPACT_MAX = 16384;
 constexpr int ROWS_COMPACT_DUPS = 8;        // repeats of one row remembered per sample before falling back to a rescan
-__global__ __launch_bounds__(256) void rows_compact_kernel(int n, int F, long long P, const long long* __restrict__ idx,
+__global__ __launch_bounds__(1024) void rows_compact_kernel(int n, int F, long long P, const long long* __restrict__ idx,
                                                            const float* __restrict__ vals, int* __restrict__ slot,
                                                            float* __restrict__ merged) {
     __shared__ __attribute__((aligned(16))) int s_idx[ROWS_COMPACT_MAX];
     __shared__ int s_first[64], s_count[64], s_dup[64 * ROWS_COMPACT_DUPS];
     const int n4 = (n + 3) & ~3;
-    for (int e = threadIdx.x; e < n4; e += 256) {
-        const long long v = e < n ? idx[e] : -1;
-        s_idx[e] = (v >= 0 && v < P) ? (int)v : -1 - e;       // invalid entries match nothing (distinct negatives)
+    for (int e0 = threadIdx.x; e0 < n4; e0 += 8 * 1024) {      // eight independent loads in flight per thread
+        long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int e = e0 + u * 1024; v[u] = e < n ? idx[e] : -1; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * 1024;
+            if (e < n4) s_idx[e] = (v[u] >= 0 && v[u] < P) ? (int)v[u] : -1 - e;   // invalid entries match nothing
+        }
     }
     if (threadIdx.x < 64) { s_first[threadIdx.x] = 0x7fffffff; s_count[threadIdx.x] = 0; }
     __syncthreads();
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 64 + lane;
     const int mine = i < n ? s_idx[i] : -0x7fffffff;
-    // wave wv scans the 16-entry groups g = wv, wv + 4, ...: four independent 16-byte LDS reads in flight per step
+    // each of the 16 waves scans every 16th block of four 16-byte groups: four independent LDS reads in flight per step
     const int4* s4 = reinterpret_cast<const int4*>(s_idx);
-    for (int g = wv * 4; g < n4 / 4; g += 16) {
+    for (int g = wv * 4; g < n4 / 4; g += 64) {
         int4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) v[u] = (g + u < n4 / 4) ? s4[g + u] : make_int4(-2, -2, -2, -2);
         bool any = false;
 #pragma unroll
-        for (int u = 0; u < 4; u++) any = any || v[u].x == mine || v[u].y == mine || v[u].z == mine || v[u].w == mine;
+        for (int u = 0; u < 4; u++) any = any | (v[u].x == mine) | (v[u].y == mine) | (v[u].z == mine) | (v[u].w == mine);
         if (__ballot(any) == 0ull) continue;
         if (any) {
 #pragma unroll
@@ -757,35 +763,34 @@ __global__ __launch_bounds__(256) void rows_compact_kernel(int n, int F, long lo
     }
     // the block's 64 rows are copied as they are (coalesced); heads with repeats are finished below
     const int i0 = blockIdx.x * 64, nrow = min(64, n - i0);
-    for (int e = threadIdx.x; e < nrow * F; e += 256) merged[(size_t)i0 * F + e] = vals[(size_t)i0 * F + e];
+    for (int e = threadIdx.x; e < nrow * F; e += 1024) merged[(size_t)i0 * F + e] = vals[(size_t)i0 * F + e];
     __syncthreads();
-    if (wv != 0 || i >= n || mine < 0 || s_first[lane] != i) return;
-    slot[mine] = i;
-    const int cnt = s_count[lane];
-    if (cnt == 1) return;
-    float* dst = merged + (size_t)i * F;
-    if (cnt <= ROWS_COMPACT_DUPS) {
-        int js[ROWS_COMPACT_DUPS];
-        int m = 0;
-        for (int k = 0; k < cnt; k++) {            // the waves appended in no particular order: insertion sort, drop i itself
-            const int j = s_dup[lane * ROWS_COMPACT_DUPS + k];
-            if (j == i) continue;
-            int t = m++;
-            while (t > 0 && js[t - 1] > j) { js[t] = js[t - 1]; t--; }
-            js[t] = j;
+    if (wv != 0) return;
+    const bool head = i < n && mine >= 0 && s_first[lane] == i;
+    if (head) slot[mine] = i;
+    // heads whose row was drawn again (rare): the whole wave finishes them one at a time, lanes = channels
+    unsigned long long todo = __ballot(head && s_count[lane] > 1);
+    while (todo != 0ull) {
+        const int L = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int hi = blockIdx.x * 64 + L, hrow = s_idx[hi], cnt = s_count[L];
+        float* dst = merged + (size_t)hi * F;
+        if (cnt <= ROWS_COMPACT_DUPS) {
+            int prev = hi;                              // ascending positions: repeated selection of the next larger one
+            for (int k = 1; k < cnt; k++) {
+                int nxt = 0x7fffffff;
+                for (int t = 0; t < cnt; t++) {
+                    const int j = s_dup[L * ROWS_COMPACT_DUPS + t];
+                    if (j > prev && j < nxt) nxt = j;
+                }
+                for (int c = lane; c < F; c += 64) dst[c] += vals[(size_t)nxt * F + c];
+                prev = nxt;
+            }
+        } else {
+            for (int j = hi + 1; j < n; j++)
+                if (s_idx[j] == hrow)
+                    for (int c = lane; c < F; c += 64) dst[c] += vals[(size_t)j * F + c];
         }
-        for (int c = 0; c < F; c++) {
-            float acc = vals[(size_t)i * F + c];
-            for (int k = 0; k < m; k++) acc += vals[(size_t)js[k] * F + c];
-            dst[c] = acc;
-        }
-        return;
-    }
-    for (int c = 0; c < F; c++) {
-        float acc = vals[(size_t)i * F + c];
-        for (int j = i + 1; j < n; j++)
-            if (s_idx[j] == mine) acc += vals[(size_t)j * F + c];
-        dst[c] = acc;
     }
 }
 

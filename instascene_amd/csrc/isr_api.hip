@@ -649,7 +649,7 @@ int iso_rows_compact(int n, int F, long long P, const long long* idx, const floa
     if (P > 0 && hipMemsetAsync(slot, 0xFF, sizeof(int) * (size_t)P, s) != hipSuccess) return fail(ISR_EHIP, "rows_compact: memset failed");
     if (n == 0 || P == 0) return ISR_OK;
     if (n > iso::ROWS_COMPACT_MAX) return fail(ISR_EINVAL, "rows_compact: at most %d rows", iso::ROWS_COMPACT_MAX);
-    hipLaunchKernelGGL(iso::rows_compact_kernel, dim3((n + 63) / 64), dim3(256), 0, s, n, F, P, idx, vals, slot, merged);
+    hipLaunchKernelGGL(iso::rows_compact_kernel, dim3((n + 63) / 64), dim3(1024), 0, s, n, F, P, idx, vals, slot, merged);
     ISR_LAUNCH_CHECK("iso_rows_compact");
     return ISR_OK;
 }
