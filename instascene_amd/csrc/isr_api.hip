@@ -154,10 +154,15 @@ int isr_forward_prepare(int P, int D, int M, int width, int height, const float*
     ISR_HIP(hipMemsetAsync(iv.tile_count, 0, sizeof(uint32_t) * (size_t)T * CNT_SUB * CNT_STRIDE, s));
     if (P > 0) {
         { ProfScope ps_("k_preprocess", s);
-        hipLaunchKernelGGL(k_preprocess, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales,
-                           scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, viewmatrix,
-                           projmatrix, cam_pos, width, height, gx, gy, radii, g, iv.tile_count,
-                           (prefiltered & ISR_PREPARE_TIGHT_RECTS) ? 1 : 0); }
+        const int tight = (prefiltered & ISR_PREPARE_TIGHT_RECTS) ? 1 : 0;
+        if (M == 16 && colors_precomp == nullptr && shs != nullptr)      // SH rows staged through LDS (coalesced reads)
+            hipLaunchKernelGGL(k_preprocess<true>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales,
+                               scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, viewmatrix,
+                               projmatrix, cam_pos, width, height, gx, gy, radii, g, iv.tile_count, tight);
+        else
+            hipLaunchKernelGGL(k_preprocess<false>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales,
+                               scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, viewmatrix,
+                               projmatrix, cam_pos, width, height, gx, gy, radii, g, iv.tile_count, tight); }
         ISR_LAUNCH_CHECK("k_preprocess");
         const int nb = (P + 1023) / 1024;
         ProfScope ps2_("k_scan_gaussians", s);

@@ -1426,8 +1426,8 @@ static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int
     unsigned long long* row_mask = dL_dextra == nullptr ? g.row_mask : nullptr;
     if (row_mask != nullptr && hipMemsetAsync(row_mask, 0, sizeof(unsigned long long) * (size_t)P, s) != hipSuccess) return -2;
     if (R > 0 && n > 0) {
-        if (hipMemsetAsync(flags, 0, (size_t)R * npass, s) != hipSuccess) return -2;
-        if (hipMemsetAsync(cnt, 0, sizeof(uint32_t) * T, s) != hipSuccess) return -2;
+        // row flags and the per-tile sample counters are neighbours in the scratch: one fill for both
+        if (hipMemsetAsync(flags, 0, (size_t)((char*)(cnt + T) - (char*)flags), s) != hipSuccess) return -2;
         ProfScope ps_("k_render_bwd", s);
         hipLaunchKernelGGL(k_sample_count, dim3((n + 255) / 256), dim3(256), 0, s, n, W, H, gx, pix, cnt);
         hipLaunchKernelGGL(k_sample_scan, dim3(1), dim3(1024), 0, s, T, cnt, off, cursor);
@@ -1439,7 +1439,7 @@ static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int
                                iv.n_contrib, pix, rows_in, off, seg_idx, pass == 0 ? row_mask : (unsigned long long*)nullptr);
         ISR_CHECK_LAUNCH_B("k_render_bwd_sparse");
     } else if (R > 0) {
-        if (hipMemsetAsync(flags, 0, (size_t)R * npass, s) != hipSuccess) return -2;
+        if (hipMemsetAsync(flags, 0, align_up((size_t)R * npass, 256), s) != hipSuccess) return -2;
     }
     if (dL_dextra == nullptr) return 0;
     const size_t total = (size_t)P * ((ED + 3) / 4);

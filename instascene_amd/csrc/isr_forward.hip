@@ -62,6 +62,7 @@ __device__ __forceinline__ F3 sh_to_rgb(int deg, F3 pos, F3 cam, const float* sh
     return {res.x < 0.0f ? 0.0f : res.x, res.y < 0.0f ? 0.0f : res.y, res.z < 0.0f ? 0.0f : res.z};
 }
 
+template <bool STAGE_SH>
 __global__ __launch_bounds__(256) void k_preprocess(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
     const float* __restrict__ rots, const float* __restrict__ opacities, const float* __restrict__ shs,
@@ -69,6 +70,29 @@ __global__ __launch_bounds__(256) void k_preprocess(
     const float* __restrict__ proj, const float* __restrict__ campos, int W, int H, int gx, int gy,
     int* __restrict__ radii_out, GeomView g, uint32_t* __restrict__ tile_count, int tight_rects) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // The workgroup's 256 SH rows (192 B each) are one contiguous 48 KB piece of `shs`: it is read with fully coalesced
+    // 16-byte loads and handed to the owning lanes through LDS.  (A lane reading its own row touches 64 different
+    // cache lines per load instruction, and with ~250 KB of rows in flight per CU the 32 KB vector cache keeps none of
+    // them between the twelve loads of a row: 0.65 GB of fetches for 0.47 GB of input.)
+    constexpr int SH_STRIDE = 52;           // floats per staged row: 48 + 4 (16-byte aligned, spreads the LDS banks)
+    __shared__ __attribute__((aligned(16))) float s_sh[STAGE_SH ? 256 * SH_STRIDE : 4];
+    if constexpr (STAGE_SH) {
+        const int i0 = blockIdx.x * 256;
+        const int nq = min(256, P - i0) * 12;                      // float4s to move
+        const float4* src = reinterpret_cast<const float4*>(shs + (size_t)i0 * 48);
+        float4 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11;      // twelve independent loads in flight
+#define ISR_SH_LD(u, v) { const int e = min((int)threadIdx.x + u * 256, nq - 1); v = src[e]; }
+        ISR_SH_LD(0, v0) ISR_SH_LD(1, v1) ISR_SH_LD(2, v2) ISR_SH_LD(3, v3) ISR_SH_LD(4, v4) ISR_SH_LD(5, v5)
+        ISR_SH_LD(6, v6) ISR_SH_LD(7, v7) ISR_SH_LD(8, v8) ISR_SH_LD(9, v9) ISR_SH_LD(10, v10) ISR_SH_LD(11, v11)
+#undef ISR_SH_LD
+#define ISR_SH_ST(u, v) { const int e = (int)threadIdx.x + u * 256;                                               \
+                          if (e < nq) { const int r = e / 12, k = e - r * 12;                                       \
+                                        *reinterpret_cast<float4*>(s_sh + r * SH_STRIDE + 4 * k) = v; } }
+        ISR_SH_ST(0, v0) ISR_SH_ST(1, v1) ISR_SH_ST(2, v2) ISR_SH_ST(3, v3) ISR_SH_ST(4, v4) ISR_SH_ST(5, v5)
+        ISR_SH_ST(6, v6) ISR_SH_ST(7, v7) ISR_SH_ST(8, v8) ISR_SH_ST(9, v9) ISR_SH_ST(10, v10) ISR_SH_ST(11, v11)
+#undef ISR_SH_ST
+        __syncthreads();
+    }
     if (i >= P) return;
     int radius_i = 0;
     uint32_t touched = 0;
@@ -159,20 +183,8 @@ __global__ __launch_bounds__(256) void k_preprocess(
         F3 rgb = {0.f, 0.f, 0.f};
         unsigned cm = 0;
         if (col_pre == nullptr) {
-            if (M == 16) {
-                // the 192-byte SH row as twelve 16-byte loads (a per-coefficient access pattern is 48 scattered dwords
-                // per lane: the texture-address unit, not HBM, was the limiter of this kernel)
-                float4 r4[12];
-                const float4* src = reinterpret_cast<const float4*>(shs + (size_t)i * 48);
-#pragma unroll
-                for (int k = 0; k < 12; k++) r4[k] = src[k];
-                float row[48];
-#pragma unroll
-                for (int k = 0; k < 12; k++) { row[4 * k] = r4[k].x; row[4 * k + 1] = r4[k].y; row[4 * k + 2] = r4[k].z; row[4 * k + 3] = r4[k].w; }
-                rgb = sh_to_rgb(D, p, F3{campos[0], campos[1], campos[2]}, row, cm);
-            } else {
-                rgb = sh_to_rgb(D, p, F3{campos[0], campos[1], campos[2]}, shs + (size_t)i * M * 3, cm);
-            }
+            if constexpr (STAGE_SH) rgb = sh_to_rgb(D, p, F3{campos[0], campos[1], campos[2]}, s_sh + threadIdx.x * SH_STRIDE, cm);
+            else rgb = sh_to_rgb(D, p, F3{campos[0], campos[1], campos[2]}, shs + (size_t)i * M * 3, cm);
         } else {
             rgb = {col_pre[3 * (size_t)i], col_pre[3 * (size_t)i + 1], col_pre[3 * (size_t)i + 2]};
         }
