@@ -137,6 +137,8 @@ def main():
     rasterizer.set_async_binning(bool(args.async_binning))
     rasterizer.set_view_cache(args.view_cache_gb)
     scene, cams, cfg = scenes.config_scene(args.config)
+    if os.environ.get("ISR_MORTON", "0") == "1":
+        scene = scenes.spatially_sorted(scene)
     trainer = SegTrainer(scene, cams[:16], device=dev, sample_batchsize=8192, use_class_feat=True, rank=rank, world=world)
     trainer.pipe.lazy_maps = bool(args.lazy_maps)
     trainer.warm_view_caches()       # per-view constants (ray tables, visible pools): setup, like the label maps

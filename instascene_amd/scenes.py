@@ -128,6 +128,27 @@ class Scene:
         return self
 
 
+def morton_order(xyz: torch.Tensor, bits: int = 10) -> torch.Tensor:
+    """Permutation that sorts points along the Z-order curve of their bounding box (``bits`` per axis)."""
+    lo, hi = xyz.min(dim=0).values, xyz.max(dim=0).values
+    q = ((xyz - lo) / (hi - lo).clamp_min(1e-12) * ((1 << bits) - 1)).round().clamp(0, (1 << bits) - 1).to(torch.int64)
+    code = torch.zeros(xyz.shape[0], dtype=torch.int64, device=xyz.device)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return torch.argsort(code, stable=True)
+
+
+def spatially_sorted(scene: "Scene") -> "Scene":
+    """The same Gaussians stored in Z-order of their centres.  Every per-view result is a per-Gaussian or per-pixel
+    quantity, so only the row order of ``[P, ...]`` tensors changes; neighbours in memory become neighbours on screen,
+    which is what the binning scatter, the record gathers and the per-Gaussian gradient rows want."""
+    perm = morton_order(scene.xyz)
+    pick = lambda t: None if t is None else t[perm].contiguous()
+    return Scene(pick(scene.xyz), pick(scene.log_scale), pick(scene.rot), pick(scene.opacity_logit), pick(scene.features_dc),
+                 pick(scene.features_rest), pick(scene.seg_feature), pick(scene.labels3d))
+
+
 def synthetic_scene(P: int, F: int, seed: int, mu_s: float, extent: float = 1.5, n_labels: int = 64) -> Scene:
     g = torch.Generator(device="cpu").manual_seed(seed)
     xyz = (torch.rand(P, 3, generator=g) * 2 - 1) * extent

@@ -9,7 +9,7 @@ f = src if src.endswith(".csv") else glob.glob(src + "/**/*kernel_trace.csv", re
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))]
 rows.sort()
-marks = [i for i, r in enumerate(rows) if "k_preprocess(" in r[2]]
+marks = [i for i, r in enumerate(rows) if "k_preprocess" in r[2] and "bwd" not in r[2]]
 lo, hi = marks[-n - 1], marks[-1]
 sel = rows[lo:hi]
 busy = sum(e - s for s, e, _ in sel)

@@ -5,7 +5,7 @@ src = sys.argv[1]
 f = src if src.endswith(".csv") else glob.glob(src + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))]
 rows.sort()
-marks = [i for i, r in enumerate(rows) if "k_preprocess(" in r[2]]
+marks = [i for i, r in enumerate(rows) if "k_preprocess" in r[2] and "bwd" not in r[2]]
 lo, hi = marks[-2], marks[-1]
 t0, end = rows[lo][0], rows[lo][0]
 for s, e, k in rows[lo:hi]:
