@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--lazy-maps", type=int, default=0,
                     help="1: evaluate render()'s seven derived normal/depth maps on first access (this step never reads "
                          "them) instead of inside render() like the reference (default 0 = reference behaviour)")
+    ap.add_argument("--spatial-sort", type=int, default=1,
+                    help="1 (default): the trainer stores the Gaussians in Z-order of their centres (sorted once at load, "
+                         "before the timed region; a pure relabelling of rows); 0: keep the generator's random order")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,9 +140,8 @@ def main():
     rasterizer.set_async_binning(bool(args.async_binning))
     rasterizer.set_view_cache(args.view_cache_gb)
     scene, cams, cfg = scenes.config_scene(args.config)
-    if os.environ.get("ISR_MORTON", "0") == "1":
-        scene = scenes.spatially_sorted(scene)
-    trainer = SegTrainer(scene, cams[:16], device=dev, sample_batchsize=8192, use_class_feat=True, rank=rank, world=world)
+    trainer = SegTrainer(scene, cams[:16], device=dev, sample_batchsize=8192, use_class_feat=True, rank=rank, world=world,
+                         spatial_sort=bool(args.spatial_sort))
     trainer.pipe.lazy_maps = bool(args.lazy_maps)
     trainer.warm_view_caches()       # per-view constants (ray tables, visible pools): setup, like the label maps
     L = lib()
@@ -224,6 +226,7 @@ def main():
                                          + (", overlapped with the next view's geometry pass)" if world > 1 else ")"),
                           "arithmetic_mode": args.mode, "tracer": bool(args.tracer),
                           "async_binning": bool(args.async_binning), "view_cache_gb": args.view_cache_gb,
+                          "gaussian_order": "z-order of the centres, sorted once at load" if args.spatial_sort else "as generated (random)",
                           "derived_render_maps": "on first access (never read by this step)" if args.lazy_maps else "inside render(), like the reference"},
                "roofline": roof}
         if not args.no_cpu_baseline:

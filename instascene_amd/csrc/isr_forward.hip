@@ -62,6 +62,37 @@ __device__ __forceinline__ F3 sh_to_rgb(int deg, F3 pos, F3 cam, const float* sh
     return {res.x < 0.0f ? 0.0f : res.x, res.y < 0.0f ? 0.0f : res.y, res.z < 0.0f ? 0.0f : res.z};
 }
 
+// ----------------------------------------------------------------------------
+// Workgroup-level aggregation of per-tile counters.  Global atomics cost one memory transaction per distinct cache line
+// per wave instruction (~26 G/s on MI355X whatever the scope, tools/micro/atomics.hip), and K1 + the key scatter issue
+// 2R of them.  When neighbouring Gaussians in memory are neighbours on screen (scenes.spatially_sorted) the 256 Gaussians
+// of a workgroup touch a few dozen tiles: their increments are first merged in a small LDS hash table (open addressing,
+// integer LDS atomics) and each distinct tile costs ONE global atomic.  A tile that finds no slot within TH_PROBES steps
+// falls back to the direct global atomic, consistently in every phase (slots never become free again).
+constexpr int TH_SIZE = 2048, TH_BITS = 11, TH_PROBES = 32;
+constexpr uint32_t TH_EMPTY = 0xffffffffu;
+__device__ __forceinline__ int th_find_or_insert(uint32_t* keys, uint32_t tile) {
+    uint32_t h = (tile * 2654435761u) >> (32 - TH_BITS);
+    for (int p = 0; p < TH_PROBES; p++) {
+        const uint32_t old = atomicCAS(&keys[h], TH_EMPTY, tile);
+        if (old == TH_EMPTY || old == tile) return (int)h;
+        h = (h + 1) & (TH_SIZE - 1);
+    }
+    return -1;
+}
+__device__ __forceinline__ int th_find(const uint32_t* keys, uint32_t tile) {
+    uint32_t h = (tile * 2654435761u) >> (32 - TH_BITS);
+    for (int p = 0; p < TH_PROBES; p++) {
+        const uint32_t k = keys[h];
+        if (k == tile) return (int)h;
+        if (k == TH_EMPTY) return -1;
+        h = (h + 1) & (TH_SIZE - 1);
+    }
+    return -1;
+}
+// every Gaussian of a workgroup uses the same sub-counter of a tile; concurrently running workgroups use different ones
+__device__ __forceinline__ int counter_sub(int block) { return block & (CNT_SUB - 1); }
+
 template <bool STAGE_SH>
 __global__ __launch_bounds__(256) void k_preprocess(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
@@ -75,7 +106,11 @@ __global__ __launch_bounds__(256) void k_preprocess(
     // cache lines per load instruction, and with ~250 KB of rows in flight per CU the 32 KB vector cache keeps none of
     // them between the twelve loads of a row: 0.65 GB of fetches for 0.47 GB of input.)
     constexpr int SH_STRIDE = 52;           // floats per staged row: 48 + 4 (16-byte aligned, spreads the LDS banks)
-    __shared__ __attribute__((aligned(16))) float s_sh[STAGE_SH ? 256 * SH_STRIDE : 4];
+    constexpr int LDS_WORDS = STAGE_SH ? 256 * SH_STRIDE : 2 * TH_SIZE;     // the tile hash reuses the SH staging area
+    static_assert(LDS_WORDS >= 2 * TH_SIZE, "tile hash does not fit");
+    __shared__ __attribute__((aligned(16))) float s_sh[LDS_WORDS];
+    uint32_t* th_key = reinterpret_cast<uint32_t*>(s_sh);
+    uint32_t* th_cnt = th_key + TH_SIZE;
     if constexpr (STAGE_SH) {
         const int i0 = blockIdx.x * 256;
         const int nq = min(256, P - i0) * 12;                      // float4s to move
@@ -93,11 +128,11 @@ __global__ __launch_bounds__(256) void k_preprocess(
 #undef ISR_SH_ST
         __syncthreads();
     }
-    if (i >= P) return;
     int radius_i = 0;
     uint32_t touched = 0;
     Rect16 rc = {0, 0, 0, 0};
     do {
+        if (i >= P) break;
         const F3 p = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
         const F3 pv = {view[0] * p.x + view[4] * p.y + view[8] * p.z + view[12],
                        view[1] * p.x + view[5] * p.y + view[9] * p.z + view[13],
@@ -198,14 +233,28 @@ __global__ __launch_bounds__(256) void k_preprocess(
         radius_i = sat_i32(radius);
         touched = (unsigned)(y1 - y0) * (unsigned)(x1 - x0);
         rc = {(uint16_t)x0, (uint16_t)y0, (uint16_t)x1, (uint16_t)y1};
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++)
-                atomicAdd(tile_count + (((size_t)y * gx + x) * CNT_SUB + (i & (CNT_SUB - 1))) * CNT_STRIDE, 1u);
     } while (false);
-    radii_out[i] = radius_i;
-    g.radii[i] = radius_i;
-    g.tiles_touched[i] = touched;
-    g.rect[i] = rc;
+    if (i < P) {
+        radii_out[i] = radius_i;
+        g.radii[i] = radius_i;
+        g.tiles_touched[i] = touched;
+        g.rect[i] = rc;
+    }
+    // ---- tile counts: merged per workgroup in LDS, one global atomic per distinct tile ----
+    __syncthreads();                        // every lane is done with its staged SH row: the area becomes the hash table
+    for (int e = threadIdx.x; e < TH_SIZE; e += 256) { th_key[e] = TH_EMPTY; th_cnt[e] = 0u; }
+    __syncthreads();
+    const int sub = counter_sub(blockIdx.x);
+    for (int y = rc.y0; y < rc.y1; y++)
+        for (int x = rc.x0; x < rc.x1; x++) {
+            const uint32_t tile = (uint32_t)y * gx + x;
+            const int slot = th_find_or_insert(th_key, tile);
+            if (slot >= 0) atomicAdd(&th_cnt[slot], 1u);
+            else atomicAdd(tile_count + ((size_t)tile * CNT_SUB + sub) * CNT_STRIDE, 1u);
+        }
+    __syncthreads();
+    for (int e = threadIdx.x; e < TH_SIZE; e += 256)
+        if (th_key[e] != TH_EMPTY) atomicAdd(tile_count + ((size_t)th_key[e] * CNT_SUB + sub) * CNT_STRIDE, th_cnt[e]);
 }
 
 // ----------------------------------------------------------------------------
@@ -296,20 +345,44 @@ __global__ __launch_bounds__(1024) void k_scan_add(int n, uint32_t* __restrict__
 }
 
 // ----------------------------------------------------------------------------
-// Scatter: one (depth_bits, gaussian) key per touched tile into that tile's bucket.
+// Scatter: one (depth_bits, gaussian) key per touched tile into that tile's bucket.  The workgroup first counts its keys
+// per tile in the LDS hash, reserves one contiguous range per distinct tile with ONE returning global atomic, and then
+// hands out the positions inside the ranges with LDS atomics — so the keys of a workgroup that go to the same bucket are
+// neighbours in memory.  (The order inside a bucket is irrelevant: the per-tile sort orders the keys completely.)
 __global__ __launch_bounds__(256) void k_scatter(int P, int gx, GeomView g, const uint32_t* __restrict__ sub_offset,
                                                  uint32_t* __restrict__ tile_cursor, unsigned long long* __restrict__ keys,
                                                  int64_t capacity) {
+    __shared__ uint32_t th_key[TH_SIZE], th_cnt[TH_SIZE], th_base[TH_SIZE];
+    for (int e = threadIdx.x; e < TH_SIZE; e += 256) { th_key[e] = TH_EMPTY; th_cnt[e] = 0u; }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    if (g.tiles_touched[i] == 0) return;
-    const Rect16 rc = g.rect[i];
-    const unsigned dbits = __float_as_uint(g.rec[(size_t)i * REC + 18]);
-    const unsigned long long key = ((unsigned long long)dbits << 32) | (unsigned)i;
+    const int sub = counter_sub(blockIdx.x);
+    Rect16 rc = {0, 0, 0, 0};
+    unsigned long long key = 0ull;
+    if (i < P && g.tiles_touched[i] != 0) {
+        rc = g.rect[i];
+        key = ((unsigned long long)__float_as_uint(g.rec[(size_t)i * REC + 18]) << 32) | (unsigned)i;
+    }
+    __syncthreads();
     for (int y = rc.y0; y < rc.y1; y++)
         for (int x = rc.x0; x < rc.x1; x++) {
-            const size_t e = ((size_t)y * gx + x) * CNT_SUB + (i & (CNT_SUB - 1));
-            const uint32_t pos = atomicAdd(tile_cursor + e * CNT_STRIDE, 1u);
+            const int slot = th_find_or_insert(th_key, (uint32_t)y * gx + x);
+            if (slot >= 0) atomicAdd(&th_cnt[slot], 1u);
+        }
+    __syncthreads();
+    for (int e = threadIdx.x; e < TH_SIZE; e += 256)
+        if (th_key[e] != TH_EMPTY) {
+            th_base[e] = atomicAdd(tile_cursor + ((size_t)th_key[e] * CNT_SUB + sub) * CNT_STRIDE, th_cnt[e]);
+            th_cnt[e] = 0u;                 // becomes the fill counter of the reserved range
+        }
+    __syncthreads();
+    for (int y = rc.y0; y < rc.y1; y++)
+        for (int x = rc.x0; x < rc.x1; x++) {
+            const uint32_t tile = (uint32_t)y * gx + x;
+            const size_t e = (size_t)tile * CNT_SUB + sub;
+            const int slot = th_find(th_key, tile);
+            uint32_t pos;
+            if (slot >= 0) pos = th_base[slot] + atomicAdd(&th_cnt[slot], 1u);
+            else pos = atomicAdd(tile_cursor + e * CNT_STRIDE, 1u);
             const int64_t at = (int64_t)sub_offset[e] + pos;
             if (at < capacity) keys[at] = key;
         }

@@ -112,8 +112,15 @@ class SegTrainer:
     def __init__(self, scene: scenes.Scene, cameras: List[scenes.Camera], device="cuda", sample_batchsize=8192,
                  n_labels=64, lambda_sv=1e-6, lambda_mv=1e-6, lambda_3d=2.5e-6, sample_mv_frames=5, use_class_feat=False,
                  multiview=False, seed=0, rank=0, world=1, prefetch_geometry=None, fused_update=None, sampled_path=True,
-                 fused_tail=None, batched_losses=None):
+                 fused_tail=None, batched_losses=None, spatial_sort=True):
         self.device = torch.device(device)
+        # Gaussians stored in Z-order of their centres (once, here): neighbours in memory are neighbours on screen, which
+        # the binning kernels' workgroup-level counter merging and every per-Gaussian gather rely on.  A pure relabelling
+        # of rows: `self.order[k]` is the caller's index of row k (see `features_in_input_order`).
+        self.order = None
+        if spatial_sort:
+            self.order = scenes.morton_order(scene.xyz)
+            scene = scenes.spatially_sorted(scene, self.order)
         self.rank, self.world = rank, world
         self.sampled_path = bool(sampled_path)      # render(sample_pixels=...) instead of indexing the feature map
         self.batched_losses = (self.device.type == "cuda") if batched_losses is None else bool(batched_losses)
@@ -158,6 +165,15 @@ class SegTrainer:
                 c.segmap = scenes.voronoi_labels(c.image_width, c.image_height, n_labels, 5000 + i, device=self.device)
                 c.sorted_segmap = c.segmap
             self.valid_idx[i] = torch.nonzero(c.segmap.reshape(-1) > 0).reshape(-1)
+
+    def features_in_input_order(self) -> torch.Tensor:
+        """The trained ``[P,F]`` feature with rows in the order of the scene passed to the constructor."""
+        f = self.model._seg_feature.detach()
+        if self.order is None:
+            return f.clone()
+        out = torch.empty_like(f)
+        out[self.order.to(f.device)] = f
+        return out
 
     def warm_view_caches(self):
         """Per-view constants that the loop otherwise builds on the first visit of a view — the camera's ray table used

@@ -139,12 +139,13 @@ def morton_order(xyz: torch.Tensor, bits: int = 10) -> torch.Tensor:
     return torch.argsort(code, stable=True)
 
 
-def spatially_sorted(scene: "Scene") -> "Scene":
+def spatially_sorted(scene: "Scene", perm: Optional[torch.Tensor] = None) -> "Scene":
     """The same Gaussians stored in Z-order of their centres.  Every per-view result is a per-Gaussian or per-pixel
     quantity, so only the row order of ``[P, ...]`` tensors changes; neighbours in memory become neighbours on screen,
     which is what the binning scatter, the record gathers and the per-Gaussian gradient rows want."""
-    perm = morton_order(scene.xyz)
-    pick = lambda t: None if t is None else t[perm].contiguous()
+    if perm is None:
+        perm = morton_order(scene.xyz)
+    pick = lambda t: None if t is None else t[perm.to(t.device)].contiguous()
     return Scene(pick(scene.xyz), pick(scene.log_scale), pick(scene.rot), pick(scene.opacity_logit), pick(scene.features_dc),
                  pick(scene.features_rest), pick(scene.seg_feature), pick(scene.labels3d))
 
