@@ -297,17 +297,35 @@ __global__ __launch_bounds__(256) void k_gather_counts(int E, const uint32_t* __
 
 __global__ __launch_bounds__(1024) void k_tile_scan(int T, uint32_t* __restrict__ sub_offset /* in: counts, out: offsets */,
                                                     uint32_t* __restrict__ offset, int64_t* header) {
+    // one workgroup; every thread owns a contiguous run of elements (serial prefix in registers, 16-byte accesses) and
+    // the 1024 run totals are scanned once — instead of E / 1024 dependent workgroup scans
     __shared__ uint32_t s_warp[32];
     const int E = T * CNT_SUB;              // scan over (tile, sub-counter) in tile-major order
+    constexpr int RUN = 8;                  // elements per thread and round
     uint32_t carry = 0;
-    for (int base = 0; base < E; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < E ? sub_offset[i] : 0u;
+    for (int base = 0; base < E; base += 1024 * RUN) {
+        const int i0 = base + threadIdx.x * RUN;
+        uint32_t v[RUN];
+        if (i0 + RUN <= E) {
+            const uint4 a = *reinterpret_cast<const uint4*>(sub_offset + i0), b = *reinterpret_cast<const uint4*>(sub_offset + i0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < RUN; u++) v[u] = i0 + u < E ? sub_offset[i0 + u] : 0u;
+        }
+        uint32_t run = 0;
+#pragma unroll
+        for (int u = 0; u < RUN; u++) { const uint32_t c = v[u]; v[u] = run; run += c; }
         uint32_t total;
-        const uint32_t ex = block_exclusive_scan_1024(v, s_warp, total);
-        if (i < E) {
-            sub_offset[i] = carry + ex;
-            if ((i & (CNT_SUB - 1)) == 0) offset[i / CNT_SUB] = carry + ex;
+        const uint32_t ex = block_exclusive_scan_1024(run, s_warp, total);
+#pragma unroll
+        for (int u = 0; u < RUN; u++) {
+            const int i = i0 + u;
+            if (i < E) {
+                const uint32_t o = carry + ex + v[u];
+                sub_offset[i] = o;
+                if ((i & (CNT_SUB - 1)) == 0) offset[i / CNT_SUB] = o;
+            }
         }
         carry += total;
     }
