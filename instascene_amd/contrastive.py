@@ -229,11 +229,26 @@ class _GatherRows(torch.autograd.Function):
         sink = _rz._ROWS_SINK
         n = idx.shape[0]
         if sink is not None and sink.row_grads is None and g.is_cuda and n <= 16384:
-            sink.row_grads = (idx, g.contiguous().float())
+            # merged per distinct row right away (iso_rows_compact), early in the backward: by the time the per-Gaussian
+            # tail runs the table is ready and the small kernel does not queue up behind the next view's binning
+            sink.row_grads = compact_row_grads(idx, g, ctx.shape[0])
             return None, None
         dense = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
         dense.index_put_((idx,), g, accumulate=True)
         return dense, None
+
+
+def compact_row_grads(idx: torch.Tensor, vals: torch.Tensor, P: int):
+    """``(slot[P] int32, merged[n,F])``: the sparse gradient ``(idx, vals)`` of a row gather with repeated rows summed in
+    index order (``iso_rows_compact``); ``slot[row]`` = position of the row's sum in ``merged`` or -1."""
+    idx = idx.contiguous().to(torch.int64)
+    vals = vals.contiguous().float()
+    slot = torch.empty(P, dtype=torch.int32, device=vals.device)
+    merged = torch.empty_like(vals)
+    with torch.cuda.device(vals.device):
+        check(lib().iso_rows_compact(idx.shape[0], vals.shape[1], P, _p(idx), _p(vals), _p(slot), _p(merged), _stream()),
+              "iso_rows_compact")
+    return slot, merged
 
 
 def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
@@ -281,8 +296,8 @@ class FeatureAdam:
         (3-D loss), ``z.grad`` (any dense rasterizer gradient) — and the partial rows ``rows`` a
         ``rasterizer.DeferredFeatureRows`` block collected: reduction, chain rule through both normalisations, Adam and
         the next normalisations in ONE kernel (``isr_feature_rows_step``).  ``grad_only``: stop at ``param.grad`` (for an
-        all-reduce; ``step()`` then completes).  ``row_grads``: ``(idx, [n,F])`` sparse gradient on ``y`` rows
-        (``gather_rows``), merged per row by ``iso_rows_compact``."""
+        all-reduce; ``step()`` then completes).  ``row_grads``: sparse gradient on ``y`` rows — ``(idx int64, [n,F])``, or
+        the ``(slot int32 [P], merged [n,F])`` pair ``compact_row_grads`` makes of it (``gather_rows`` does so itself)."""
         p = self.param
         if self.leaves is None:
             raise RuntimeError("step_rows: normalized_chain() was not called in leaf mode")
@@ -302,16 +317,11 @@ class FeatureAdam:
             y, z = torch.empty_like(p.data), torch.empty_like(p.data)
             self.step_count += 1
         slot = merged = None
+        if row_grads is not None:
+            a, b = row_grads
+            # already merged (slot table + merged rows, from gather_rows' backward) or raw (indices, rows)
+            slot, merged = (a, b) if a.dtype == torch.int32 else compact_row_grads(a, b, P)
         with torch.cuda.device(p.device):
-            if row_grads is not None:
-                idx, vals = row_grads
-                idx = idx.contiguous().to(torch.int64)
-                vals = vals.contiguous().float()
-                if self._slot is None or self._slot.shape[0] != P:
-                    self._slot = torch.empty(P, dtype=torch.int32, device=p.device)
-                slot, merged = self._slot, torch.empty_like(vals)
-                check(L.iso_rows_compact(idx.shape[0], F, P, _p(idx), _p(vals), _p(slot), _p(merged), _stream()),
-                      "iso_rows_compact")
             check(L.isr_feature_rows_step(P, rows.R if rows is not None else 0, F, _p(rows.geom) if rows is not None else None,
                                           _p(rows.scratch) if rows is not None else None, _p(gz), _p(gy), _p(slot), _p(merged),
                                           float(self.norm_eps[0]), float(self.norm_eps[1]), _p(p.data), _p(grad_out), self.lr,

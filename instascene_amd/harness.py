@@ -124,8 +124,9 @@ class SegTrainer:
         self.rank, self.world = rank, world
         self.sampled_path = bool(sampled_path)      # render(sample_pixels=...) instead of indexing the feature map
         self.batched_losses = (self.device.type == "cuda") if batched_losses is None else bool(batched_losses)
-        # overlap of the gradient all-reduce with the next view's geometry pass (default: whenever there is one)
-        self.prefetch = (world > 1) if prefetch_geometry is None else bool(prefetch_geometry)
+        # the next view's geometry pass + binning run on a side stream next to the rest of this step (_prefetch_next)
+        self.prefetch = True if prefetch_geometry is None else bool(prefetch_geometry)
+        self._side = None
         F = scene.seg_feature.shape[1]
         class_feat = None
         if use_class_feat:
@@ -228,6 +229,10 @@ class SegTrainer:
             pick = torch.randint(0, pool.numel(), (2 * self.batch,), device=self.device, generator=self.gen)
             pix = pool[pick]
         pkg = render(cam, m, self.pipe, self.bg, sample_pixels=pix if self.sampled_path else None)
+        fwd_done = None
+        if self.prefetch and self.device.type == "cuda":
+            fwd_done = torch.cuda.Event()
+            fwd_done.record()
         seg_feature, vis = pkg["seg_feature"], pkg["visibility_filter"]
         # the step's prototype-contrastive losses, as (features, labels, predefined prototypes, weight)
         problems = []
@@ -281,8 +286,9 @@ class SegTrainer:
         if self.fused_tail:
             with DeferredFeatureRows() as sink:
                 loss.backward()
-            if self.world == 1 and not self.prefetch:
+            if self.world == 1:
                 self.opt.step_rows(sink.rows, row_grads=sink.row_grads)
+                self._prefetch_next(it, fwd_done)
                 m._seg_cache = None
                 return loss.detach()
             self.opt.step_rows(sink.rows, grad_only=True, row_grads=sink.row_grads)     # dL/dparam; Adam after the all-reduce
@@ -290,9 +296,8 @@ class SegTrainer:
         else:
             loss.backward()
         if self.prefetch:
-            # the next view's geometry pass does not read the feature: it runs while RCCL sums the gradient
             works = allreduce_grads_async([m._seg_feature], self.world)
-            prefetch(self.cams[self.view_index(it + 1)], m, self.pipe, self.bg)
+            self._prefetch_next(it, fwd_done)
             wait_all(works)
         else:
             allreduce_grads([m._seg_feature], self.world)
@@ -300,6 +305,21 @@ class SegTrainer:
         self.opt.zero_grad(set_to_none=True)
         m._seg_cache = None          # the graph of this step is gone
         return loss.detach()
+
+    def _prefetch_next(self, it, fwd_done):
+        """Software pipelining across iterations: the NEXT view's geometry pass and binning (K1, scans, key scatter, tile
+        sort — atomic- and latency-bound kernels that read only frozen geometry and SH) are issued on a side stream that
+        waits for this step's forward only, so they run next to this step's loss kernels (microseconds each), its backward
+        and the bandwidth-bound per-Gaussian tail (and next to RCCL's all-reduce when there are several ranks).  The next
+        ``render()`` waits for them and starts at the blend kernel."""
+        if not self.prefetch:
+            return
+        if self.device.type != "cuda":
+            prefetch(self.cams[self.view_index(it + 1)], self.model, self.pipe, self.bg)
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        prefetch(self.cams[self.view_index(it + 1)], self.model, self.pipe, self.bg, stream=self._side, after=fwd_done)
 
 
 class RgbGaussianModel:

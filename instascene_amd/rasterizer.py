@@ -11,6 +11,7 @@ plumbing; all arithmetic happens in ``libinstascene_hip.so``.
 from __future__ import annotations
 
 import collections
+import contextlib
 import ctypes
 import weakref
 import os
@@ -181,11 +182,16 @@ def _prepare(L, mode, key, st, P, degree, M, W, H, means3D, sh, colors, opacity,
 
 
 def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp, viewmatrix,
-                      projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered) -> bool:
-    """Issue the geometry pass (K1, tile counts, scan) and the binning (key scatter, tile sort) of a view NOW, on the current stream, for a
+                      projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
+                      stream=None, after=None) -> bool:
+    """Issue the geometry pass (K1, tile counts, scan) and the binning (key scatter, tile sort) of a view NOW, for a
     ``rasterize_gaussians`` call that will follow with exactly these inputs.  It reads no feature, so a trainer can
-    overlap it with the all-reduce of the feature gradient.  Needs async binning and a known size estimate for this
-    (P, W, H); returns False (and does nothing) otherwise.  An entry that is never consumed is simply dropped."""
+    overlap it with the rest of the current step (small, latency-bound loss kernels, the bandwidth-bound per-Gaussian
+    tail, the all-reduce of the gradient): ``stream`` = a side ``torch.cuda.Stream`` to issue it on (default: the current
+    stream), ``after`` = an event that stream waits for first (default: everything enqueued on the current stream so
+    far).  The forward that consumes the entry waits for its completion event.  Needs async binning and a known size
+    estimate for this (P, W, H); returns False (and does nothing) otherwise.  An entry that is never consumed is simply
+    dropped."""
     L = lib()
     dev = means3D.device
     P, H, W = means3D.shape[0], int(image_height), int(image_width)
@@ -206,16 +212,27 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
     kept = _VIEW_CACHE.get(sig) if _CONFIG.get("view_cache_bytes", 0) > 0 else None
     if kept is not None and kept.busy == 0:
         return False                      # the view cache already holds this view's state
-    radii = torch.empty((P,), dtype=torch.int32, device=dev)
-    geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
-    img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        st = _stream()
-        R = _prepare(L, mode, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
-                     transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img)
-        binning = torch.empty(L.isr_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
-        check(L.isr_forward_bin(P, W, H, _ptr(geom), _ptr(binning), R, _ptr(img), st), "isr_forward_bin")
-    _PREFETCHED[key] = (sig, radii, geom, img, R, binning)
+        done = None
+        side = stream if (stream is not None and stream != torch.cuda.current_stream()) else None
+        if side is not None:
+            if after is None:
+                after = torch.cuda.Event()
+                after.record()
+            side.wait_event(after)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
+            img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
+            st = _stream()
+            R = _prepare(L, mode, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
+                         transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img)
+            binning = torch.empty(L.isr_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
+            check(L.isr_forward_bin(P, W, H, _ptr(geom), _ptr(binning), R, _ptr(img), st), "isr_forward_bin")
+            if side is not None:
+                done = torch.cuda.Event()
+                done.record()
+    _PREFETCHED[key] = (sig, radii, geom, img, R, binning, done)
     return True
 
 
@@ -279,7 +296,12 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
             if _state_out is not None:
                 _state_out.append(kept)
         elif ahead is not None and ahead[0] == sig:
-            radii, geom, img, R, binning = ahead[1:]     # the geometry pass of this view was issued by prefetch_geometry()
+            radii, geom, img, R, binning, done = ahead[1:]     # the geometry pass of this view was issued by prefetch_geometry()
+            if done is not None:                # ... on a side stream: order this stream behind it, keep its buffers alive
+                cur = torch.cuda.current_stream()
+                cur.wait_event(done)
+                for t in (radii, geom, img, binning):
+                    t.record_stream(cur)
             prebinned = MODE_PREBINNED
             global PREFETCH_HITS
             PREFETCH_HITS += 1
@@ -618,14 +640,14 @@ class GaussianRasterizer(nn.Module):
             return mark_visible(positions, rs.viewmatrix, rs.projmatrix)
 
     def prefetch(self, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                 cov3D_precomp=None) -> bool:
+                 cov3D_precomp=None, stream=None, after=None) -> bool:
         """Issue the geometry pass of the ``forward`` call that will follow with these inputs (extension; see
         :func:`prefetch_geometry`)."""
         rs = self.raster_settings
         with torch.no_grad():
             return prefetch_geometry(means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier,
                                      cov3D_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
-                                     rs.image_width, shs, rs.sh_degree, rs.campos, rs.prefiltered)
+                                     rs.image_width, shs, rs.sh_degree, rs.campos, rs.prefiltered, stream=stream, after=after)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, extra_attrs=None, sample_pixels=None):

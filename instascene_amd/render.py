@@ -212,13 +212,15 @@ def _geometry_inputs(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, ove
         cov3D_precomp=cov3D_precomp)
 
 
-def prefetch(viewpoint_camera, pc, pipe, bg_color=None, scaling_modifier=1.0, override_color=None) -> bool:
+def prefetch(viewpoint_camera, pc, pipe, bg_color=None, scaling_modifier=1.0, override_color=None, stream=None,
+             after=None) -> bool:
     """Issue the geometry pass and binning (projection, tile counts, scan, key scatter, tile sort) of the NEXT
     ``render()`` of this view now (extension).  They depend on the Gaussians' geometry and SH only, so a data-parallel
-    trainer runs them while the feature gradient is being all-reduced; ``render()`` then starts at the blend kernel.
-    No effect (False) without async binning."""
+    trainer runs them next to the rest of the current step (``stream`` / ``after``: see
+    ``rasterizer.prefetch_geometry``); ``render()`` then starts at the blend kernel.  No effect (False) without async
+    binning."""
     rasterizer, geo = _geometry_inputs(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color)
-    return rasterizer.prefetch(**geo)
+    return rasterizer.prefetch(**geo, stream=stream, after=after)
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
