@@ -229,10 +229,10 @@ class SegTrainer:
             pick = torch.randint(0, pool.numel(), (2 * self.batch,), device=self.device, generator=self.gen)
             pix = pool[pick]
         pkg = render(cam, m, self.pipe, self.bg, sample_pixels=pix if self.sampled_path else None)
-        fwd_done = None
-        if self.prefetch and self.device.type == "cuda":
-            fwd_done = torch.cuda.Event()
-            fwd_done.record()
+        # the next view's geometry pass + binning: enqueued now (the host runs only slightly ahead of the GPU), on a side
+        # stream that waits for the forward just issued.  (Started together with the forward it slows the forward by more
+        # than it hides: measured.)
+        self._prefetch_next(it)
         seg_feature, vis = pkg["seg_feature"], pkg["visibility_filter"]
         # the step's prototype-contrastive losses, as (features, labels, predefined prototypes, weight)
         problems = []
@@ -288,7 +288,6 @@ class SegTrainer:
                 loss.backward()
             if self.world == 1:
                 self.opt.step_rows(sink.rows, row_grads=sink.row_grads)
-                self._prefetch_next(it, fwd_done)
                 m._seg_cache = None
                 return loss.detach()
             self.opt.step_rows(sink.rows, grad_only=True, row_grads=sink.row_grads)     # dL/dparam; Adam after the all-reduce
@@ -296,9 +295,7 @@ class SegTrainer:
         else:
             loss.backward()
         if self.prefetch:
-            works = allreduce_grads_async([m._seg_feature], self.world)
-            self._prefetch_next(it, fwd_done)
-            wait_all(works)
+            wait_all(allreduce_grads_async([m._seg_feature], self.world))
         else:
             allreduce_grads([m._seg_feature], self.world)
         self.opt.step()
@@ -306,7 +303,7 @@ class SegTrainer:
         m._seg_cache = None          # the graph of this step is gone
         return loss.detach()
 
-    def _prefetch_next(self, it, fwd_done):
+    def _prefetch_next(self, it):
         """Software pipelining across iterations: the NEXT view's geometry pass and binning (K1, scans, key scatter, tile
         sort — atomic- and latency-bound kernels that read only frozen geometry and SH) are issued on a side stream that
         waits for this step's forward only, so they run next to this step's loss kernels (microseconds each), its backward
@@ -319,7 +316,7 @@ class SegTrainer:
             return
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
-        prefetch(self.cams[self.view_index(it + 1)], self.model, self.pipe, self.bg, stream=self._side, after=fwd_done)
+        prefetch(self.cams[self.view_index(it + 1)], self.model, self.pipe, self.bg, stream=self._side)
 
 
 class RgbGaussianModel:

@@ -35,7 +35,7 @@ _CONFIG = {
 }
 _ASYNC_GROWTH, _ASYNC_SLACK = 1.25, 65536
 _R_ESTIMATE = {}      # (device, P, W, H) -> last verified instance count
-_PENDING = {}         # (device, P, W, H) -> (pinned int64 tensor, event, capacity)
+_PENDING = {}         # (device, P, W, H) -> (pinned int64 tensor, event, capacity, address of the geometry buffer)
 
 
 LAST_NUM_RENDERED = 0   # instance count of the most recent forward (reporting only)
@@ -101,12 +101,17 @@ class BinningOverflow(RuntimeError):
     pass
 
 
-def _verify_pending(key):
-    """Check an asynchronously read instance count against the capacity that forward ran with."""
-    pend = _PENDING.pop(key, None)
+def _verify_pending(key, owner=None):
+    """Check an asynchronously read instance count against the capacity that forward ran with.  ``owner``: the geometry
+    buffer of the forward the caller is about to differentiate — a pending count that belongs to ANOTHER geometry pass
+    (the next view's, issued ahead on a side stream) is left alone instead of being waited for."""
+    pend = _PENDING.get(key)
     if pend is None:
         return
-    pinned, event, capacity = pend
+    if owner is not None and pend[3] != owner:
+        return
+    del _PENDING[key]
+    pinned, event, capacity = pend[:3]
     event.synchronize()
     R = int(pinned.item())
     _R_ESTIMATE[key] = R
@@ -139,7 +144,7 @@ def _f32c(t: Optional[torch.Tensor], name: str):
 
 # ISR_PREPARE_TIGHT_RECTS: FAST mode bins a splat only into tiles it can reach (ISR_TIGHT_RECTS=0 turns it off: A/B, debugging)
 _TIGHT_RECTS = 0x100 if os.environ.get("ISR_TIGHT_RECTS", "1") != "0" else 0
-_PREFETCHED = {}      # (device, P, W, H) -> (signature, radii, geom, img, R, binning): a geometry pass + binning issued ahead of its forward
+_PREFETCHED = {}      # signature -> (signature, radii, geom, img, R, binning, done event): geometry pass + binning issued ahead of its forward
 PREFETCH_HITS = 0     # forwards that found their geometry pass already issued (statistics / tests)
 
 
@@ -172,7 +177,7 @@ def _prepare(L, mode, key, st, P, degree, M, W, H, means3D, sh, colors, opacity,
         pinned.copy_(geom[:8].view(torch.int64), non_blocking=True)   # header[0] = R
         ev = torch.cuda.Event()
         ev.record()
-        _PENDING[key] = (pinned, ev, R)
+        _PENDING[key] = (pinned, ev, R, geom.data_ptr())
         LAST_NUM_RENDERED = _R_ESTIMATE[key]
     else:
         R = int(num_rendered.value)
@@ -215,7 +220,7 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
     with torch.cuda.device(dev):
         done = None
         side = stream if (stream is not None and stream != torch.cuda.current_stream()) else None
-        if side is not None:
+        if side is not None and after is not False:      # after=False: start at once (inputs are long-lived constants)
             if after is None:
                 after = torch.cuda.Event()
                 after.record()
@@ -232,7 +237,9 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
             if side is not None:
                 done = torch.cuda.Event()
                 done.record()
-    _PREFETCHED[key] = (sig, radii, geom, img, R, binning, done)
+    _PREFETCHED[sig] = (sig, radii, geom, img, R, binning, done)
+    while len(_PREFETCHED) > 2:                 # entries nobody came for
+        _PREFETCHED.pop(next(iter(_PREFETCHED)))
     return True
 
 
@@ -284,7 +291,7 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
         sig = _geometry_signature(mode, P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered,
                                   (means3D, sh, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix,
                                    campos))
-        ahead = _PREFETCHED.pop(key, None)
+        ahead = _PREFETCHED.pop(sig, None)
         prebinned = 0
         kept = _VIEW_CACHE.get(sig) if _CONFIG.get("view_cache_bytes", 0) > 0 else None
         if kept is not None and kept.busy == 0:
@@ -378,7 +385,7 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, 
     if P == 0 or grad_mask == 0:
         return g2, gc, go, g3, gt, gsh, gs, gr, (ge if F else torch.empty(0, device=dev))
     if _CONFIG["async_binning"]:
-        _verify_pending((dev.index, P, W, H))
+        _verify_pending((dev.index, P, W, H), owner=geomBuffer.data_ptr())
     nbytes = L.isr_backward_scratch_bytes(int(R), F, grad_mask)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
@@ -447,7 +454,7 @@ def rasterize_gaussians_backward_sampled(P, F, W, H, R, pixels, dL_dsampled, tra
     dev = geomBuffer.device
     mode = _CONFIG["mode"] if mode is None else mode
     if _CONFIG["async_binning"]:
-        _verify_pending((dev.index, P, W, H))
+        _verify_pending((dev.index, P, W, H), owner=geomBuffer.data_ptr())
     pix = pixels.contiguous().to(torch.int64)
     g = dL_dsampled.contiguous().float()
     n = pix.shape[0]
