@@ -127,6 +127,7 @@ class SegTrainer:
         # the next view's geometry pass + binning run on a side stream next to the rest of this step (_prefetch_next)
         self.prefetch = True if prefetch_geometry is None else bool(prefetch_geometry)
         self._side = None
+        self.split_tail = False      # tests: take the multi-rank form of the tail (dL/dx, all-reduce, Adam) with one rank
         F = scene.seg_feature.shape[1]
         class_feat = None
         if use_class_feat:
@@ -286,7 +287,7 @@ class SegTrainer:
         if self.fused_tail:
             with DeferredFeatureRows() as sink:
                 loss.backward()
-            if self.world == 1:
+            if self.world == 1 and not self.split_tail:
                 self.opt.step_rows(sink.rows, row_grads=sink.row_grads)
                 m._seg_cache = None
                 return loss.detach()

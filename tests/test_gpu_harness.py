@@ -272,3 +272,26 @@ def test_batched_losses_change_nothing():
     assert outs[0][0] == outs[1][0]
     assert torch.equal(outs[0][1], outs[1][1])
     rz.set_tracer(True)
+
+
+def test_multi_rank_form_of_the_tail_with_one_rank():
+    """With several ranks the per-Gaussian tail stops at dL/dx (isr_feature_rows_step, grad_out), the gradient is
+    all-reduced, and iso_adam_rownorm2 finishes.  Forced with one rank (the collective is then the identity) it must give
+    the parameters of the one-pass tail bit for bit."""
+    rz.set_mode("fast")
+    rz.set_tracer(False)
+    rz.set_async_binning(True)
+    try:
+        outs = []
+        for split in (False, True):
+            sc, cams = _scene()
+            tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=2048, n_labels=12, use_class_feat=True, seed=3)
+            tr.split_tail = split
+            losses = [float(tr.step(it)) for it in range(9)]
+            outs.append((losses, tr.model._seg_feature.detach().clone(), tr.opt.exp_avg_sq.clone(), tr.opt.step_count))
+        assert outs[0][0] == outs[1][0] and outs[0][3] == outs[1][3] == 9
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    finally:
+        rz.set_async_binning(False)
+        rz.set_mode("exact")
+        rz.set_tracer(True)
