@@ -143,7 +143,9 @@ int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int hei
 
 /* ---- extension: the per-Gaussian tail of a feature-training step in one pass over [P, ED] (ED % 4 == 0, ED <= 256).
  * isr_backward_sampled called with dL_dextra == NULL leaves the per-(tile, Gaussian) partial rows in its scratch
- * ("rows_scratch" here, NULL = no rows).  This entry then, for every Gaussian row:
+ * ("rows_scratch" here, NULL = no rows).  This entry then, for every Gaussian row in [row_begin, row_begin + row_count)
+ * (all [P, ED] pointers are the tables' base addresses; a data-parallel caller walks the table in a few row ranges so that
+ * the all-reduce of one range overlaps the kernels of the others):
  *   dL/dz  = sum of its flagged partial rows (+ gz_dense[P, ED] if not NULL)
  *   dL/dy  = gy[P, ED] (or NULL) + the sparse part (gy_slot[P], gy_merged) made by iso_rows_compact (or NULL, NULL)
  *   dL/dx  = chain of dL/dz and dL/dy through  y = x/(|x|+eps1), z = y/(|y|+eps2)
@@ -151,7 +153,8 @@ int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int hei
  *   grad_out != NULL:  grad_out = dL/dx, nothing else is written (a data-parallel caller all-reduces it);
  *   grad_out == NULL:  torch.optim.Adam step (lr, betas, eps, step counted from 1; scene/gaussian_model.py:249) on
  *                      x / exp_avg / exp_avg_sq in place, and y, z of the UPDATED rows are written for the next forward. */
-int isr_feature_rows_step(int P, int64_t num_rendered, int ED, const void* geom_buffer, const void* rows_scratch,
+int isr_feature_rows_step(int P, int row_begin, int row_count, int64_t num_rendered, int ED, const void* geom_buffer,
+                          const void* rows_scratch,
                           const float* gz_dense, const float* gy, const int* gy_slot, const float* gy_merged, float eps1,
                           float eps2, float* x, float* grad_out, double lr, double beta1, double beta2, double eps,
                           long long step, float* exp_avg, float* exp_avg_sq, float* y, float* z, void* stream);

@@ -44,7 +44,7 @@ SIGNATURES = {
     "isr_sample_extra": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "isr_backward_sampled": (c_int, [c_int, c_int64, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P,
                                      c_size_t, _P]),
-    "isr_feature_rows_step": (c_int, [c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, ctypes.c_double,
+    "isr_feature_rows_step": (c_int, [c_int, c_int, c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_longlong, _P, _P, _P, _P,
                                       _P]),
     "isr_mark_visible": (c_int, [c_int, _P, _P, _P, _P, _P]),

@@ -298,6 +298,19 @@ class FeatureAdam:
         the next normalisations in ONE kernel (``isr_feature_rows_step``).  ``grad_only``: stop at ``param.grad`` (for an
         all-reduce; ``step()`` then completes).  ``row_grads``: sparse gradient on ``y`` rows — ``(idx int64, [n,F])``, or
         the ``(slot int32 [P], merged [n,F])`` pair ``compact_row_grads`` makes of it (``gather_rows`` does so itself)."""
+        tail = self.begin_tail(rows, row_grads)
+        if tail is None:
+            return
+        P = self.param.shape[0]
+        if grad_only:
+            self.tail_gradient(tail, 0, P)
+        else:
+            self.tail_update(tail)
+
+    # -- the tail in pieces (a data-parallel trainer walks the table in row ranges: see SegTrainer) ------------------
+    def begin_tail(self, rows=None, row_grads=None):
+        """Collect what the leaves received; returns an opaque state for ``tail_gradient`` / ``tail_update`` (None when
+        nothing carries a gradient)."""
         p = self.param
         if self.leaves is None:
             raise RuntimeError("step_rows: normalized_chain() was not called in leaf mode")
@@ -306,31 +319,69 @@ class FeatureAdam:
         gz = None if z_leaf.grad is None else z_leaf.grad.contiguous().float()
         self.leaves = None
         if rows is None and gy is None and gz is None and row_grads is None:
-            return
+            return None
         if rows is not None and (rows.P != p.shape[0] or rows.F != p.shape[1]):
             raise ValueError("step_rows: rows of a different model")
-        L = lib()
-        P, F = p.shape
-        grad_out = torch.empty_like(p.data) if grad_only else None
-        y = z = None
-        if not grad_only:
-            y, z = torch.empty_like(p.data), torch.empty_like(p.data)
-            self.step_count += 1
         slot = merged = None
         if row_grads is not None:
             a, b = row_grads
             # already merged (slot table + merged rows, from gather_rows' backward) or raw (indices, rows)
-            slot, merged = (a, b) if a.dtype == torch.int32 else compact_row_grads(a, b, P)
+            slot, merged = (a, b) if a.dtype == torch.int32 else compact_row_grads(a, b, p.shape[0])
+        return (rows, gy, gz, slot, merged)
+
+    def _rows_kernel(self, tail, r0, n, grad_out, y, z):
+        rows, gy, gz, slot, merged = tail
+        p = self.param
+        P, F = p.shape
         with torch.cuda.device(p.device):
-            check(L.isr_feature_rows_step(P, rows.R if rows is not None else 0, F, _p(rows.geom) if rows is not None else None,
-                                          _p(rows.scratch) if rows is not None else None, _p(gz), _p(gy), _p(slot), _p(merged),
-                                          float(self.norm_eps[0]), float(self.norm_eps[1]), _p(p.data), _p(grad_out), self.lr,
-                                          float(self.betas[0]), float(self.betas[1]), self.eps, max(1, self.step_count),
-                                          _p(self.exp_avg), _p(self.exp_avg_sq), _p(y), _p(z), _stream()),
-                  "isr_feature_rows_step")
-        if grad_only:
-            p.grad = grad_out
+            check(lib().isr_feature_rows_step(P, int(r0), int(n), rows.R if rows is not None else 0, F,
+                                              _p(rows.geom) if rows is not None else None,
+                                              _p(rows.scratch) if rows is not None else None, _p(gz), _p(gy), _p(slot),
+                                              _p(merged), float(self.norm_eps[0]), float(self.norm_eps[1]), _p(p.data),
+                                              _p(grad_out), self.lr, float(self.betas[0]), float(self.betas[1]), self.eps,
+                                              max(1, self.step_count), _p(self.exp_avg), _p(self.exp_avg_sq), _p(y), _p(z),
+                                              _stream()), "isr_feature_rows_step")
+
+    def tail_gradient(self, tail, r0: int, r1: int):
+        """``param.grad[r0:r1]`` = dL/dparam of those rows (allocated on first use)."""
+        p = self.param
+        if p.grad is None:
+            p.grad = torch.empty_like(p.data)
+        self._rows_kernel(tail, r0, r1 - r0, p.grad, None, None)
+
+    def tail_update(self, tail):
+        """Reduction + chain rule + Adam + next normalisations of every row in one pass."""
+        p = self.param
+        y, z = torch.empty_like(p.data), torch.empty_like(p.data)
+        self.step_count += 1
+        self._rows_kernel(tail, 0, p.shape[0], None, y, z)
+        torch.autograd.graph.increment_version(p)
+        self.normalized = (p._version, y, z)
+
+    def begin_step(self):
+        """Start an Adam step applied in row ranges (``step_range``), finished by ``end_step``."""
+        p = self.param
+        self.step_count += 1
+        self._pending_yz = (torch.empty_like(p.data), torch.empty_like(p.data))
+
+    def step_range(self, r0: int, r1: int):
+        """Adam + the two normalisations on rows ``[r0, r1)`` from ``param.grad`` (``iso_adam_rownorm2`` on the slice)."""
+        p = self.param
+        if r1 <= r0:
             return
+        F = p.shape[1]
+        y, z = self._pending_yz
+        at = lambda t: ctypes.c_void_p(t.data_ptr() + 4 * F * int(r0))
+        with torch.cuda.device(p.device):
+            check(lib().iso_adam_rownorm2(int(r1 - r0), F, self.lr, float(self.betas[0]), float(self.betas[1]), self.eps,
+                                          self.step_count, float(self.norm_eps[0]), float(self.norm_eps[1]), at(p.data),
+                                          at(p.grad), at(self.exp_avg), at(self.exp_avg_sq), at(y), at(z), _stream()),
+                  "iso_adam_rownorm2")
+
+    def end_step(self):
+        p = self.param
+        y, z = self._pending_yz
+        self._pending_yz = None
         torch.autograd.graph.increment_version(p)
         self.normalized = (p._version, y, z)
 

@@ -297,12 +297,14 @@ int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int hei
     return ISR_OK;
 }
 
-int isr_feature_rows_step(int P, int64_t num_rendered, int ED, const void* geom_buffer, const void* rows_scratch,
+int isr_feature_rows_step(int P, int row_begin, int row_count, int64_t num_rendered, int ED, const void* geom_buffer,
+                          const void* rows_scratch,
                           const float* gz_dense, const float* gy, const int* gy_slot, const float* gy_merged, float eps1,
                           float eps2, float* x, float* grad_out, double lr, double beta1, double beta2, double eps,
                           long long step, float* exp_avg, float* exp_avg_sq, float* y, float* z, void* stream) {
     if (P < 0 || ED <= 0 || (ED & 3) != 0 || ED > 256) return fail(ISR_EINVAL, "feature_rows_step needs ED % 4 == 0 and ED <= 256");
-    if (P == 0) return ISR_OK;
+    if (row_begin < 0 || row_count < 0 || row_begin + row_count > P) return fail(ISR_EINVAL, "feature_rows_step: bad row range");
+    if (P == 0 || row_count == 0) return ISR_OK;
     if (!x || (rows_scratch && !geom_buffer) || ((gy_slot != nullptr) != (gy_merged != nullptr)))
         return fail(ISR_EINVAL, "feature_rows_step: null pointer");
     float lr_over_bc1 = 0.f, inv_sqrt_bc2 = 0.f;
@@ -313,7 +315,7 @@ int isr_feature_rows_step(int P, int64_t num_rendered, int ED, const void* geom_
         lr_over_bc1 = (float)(lr / bc1);
         inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     }
-    const int rc = launch_feature_rows_step(P, num_rendered, ED, geom_buffer, rows_scratch, gz_dense, gy, gy_slot, gy_merged, eps1,
+    const int rc = launch_feature_rows_step(P, row_begin, row_count, num_rendered, ED, geom_buffer, rows_scratch, gz_dense, gy, gy_slot, gy_merged, eps1,
                                             eps2, x, grad_out, lr_over_bc1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
                                             inv_sqrt_bc2, (float)eps, exp_avg, exp_avg_sq, y, z, (hipStream_t)stream);
     if (rc != 0) return fail(ISR_EHIP, "feature_rows_step launch failed (%d)", rc);

@@ -978,7 +978,7 @@ __global__ __launch_bounds__(256) void k_reduce_rows(int P, int ncol, const uint
 // Same expressions as the three kernels it replaces (bit-identical results).
 template <bool ADAM>
 __global__ __launch_bounds__(256) void k_feature_rows_step(
-    int P, int F, const uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ tiles_touched,
+    int row0, int P, int F, const uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ tiles_touched,
     const unsigned long long* __restrict__ row_mask, const float* __restrict__ partial,
     const uint8_t* __restrict__ row_flags, int64_t R, int row_stride,
     const float* __restrict__ gz_dense, const float* __restrict__ gy, const int* __restrict__ gy_slot,
@@ -989,7 +989,7 @@ __global__ __launch_bounds__(256) void k_feature_rows_step(
     int lpr = 1;
     while (lpr < q) lpr <<= 1;
     const int sub = (threadIdx.x & 63) & (lpr - 1);
-    const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) / lpr;
+    const long long row = row0 + ((long long)blockIdx.x * 256 + threadIdx.x) / lpr;      // rows [row0, P) of the table
     const bool ok = row < P && sub < q;
     const int c = 4 * sub;
     const size_t off = (size_t)(row < P ? row : 0) * F + c;
@@ -1450,26 +1450,27 @@ static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int
     return 0;
 }
 
-int launch_feature_rows_step(int P, int64_t R, int F, const void* geom, const void* rows_scratch, const float* gz_dense,
+int launch_feature_rows_step(int P, int row_begin, int row_count, int64_t R, int F, const void* geom, const void* rows_scratch, const float* gz_dense,
                              const float* gy, const int* gy_slot, const float* gy_merged, float eps1, float eps2, float* x, float* grad_out, float lr_over_bc1,
                              float om1, float beta2, float om2, float inv_sqrt_bc2, float eps, float* m, float* v, float* y,
                              float* z, hipStream_t s) {
-    if (P <= 0) return 0;
+    if (P <= 0 || row_count <= 0) return 0;
     GeomView g = geom_view(const_cast<void*>(geom), P);
     const float* partial = (const float*)rows_scratch;
     const uint8_t* flags = rows_scratch ? (const uint8_t*)rows_scratch + rows_bytes(R, F, 1u) : nullptr;
     const int stride = row_floats(F, 1u);
     int q = F >> 2, lpr = 1;
     while (lpr < q) lpr <<= 1;
-    const unsigned blocks = (unsigned)(((long long)P * lpr + 255) / 256);
+    const unsigned blocks = (unsigned)(((long long)row_count * lpr + 255) / 256);
+    const int row_end = row_begin + row_count;
     ProfScope ps_("k_feature_rows_step", s);
     if (grad_out != nullptr)
-        hipLaunchKernelGGL(k_feature_rows_step<false>, dim3(blocks), dim3(256), 0, s, P, F, g.point_offsets, g.tiles_touched,
-                           g.row_mask, partial, flags, R, stride, gz_dense, gy, gy_slot, gy_merged, eps1, eps2, x, grad_out, lr_over_bc1, om1, beta2, om2,
+        hipLaunchKernelGGL(k_feature_rows_step<false>, dim3(blocks), dim3(256), 0, s, row_begin, row_end, F, g.point_offsets,
+                           g.tiles_touched, g.row_mask, partial, flags, R, stride, gz_dense, gy, gy_slot, gy_merged, eps1, eps2, x, grad_out, lr_over_bc1, om1, beta2, om2,
                            inv_sqrt_bc2, eps, m, v, y, z);
     else
-        hipLaunchKernelGGL(k_feature_rows_step<true>, dim3(blocks), dim3(256), 0, s, P, F, g.point_offsets, g.tiles_touched,
-                           g.row_mask, partial, flags, R, stride, gz_dense, gy, gy_slot, gy_merged, eps1, eps2, x, grad_out, lr_over_bc1, om1, beta2, om2,
+        hipLaunchKernelGGL(k_feature_rows_step<true>, dim3(blocks), dim3(256), 0, s, row_begin, row_end, F, g.point_offsets,
+                           g.tiles_touched, g.row_mask, partial, flags, R, stride, gz_dense, gy, gy_slot, gy_merged, eps1, eps2, x, grad_out, lr_over_bc1, om1, beta2, om2,
                            inv_sqrt_bc2, eps, m, v, y, z);
     ISR_CHECK_LAUNCH_B("k_feature_rows_step");
     return 0;

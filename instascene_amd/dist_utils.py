@@ -44,9 +44,25 @@ def allreduce_grads_async(params: Iterable[torch.nn.Parameter], world: int):
     return works
 
 
+def row_ranges(n_rows: int, chunks: int):
+    """``chunks`` contiguous row ranges ``(r0, r1)`` covering ``[0, n_rows)``."""
+    c = max(1, min(int(chunks), max(1, n_rows)))
+    return [(n_rows * k // c, n_rows * (k + 1) // c) for k in range(c)]
+
+
+def allreduce_rows_async(t: torch.Tensor, r0: int, r1: int, world: int):
+    """Start the sum all-reduce of rows ``[r0, r1)`` of a contiguous ``[P, ...]`` tensor; returns the work handle (None for
+    one rank or an empty range).  A trainer that produces the gradient range by range overlaps the collective of one range
+    with the kernels of the others (SegTrainer._tail_with_allreduce)."""
+    if world <= 1 or r1 <= r0:
+        return None
+    return dist.all_reduce(t[r0:r1], op=dist.ReduceOp.SUM, async_op=True)
+
+
 def wait_all(works) -> None:
     for w in works:
-        w.wait()
+        if w is not None:
+            w.wait()
 
 
 def replicas_in_sync(t: torch.Tensor, world: int) -> bool:

@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import scenes
 from .contrastive import contrastive_loss, contrastive_loss_batch, gather_rows, row_normalize_chain
-from .dist_utils import allreduce_grads, allreduce_grads_async, view_for, wait_all
+from .dist_utils import allreduce_grads, allreduce_grads_async, allreduce_rows_async, row_ranges, view_for, wait_all
 from .rasterizer import DeferredFeatureRows
 from .render import prefetch, render
 
@@ -128,6 +128,7 @@ class SegTrainer:
         self.prefetch = True if prefetch_geometry is None else bool(prefetch_geometry)
         self._side = None
         self.split_tail = False      # tests: take the multi-rank form of the tail (dL/dx, all-reduce, Adam) with one rank
+        self.tail_chunks = 4         # row ranges of that form (all-reduce of one overlaps the kernels of the others)
         F = scene.seg_feature.shape[1]
         class_feat = None
         if use_class_feat:
@@ -291,10 +292,10 @@ class SegTrainer:
                 self.opt.step_rows(sink.rows, row_grads=sink.row_grads)
                 m._seg_cache = None
                 return loss.detach()
-            self.opt.step_rows(sink.rows, grad_only=True, row_grads=sink.row_grads)     # dL/dparam; Adam after the all-reduce
-            del sink
-        else:
-            loss.backward()
+            self._tail_with_allreduce(sink)
+            m._seg_cache = None
+            return loss.detach()
+        loss.backward()
         if self.prefetch:
             wait_all(allreduce_grads_async([m._seg_feature], self.world))
         else:
@@ -303,6 +304,28 @@ class SegTrainer:
         self.opt.zero_grad(set_to_none=True)
         m._seg_cache = None          # the graph of this step is gone
         return loss.detach()
+
+    def _tail_with_allreduce(self, sink):
+        """Several ranks: dL/dparam must be summed before Adam.  The [P,F] table is walked in ``tail_chunks`` row ranges:
+        the gradient kernel of range c is followed at once by its all-reduce (RCCL's own stream), so the collective of one
+        range runs while the gradient kernels of the next ranges and the Adam kernels of the previous ones execute —
+        instead of kernel, 192 MB collective, kernel in sequence."""
+        opt, p = self.opt, self.model._seg_feature
+        tail = opt.begin_tail(sink.rows, sink.row_grads)
+        if tail is None:
+            return
+        bounds = row_ranges(p.shape[0], self.tail_chunks)
+        works = []
+        for r0, r1 in bounds:
+            opt.tail_gradient(tail, r0, r1)
+            works.append(allreduce_rows_async(p.grad, r0, r1, self.world))
+        opt.begin_step()
+        for (r0, r1), w in zip(bounds, works):
+            if w is not None:
+                w.wait()                 # the compute stream waits for this range's collective; the host does not
+            opt.step_range(r0, r1)
+        opt.end_step()
+        opt.zero_grad(set_to_none=True)
 
     def _prefetch_next(self, it):
         """Software pipelining across iterations: the NEXT view's geometry pass and binning (K1, scans, key scatter, tile

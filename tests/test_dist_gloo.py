@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from instascene_amd.dist_utils import allreduce_grads, allreduce_grads_async, replicas_in_sync, view_for, wait_all
+from instascene_amd.dist_utils import (allreduce_grads, allreduce_grads_async, allreduce_rows_async, replicas_in_sync,
+                                       row_ranges, view_for, wait_all)
 
 
 def _toy_loss(param, view):
@@ -30,7 +31,11 @@ def _worker(rank, world, port, steps, n_views, out, overlapped=False):
         v = view_for(it, rank, world, n_views)
         seen.append(v)
         _toy_loss(p, v).backward()
-        if overlapped:       # the trainer's overlapped form: start, do gradient-independent work, wait
+        if overlapped == "ranges":   # the trainer's pipelined form: the table in row ranges, one collective per range
+            works = [allreduce_rows_async(p.grad, r0, r1, world) for r0, r1 in row_ranges(p.shape[0], 3)]
+            for w in works:
+                w.wait()
+        elif overlapped:     # the trainer's overlapped form: start, do gradient-independent work, wait
             works = allreduce_grads_async([p], world)
             _ = torch.randn(16).sum()
             wait_all(works)
@@ -52,7 +57,7 @@ def _free_port():
 
 
 @pytest.mark.timeout(120)
-@pytest.mark.parametrize("overlapped", [False, True])
+@pytest.mark.parametrize("overlapped", [False, True, "ranges"])
 def test_two_rank_gradient_allreduce_equals_sum_of_view_gradients(tmp_path, overlapped):
     world, steps, n_views = 2, 4, 7
     mp.spawn(_worker, args=(world, _free_port(), steps, n_views, str(tmp_path), overlapped), nprocs=world, join=True)
