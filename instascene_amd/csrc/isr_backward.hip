@@ -110,7 +110,7 @@ __device__ __forceinline__ void wave_sum12(const float (&g)[12], float (&out)[3]
 // QF: feature channels whose dL/dfeature(pixel) is kept in registers for the q-dot of the geometry pass
 //     (channels beyond QF are read from global memory; QF = 0 when there is no geometry pass or no feature).
 template <class Math, bool GEOM, bool FEAT, int QF>
-__global__ __launch_bounds__(256, 2) void k_render_bwd(
+__global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_render_bwd(
     int W, int H, int ED, int ch_base, int gx, const uint32_t* __restrict__ tile_offset,
     const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ box4, const float* __restrict__ rec,
     const float* __restrict__ col_pre, const float* __restrict__ tm_pre, const float* __restrict__ extras,

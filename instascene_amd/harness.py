@@ -376,13 +376,18 @@ class RgbTrainer:
     lambda_normal*(1 - <rend_normal, surf_normal>) -> backward (full geometry gradients) -> Adam."""
 
     def __init__(self, scene, cameras, targets, device="cuda", lambda_dssim=0.2, lambda_normal=0.05, lambda_dist=0.0,
-                 rank=0, world=1, densify=None, scene_extent=None):
-        """``densify``: None (off) or a dict overriding the reference's schedule (arguments/__init__.py:106-125):
+                 rank=0, world=1, densify=None, scene_extent=None, spatial_sort=True):
+        """``spatial_sort``: store the Gaussians in Z-order of their centres (a row permutation, once, here; rows that the
+        density control appends later go to the end).  ``densify``: None (off) or a dict overriding the reference's schedule (arguments/__init__.py:106-125):
         ``from_iter=500, until_iter=15000, interval=100, opacity_reset_interval=3000, grad_threshold=0.0002,
         opacity_cull=0.05, percent_dense=0.01``; ``scene_extent`` = the reference's ``cameras_extent``."""
         from .losses import l1_loss, ssim
         self.l1, self.ssim = l1_loss, ssim
         self.device = torch.device(device)
+        self.order = None
+        if spatial_sort:
+            self.order = scenes.morton_order(scene.xyz)
+            scene = scenes.spatially_sorted(scene, self.order)
         self.model = RgbGaussianModel(scene, self.device)
         self.cams = [c.to(self.device) for c in cameras]
         self.targets = [t.to(self.device) for t in targets]
