@@ -395,7 +395,7 @@ class RgbTrainer:
         self.bg = torch.zeros(3, dtype=torch.float32, device=self.device)
         self.ld, self.ln, self.ldist = lambda_dssim, lambda_normal, lambda_dist
         self.rank, self.world = rank, world
-        self.opt = torch.optim.Adam(self.model.param_groups(), lr=0.0, eps=1e-15)
+        self.opt = torch.optim.Adam(self.model.param_groups(), lr=0.0, eps=1e-15, fused=self.device.type == "cuda")
         self.densify_cfg = None
         if densify is not None:
             from .densify import Densifier
