@@ -224,3 +224,42 @@ def test_c3_trainer_formulations_agree_bit_for_bit():
         rz.set_async_binning(False)
         rz.set_mode("exact")
         rz.set_tracer(True)
+
+
+def test_c5_two_feature_passes_adjoint_and_trainer():
+    """Config C5 (5 M Gaussians, 1296x968, F = 64): the feature channels take two 32-channel passes through every blend
+    kernel.  Adjoint identity of the sampled backward, and the trainer's fused tail against the plain formulation."""
+    from instascene_amd.harness import SegTrainer
+    scene, cams, cfg = scenes.config_scene("C5")
+    P, W, H, F = cfg["P"], cfg["W"], cfg["H"], cfg["F"]
+    assert F == 64 and P == 5_000_000
+    inp = {k: (None if v is None else v.cuda()) for k, v in scenes.activated_inputs(scene).items()}
+    g = torch.Generator(device="cuda").manual_seed(2)
+    E = torch.randn(P, F, device="cuda", generator=g)
+    a, o = _forward(inp, cams[5], cfg, MODE_FAST, E)
+    pix = torch.randint(0, W * H, (16384,), device="cuda", generator=g)
+    rows = torch.randn(16384, F, device="cuda", generator=g)
+    sampled = rz.sample_extra(o[4], pix)
+    lhs = float((sampled.double() * rows.double()).sum())
+    dE = rz.rasterize_gaussians_backward_sampled(P, F, W, H, o[0], pix, rows, None, o[5], o[6], o[7], mode=MODE_FAST)
+    rhs = float((E.double() * dE.double()).sum())
+    assert abs(lhs - rhs) <= 2e-5 * float((sampled.double().abs() * rows.double().abs()).sum())
+    del inp, E, a, o, dE
+    torch.cuda.empty_cache()
+    rz.set_mode("fast")
+    rz.set_tracer(False)
+    rz.set_async_binning(True)
+    try:
+        outs = []
+        for plain in (False, True):
+            kw = dict(fused_tail=False, batched_losses=False, prefetch_geometry=False) if plain else {}
+            tr = SegTrainer(scene, cams[:3], device="cuda", sample_batchsize=8192, use_class_feat=True, seed=1, **kw)
+            losses = [float(tr.step(it)) for it in range(3)]
+            outs.append((losses, tr.model._seg_feature.detach().clone()))
+            del tr
+            torch.cuda.empty_cache()
+        assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+    finally:
+        rz.set_async_binning(False)
+        rz.set_mode("exact")
+        rz.set_tracer(True)
