@@ -313,11 +313,14 @@ class SegTrainer:
         opt, p = self.opt, self.model._seg_feature
         tail = opt.begin_tail(sink.rows, sink.row_grads)
         if tail is None:
-            return
+            if self.world == 1:
+                return
+            p.grad = torch.zeros_like(p.data)      # nothing reached this rank's leaves: it still takes part in the sums
         bounds = row_ranges(p.shape[0], self.tail_chunks)
         works = []
         for r0, r1 in bounds:
-            opt.tail_gradient(tail, r0, r1)
+            if tail is not None:
+                opt.tail_gradient(tail, r0, r1)
             works.append(allreduce_rows_async(p.grad, r0, r1, self.world))
         opt.begin_step()
         for (r0, r1), w in zip(bounds, works):
