@@ -143,6 +143,10 @@ def main():
     rasterizer.set_async_binning(bool(args.async_binning))
     rasterizer.set_view_cache(args.view_cache_gb)
     scene, cams, cfg = scenes.config_scene(args.config)
+    if cfg["F"] == 0:
+        print("bench.py measures the feature-training step: the config needs F > 0 (C3, C5); the RGB + geometry step of "
+              "C1 / C2 is tools/bench_rgb.py", file=sys.stderr)
+        sys.exit(2)
     trainer = SegTrainer(scene, cams[:16], device=dev, sample_batchsize=8192, use_class_feat=True, rank=rank, world=world,
                          spatial_sort=bool(args.spatial_sort))
     trainer.split_tail = bool(args.split_tail)
