@@ -152,6 +152,7 @@ def main():
     trainer.split_tail = bool(args.split_tail)
     trainer.pipe.lazy_maps = bool(args.lazy_maps)
     trainer.warm_view_caches()       # per-view constants (ray tables, visible pools): setup, like the label maps
+    trainer.prime()                  # code objects, allocator pools, side stream: two steps whose effect is undone
     L = lib()
 
     for it in range(args.warmup):

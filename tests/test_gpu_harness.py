@@ -295,3 +295,27 @@ def test_multi_rank_form_of_the_tail_with_one_rank():
         rz.set_async_binning(False)
         rz.set_mode("exact")
         rz.set_tracer(True)
+
+
+def test_prime_leaves_no_trace():
+    """SegTrainer.prime() runs steps for their side effects on the runtime (code objects, allocator, streams) and undoes
+    their effect on the training state: the steps that follow are the steps of an unprimed trainer, bit for bit."""
+    rz.set_mode("fast")
+    rz.set_tracer(False)
+    rz.set_async_binning(True)
+    try:
+        outs = []
+        for primed in (False, True):
+            sc, cams = _scene()
+            tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=2048, n_labels=12, use_class_feat=True, seed=3)
+            tr.warm_view_caches()
+            if primed:
+                tr.prime()
+            losses = [float(tr.step(it)) for it in range(6)]
+            outs.append((losses, tr.model._seg_feature.detach().clone(), tr.opt.step_count))
+        assert outs[0][0] == outs[1][0] and outs[0][2] == outs[1][2] == 6
+        assert torch.equal(outs[0][1], outs[1][1])
+    finally:
+        rz.set_async_binning(False)
+        rz.set_mode("exact")
+        rz.set_tracer(True)
