@@ -238,7 +238,9 @@ def main():
                           "gaussian_order": "z-order of the centres, sorted once at load" if args.spatial_sort else "as generated (random)",
                           "derived_render_maps": "on first access (never read by this step)" if args.lazy_maps else "inside render(), like the reference"},
                "roofline": roof}
-        if not args.no_cpu_baseline:
+        if world > 1:
+            out["cpu_baseline"] = None       # timed on rank 0 at N=1 only (task contract)
+        elif not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg)
             except Exception as e:   # the bench line must still be printed
