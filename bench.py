@@ -128,11 +128,17 @@ def main():
     if args.gpus > 1 and world == 1:
         print("launch with torch.distributed.run for --gpus > 1", file=sys.stderr)
         sys.exit(2)
+    # ISR_DIST_BACKEND=gloo (testing only): several ranks may then share one GPU, which RCCL does not allow
+    backend = os.environ.get("ISR_DIST_BACKEND", "nccl")
+    local = local if backend == "nccl" else local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from instascene_amd import scenes, rasterizer
     from instascene_amd._lib import lib

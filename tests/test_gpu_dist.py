@@ -1,0 +1,107 @@
+"""Two ranks on ONE GPU with the gloo backend (RCCL refuses two ranks per device; gloo moves CUDA tensors through the host):
+the multi-rank code path of the trainer on the real kernels - range-pipelined asynchronous all-reduce of dL/dparam, Adam per
+range, next view's binning on the side stream - must keep the replicas bit-identical and must equal, step by step, what one
+process computes from the same two views."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _trainer(rank, world):
+    import math
+    from instascene_amd import scenes, rasterizer as rz
+    from instascene_amd.harness import SegTrainer
+    rz.set_mode("fast")
+    rz.set_tracer(False)
+    rz.set_async_binning(True)
+    sc = scenes.synthetic_scene(4000, 16, 5, math.log(0.04))
+    cams = scenes.ring_cameras(6, 128, 96)
+    return SegTrainer(sc, cams, device="cuda", sample_batchsize=2048, n_labels=12, use_class_feat=True, seed=3, rank=rank,
+                      world=world)
+
+
+def _worker(rank, world, port, steps, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from instascene_amd.dist_utils import replicas_in_sync
+    tr = _trainer(rank, world)
+    tr.warm_view_caches()
+    tr.prime()
+    grads = []
+    for it in range(steps):
+        tr.step(it)
+        assert replicas_in_sync(tr.model._seg_feature.data, world), it
+    torch.save({"p": tr.model._seg_feature.detach().cpu(), "m": tr.opt.exp_avg.cpu(), "count": tr.opt.step_count},
+               os.path.join(out, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_share_a_gpu_and_stay_in_sync(tmp_path):
+    world, steps = 2, 5
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["p"], r1["p"]) and torch.equal(r0["m"], r1["m"]) and r0["count"] == r1["count"] == steps
+    # one process, the same views and samples: the two ranks' gradients summed by hand, then the same optimiser step
+    ref = [_trainer(r, world) for r in range(world)]
+    for t in ref:
+        t.warm_view_caches()
+        t.split_tail = True
+        t.tail_chunks = 1
+    p0 = ref[0].model._seg_feature
+    for it in range(steps):
+        total = None
+        for t in ref:
+            t.model._seg_feature.data.copy_(p0.data)
+            t.opt.exp_avg.copy_(ref[0].opt.exp_avg)
+            t.opt.exp_avg_sq.copy_(ref[0].opt.exp_avg_sq)
+            t.opt.step_count = ref[0].opt.step_count
+            t.opt.normalized = None
+            g = _gradient_of_step(t, it)
+            total = g if total is None else total + g
+        ref[0].model._seg_feature.grad = total
+        ref[0].opt.step()
+        ref[0].opt.zero_grad(set_to_none=True)
+    torch.testing.assert_close(r0["p"].cuda(), p0.detach(), rtol=0, atol=1e-6)
+
+
+def _gradient_of_step(tr, it):
+    """dL/dparam of iteration ``it`` of this trainer (its view, its sampling RNG), without applying it."""
+    from instascene_amd.rasterizer import DeferredFeatureRows
+    tr.model._seg_cache = None
+    tr.opt.leaf_mode = True
+    try:
+        captured = {}
+        orig = tr._tail_with_allreduce
+
+        def capture(sink):
+            tail = tr.opt.begin_tail(sink.rows, sink.row_grads)
+            tr.opt.tail_gradient(tail, 0, tr.model._seg_feature.shape[0])
+            captured["g"] = tr.model._seg_feature.grad.clone()
+            tr.opt.zero_grad(set_to_none=True)
+
+        tr._tail_with_allreduce = capture
+        tr._step(it)
+        tr._tail_with_allreduce = orig
+        return captured["g"]
+    finally:
+        tr.opt.leaf_mode = False
+        tr.opt.leaves = None
+        tr.model._seg_cache = None
