@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256) void k_bwd_live_pixels(int W, int H, int ED, i
 //                  tile.  A tile's samples are walked in groups of SPARSE_LMAX; from the second group on the lane adds to
 //                  the row it wrote before (always the same lane of the same wave: no race).  A pixel sampled twice is
 //                  two list entries — no merging needed.  Summation order is fixed (sample index) as long as a tile
-//                  has at most 1024 samples; beyond that only the order between blocks of 1024 is the fill kernel's.
+//                  has at most 512 samples; beyond that only the order between blocks of 512 is the fill kernel's.
 template <class Math, bool SAMPLED>
 __global__ __launch_bounds__(64) void k_render_bwd_sparse(
     int W, int H, int ED, int ch_base, int gx, const uint32_t* __restrict__ tile_offset,
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_sparse(
     __shared__ unsigned s_llast[SPARSE_LMAX];          // their last contributor
     __shared__ unsigned s_sample[SPARSE_LMAX];
     __shared__ __attribute__((aligned(16))) float s_ldE[SPARSE_LMAX * 32];
-    constexpr int SEG_SORT = SAMPLED ? 1024 : 1;       // samples of a tile put in index order (fixed summation order)
+    constexpr int SEG_SORT = SAMPLED ? 512 : 1;        // samples of a tile put in index order (fixed summation order)
     __shared__ unsigned s_seg_in[SEG_SORT], s_seg[SEG_SORT];
 
     const int tile = blockIdx.x;
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(64) void k_render_bwd_sparse(
     if constexpr (SAMPLED) {
         __syncthreads();                                   // the previous group is done with the LDS lists
         if ((g0 % SEG_SORT) == 0) {
-            // the fill kernel placed the tile's samples in the order of its atomics: rank-sort the next (up to) 1024 of
+            // the fill kernel placed the tile's samples in the order of its atomics: rank-sort the next (up to) 512 of
             // them by sample index, so that the groups and the order inside them do not depend on that race
             const int nseg = min(SEG_SORT, ntotal - g0);
             for (int e = lane; e < nseg; e += 64) s_seg_in[e] = seg_idx[seg0 + g0 + e];
