@@ -60,6 +60,16 @@ def test_two_ranks_share_a_gpu_and_stay_in_sync(tmp_path):
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     assert torch.equal(r0["p"], r1["p"]) and torch.equal(r0["m"], r1["m"]) and r0["count"] == r1["count"] == steps
     # one process, the same views and samples: the two ranks' gradients summed by hand, then the same optimiser step
+    from instascene_amd import rasterizer as rz
+    try:
+        _single_process_reference(world, steps, r0)
+    finally:
+        rz.set_async_binning(False)
+        rz.set_mode("exact")
+        rz.set_tracer(True)
+
+
+def _single_process_reference(world, steps, r0):
     ref = [_trainer(r, world) for r in range(world)]
     for t in ref:
         t.warm_view_caches()
