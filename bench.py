@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--spatial-sort", type=int, default=1,
                     help="1 (default): the trainer stores the Gaussians in Z-order of their centres (sorted once at load, "
                          "before the timed region; a pure relabelling of rows); 0: keep the generator's random order")
+    ap.add_argument("--fused-sampling", type=int, default=1,
+                    help="1 (default): one kernel draws every index of a step (iso_sample_step); 0: torch.randint + gathers")
     ap.add_argument("--split-tail", type=int, default=0,
                     help="1: with one rank, take the multi-rank form of the per-Gaussian tail (dL/dx kernel, [no-op] "
                          "all-reduce, Adam kernel) to measure what it costs next to the one-pass tail")
@@ -154,7 +156,7 @@ def main():
               "C1 / C2 is tools/bench_rgb.py", file=sys.stderr)
         sys.exit(2)
     trainer = SegTrainer(scene, cams[:16], device=dev, sample_batchsize=8192, use_class_feat=True, rank=rank, world=world,
-                         spatial_sort=bool(args.spatial_sort))
+                         spatial_sort=bool(args.spatial_sort), fused_sampling=bool(args.fused_sampling))
     trainer.split_tail = bool(args.split_tail)
     trainer.pipe.lazy_maps = bool(args.lazy_maps)
     trainer.warm_view_caches()       # per-view constants (ray tables, visible pools): setup, like the label maps

@@ -131,6 +131,16 @@ int iso_adam_rownorm2(long long N, int F, double lr, double beta1, double beta2,
 int iso_rows_compact(int n, int F, long long P, const long long* idx, const float* vals, int* slot /*[P]*/,
                      float* merged /*[n,F]*/, void* stream);
 
+/* The index sampling of one train_semantic.py iteration (:118-129, :163-168, :183-190) as one launch: pix[2B] = 2B uniform
+ * draws with replacement from pool2d[n_pool2d] (flat indices of the view's labelled pixels), lab_a[B] = segmap_a[pix[:B]],
+ * lab_b[B] = segmap_b[pix[B:]]; pick3d[B] = B draws from pool3d[n_pool3d] (visible labelled Gaussians), lab3d = labels3d[
+ * pick3d].  Counter-based generator (splitmix64 of seed, step, draw): the same (seed, step) gives the same samples.  A
+ * pool of size 0 leaves its outputs untouched. */
+int iso_sample_step(unsigned long long seed, unsigned long long step, int B, long long n_pool2d, const long long* pool2d,
+                    const long long* segmap_a, const long long* segmap_b, long long n_pool3d, const long long* pool3d,
+                    const long long* labels3d, long long* pix, long long* lab_a, long long* lab_b, long long* pick3d,
+                    long long* lab3d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

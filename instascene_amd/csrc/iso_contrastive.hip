@@ -794,6 +794,44 @@ __global__ __launch_bounds__(1024) void rows_compact_kernel(int n, int F, long l
     }
 }
 
+// The sampling of one train_semantic iteration (train_semantic.py:118-129,163-168,183-190) in ONE launch: 2*B labelled
+// pixels of the view (B for each of the two single-view losses) with their labels from the two label maps, and B visible
+// labelled Gaussians with their labels - eight torch kernels (randint x2, five gathers, an index_select) otherwise.
+// Uniform draws with replacement from a counter-based generator: splitmix64 of (seed, step, draw), mapped to [0, n) by
+// the high half of a 64 x 64-bit product.
+__device__ __forceinline__ unsigned long long sm64(unsigned long long z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void sample_step_kernel(unsigned long long seed, unsigned long long step, int B,
+                                                          long long n_pool2d, const long long* __restrict__ pool2d,
+                                                          const long long* __restrict__ segmap_a,
+                                                          const long long* __restrict__ segmap_b, long long n_pool3d,
+                                                          const long long* __restrict__ pool3d,
+                                                          const long long* __restrict__ labels3d,
+                                                          long long* __restrict__ pix, long long* __restrict__ lab_a,
+                                                          long long* __restrict__ lab_b, long long* __restrict__ pick3d,
+                                                          long long* __restrict__ lab3d) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 3 * B) return;
+    const unsigned long long r = sm64(sm64(seed ^ (step * 0xd1342543de82ef95ull)) + (unsigned long long)i);
+    if (i < 2 * B) {
+        if (n_pool2d <= 0) return;
+        const long long q = pool2d[(long long)__umul64hi(r, (unsigned long long)n_pool2d)];
+        pix[i] = q;
+        if (i < B) lab_a[i] = segmap_a[q];
+        else lab_b[i - B] = segmap_b[q];
+    } else {
+        if (n_pool3d <= 0) return;
+        const int k = i - 2 * B;
+        const long long g = pool3d[(long long)__umul64hi(r, (unsigned long long)n_pool3d)];
+        pick3d[k] = g;
+        lab3d[k] = labels3d[g];
+    }
+}
+
 __global__ __launch_bounds__(256) void rn_scalar(long long N, int F, float eps, int bwd, const float* __restrict__ x,
                                                  const float* __restrict__ dy, float* __restrict__ out) {
     const long long row = (long long)blockIdx.x * 256 + threadIdx.x;

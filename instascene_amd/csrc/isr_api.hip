@@ -647,6 +647,20 @@ int iso_adam_rownorm2(long long N, int F, double lr, double beta1, double beta2,
     return ISR_OK;
 }
 
+int iso_sample_step(unsigned long long seed, unsigned long long step, int B, long long n_pool2d, const long long* pool2d,
+                    const long long* segmap_a, const long long* segmap_b, long long n_pool3d, const long long* pool3d,
+                    const long long* labels3d, long long* pix, long long* lab_a, long long* lab_b, long long* pick3d,
+                    long long* lab3d, void* stream) {
+    if (B < 0 || n_pool2d < 0 || n_pool3d < 0) return fail(ISR_EINVAL, "sample_step: bad sizes");
+    if (B == 0) return ISR_OK;
+    if (n_pool2d > 0 && (!pool2d || !segmap_a || !segmap_b || !pix || !lab_a || !lab_b)) return fail(ISR_EINVAL, "sample_step: null 2-D argument");
+    if (n_pool3d > 0 && (!pool3d || !labels3d || !pick3d || !lab3d)) return fail(ISR_EINVAL, "sample_step: null 3-D argument");
+    hipLaunchKernelGGL(iso::sample_step_kernel, dim3((3 * B + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed, step, B,
+                       n_pool2d, pool2d, segmap_a, segmap_b, n_pool3d, pool3d, labels3d, pix, lab_a, lab_b, pick3d, lab3d);
+    ISR_LAUNCH_CHECK("iso_sample_step");
+    return ISR_OK;
+}
+
 int iso_rows_compact(int n, int F, long long P, const long long* idx, const float* vals, int* slot, float* merged,
                      void* stream) {
     hipStream_t s = (hipStream_t)stream;

@@ -112,7 +112,7 @@ class SegTrainer:
     def __init__(self, scene: scenes.Scene, cameras: List[scenes.Camera], device="cuda", sample_batchsize=8192,
                  n_labels=64, lambda_sv=1e-6, lambda_mv=1e-6, lambda_3d=2.5e-6, sample_mv_frames=5, use_class_feat=False,
                  multiview=False, seed=0, rank=0, world=1, prefetch_geometry=None, fused_update=None, sampled_path=True,
-                 fused_tail=None, batched_losses=None, spatial_sort=True):
+                 fused_tail=None, batched_losses=None, spatial_sort=True, fused_sampling=None):
         self.device = torch.device(device)
         # Gaussians stored in Z-order of their centres (once, here): neighbours in memory are neighbours on screen, which
         # the binning kernels' workgroup-level counter merging and every per-Gaussian gather rely on.  A pure relabelling
@@ -158,6 +158,10 @@ class SegTrainer:
         if self.fused_tail and not (fused_update and self.sampled_path):
             raise ValueError("fused_tail needs fused_update and sampled_path")
         self.gen = torch.Generator(device=self.device).manual_seed(1000 + seed * 131 + rank)
+        self.sample_seed = 1000 + seed * 131 + rank
+        # all of a step's index sampling in one kernel (iso_sample_step; its own counter-based generator, so the samples
+        # differ from the torch.randint ones of fused_sampling=False - same distribution)
+        self.fused_sampling = (self.device.type == "cuda") if fused_sampling is None else bool(fused_sampling)
         # label maps are static per view: index the labelled pixels once (the reference re-derives the
         # boolean mask every iteration, train_semantic.py:118-125)
         self.n_labels = n_labels
@@ -223,6 +227,27 @@ class SegTrainer:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 
+    def _draw_samples(self, it, vi):
+        """``(pix[2B], labels_a[B], labels_b[B], pick3d[B] | None, labels3d[pick3d] | None)`` of iteration ``it`` from ONE
+        kernel (``iso_sample_step``) instead of two ``randint`` and six gathers; the 3-D part needs the view's pool of
+        visible labelled Gaussians (``warm_view_caches`` or a first visit), else it is drawn later the torch way."""
+        import ctypes
+        from ._lib import check, lib
+        B, dev = self.batch, self.device
+        cam = self.cams[vi]
+        pool2d = self.valid_idx[vi]
+        pool3d = self.vis_pool.get(vi) if self.l3d > 0 else None
+        n3 = 0 if pool3d is None else int(pool3d.numel())
+        out = torch.empty(6 * B, dtype=torch.int64, device=dev)
+        pix, la, lb, pick3d, lab3d = out[:2 * B], out[2 * B:3 * B], out[3 * B:4 * B], out[4 * B:5 * B], out[5 * B:]
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        with torch.cuda.device(dev):
+            check(lib().iso_sample_step(self.sample_seed, int(it), B, int(pool2d.numel()), p(pool2d), p(cam.segmap.reshape(-1)),
+                                        p(cam.sorted_segmap.reshape(-1)), n3, p(pool3d) if n3 else None,
+                                        p(self.labels3d) if n3 else None, p(pix), p(la), p(lb), p(pick3d), p(lab3d),
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "iso_sample_step")
+        return (pix, la, lb, pick3d if n3 else None, lab3d if n3 else None)
+
     def _sample_view_loss(self, vi, seg_feature, segmap, predef, weight):
         idx_pool = self.valid_idx[vi]
         if idx_pool.numel() == 0:
@@ -256,7 +281,12 @@ class SegTrainer:
         cam = self.cams[vi]
         merged = m.class_feat is not None and self.valid_idx[vi].numel() > 0
         pix = None
-        if merged:
+        drawn = None
+        if merged and self.fused_sampling:
+            # every index this step needs, from one kernel (iso_sample_step): pixels + their labels, 3-D picks + theirs
+            drawn = self._draw_samples(it, vi)
+            pix = drawn[0]
+        elif merged:
             # the pixels do not depend on the render: choose them first and let the rasterizer hand back the features at
             # those pixels (both single-view sample sets in ONE list; no dense dL/dfeature map in the backward)
             pool = self.valid_idx[vi]
@@ -273,8 +303,11 @@ class SegTrainer:
         if merged:
             feats = pkg["sampled_seg_feature"] if self.sampled_path else seg_feature.reshape(seg_feature.shape[0], -1)[:, pix].T
             fa, fb = feats.split(self.batch)          # one cat in the backward instead of two zero-fill + copy + add
-            la = cam.segmap.reshape(-1)[pix[:self.batch]]
-            lb = cam.sorted_segmap.reshape(-1)[pix[self.batch:]]
+            if drawn is not None:
+                la, lb = drawn[1], drawn[2]
+            else:
+                la = cam.segmap.reshape(-1)[pix[:self.batch]]
+                lb = cam.sorted_segmap.reshape(-1)[pix[self.batch:]]
             problems.append((fa, la, None, self.lsv * 0.5))
             problems.append((fb, lb, m.class_feat, self.lsv * 1.0))
             loss = None
@@ -288,9 +321,13 @@ class SegTrainer:
                 pool = torch.nonzero(vis & (self.labels3d > 0)).reshape(-1)
                 self.vis_pool[vi] = pool
             if pool.numel() > 0:
-                pick = pool[torch.randint(0, pool.numel(), (self.batch,), device=self.device, generator=self.gen)]
+                if drawn is not None and drawn[3] is not None:
+                    pick, lab3d = drawn[3], drawn[4]
+                else:
+                    pick = pool[torch.randint(0, pool.numel(), (self.batch,), device=self.device, generator=self.gen)]
+                    lab3d = self.labels3d[pick]
                 rows3d = gather_rows(m.get_seg_feature, pick) if self.fused_tail else m.get_seg_feature[pick]
-                problems.append((rows3d, self.labels3d[pick], m.class_feat, self.l3d))
+                problems.append((rows3d, lab3d, m.class_feat, self.l3d))
         if problems:
             K = self.n_labels + 1
             same = all(f.shape == problems[0][0].shape and (u is None or u.shape[0] == K) for f, _, u, _ in problems)

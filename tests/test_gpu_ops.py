@@ -389,3 +389,40 @@ def test_feature_adam_matches_torch_adam_and_emits_the_normalisation_chain():
         b.mul_(2.0)
     y3 = opt.normalized_chain()
     assert torch.equal(y3.detach(), row_normalize_chain(b.detach(), 1e-6, 1e-9))
+
+
+def test_sample_step_draws_uniformly_and_gathers_labels():
+    """iso_sample_step: one launch for a step's index sampling.  Draws lie in the pools, labels equal the gathers torch
+    would do, (seed, step) reproduces, different steps differ, and the draws are uniform over the pool (chi-square)."""
+    import ctypes
+    from instascene_amd._lib import check, lib
+    g = torch.Generator().manual_seed(0)
+    N, P, B = 5000, 3000, 8192
+    pool2d = torch.randperm(N, generator=g)[:1000].sort().values.cuda()
+    seg_a = torch.randint(0, 9, (N,), generator=g).cuda()
+    seg_b = torch.randint(0, 9, (N,), generator=g).cuda()
+    pool3d = torch.randperm(P, generator=g)[:700].cuda()
+    lab3 = torch.randint(0, 9, (P,), generator=g).cuda()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def draw(seed, step, n3=pool3d.numel()):
+        out = torch.full((6 * B,), -7, dtype=torch.int64, device="cuda")
+        check(lib().iso_sample_step(seed, step, B, pool2d.numel(), p(pool2d), p(seg_a), p(seg_b), n3, p(pool3d), p(lab3),
+                                    p(out[:2 * B]), p(out[2 * B:3 * B]), p(out[3 * B:4 * B]), p(out[4 * B:5 * B]), p(out[5 * B:]),
+                                    None), "iso_sample_step")
+        return out[:2 * B], out[2 * B:3 * B], out[3 * B:4 * B], out[4 * B:5 * B], out[5 * B:]
+
+    pix, la, lb, pk, l3 = draw(42, 7)
+    assert bool(torch.isin(pix, pool2d).all()) and bool(torch.isin(pk, pool3d).all())
+    assert torch.equal(la, seg_a[pix[:B]]) and torch.equal(lb, seg_b[pix[B:]]) and torch.equal(l3, lab3[pk])
+    again = draw(42, 7)
+    assert all(torch.equal(a, b) for a, b in zip((pix, la, lb, pk, l3), again))
+    other = draw(42, 8)
+    assert not torch.equal(pix, other[0]) and not torch.equal(pk, other[3])
+    assert not torch.equal(pix, draw(43, 7)[0])
+    # uniformity: 16384 draws over 1000 pool entries, chi-square with 999 degrees of freedom (mean 999, sd ~45)
+    counts = torch.bincount(torch.searchsorted(pool2d, pix), minlength=1000).double()
+    chi2 = float(((counts - 2 * B / 1000) ** 2 / (2 * B / 1000)).sum())
+    assert 800 < chi2 < 1200, chi2
+    # an empty 3-D pool leaves its outputs alone
+    assert bool((draw(42, 7, n3=0)[3] == -7).all())
