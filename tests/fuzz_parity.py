@@ -5,7 +5,7 @@ import math, os, sys
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))      # (lives in tests/: it uses the oracle)
 import oracle
 from helpers import small_scene, oracle_forward
 import test_gpu_rasterizer as T
