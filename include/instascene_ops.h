@@ -131,6 +131,12 @@ int iso_adam_rownorm2(long long N, int F, double lr, double beta1, double beta2,
 int iso_rows_compact(int n, int F, long long P, const long long* idx, const float* vals, int* slot /*[P]*/,
                      float* merged /*[n,F]*/, void* stream);
 
+/* out[i, :] = x[idx[i], :] / (|x[idx[i], :]|_2 + eps), i < n: rows of the normalised feature (scene/gaussian_model.py:122-125)
+ * gathered straight from the raw parameter x[P, F] - bit-identical to gathering them from iso_rownorm2's / iso_adam_rownorm2's
+ * `y`, which a trainer that only ever reads a few thousand rows of it (train_semantic.py:183-190) need not store.
+ * F % 4 == 0, F <= 256; indices outside [0, P) give zero rows. */
+int iso_gather_rownorm(int n, int F, long long P, float eps, const float* x, const long long* idx, float* out, void* stream);
+
 /* The index sampling of one train_semantic.py iteration (:118-129, :163-168, :183-190) as one launch: pix[2B] = 2B uniform
  * draws with replacement from pool2d[n_pool2d] (flat indices of the view's labelled pixels), lab_a[B] = segmap_a[pix[:B]],
  * lab_b[B] = segmap_b[pix[B:]]; pick3d[B] = B draws from pool3d[n_pool3d] (visible labelled Gaussians), lab3d = labels3d[

@@ -152,7 +152,8 @@ int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int hei
  *            (scene/gaussian_model.py:122-125 and gaussian_renderer/__init__.py:61-62)
  *   grad_out != NULL:  grad_out = dL/dx, nothing else is written (a data-parallel caller all-reduces it);
  *   grad_out == NULL:  torch.optim.Adam step (lr, betas, eps, step counted from 1; scene/gaussian_model.py:249) on
- *                      x / exp_avg / exp_avg_sq in place, and y, z of the UPDATED rows are written for the next forward. */
+ *                      x / exp_avg / exp_avg_sq in place, and y, z of the UPDATED rows are written for the next forward
+ *                      (y may be NULL: not stored; iso_gather_rownorm recomputes the rows a caller needs). */
 int isr_feature_rows_step(int P, int row_begin, int row_count, int64_t num_rendered, int ED, const void* geom_buffer,
                           const void* rows_scratch,
                           const float* gz_dense, const float* gy, const int* gy_slot, const float* gy_merged, float eps1,

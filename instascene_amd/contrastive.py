@@ -220,7 +220,19 @@ class _GatherRows(torch.autograd.Function):
     def forward(ctx, table, idx):
         ctx.save_for_backward(idx)
         ctx.shape = table.shape
-        return table.index_select(0, idx)
+        src = getattr(table, _ROW_SOURCE_ATTR, None)
+        ctx.placeholder = src is not None
+        if src is None:
+            return table.index_select(0, idx)
+        # the table is a placeholder for normalize(x) that was never stored (FeatureAdam.store_y = False): gather the rows
+        # from x and normalise them on the way (iso_gather_rownorm; the bits of the stored table's rows)
+        x, eps = src
+        ix = idx.contiguous().to(torch.int64)
+        out = torch.empty((ix.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib().iso_gather_rownorm(ix.shape[0], x.shape[1], x.shape[0], float(eps), _p(x), _p(ix), _p(out), _stream()),
+                  "iso_gather_rownorm")
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -233,9 +245,15 @@ class _GatherRows(torch.autograd.Function):
             # tail runs the table is ready and the small kernel does not queue up behind the next view's binning
             sink.row_grads = compact_row_grads(idx, g, ctx.shape[0])
             return None, None
+        if ctx.placeholder:
+            raise RuntimeError("gather_rows: the table is a placeholder (FeatureAdam.store_y = False); its gradient can only "
+                               "be collected by a rasterizer.DeferredFeatureRows block, once per step")
         dense = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
         dense.index_put_((idx,), g, accumulate=True)
         return dense, None
+
+
+_ROW_SOURCE_ATTR = "_isr_row_source"
 
 
 def compact_row_grads(idx: torch.Tensor, vals: torch.Tensor, P: int):
@@ -275,6 +293,10 @@ class FeatureAdam:
         self.leaf_mode = False
         self.leaves = None
         self._slot = None
+        # False: the one-pass tail does not write y = normalize(param) (one of its nine [P,F] streams); leaf mode then hands
+        # out a placeholder whose rows gather_rows computes from the parameter.  For callers that read y only through
+        # gather_rows (SegTrainer: the 3-D loss' 8 192 rows).
+        self.store_y = True
 
     def step(self):
         p = self.param
@@ -315,6 +337,9 @@ class FeatureAdam:
         if self.leaves is None:
             raise RuntimeError("step_rows: normalized_chain() was not called in leaf mode")
         y_leaf, z_leaf = self.leaves
+        if y_leaf.numel() == 1 and y_leaf.grad is not None:
+            raise RuntimeError("the values of the placeholder for the normalised feature were used directly; with "
+                               "FeatureAdam.store_y = False only gather_rows may read it")
         gy = None if y_leaf.grad is None else y_leaf.grad.contiguous().float()
         gz = None if z_leaf.grad is None else z_leaf.grad.contiguous().float()
         self.leaves = None
@@ -352,7 +377,8 @@ class FeatureAdam:
     def tail_update(self, tail):
         """Reduction + chain rule + Adam + next normalisations of every row in one pass."""
         p = self.param
-        y, z = torch.empty_like(p.data), torch.empty_like(p.data)
+        y = torch.empty_like(p.data) if self.store_y else None
+        z = torch.empty_like(p.data)
         self.step_count += 1
         self._rows_kernel(tail, 0, p.shape[0], None, y, z)
         torch.autograd.graph.increment_version(p)
@@ -399,12 +425,19 @@ class FeatureAdam:
                 with torch.no_grad():
                     y0, z0 = _RowNorm2.apply(p.detach(), *self.norm_eps)
                 self.normalized = (p._version, y0, z0)
-            y = self.normalized[1].detach().requires_grad_(True)
             z = self.normalized[2].detach().requires_grad_(True)
+            if self.normalized[1] is not None:
+                y = y_leaf = self.normalized[1].detach().requires_grad_(True)
+            else:
+                # y was not stored (store_y = False): a zero-stride placeholder of the right shape that knows where its rows
+                # come from (gather_rows reads them from the parameter); nothing else may read its values
+                y_leaf = torch.zeros(1, dtype=p.dtype, device=p.device, requires_grad=True)
+                y = y_leaf.expand(p.shape[0], p.shape[1])
+                setattr(y, _ROW_SOURCE_ATTR, (p.detach(), float(self.norm_eps[0])))
             setattr(y, _MEMO_ATTR, (float(self.norm_eps[1]), z, y._version))
-            self.leaves = (y, z)
+            self.leaves = (y_leaf, z)
             return y
-        if self.normalized is not None and self.normalized[0] == p._version:
+        if self.normalized is not None and self.normalized[0] == p._version and self.normalized[1] is not None:
             y, z = _RowNorm2Given.apply(p, self.normalized[1], self.normalized[2], *self.norm_eps)
             setattr(y, _MEMO_ATTR, (float(self.norm_eps[1]), z, y._version))
             return y

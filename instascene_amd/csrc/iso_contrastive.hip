@@ -794,6 +794,26 @@ __global__ __launch_bounds__(1024) void rows_compact_kernel(int n, int F, long l
     }
 }
 
+// out[i, :] = x[idx[i], :] / (|x[idx[i], :]| + eps): rows of the normalised table without the table (the same lanes-per-row
+// layout and summation order as rn2_kernel / adam_rn2_kernel, hence the same bits as their `y` rows).  Rows with an index
+// outside [0, P) are zero.
+__global__ __launch_bounds__(256) void gather_rownorm_kernel(int n, int F, long long P, float eps, const float* __restrict__ x,
+                                                             const long long* __restrict__ idx, float* __restrict__ out) {
+    const int q = F >> 2;
+    int lpr = 1;
+    while (lpr < q) lpr <<= 1;
+    const int sub = (threadIdx.x & 63) & (lpr - 1);
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) / lpr;
+    const long long row = i < n ? idx[i] : -1;
+    const bool ok = i < n && sub < q && row >= 0 && row < P;
+    const float4 v = ok ? *reinterpret_cast<const float4*>(x + (size_t)row * F + 4 * sub) : make_float4(0, 0, 0, 0);
+    float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    for (int o = lpr >> 1; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+    const float r1 = 1.0f / (__builtin_sqrtf(ss) + eps);
+    if (i < n && sub < q)
+        *reinterpret_cast<float4*>(out + (size_t)i * F + 4 * sub) = make_float4(v.x * r1, v.y * r1, v.z * r1, v.w * r1);
+}
+
 // The sampling of one train_semantic iteration (train_semantic.py:118-129,163-168,183-190) in ONE launch: 2*B labelled
 // pixels of the view (B for each of the two single-view losses) with their labels from the two label maps, and B visible
 // labelled Gaussians with their labels - eight torch kernels (randint x2, five gathers, an index_select) otherwise.

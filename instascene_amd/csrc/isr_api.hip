@@ -309,7 +309,7 @@ int isr_feature_rows_step(int P, int row_begin, int row_count, int64_t num_rende
         return fail(ISR_EINVAL, "feature_rows_step: null pointer");
     float lr_over_bc1 = 0.f, inv_sqrt_bc2 = 0.f;
     if (grad_out == nullptr) {
-        if (!exp_avg || !exp_avg_sq || !y || !z) return fail(ISR_EINVAL, "feature_rows_step: Adam state / outputs required");
+        if (!exp_avg || !exp_avg_sq || !z) return fail(ISR_EINVAL, "feature_rows_step: Adam state / outputs required");
         if (step < 1) return fail(ISR_EINVAL, "feature_rows_step: step counts from 1");
         const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
         lr_over_bc1 = (float)(lr / bc1);
@@ -644,6 +644,18 @@ int iso_adam_rownorm2(long long N, int F, double lr, double beta1, double beta2,
                        (float)beta2, (float)(1.0 - beta2), (float)(1.0 / sqrt(bc2)), (float)eps, eps1, eps2, param, grad,
                        exp_avg, exp_avg_sq, y, z);
     ISR_LAUNCH_CHECK("iso_adam_rownorm2");
+    return ISR_OK;
+}
+
+int iso_gather_rownorm(int n, int F, long long P, float eps, const float* x, const long long* idx, float* out, void* stream) {
+    if (n < 0 || F <= 0 || (F & 3) != 0 || F > 256 || P < 0) return fail(ISR_EINVAL, "gather_rownorm needs F % 4 == 0 and F <= 256");
+    if (n == 0) return ISR_OK;
+    if (!x || !idx || !out) return fail(ISR_EINVAL, "gather_rownorm: null pointer");
+    int q = F >> 2, lpr = 1;
+    while (lpr < q) lpr <<= 1;
+    hipLaunchKernelGGL(iso::gather_rownorm_kernel, dim3((unsigned)(((long long)n * lpr + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, n, F, P, eps, x, idx, out);
+    ISR_LAUNCH_CHECK("iso_gather_rownorm");
     return ISR_OK;
 }
 

@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(256) void k_feature_rows_step(
         for (int o = lpr >> 1; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
         const float q2 = 1.0f / (__builtin_sqrtf(s2) + eps2);
         if (ok) {
-            *reinterpret_cast<float4*>(y + off) = y4;
+            if (y != nullptr) *reinterpret_cast<float4*>(y + off) = y4;      // optional: iso_gather_rownorm recomputes rows
             *reinterpret_cast<float4*>(z + off) = make_float4(y4.x * q2, y4.y * q2, y4.z * q2, y4.w * q2);
         }
     }

@@ -157,6 +157,8 @@ class SegTrainer:
         self.fused_tail = bool(fused_update and self.sampled_path) if fused_tail is None else bool(fused_tail)
         if self.fused_tail and not (fused_update and self.sampled_path):
             raise ValueError("fused_tail needs fused_update and sampled_path")
+        if self.fused_tail:
+            self.opt.store_y = False         # the step reads normalize(param) only through gather_rows (3-D loss)
         self.gen = torch.Generator(device=self.device).manual_seed(1000 + seed * 131 + rank)
         self.sample_seed = 1000 + seed * 131 + rank
         # all of a step's index sampling in one kernel (iso_sample_step; its own counter-based generator, so the samples

@@ -426,3 +426,35 @@ def test_sample_step_draws_uniformly_and_gathers_labels():
     assert 800 < chi2 < 1200, chi2
     # an empty 3-D pool leaves its outputs alone
     assert bool((draw(42, 7, n3=0)[3] == -7).all())
+
+
+@pytest.mark.parametrize("P,F", [(5000, 32), (777, 16), (300, 64), (129, 40)])
+def test_gather_rownorm_gives_the_stored_rows(P, F):
+    """iso_gather_rownorm: rows of normalize(x) gathered from x itself == the same rows of the stored table (iso_rownorm2's
+    y), bit for bit; out-of-range indices give zero rows.  And the placeholder FeatureAdam hands out with store_y = False
+    may only be read through gather_rows inside a DeferredFeatureRows block."""
+    import ctypes
+    from instascene_amd._lib import check, lib
+    from instascene_amd.contrastive import FeatureAdam, _RowNorm2, gather_rows
+    g = torch.Generator().manual_seed(P)
+    x = (torch.randn(P, F, generator=g) * 2.0).cuda()
+    x[3] = 0.0
+    y, _ = _RowNorm2.apply(x, 1e-6, 1e-9)
+    idx = torch.randint(0, P, (2000,), generator=g).cuda()
+    idx[5], idx[6] = -1, P
+    out = torch.full((2000, F), 7.0, device="cuda")
+    pp = lambda t: ctypes.c_void_p(t.data_ptr())
+    check(lib().iso_gather_rownorm(2000, F, P, 1e-6, pp(x), pp(idx), pp(out), None), "iso_gather_rownorm")
+    ok = (idx >= 0) & (idx < P)
+    assert torch.equal(out[ok], y[idx[ok]]) and float(out[~ok].abs().max()) == 0.0
+    if F % 4 == 0 and F <= 256:
+        p = torch.nn.Parameter(x.clone())
+        opt = FeatureAdam(p, lr=0.025, eps=1e-15)
+        opt.store_y = False
+        opt.leaf_mode = True
+        opt.normalized = (p._version, None, y.clone())          # as the one-pass tail leaves it
+        table = opt.normalized_chain()
+        rows = gather_rows(table, idx[ok])
+        assert torch.equal(rows.detach(), y[idx[ok]])
+        with pytest.raises(RuntimeError):
+            rows.sum().backward()                                # no DeferredFeatureRows block: refused, not silently lost
