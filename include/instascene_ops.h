@@ -118,7 +118,7 @@ int iso_densify_stats(int P, int C, const float* viewspace_grad, const unsigned 
 /* Adam update of a [N,F] parameter (torch.optim.Adam arithmetic: no weight decay, no amsgrad; `step` counts from 1;
  * scene/gaussian_model.py:249 with the group's lr and eps) fused with the two chained row normalisations of the updated
  * rows (iso_rownorm2 forward): param / exp_avg / exp_avg_sq are updated in place, y and z receive the normalised rows the
- * next forward needs.  F % 4 == 0, F <= 256. */
+ * next forward needs (y may be NULL: not stored, see iso_gather_rownorm).  F % 4 == 0, F <= 256. */
 int iso_adam_rownorm2(long long N, int F, double lr, double beta1, double beta2, double eps, long long step, float eps1,
                       float eps2, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* y, float* z,
                       void* stream);

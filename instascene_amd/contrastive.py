@@ -388,7 +388,7 @@ class FeatureAdam:
         """Start an Adam step applied in row ranges (``step_range``), finished by ``end_step``."""
         p = self.param
         self.step_count += 1
-        self._pending_yz = (torch.empty_like(p.data), torch.empty_like(p.data))
+        self._pending_yz = (torch.empty_like(p.data) if self.store_y else None, torch.empty_like(p.data))
 
     def step_range(self, r0: int, r1: int):
         """Adam + the two normalisations on rows ``[r0, r1)`` from ``param.grad`` (``iso_adam_rownorm2`` on the slice)."""
@@ -397,7 +397,7 @@ class FeatureAdam:
             return
         F = p.shape[1]
         y, z = self._pending_yz
-        at = lambda t: ctypes.c_void_p(t.data_ptr() + 4 * F * int(r0))
+        at = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr() + 4 * F * int(r0))
         with torch.cuda.device(p.device):
             check(lib().iso_adam_rownorm2(int(r1 - r0), F, self.lr, float(self.betas[0]), float(self.betas[1]), self.eps,
                                           self.step_count, float(self.norm_eps[0]), float(self.norm_eps[1]), at(p.data),

@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void adam_rn2_kernel(long long N, int F, float
     for (int o = lpr >> 1; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
     const float r2 = 1.0f / (__builtin_sqrtf(s2) + eps2);
     if (ok) {
-        *reinterpret_cast<float4*>(y + off) = y4;
+        if (y != nullptr) *reinterpret_cast<float4*>(y + off) = y4;
         *reinterpret_cast<float4*>(z + off) = make_float4(y4.x * r2, y4.y * r2, y4.z * r2, y4.w * r2);
     }
 }

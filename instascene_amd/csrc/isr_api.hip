@@ -633,7 +633,7 @@ int iso_adam_rownorm2(long long N, int F, double lr, double beta1, double beta2,
     hipStream_t s = (hipStream_t)stream;
     if (N < 0 || F <= 0 || (F & 3) != 0 || F > 256) return fail(ISR_EINVAL, "adam_rownorm2 needs F % 4 == 0 and F <= 256");
     if (step < 1) return fail(ISR_EINVAL, "adam_rownorm2: step counts from 1");
-    if (N > 0 && (!param || !grad || !exp_avg || !exp_avg_sq || !y || !z)) return fail(ISR_EINVAL, "adam_rownorm2: null pointer");
+    if (N > 0 && (!param || !grad || !exp_avg || !exp_avg_sq || !z)) return fail(ISR_EINVAL, "adam_rownorm2: null pointer");
     if (N == 0) return ISR_OK;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     int q = F >> 2, lpr = 1;
