@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
     float T = GEOM ? T_final : 1.0f;
     float acc_r0 = 0, acc_r1 = 0, acc_r2 = 0, lc0 = 0, lc1 = 0, lc2 = 0;
     float accum_depth_rec = 0, last_depth = 0, accum_alpha_rec = 0, an0 = 0, an1 = 0, an2 = 0, ln0 = 0, ln1 = 0, ln2 = 0;
-    float last_dL_dT = 0, last_alpha = 0, accum_q = 0, last_q = 0;
+    float last_dL_dT = 0, last_alpha = 0, accum_q = 0, last_q = 0, accum_S = 0;
     const float bg_dot = GEOM ? (bg[0] * dpx0 + bg[1] * dpx1) + bg[2] * dpx2 : 0.0f;
 
     // GEOM walks back to front (reference order); features-only walks front to back.
@@ -427,39 +427,57 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
                         if (act) {
                             const float4 col = reinterpret_cast<const float4*>(s_rgb)[j];
                             float dL_dalpha = 0.0f;
-                            acc_r0 = last_alpha * lc0 + (1.f - last_alpha) * acc_r0; lc0 = col.x; dL_dalpha += (col.x - acc_r0) * dpx0;
-                            acc_r1 = last_alpha * lc1 + (1.f - last_alpha) * acc_r1; lc1 = col.y; dL_dalpha += (col.y - acc_r1) * dpx1;
-                            acc_r2 = last_alpha * lc2 + (1.f - last_alpha) * acc_r2; lc2 = col.z; dL_dalpha += (col.z - acc_r2) * dpx2;
                             float dL_dz = 0.0f;
                             const float m_d = mscale * (1 - Math::div(NEAR_N, c_d));
                             const float dmd_dd = Math::div(FAR_N * NEAR_N, (FAR_N - NEAR_N) * c_d * c_d);
                             if (contributor == median_contributor - 1u) dL_dz += dL_dmedian;
                             const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
-                            dL_dalpha += dL_dweight - last_dL_dT;
-                            last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
                             const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
                             dL_dz += dL_dmd * dmd_dd;
-                            accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
-                            last_depth = c_d;
-                            dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
-                            accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
-                            dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
                             const float nx = c.w, ny = d.x, nz = d.y;
-                            an0 = last_alpha * ln0 + (1.f - last_alpha) * an0; ln0 = nx; dL_dalpha += (nx - an0) * dn0;
-                            an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = ny; dL_dalpha += (ny - an1) * dn1;
-                            an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = nz; dL_dalpha += (nz - an2) * dn2;
+                            float q = 0.0f;
                             if constexpr (QF > 0) {
                                 const float* fj = s_feat + j * QF;
-                                float q = 0.0f;
     #pragma unroll
                                 for (int ch = 0; ch < QF; ch++) q = __builtin_fmaf(fj[ch], dEp[ch], q);
                                 if (ED > QF && dE != nullptr) {     // rare: more feature channels than the register budget
                                     const float* fg = extras + (size_t)s_id[sub_lo + j] * ED;
                                     for (int ch = QF; ch < ED; ch++) q = __builtin_fmaf(fg[ch], dE[(size_t)ch * N + pix], q);
                                 }
-                                accum_q = last_alpha * last_q + (1.f - last_alpha) * accum_q;
-                                last_q = q;
-                                dL_dalpha += q - accum_q;
+                            }
+                            if constexpr (Math::fast) {
+                                // Every "what lies behind this splat" term of the reference - colour, normal, depth, alpha,
+                                // distortion weight, feature - follows the SAME recurrence
+                                //     acc <- alpha_prev * x_prev + (1 - alpha_prev) * acc,    dL/dalpha += (x - acc) * g
+                                // and is linear in x, so they collapse into ONE recurrence on the pixel's scalar
+                                // S = sum_x x * g (nine registers of state and ~30 instructions per pair fewer).
+                                float S = col.x * dpx0;
+                                S = __builtin_fmaf(col.y, dpx1, S); S = __builtin_fmaf(col.z, dpx2, S);
+                                S = __builtin_fmaf(c_d, dL_ddepth, S); S += dL_daccum;
+                                S = __builtin_fmaf(nx, dn0, S); S = __builtin_fmaf(ny, dn1, S); S = __builtin_fmaf(nz, dn2, S);
+                                S += dL_dweight;
+                                if constexpr (QF > 0) S += q;
+                                dL_dalpha = S - accum_S;
+                                accum_S = __builtin_fmaf(alpha, dL_dalpha, accum_S);      // alpha * S + (1 - alpha) * accum_S
+                            } else {
+                                acc_r0 = last_alpha * lc0 + (1.f - last_alpha) * acc_r0; lc0 = col.x; dL_dalpha += (col.x - acc_r0) * dpx0;
+                                acc_r1 = last_alpha * lc1 + (1.f - last_alpha) * acc_r1; lc1 = col.y; dL_dalpha += (col.y - acc_r1) * dpx1;
+                                acc_r2 = last_alpha * lc2 + (1.f - last_alpha) * acc_r2; lc2 = col.z; dL_dalpha += (col.z - acc_r2) * dpx2;
+                                dL_dalpha += dL_dweight - last_dL_dT;
+                                last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
+                                accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                                last_depth = c_d;
+                                dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
+                                accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
+                                dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
+                                an0 = last_alpha * ln0 + (1.f - last_alpha) * an0; ln0 = nx; dL_dalpha += (nx - an0) * dn0;
+                                an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = ny; dL_dalpha += (ny - an1) * dn1;
+                                an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = nz; dL_dalpha += (nz - an2) * dn2;
+                                if constexpr (QF > 0) {
+                                    accum_q = last_alpha * last_q + (1.f - last_alpha) * accum_q;
+                                    last_q = q;
+                                    dL_dalpha += q - accum_q;
+                                }
                             }
                             dL_dalpha *= T;
                             last_alpha = alpha;
