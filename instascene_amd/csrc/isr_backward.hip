@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
         }
         has_grad = (pm >> lane) & 1ull;
     }
+    const bool wave_reg = GEOM && __ballot(dL_dreg != 0.0f) != 0ull;
     const bool lane_live = inside && has_grad && last_contributor > 0u;
     const bool wave_live = __ballot(lane_live) != 0ull;
     float ax0 = lane_live ? pxf : 3.0e38f, ax1 = lane_live ? pxf : -3.0e38f;
@@ -428,12 +429,16 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
                             const float4 col = reinterpret_cast<const float4*>(s_rgb)[j];
                             float dL_dalpha = 0.0f;
                             float dL_dz = 0.0f;
-                            const float m_d = mscale * (1 - Math::div(NEAR_N, c_d));
-                            const float dmd_dd = Math::div(FAR_N * NEAR_N, (FAR_N - NEAR_N) * c_d * c_d);
                             if (contributor == median_contributor - 1u) dL_dz += dL_dmedian;
-                            const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
-                            const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
-                            dL_dz += dL_dmd * dmd_dd;
+                            float dL_dweight = 0.0f;
+                            if (wave_reg) {     // wave-uniform: no pixel of this wave has a distortion gradient (lambda_dist = 0)
+                                                // -> every term below is an exact zero
+                                const float m_d = mscale * (1 - Math::div(NEAR_N, c_d));
+                                const float dmd_dd = Math::div(FAR_N * NEAR_N, (FAR_N - NEAR_N) * c_d * c_d);
+                                dL_dweight = (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
+                                const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
+                                dL_dz += dL_dmd * dmd_dd;
+                            }
                             const float nx = c.w, ny = d.x, nz = d.y;
                             float q = 0.0f;
                             if constexpr (QF > 0) {
