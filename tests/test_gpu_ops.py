@@ -458,3 +458,31 @@ def test_gather_rownorm_gives_the_stored_rows(P, F):
         assert torch.equal(rows.detach(), y[idx[ok]])
         with pytest.raises(RuntimeError):
             rows.sum().backward()                                # no DeferredFeatureRows block: refused, not silently lost
+
+
+@pytest.mark.parametrize("nb,consider_negative,min_pixnum", [(2, False, 0), (4, True, 0), (3, False, 40)])
+def test_contrastive_batch_variants(nb, consider_negative, min_pixnum):
+    """Batches of 2 and 4, labels that include 0 as a class (consider_negative), small clusters dropped (min_pixnum):
+    the batch equals the separate calls bit for bit."""
+    from instascene_amd.contrastive import contrastive_loss_batch
+    g = torch.Generator().manual_seed(nb * 7 + min_pixnum)
+    N, F, K = 3000, 32, 40
+    feats = [torch.randn(N, F, generator=g).cuda() for _ in range(nb)]
+    labels = [torch.randint(0, K, (N,), generator=g).cuda() for _ in range(nb)]
+    labels[0][:25] = K - 1                                        # a cluster that min_pixnum = 40 may drop
+    pre = torch.nn.functional.normalize(torch.randn(K, F, generator=g), dim=1).cuda()
+    predefs = [None if b % 2 == 0 else pre for b in range(nb)]
+    w = [0.5 + 0.25 * b for b in range(nb)]
+    a = [f.clone().requires_grad_(True) for f in feats]
+    want = None
+    for f, l, u, wi in zip(a, labels, predefs, w):
+        t = contrastive_loss(f, l, predef_u_list=u, num_labels=K, consider_negative=consider_negative, min_pixnum=min_pixnum) * wi
+        want = t if want is None else want + t
+    want.backward()
+    b = [f.clone().requires_grad_(True) for f in feats]
+    got, _ = contrastive_loss_batch(b, labels, predefs, w, num_labels=K, consider_negative=consider_negative,
+                                    min_pixnum=min_pixnum)
+    got.backward()
+    assert float(got.detach()) == float(want.detach())
+    for x, y in zip(a, b):
+        assert torch.equal(x.grad, y.grad)

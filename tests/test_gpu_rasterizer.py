@@ -507,6 +507,47 @@ def test_feature_rows_step_equals_the_three_passes(F):
             assert opt_b.step_count == opt_a.step_count == 7
 
 
+@pytest.mark.parametrize("F", [64, 256, 8])
+def test_feature_rows_step_wide_rows_and_row_ranges(F):
+    """The one-pass tail with 16 / 64 / 2 lanes per row, and walked in row ranges (the multi-rank form): the ranges together
+    equal the single call, for the gradient and for the Adam form."""
+    from instascene_amd.contrastive import FeatureAdam
+    from instascene_amd.dist_utils import row_ranges
+    P = 1500
+    rng = np.random.RandomState(F)
+    x0 = torch.tensor(rng.randn(P, F).astype(np.float32)).cuda()
+    gz = torch.tensor(rng.randn(P, F).astype(np.float32)).cuda()
+    idx = torch.tensor(rng.randint(0, P, 400), dtype=torch.int64).cuda()
+    vals = torch.tensor(rng.randn(400, F).astype(np.float32)).cuda()
+
+    def fresh():
+        p = torch.nn.Parameter(x0.clone())
+        opt = FeatureAdam(p, lr=0.025, eps=1e-15)
+        opt.leaf_mode = True
+        y = opt.normalized_chain()
+        opt.leaves[1].grad = gz.clone()
+        return p, opt
+
+    p_a, opt_a = fresh()
+    tail = opt_a.begin_tail(None, (idx, vals))
+    opt_a.tail_gradient(tail, 0, P)
+    whole = p_a.grad.clone()
+    p_b, opt_b = fresh()
+    tail = opt_b.begin_tail(None, (idx, vals))
+    for r0, r1 in row_ranges(P, 5):
+        opt_b.tail_gradient(tail, r0, r1)
+    assert torch.equal(p_b.grad, whole)
+    # Adam: one call over all rows == begin_step / step_range ... / end_step on the same gradient
+    p_c, opt_c = fresh()
+    opt_c.tail_update(opt_c.begin_tail(None, (idx, vals)))
+    opt_b.begin_step()
+    for r0, r1 in row_ranges(P, 3):
+        opt_b.step_range(r0, r1)
+    opt_b.end_step()
+    assert torch.equal(p_b.data, p_c.data) and torch.equal(opt_b.exp_avg_sq, opt_c.exp_avg_sq)
+    assert torch.equal(opt_b.normalized[2], opt_c.normalized[2])
+
+
 def test_sparse_row_gradient_equals_dense_index_put():
     """iso_rows_compact + isr_feature_rows_step(gy_slot, gy_merged) == the dense dL/dy that index_put_(accumulate=True)
     builds, bit for bit; rows drawn with replacement (pairs, a 5-fold repeat), out-of-range indices ignored."""
