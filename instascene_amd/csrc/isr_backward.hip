@@ -602,6 +602,10 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
 // no cross-lane reduction, no barrier in the walk, deterministic.
 // Tiles with more than SPARSE_LMAX live pixels are flagged in tile_mode[] and left to k_render_bwd.
 constexpr int SPARSE_LMAX = 32;
+constexpr int SPARSE_ROW_PITCH = 36;     // floats between staged rows (32 + 4: keeps float4 alignment, spreads the banks)
+constexpr int SPARSE_REC_PITCH4 = 5;     // float4s between staged records (4 + 1)
+constexpr int SPARSE_ROUND = 256;       // k_render_bwd_sparse, pass 1: splats culled per memory round trip
+constexpr int SPARSE_QUEUE = SPARSE_ROUND + 64;   // culled splats waiting for pass 2 (one round + up to 63 left over)
 
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ float dpp_fetch(float v, float fill) {
@@ -717,12 +721,20 @@ __global__ __launch_bounds__(256) void k_bwd_live_pixels(int W, int H, int ED, i
 // SAMPLED = false: live pixels come from k_bwd_live_pixels (dense dL/dE map, at most SPARSE_LMAX per tile).
 // SAMPLED = true : the upstream gradient is given for n SAMPLES, dL/dE(pix[i], :) = sample_rows[i, :] (the map was
 //                  only read at those pixels: render(..., sample_pixels=)); seg_off / seg_idx list the samples of every
-//                  tile.  A tile's samples are walked in groups of SPARSE_LMAX; from the second group on the lane adds to
+//                  tile as records (sample, tile-relative pixel, last contributor) written by k_sample_fill.  A tile's samples are walked in groups of SPARSE_LMAX; from the second group on the lane adds to
 //                  the row it wrote before (always the same lane of the same wave: no race).  A pixel sampled twice is
 //                  two list entries — no merging needed.  Summation order is fixed (sample index) as long as a tile
 //                  has at most 512 samples; beyond that only the order between blocks of 512 is the fill kernel's.
+// A workgroup of k_render_bwd_sparse is ONE wave: its LDS accesses execute in program order, so between a lane's LDS
+// write and another lane's read only the compiler has to be held back.  __syncthreads() would also drain the wave's
+// outstanding global loads and stores (workgroup-scope release), i.e. put a memory round trip where none is needed.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <class Math, bool SAMPLED>
-__global__ __launch_bounds__(64) void k_render_bwd_sparse(
+__global__ __launch_bounds__(64, 3) void k_render_bwd_sparse(
     int W, int H, int ED, int ch_base, int gx, const uint32_t* __restrict__ tile_offset,
     const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ box4, const float* __restrict__ rec,
     const float* __restrict__ tm_pre, const float* __restrict__ dE, const uint32_t* __restrict__ point_offsets,
@@ -735,8 +747,15 @@ __global__ __launch_bounds__(64) void k_render_bwd_sparse(
     __shared__ unsigned s_llast[SPARSE_LMAX];          // their last contributor
     __shared__ unsigned s_sample[SPARSE_LMAX];
     __shared__ __attribute__((aligned(16))) float s_ldE[SPARSE_LMAX * 32];
-    constexpr int SEG_SORT = SAMPLED ? 512 : 1;        // samples of a tile put in index order (fixed summation order)
-    __shared__ unsigned s_seg_in[SEG_SORT], s_seg[SEG_SORT];
+    constexpr int SEG_SORT = 512;                      // samples of a tile put in index order (fixed summation order)
+    // staging area: a chunk's records on their way in (64 x 80 B), then half a wave's finished rows on their way out
+    __shared__ __attribute__((aligned(16))) float s_rows[64 * 4 * SPARSE_REC_PITCH4];
+    static_assert(64 * 4 * SPARSE_REC_PITCH4 >= 32 * SPARSE_ROW_PITCH, "rows and records share the staging area");
+    __shared__ unsigned s_q[2 * SPARSE_QUEUE];         // pass-1 survivors of the tile's list: Gaussian id ...
+    int* const s_qid = reinterpret_cast<int*>(s_q);
+    unsigned* const s_qhk = s_q + SPARSE_QUEUE;        // ... and which live pixels it may touch
+    unsigned* const s_seg_in = s_q;                    // (the queue is empty whenever the samples are ranked)
+    static_assert(2 * SPARSE_QUEUE >= SEG_SORT, "the sample ranking borrows the queue");
 
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
@@ -756,28 +775,31 @@ __global__ __launch_bounds__(64) void k_render_bwd_sparse(
     unsigned mylast = 0u;
     if constexpr (SAMPLED) {
         __syncthreads();                                   // the previous group is done with the LDS lists
-        if ((g0 % SEG_SORT) == 0) {
-            // the fill kernel placed the tile's samples in the order of its atomics: rank-sort the next (up to) 512 of
-            // them by sample index, so that the groups and the order inside them do not depend on that race
-            const int nseg = min(SEG_SORT, ntotal - g0);
-            for (int e = lane; e < nseg; e += 64) s_seg_in[e] = seg_idx[seg0 + g0 + e];
+        {
+            // the fill kernel placed the tile's samples in the order of its atomics: rank the (up to) 512 of this block
+            // by sample index and take the 32 whose ranks are this group's, so that the groups and the order inside
+            // them do not depend on that race.  (Ranked again for every group: a tile with more than 32 samples is rare.)
+            const int blk0 = g0 - (g0 % SEG_SORT);
+            const int nseg = min(SEG_SORT, ntotal - blk0);
+            const uint32_t* recs = seg_idx + 3 * (size_t)(seg0 + blk0);
+            unsigned xy0 = 0u, last0 = 0u;                 // the rest of this lane's first record, fetched alongside
+            for (int e = lane; e < nseg; e += 64) s_seg_in[e] = recs[3 * e];
+            if (lane < nseg) { xy0 = recs[3 * lane + 1]; last0 = recs[3 * lane + 2]; }
             __syncthreads();
             for (int e = lane; e < nseg; e += 64) {
                 const unsigned mine = s_seg_in[e];
                 int rank = 0;
                 for (int j = 0; j < nseg; j++) rank += (s_seg_in[j] < mine) ? 1 : 0;
-                s_seg[rank] = mine;
+                rank -= g0 - blk0;
+                if (rank >= 0 && rank < nlive) {
+                    const unsigned xy = e == lane ? xy0 : recs[3 * e + 1];
+                    const unsigned last = e == lane ? last0 : recs[3 * e + 2];
+                    s_sample[rank] = mine;
+                    s_lxy[rank] = (int)xy;
+                    s_llast[rank] = last;
+                    mylast = max(mylast, last);
+                }
             }
-            __syncthreads();
-        }
-        if (lane < nlive) {
-            const unsigned mine = s_seg[(g0 % SEG_SORT) + lane];
-            const long long q = sample_pix[mine];
-            const int qx = (int)(q % W), qy = (int)(q / W);
-            mylast = n_contrib[q];
-            s_lxy[lane] = (qx - tx * TILE) | ((qy - ty * TILE) << 8);
-            s_llast[lane] = mylast;
-            s_sample[lane] = mine;
         }
     } else {
         if (lane < nlive) {
@@ -803,96 +825,194 @@ __global__ __launch_bounds__(64) void k_render_bwd_sparse(
     const int len_eff = min(len, (int)mylast);
     const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
     float Tvec = 1.0f;                 // lane k: running transmittance of live pixel k
-    // (id, cull box) of the NEXT chunk are fetched while the current one is evaluated: one memory round trip per
-    // chunk on the critical path of the walk instead of two
-    int id_n = 0;
-    unsigned bx_n = 0u;
-    if (lane < len_eff) { id_n = (int)point_list[r0 + lane]; bx_n = box4[r0 + lane]; }
-    for (int base = 0; base < len_eff; base += 64) {
-        const int idx = base + lane;
-        unsigned hk = 0u;              // bit k: this lane's splat may touch live pixel k
-        const int id = id_n;
-        const unsigned bx = bx_n;
-        if (idx + 64 < len_eff) { id_n = (int)point_list[r0 + idx + 64]; bx_n = box4[r0 + idx + 64]; }
-        if (idx < len_eff) {
-            const int xl = (int)(signed char)(bx & 255u), xh = (int)(signed char)((bx >> 8) & 255u);
-            const int yl = (int)(signed char)((bx >> 16) & 255u), yh = (int)(signed char)(bx >> 24);
-            for (int k = 0; k < nlive; k++) {
-                const int xy = s_lxy[k];
-                const int x = xy & 255, y = xy >> 8;
-                if (xl <= x && xh >= x && yl <= y && yh >= y && (unsigned)idx < s_llast[k]) hk |= 1u << k;
+    // The list is walked in two alternating passes.  Pass 1 only culls: (id, cull box) of 256 splats per round, coalesced
+    // and independent of anything computed, against the live pixels; the splats that may touch one are appended, in list
+    // order, to an LDS queue (id, hit mask).  Pass 2 takes 64 queued splats at a time - every lane has work - and does
+    // what needs the dependent loads (record, rectangle, row offset) and the product scan.  The tile's walk is the critical
+    // path of this kernel (one wave per tile), and with a handful of live pixels per tile 4 of 5 splats never reach pass 2.
+    int n_c = 0;                       // queued splats (uniform)
+    for (int base = 0; base < len_eff || n_c > 0;) {
+        while (base < len_eff && n_c <= SPARSE_QUEUE - SPARSE_ROUND) {
+            int idv[SPARSE_ROUND / 64];
+            unsigned bxv[SPARSE_ROUND / 64];
+#pragma unroll
+            for (int u = 0; u < SPARSE_ROUND / 64; u++) {
+                const int i = base + 64 * u + lane;
+                idv[u] = 0; bxv[u] = 0u;
+                if (i < len_eff) { idv[u] = (int)point_list[r0 + i]; bxv[u] = box4[r0 + i]; }
             }
+#pragma unroll
+            for (int u = 0; u < SPARSE_ROUND / 64; u++) {
+                const int i = base + 64 * u + lane;
+                unsigned hk = 0u;      // bit k: this lane's splat may touch live pixel k
+                if (i < len_eff) {
+                    const unsigned bx = bxv[u];
+                    const int xl = (int)(signed char)(bx & 255u), xh = (int)(signed char)((bx >> 8) & 255u);
+                    const int yl = (int)(signed char)((bx >> 16) & 255u), yh = (int)(signed char)(bx >> 24);
+                    for (int k = 0; k < nlive; k++) {
+                        const int xy = s_lxy[k];
+                        const int x = xy & 255, y = xy >> 8;
+                        if (xl <= x && xh >= x && yl <= y && yh >= y && (unsigned)i < s_llast[k]) hk |= 1u << k;
+                    }
+                }
+                const unsigned long long b = __ballot(hk != 0u);
+                if (hk != 0u) {
+                    const int pos = n_c + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+                    s_qid[pos] = idv[u];
+                    s_qhk[pos] = hk;
+                }
+                n_c += __popcll(b);
+            }
+            base += SPARSE_ROUND;
         }
-        if (__ballot(hk != 0u) == 0ull) continue;
-        F3 Tu = {0, 0, 0}, Tv = {0, 0, 0}, Tw = {0, 0, 1};
-        float cx = 0, cy = 0, opa = 0, skip = 0;
-        unsigned slot = 0, ordinal = 0;
-        if (hk != 0u) {
-            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
-            float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3];
-            if (tm_pre != nullptr) {
+        wave_lds_sync();
+        const bool drained = base >= len_eff;
+        int done = 0;
+        // one chunk of the queue is in flight while the previous one is evaluated
+        int id_n = 0;
+        unsigned hk_n = 0u, po_n = 0u;
+        // The 64-byte records are fetched four lanes to a record (piece lane & 3 of the records of queue entries
+        // 16 j + lane / 4): an instruction touches 16 cache lines instead of 64.  They are turned round through LDS when
+        // the chunk's turn comes.
+        float4 piece_n[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) piece_n[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        Rect16 rc_n = {0, 0, 0, 0};
+        auto fetch = [&](int at) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int e = at + 16 * j + (lane >> 2);
+                if (e < n_c)
+                    piece_n[j] = reinterpret_cast<const float4*>(rec + (size_t)s_qid[e] * REC)[lane & 3];
+            }
+            const int e = at + lane;
+            hk_n = 0u; id_n = 0;
+            if (e < n_c) { id_n = s_qid[e]; hk_n = s_qhk[e]; }
+            if (hk_n != 0u) {
+                rc_n = rects[id_n];
+                po_n = point_offsets[id_n];
+            }
+        };
+        auto ready = [&](int at) { return n_c - at >= 64 || (drained && at < n_c); };
+        if (ready(0)) fetch(0);
+        while (ready(done)) {
+            const int id = id_n;
+            const unsigned hk = hk_n, po = po_n;
+            const Rect16 rc = rc_n;
+            wave_lds_sync();                                   // the staging area is free (rows of the previous chunk are out)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                reinterpret_cast<float4*>(s_rows)[(16 * j + (lane >> 2)) * SPARSE_REC_PITCH4 + (lane & 3)] = piece_n[j];
+            wave_lds_sync();
+            float4 a, b, c, d;
+            {
+                const float4* mine = reinterpret_cast<const float4*>(s_rows) + lane * SPARSE_REC_PITCH4;
+                a = mine[0]; b = mine[1]; c = mine[2]; d = mine[3];
+            }
+            if (tm_pre != nullptr && hk != 0u) {               // precomputed transforms replace the first nine entries
                 const float* tp = tm_pre + 9 * (size_t)id;
                 a = make_float4(tp[0], tp[1], tp[2], tp[3]);
                 b = make_float4(tp[4], tp[5], tp[6], tp[7]);
                 c.x = tp[8];
             }
-            const Rect16 rc = rects[id];
-            ordinal = (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
-            slot = point_offsets[id] + ordinal;
-            Tu = {a.x, a.y, a.z}; Tv = {a.w, b.x, b.y}; Tw = {b.z, b.w, c.x};
-            cx = c.y; cy = c.z; opa = d.z;
-            skip = __builtin_inff();
-            if (opa <= 1.0f) {
-                const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
-                skip = 2.0f * l * 1.01f + 0.05f;
+            wave_lds_sync();
+            if (ready(done + 64)) fetch(done + 64);
+            done += 64;
+            F3 Tu = {0, 0, 0}, Tv = {0, 0, 0}, Tw = {0, 0, 1};
+            float cx = 0, cy = 0, opa = 0, skip = 0;
+            unsigned slot = 0, ordinal = 0;
+            if (hk != 0u) {
+                ordinal = (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
+                slot = po + ordinal;
+                Tu = {a.x, a.y, a.z}; Tv = {a.w, b.x, b.y}; Tw = {b.z, b.w, c.x};
+                cx = c.y; cy = c.z; opa = d.z;
+                skip = __builtin_inff();
+                if (opa <= 1.0f) {
+                    const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
+                    skip = 2.0f * l * 1.01f + 0.05f;
+                }
             }
-        }
-        float acc[32];
+            float acc[32];
 #pragma unroll
-        for (int c = 0; c < 32; c++) acc[c] = 0.0f;
-        bool wrote = false;
-        for (int k = 0; k < nlive; k++) {
-            if (__ballot((hk >> k) & 1u) == 0ull) continue;
-            const int xy = s_lxy[k];
-            float alpha = 0.0f;
-            if ((hk >> k) & 1u)
-                alpha = splat_alpha<Math>(Tu, Tv, Tw, cx, cy, opa, skip, tile_x0 + (float)(xy & 255), tile_y0 + (float)(xy >> 8));
-            if (__ballot(alpha != 0.0f) == 0ull) continue;
-            const float incl = wave_scan_mul(1.0f - alpha);
-            const float excl = dpp_fetch<0x138, 0xF>(incl, 1.0f);        // wave_shr:1
-            const float Tk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tvec), k));
-            const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
-            if (lane == k) Tvec = Tk * total;
-            const float w = alpha * (Tk * excl);
-            if (w != 0.0f) {
-                wrote = true;
-                const float4* e4 = reinterpret_cast<const float4*>(s_ldE + k * 32);
+            for (int c2 = 0; c2 < 32; c2++) acc[c2] = 0.0f;
+            bool wrote = false;
+            for (int k = 0; k < nlive; k++) {
+                if (__ballot((hk >> k) & 1u) == 0ull) continue;
+                const int xy = s_lxy[k];
+                float alpha = 0.0f;
+                if ((hk >> k) & 1u)
+                    alpha = splat_alpha<Math>(Tu, Tv, Tw, cx, cy, opa, skip, tile_x0 + (float)(xy & 255), tile_y0 + (float)(xy >> 8));
+                if (__ballot(alpha != 0.0f) == 0ull) continue;
+                const float incl = wave_scan_mul(1.0f - alpha);
+                const float excl = dpp_fetch<0x138, 0xF>(incl, 1.0f);        // wave_shr:1
+                const float Tk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tvec), k));
+                const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+                if (lane == k) Tvec = Tk * total;
+                const float w = alpha * (Tk * excl);
+                if (w != 0.0f) {
+                    wrote = true;
+                    const float4* e4 = reinterpret_cast<const float4*>(s_ldE + k * 32);
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const float4 v = e4[q];
-                    acc[4 * q + 0] = __builtin_fmaf(w, v.x, acc[4 * q + 0]);
-                    acc[4 * q + 1] = __builtin_fmaf(w, v.y, acc[4 * q + 1]);
-                    acc[4 * q + 2] = __builtin_fmaf(w, v.z, acc[4 * q + 2]);
-                    acc[4 * q + 3] = __builtin_fmaf(w, v.w, acc[4 * q + 3]);
+                    for (int q = 0; q < 8; q++) {
+                        const float4 v = e4[q];
+                        acc[4 * q + 0] = __builtin_fmaf(w, v.x, acc[4 * q + 0]);
+                        acc[4 * q + 1] = __builtin_fmaf(w, v.y, acc[4 * q + 1]);
+                        acc[4 * q + 2] = __builtin_fmaf(w, v.z, acc[4 * q + 2]);
+                        acc[4 * q + 3] = __builtin_fmaf(w, v.w, acc[4 * q + 3]);
+                    }
+                }
+            }
+            const unsigned long long wmask = __ballot(wrote);
+            if (wmask != 0ull) {
+                if (SAMPLED && g0 > 0 && wrote && row_flags[slot]) {   // an earlier group of this tile's samples reached the splat too
+                    const float4* o4 = reinterpret_cast<const float4*>(partial + (size_t)slot * row_stride + feat_off);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const float4 o = o4[q];
+                        acc[4 * q] += o.x; acc[4 * q + 1] += o.y; acc[4 * q + 2] += o.z; acc[4 * q + 3] += o.w;
+                    }
+                }
+                // The rows leave through LDS, half a wave at a time: a lane storing its own 128-byte row makes every store
+                // instruction touch 64 cache lines with 16 bytes each; turned round, 8 lanes write one row and an
+                // instruction touches 8 whole lines.  (Measured: the row stores were a quarter of this kernel.)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if (((wmask >> (32 * h)) & 0xffffffffull) == 0ull) continue;
+                    wave_lds_sync();
+                    if ((lane >> 5) == h && wrote) {
+                        float4* t4 = reinterpret_cast<float4*>(s_rows + (lane & 31) * SPARSE_ROW_PITCH);
+#pragma unroll
+                        for (int q = 0; q < 8; q++) t4[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                    }
+                    wave_lds_sync();
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int row = 8 * j + (lane >> 3), src = 32 * h + row;
+                        const unsigned to = (unsigned)__shfl((int)slot, src);
+                        if ((wmask >> src) & 1ull) {
+                            const float4 v = *reinterpret_cast<const float4*>(s_rows + row * SPARSE_ROW_PITCH + 4 * (lane & 7));
+                            *reinterpret_cast<float4*>(partial + (size_t)to * row_stride + feat_off + 4 * (lane & 7)) = v;
+                        }
+                    }
+                }
+                if (wrote) {
+                    row_flags[slot] = 1;
+                    // per-Gaussian summary of the flags (an OR: order-independent), so that the per-Gaussian pass finds the
+                    // rows of a Gaussian with one load instead of one per tile instance
+                    if (row_mask != nullptr) atomicOr(row_mask + id, 1ull << (ordinal < 63u ? ordinal : 63u));
                 }
             }
         }
-        if (wrote) {
-            float4* o4 = reinterpret_cast<float4*>(partial + (size_t)slot * row_stride + feat_off);
-            if (SAMPLED && g0 > 0 && row_flags[slot]) {      // an earlier group of this tile's samples reached the splat too
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const float4 o = o4[q];
-                    acc[4 * q] += o.x; acc[4 * q + 1] += o.y; acc[4 * q + 2] += o.z; acc[4 * q + 3] += o.w;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; q++) o4[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-            row_flags[slot] = 1;
-            // per-Gaussian summary of the flags (an OR: order-independent), so that the per-Gaussian pass finds the rows
-            // of a Gaussian with one load instead of one per tile instance
-            if (row_mask != nullptr) atomicOr(row_mask + id, 1ull << (ordinal < 63u ? ordinal : 63u));
-        }
+        // what is left (less than a chunk, unless the list is drained) moves to the front of the queue
+        const int rem = n_c - done;
+        int id_keep = 0;
+        unsigned hk_keep = 0u;
+        if (lane < rem) { id_keep = s_qid[done + lane]; hk_keep = s_qhk[done + lane]; }
+        wave_lds_sync();
+        if (lane < rem) { s_qid[lane] = id_keep; s_qhk[lane] = hk_keep; }
+        n_c = rem > 0 ? rem : 0;
+        wave_lds_sync();
     }
   }
 }
@@ -923,13 +1043,19 @@ __global__ __launch_bounds__(1024) void k_sample_scan(int T, const uint32_t* __r
 }
 __global__ __launch_bounds__(256) void k_sample_fill(int n, int W, int H, int gx, const long long* __restrict__ pix,
                                                      const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor,
-                                                     uint32_t* __restrict__ seg_idx) {
+                                                     const uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ seg_rec) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const long long q = pix[i];
     if (q < 0 || q >= (long long)W * H) return;
-    const int t = ((int)(q / W) / TILE) * gx + ((int)(q % W) / TILE);
-    seg_idx[off[t] + atomicAdd(cursor + t, 1u)] = (uint32_t)i;
+    const int qx = (int)(q % W), qy = (int)(q / W);
+    const int t = (qy / TILE) * gx + (qx / TILE);
+    // (sample, tile-relative pixel, last contributor): everything the tile's wave needs about the sample, so that it
+    // gets it with one load instead of three dependent ones
+    uint32_t* r = seg_rec + 3 * (size_t)(off[t] + atomicAdd(cursor + t, 1u));
+    r[0] = (uint32_t)i;
+    r[1] = (uint32_t)((qx % TILE) | ((qy % TILE) << 8));
+    r[2] = n_contrib[q];
 }
 // out[i, :] = map[:, pix[i]]  (the forward half of the sampled path)
 __global__ __launch_bounds__(256) void k_sample_gather(int n, int F, long long N, const float* __restrict__ map,
@@ -1423,10 +1549,10 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
 }
 
 // Feature gradient from SAMPLED pixels: scratch = rows + flags (as backward_scratch_bytes(R, ED, GRAD_EXTRA)) followed by
-// cnt[T], off[T+1], cursor[T], seg_idx[n] (u32).
+// cnt[T], off[T+1], cursor[T], seg_rec[3 n] (u32).
 size_t backward_sampled_scratch_bytes(int64_t R, int ED, int n, int W, int H) {
     const size_t T = (size_t)tiles_x(W) * tiles_y(H);
-    return backward_scratch_bytes(R, ED, 1u) + align_up((3 * T + 1 + (size_t)(n > 0 ? n : 1)) * sizeof(uint32_t), 256) + 256;
+    return backward_scratch_bytes(R, ED, 1u) + align_up((3 * T + 1 + 3 * (size_t)(n > 0 ? n : 1)) * sizeof(uint32_t), 256) + 256;
 }
 
 template <class Math>
@@ -1454,7 +1580,7 @@ static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int
         ProfScope ps_("k_render_bwd", s);
         hipLaunchKernelGGL(k_sample_count, dim3((n + 255) / 256), dim3(256), 0, s, n, W, H, gx, pix, cnt);
         hipLaunchKernelGGL(k_sample_scan, dim3(1), dim3(1024), 0, s, T, cnt, off, cursor);
-        hipLaunchKernelGGL(k_sample_fill, dim3((n + 255) / 256), dim3(256), 0, s, n, W, H, gx, pix, off, cursor, seg_idx);
+        hipLaunchKernelGGL(k_sample_fill, dim3((n + 255) / 256), dim3(256), 0, s, n, W, H, gx, pix, off, cursor, iv.n_contrib, seg_idx);
         for (int pass = 0, ch = 0; ch < ED; pass++, ch += 32)
             hipLaunchKernelGGL((k_render_bwd_sparse<Math, true>), dim3(T), dim3(64), 0, s, W, H, ED, ch, gx, iv.tile_offset,
                                bv.point_list, bv.box4, g.rec, tm_pre, (const float*)nullptr, g.point_offsets, g.rect, partial,
