@@ -477,6 +477,51 @@ __device__ __forceinline__ void bitonic_flip_sort(KeyPtr a, int n) {
         }
     }
 }
+// The same network for a bucket that lives in LDS - the common case, and instruction-bound: 30 passes of ~90 vector
+// instructions over 8160 tiles x 4 waves were 0.13 ms at 1080p.  Here the slots [n, npad) really hold +inf (the array has
+// room up to the next power of two), so no access is bounds-checked, and every index is shifts and masks of powers of two
+// instead of divisions by run-time values.
+__device__ __forceinline__ void sort_group4_lds(unsigned long long* a, int i0, int i1, int i2, int i3, bool flip_first) {
+    unsigned long long v0 = a[i0], v1 = a[i1], v2 = a[i2], v3 = a[i3];
+    if (flip_first) { ISR_CMPX(v0, v3); ISR_CMPX(v1, v2); ISR_CMPX(v0, v1); ISR_CMPX(v2, v3); }
+    else { ISR_CMPX(v0, v2); ISR_CMPX(v1, v3); ISR_CMPX(v0, v1); ISR_CMPX(v2, v3); }
+    a[i0] = v0; a[i1] = v1; a[i2] = v2; a[i3] = v3;
+}
+__device__ __forceinline__ void sort_pairs_lds(unsigned long long* a, int half) {
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        const unsigned long long x = a[2 * i], y = a[2 * i + 1];
+        if (y < x) { a[2 * i] = y; a[2 * i + 1] = x; }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void bitonic_flip_sort_lds(unsigned long long* a, int n) {
+    int lg = 0;
+    while ((1 << lg) < n) lg++;
+    const int npad = 1 << lg, half = npad >> 1, quarter = npad >> 2;
+    for (int i = n + threadIdx.x; i < npad; i += blockDim.x) a[i] = ~0ull;
+    __syncthreads();
+    for (int lk = 1; lk <= lg; lk++) {          // k = 1 << lk
+        if (lk == 1) { sort_pairs_lds(a, half); continue; }
+        {   // flip(k) + step(k/4)
+            const int lq = lk - 2, q = 1 << lq, k1 = (1 << lk) - 1;
+            for (int i = threadIdx.x; i < quarter; i += blockDim.x) {
+                const int o = i & (q - 1), base = (i >> lq) << lk;
+                sort_group4_lds(a, base + o, base + o + q, base + k1 - o - q, base + k1 - o, true);
+            }
+            __syncthreads();
+        }
+        int lj = lk - 3;                        // j = k / 8 = 1 << lj
+        for (; lj >= 1; lj -= 2) {              // step(j) + step(j/2)
+            const int j = 1 << lj, h = j >> 1, lh = lj - 1;
+            for (int i = threadIdx.x; i < quarter; i += blockDim.x) {
+                const int p = ((i >> lh) << (lj + 1)) + (i & (h - 1));
+                sort_group4_lds(a, p, p + h, p + j, p + j + h, false);
+            }
+            __syncthreads();
+        }
+        if (lj == 0) sort_pairs_lds(a, half);   // a single step(1) is left over
+    }
+}
 #undef ISR_CMPX
 
 __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ tile_offset, unsigned long long* keys,
@@ -491,8 +536,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
     unsigned long long* seg = keys + r0;
     if (n <= SORT_LDS_KEYS) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) s_keys[i] = seg[i];
-        __syncthreads();
-        bitonic_flip_sort(s_keys, n);
+        bitonic_flip_sort_lds(s_keys, n);         // (its first barrier also covers the loads above)
         for (int i = threadIdx.x; i < n; i += blockDim.x) point_list[r0 + i] = (uint32_t)s_keys[i];
     } else {
         // rare: bucket larger than the LDS budget — same network, in place in global memory
