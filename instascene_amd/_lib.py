@@ -93,6 +93,10 @@ def lib():
             raise RuntimeError(
                 f"instascene_amd: {LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+        # torch first: it brings its own copy of the HIP runtime (same SONAME), and a process must end up with ONE runtime.
+        # Loaded the other way round, the library binds /opt/rocm's copy and torch's kernels and ours no longer share
+        # streams and devices ("no ROCm-capable device is detected" from the second runtime).
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)        # AttributeError if the symbol is not exported: fail loudly

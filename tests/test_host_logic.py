@@ -24,6 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     from instascene_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
         _lib.build()
+    import torch  # noqa: F401  (one HIP runtime per process: torch's is loaded first, see _lib.lib)
     L = ctypes.CDLL(_lib.LIB_PATH)
     decl = _declared_symbols()
     assert len(decl) >= 15
