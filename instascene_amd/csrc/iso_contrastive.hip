@@ -623,7 +623,8 @@ __global__ __launch_bounds__(256) void rn2_kernel(long long N, int F, float eps1
     const bool ok = row < N && sub < q;
     const float4 z4 = make_float4(0, 0, 0, 0);
     const size_t off = (size_t)(row < N ? row : 0) * F + 4 * sub;
-    const float4 v = ok ? *reinterpret_cast<const float4*>(x + off) : z4;
+    float4 v = z4;                       // (`if`, not `ok ? *p : z4`: see k_feature_rows_step)
+    if (ok) v = *reinterpret_cast<const float4*>(x + off);
     float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     if (!BWD) {
         for (int o = lpr >> 1; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
@@ -637,8 +638,9 @@ __global__ __launch_bounds__(256) void rn2_kernel(long long N, int F, float eps1
             *reinterpret_cast<float4*>(out2 + off) = make_float4(y.x * r2, y.y * r2, y.z * r2, y.w * r2);
         }
     } else {
-        const float4 a = (ok && gy != nullptr) ? *reinterpret_cast<const float4*>(gy + off) : z4;
-        const float4 b = (ok && gz != nullptr) ? *reinterpret_cast<const float4*>(gz + off) : z4;
+        float4 a = z4, b = z4;
+        if (ok && gy != nullptr) a = *reinterpret_cast<const float4*>(gy + off);
+        if (ok && gz != nullptr) b = *reinterpret_cast<const float4*>(gz + off);
         float sa = v.x * a.x + v.y * a.y + v.z * a.z + v.w * a.w;      // <x, gy>
         float sb = v.x * b.x + v.y * b.y + v.z * b.z + v.w * b.w;      // <x, gz>
         for (int o = lpr >> 1; o >= 1; o >>= 1) {
@@ -806,7 +808,8 @@ __global__ __launch_bounds__(256) void gather_rownorm_kernel(int n, int F, long 
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) / lpr;
     const long long row = i < n ? idx[i] : -1;
     const bool ok = i < n && sub < q && row >= 0 && row < P;
-    const float4 v = ok ? *reinterpret_cast<const float4*>(x + (size_t)row * F + 4 * sub) : make_float4(0, 0, 0, 0);
+    float4 v = make_float4(0, 0, 0, 0);
+    if (ok) v = *reinterpret_cast<const float4*>(x + (size_t)row * F + 4 * sub);
     float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     for (int o = lpr >> 1; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
     const float r1 = 1.0f / (__builtin_sqrtf(ss) + eps);

@@ -1143,14 +1143,20 @@ __global__ __launch_bounds__(256) void k_feature_rows_step(
     const int c = 4 * sub;
     const size_t off = (size_t)(row < P ? row : 0) * F + c;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // the row's streams are requested first: they are in flight while the partial rows are chased (flag, then row)
-    const float4 xv = ok ? *reinterpret_cast<const float4*>(x + off) : z4;
-    float4 a = (ok && gy != nullptr) ? *reinterpret_cast<const float4*>(gy + off) : z4;
+    // the row's streams are requested first: they are in flight while the partial rows are chased (flag, then row).
+    // (Written as `if`, not `ok ? *p : z4`: on a class type such as float4 the conditional operator selects between two
+    // LVALUES - the compiler parks the zeros in scratch memory, picks an address and reads it with four flat dword loads;
+    // every lane then also WRITES 16 bytes of scratch, a whole extra [P,F] stream, which is how it was found: WRITE_SIZE
+    // showed five written streams for a kernel that stores four.)
+    float4 xv = z4, a = z4;
+    if (ok) xv = *reinterpret_cast<const float4*>(x + off);
+    if (ok && gy != nullptr) a = *reinterpret_cast<const float4*>(gy + off);
     const int gslot = (ok && gy_slot != nullptr) ? gy_slot[row] : -1;       // dL/dy as (row -> merged entry), iso_rows_compact
     float4 m4 = z4, v4 = z4;
     if (ADAM && ok) { m4 = *reinterpret_cast<const float4*>(m + off); v4 = *reinterpret_cast<const float4*>(v + off); }
     // (1) dL/dz row: flagged per-tile partial rows in row order (+ a dense contribution, if any)
-    const float4 bd = ok && gz_dense != nullptr ? *reinterpret_cast<const float4*>(gz_dense + off) : z4;
+    float4 bd = z4;
+    if (ok && gz_dense != nullptr) bd = *reinterpret_cast<const float4*>(gz_dense + off);
     float4 b = z4;
     if (ok && partial != nullptr) {
         // which of the Gaussian's tile instances hold a row: one 64-bit word (k_render_bwd_sparse) — two dependent memory
@@ -1169,8 +1175,10 @@ __global__ __launch_bounds__(256) void k_feature_rows_step(
                 }
                 float4 pv[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                    pv[u] = idx[u] >= 0 ? *reinterpret_cast<const float4*>(partial + (base + idx[u]) * row_stride + c) : z4;
+                for (int u = 0; u < 4; u++) {
+                    pv[u] = z4;
+                    if (idx[u] >= 0) pv[u] = *reinterpret_cast<const float4*>(partial + (base + idx[u]) * row_stride + c);
+                }
 #pragma unroll
                 for (int u = 0; u < 4; u++)
                     if (idx[u] >= 0) { b.x += pv[u].x; b.y += pv[u].y; b.z += pv[u].z; b.w += pv[u].w; }
