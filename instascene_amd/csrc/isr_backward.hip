@@ -570,10 +570,13 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
                     const int inst = e / Q4, q = e - inst * Q4;
                     if (!((hany >> inst) & 1u)) continue;
                     // a wave that culled the whole sub-batch never zeroed its block: treat it as zero
-                    const float4 v0 = (h0 != 0u) ? reinterpret_cast<const float4*>(P0 + inst * PART)[q] : z4;
-                    const float4 v1 = (h1 != 0u) ? reinterpret_cast<const float4*>(P1 + inst * PART)[q] : z4;
-                    const float4 v2 = (h2 != 0u) ? reinterpret_cast<const float4*>(P2 + inst * PART)[q] : z4;
-                    const float4 v3 = (h3 != 0u) ? reinterpret_cast<const float4*>(P3 + inst * PART)[q] : z4;
+                    // (`if`, not `h ? *p : z4`: on float4 the conditional operator picks an ADDRESS - LDS or a scratch copy of
+                    // the zeros - and the read becomes a flat load; see k_feature_rows_step)
+                    float4 v0 = z4, v1 = z4, v2 = z4, v3 = z4;
+                    if (h0 != 0u) v0 = reinterpret_cast<const float4*>(P0 + inst * PART)[q];
+                    if (h1 != 0u) v1 = reinterpret_cast<const float4*>(P1 + inst * PART)[q];
+                    if (h2 != 0u) v2 = reinterpret_cast<const float4*>(P2 + inst * PART)[q];
+                    if (h3 != 0u) v3 = reinterpret_cast<const float4*>(P3 + inst * PART)[q];
                     const float4 v = make_float4((v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y),
                                                  (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w));
                     int dst;
