@@ -55,7 +55,7 @@ static bool debug_sync() {
 
 template <class Math>
 static int launch_render_fwd(int tiles, hipStream_t s, int W, int H, int ED, int gx, const ImageView& iv,
-                             const BinView& bv, const float* rec, const float* col_pre, const float* tm_pre,
+                             const BinView& bv, const float* rec, const float* cull, const float* col_pre, const float* tm_pre,
                              const float* extras, const float* bg, float* out_color, float* out_others, float* out_extra,
                              int32_t* tracer, long long tcap, int32_t* tcount, int64_t capacity) {
     // first pass: geometry/colour/aux + the first feature chunk; further passes add 32 channels each
@@ -65,7 +65,7 @@ static int launch_render_fwd(int tiles, hipStream_t s, int W, int H, int ED, int
         const int rem = ED - ch;
 #define ISR_GO(F, B)                                                                                                 \
     hipLaunchKernelGGL((k_render_fwd<Math, F, B>), dim3(tiles), dim3(256), 0, s, W, H, ED, ch, first, gx,             \
-                       iv.tile_offset, bv.point_list, rec, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,    \
+                       iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,    \
                        out_color, out_others, out_extra, tracer, tcap, tcount, bv.box4, capacity)
         if (rem <= 0) ISR_GO(0, 256);
         else if (rem <= 8) ISR_GO(8, 256);
@@ -230,10 +230,10 @@ int isr_forward_render(int P, int ED, int width, int height, int mode, const flo
         if (rc != ISR_OK) return rc;
     }
     if (mode == ISR_MODE_EXACT)
-        return launch_render_fwd<ExactMath>(T, s, width, height, ED, gx, iv, bv, g.rec, colors_precomp, transMat_precomp,
+        return launch_render_fwd<ExactMath>(T, s, width, height, ED, gx, iv, bv, g.rec, g.cull, colors_precomp, transMat_precomp,
                                             extra_attrs, background, out_color, out_others, out_extra, tracer_pairs,
                                             (long long)tracer_capacity, tracer_count, binning_capacity);
-    return launch_render_fwd<FastMath>(T, s, width, height, ED, gx, iv, bv, g.rec, colors_precomp, transMat_precomp,
+    return launch_render_fwd<FastMath>(T, s, width, height, ED, gx, iv, bv, g.rec, g.cull, colors_precomp, transMat_precomp,
                                        extra_attrs, background, out_color, out_others, out_extra, tracer_pairs,
                                        (long long)tracer_capacity, tracer_count, binning_capacity);
 }

@@ -37,6 +37,7 @@ struct GeomView {          // carved from the caller's geometry workspace
     uint8_t* clamped;      // [P] bit mask (bit c set = channel c clamped)
     int* radii;            // [P] private copy (caller's radii may be freed before backward)
     uint32_t* scan_tmp;    // block sums for the scan
+    float* cull;           // [P,8] per-Gaussian cull bounds in pixels: box (x_lo, x_hi, y_lo, y_hi), then the same along x+y, x-y
     unsigned long long* row_mask;   // [P] sampled backward only: bit i = the Gaussian's i-th tile instance received a
                                     // partial row (bit 63 = an instance >= 63 did: consult the byte flags from there on)
 };
@@ -83,11 +84,12 @@ inline GeomView geom_view(void* buf, int P) {
     g.radii = carve<int>(p, P);
     g.scan_tmp = carve<uint32_t>(p, (size_t)(P / 1024 + 2) * 2);
     g.row_mask = carve<unsigned long long>(p, P);
+    g.cull = carve<float>(p, (size_t)P * 8);
     return g;
 }
 inline size_t geom_bytes(int P) {
     GeomView g = geom_view((void*)0, P);
-    return (size_t)(g.row_mask + P) + 256;
+    return (size_t)(g.cull + (size_t)P * 8) + 256;
 }
 inline ImageView image_view(void* buf, int W, int H) {
     char* p = (char*)buf;

@@ -192,18 +192,24 @@ __global__ __launch_bounds__(256) void k_preprocess(
         int x0, y0, x1, y1;
         tile_rect(cx, cy, sat_i32(radius), gx, gy, x0, y0, x1, y1);
         if ((unsigned)(x1 - x0) * (unsigned)(y1 - y0) == 0u) break;
+        // Bounds outside which alpha < 1/255 is certain, in pixels: a box and the same along the two diagonals.  They depend
+        // on the Gaussian only, so they are computed here, once, and every (tile, Gaussian) instance the blend kernel stages
+        // reads them (they used to be recomputed per instance and per feature pass: a division, three square roots and
+        // ~200 instructions each, by two of a workgroup's four waves while the other two waited at the barrier).
+        const float opa = opacities[i];
+        float skip = __builtin_inff();
+        if (opa <= 1.0f) {
+            const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
+            skip = 2.0f * l * 1.01f + 0.05f;
+        }
+        const float4 cb = splat_cull_box(Tu, Tv, Tw, cx, cy, skip);
+        reinterpret_cast<float4*>(g.cull + (size_t)i * 8)[0] = cb;
+        reinterpret_cast<float4*>(g.cull + (size_t)i * 8)[1] = splat_cull_diag(Tu, Tv, Tw, cx, cy, skip);
         if (tight_rects) {
-            // The reference bins a splat into the SQUARE of its larger 3-sigma extent.  Outside the box below
+            // The reference bins a splat into the SQUARE of its larger 3-sigma extent.  Outside the box above
             // alpha < 1/255 is certain (the blend loops skip such pairs anyway), so tiles the box does not reach are
             // dropped from the splat's rectangle: fewer instances to count, scatter, sort and stage.  `radii` is not
             // changed.  Not used in the EXACT mode, whose tile lists are the reference's bit for bit.
-            const float opa = opacities[i];
-            float skip = __builtin_inff();
-            if (opa <= 1.0f) {
-                const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
-                skip = 2.0f * l * 1.01f + 0.05f;
-            }
-            const float4 cb = splat_cull_box(Tu, Tv, Tw, cx, cy, skip);
             if (cb.x > -1e30f && cb.y < 1e30f && cb.z > -1e30f && cb.w < 1e30f) {
                 const int bx0 = (int)fmaxf(0.0f, __builtin_floorf(cb.x * (1.0f / TILE)));
                 const int bx1 = (int)fminf((float)gx, __builtin_floorf(cb.y * (1.0f / TILE)) + 1.0f);
@@ -553,9 +559,9 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
 template <class Math, int FCH, int BATCH>
 __global__ __launch_bounds__(256, 4) void k_render_fwd(
     int W, int H, int ED, int ch_base, int first_pass, int gx, const uint32_t* __restrict__ tile_offset,
-    const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ col_pre,
-    const float* __restrict__ tm_pre, const float* __restrict__ extras, const float* __restrict__ bg,
-    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+    const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ cull,
+    const float* __restrict__ col_pre, const float* __restrict__ tm_pre, const float* __restrict__ extras,
+    const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_others, float* __restrict__ out_extra, int32_t* __restrict__ tracer, long long tracer_cap,
     int32_t* __restrict__ tracer_count, uint32_t* __restrict__ box4, int64_t capacity) {
     constexpr int RS = 16;   // staged floats per instance: Tu Tv Tw cx cy nx ny nz opa skip = 16
@@ -660,9 +666,9 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
             s4[1] = b;                                      // Tv.yz Tw.xy
             s4[2] = make_float4(c.x, c.y, c.z, c.w);        // Tw.z cx cy nx
             s4[3] = make_float4(d.x, d.y, opa, skip);       // ny nz opa skip
-            const float4 cb = splat_cull_box(F3{a.x, a.y, a.z}, F3{a.w, b.x, b.y}, F3{b.z, b.w, c.x}, c.y, c.z, skip);
+            const float4 cb = reinterpret_cast<const float4*>(cull + (size_t)id * 8)[0];      // per-Gaussian bounds from K1
             s_box[t] = cb;
-            s_diag[t] = splat_cull_diag(F3{a.x, a.y, a.z}, F3{a.w, b.x, b.y}, F3{b.z, b.w, c.x}, c.y, c.z, skip);
+            s_diag[t] = reinterpret_cast<const float4*>(cull + (size_t)id * 8)[1];
             if (first_pass) box4[base + t] = pack_box4(cb, (float)(tx * TILE), (float)(ty * TILE));
             reinterpret_cast<float4*>(s_rgb)[t] = make_float4(d.w, e.x, e.y, 0.0f);
         }
@@ -859,7 +865,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
 // explicit instantiations used by the host API (isr_api.hip)
 #define ISR_INST_FWD(M, F, B)                                                                                          \
     template __global__ void k_render_fwd<M, F, B>(int, int, int, int, int, int, const uint32_t*, const uint32_t*,     \
-                                                   const float*, const float*, const float*, const float*,            \
+                                                   const float*, const float*, const float*, const float*, const float*, \
                                                    const float*, float*, uint32_t*, float*, float*, float*, int32_t*, \
                                                    long long, int32_t*, uint32_t*, int64_t);
 ISR_INST_FWD(ExactMath, 0, 256)
