@@ -55,6 +55,11 @@ int isr_version(void);
  * step instead of ~25: the timed region of bench.py), (0) stops; isr_profile_summary() synchronises and writes one
  * "kernel_name launches total_ms" line per kernel into buf (returns bytes written). */
 void isr_profile_enable(int on);
+/* Work counters of the forward blend kernel (bench.py's `roofline.valu`): the NEXT isr_forward_render call of this host
+ * thread in ISR_MODE_FAST also adds, into device_counters[0..3] (u64, device memory, zeroed by the caller): (wave, splat)
+ * cull tests, (wave, splat) pairs evaluated, pairs with at least one blending lane, and blending (pixel, splat) pairs.
+ * One extra atomic per wave; not meant for timed runs. */
+void isr_forward_set_counters(unsigned long long* device_counters);
 size_t isr_profile_summary(char* buf, size_t len);
 
 /* ---- workspace sizes (bytes); the layouts are opaque forward->backward hand-offs

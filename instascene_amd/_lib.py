@@ -24,6 +24,7 @@ SIGNATURES = {
     "isr_last_error": (c_char_p, []),
     "isr_version": (c_int, []),
     "isr_profile_enable": (None, [c_int]),
+    "isr_forward_set_counters": (None, [_P]),
     "isr_profile_summary": (c_size_t, [_P, c_size_t]),
     "isr_geom_bytes": (c_size_t, [c_int]),
     "isr_image_bytes": (c_size_t, [c_int, c_int]),

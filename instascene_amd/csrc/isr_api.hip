@@ -4,6 +4,7 @@
 // where the header says so.
 #include "isr_common.hpp"
 #include "isr_forward.hip"    // unity build: kernels are defined before the entry points
+#include "isr_forward_fast.hip"
 #include "isr_backward.hip"
 #include "iso_knn.hip"
 #include "iso_contrastive.hip"
@@ -53,6 +54,32 @@ static bool debug_sync() {
         if (e_ != hipSuccess) return fail(ISR_EHIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
+thread_local unsigned long long* g_fwd_counters = nullptr;    // isr_forward_set_counters: consumed by the next FAST forward
+
+// FAST arithmetic: k_render_fwd_fast (isr_forward_fast.hip), 32 feature channels per pass
+static int launch_render_fwd_fast(int tiles, hipStream_t s, int W, int H, int ED, int gx, const ImageView& iv,
+                                  const BinView& bv, const float* rec, const float* cull, const float* col_pre, const float* tm_pre,
+                                  const float* extras, const float* bg, float* out_color, float* out_others, float* out_extra,
+                                  int32_t* tracer, long long tcap, int32_t* tcount, int64_t capacity) {
+    unsigned long long* counters = g_fwd_counters;
+    g_fwd_counters = nullptr;
+    int ch = 0, first = 1;
+    do {
+        ProfScope ps_("k_render_fwd", s);
+#define ISR_GO(FEAT, STATS)                                                                                           \
+    hipLaunchKernelGGL((k_render_fwd_fast<FEAT, STATS>), dim3(tiles), dim3(256), 0, s, W, H, ED, ch, first, gx,        \
+                       iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,    \
+                       out_color, out_others, out_extra, tracer, tcap, tcount, bv.box4, capacity, counters)
+        if (ED - ch <= 0) { if (counters) ISR_GO(false, true); else ISR_GO(false, false); }
+        else { if (counters) ISR_GO(true, true); else ISR_GO(true, false); }
+#undef ISR_GO
+        ISR_LAUNCH_CHECK("k_render_fwd_fast");
+        ch += MAX_FCHUNK;
+        first = 0;
+    } while (ch < ED);
+    return ISR_OK;
+}
+
 template <class Math>
 static int launch_render_fwd(int tiles, hipStream_t s, int W, int H, int ED, int gx, const ImageView& iv,
                              const BinView& bv, const float* rec, const float* cull, const float* col_pre, const float* tm_pre,
@@ -87,6 +114,8 @@ extern "C" {
 
 const char* isr_last_error(void) { return g_err; }
 int isr_version(void) { return 1; }
+
+void isr_forward_set_counters(unsigned long long* device_counters) { g_fwd_counters = device_counters; }
 
 void isr_profile_enable(int on) {
     Prof& p = prof();
@@ -233,9 +262,9 @@ int isr_forward_render(int P, int ED, int width, int height, int mode, const flo
         return launch_render_fwd<ExactMath>(T, s, width, height, ED, gx, iv, bv, g.rec, g.cull, colors_precomp, transMat_precomp,
                                             extra_attrs, background, out_color, out_others, out_extra, tracer_pairs,
                                             (long long)tracer_capacity, tracer_count, binning_capacity);
-    return launch_render_fwd<FastMath>(T, s, width, height, ED, gx, iv, bv, g.rec, g.cull, colors_precomp, transMat_precomp,
-                                       extra_attrs, background, out_color, out_others, out_extra, tracer_pairs,
-                                       (long long)tracer_capacity, tracer_count, binning_capacity);
+    return launch_render_fwd_fast(T, s, width, height, ED, gx, iv, bv, g.rec, g.cull, colors_precomp, transMat_precomp,
+                                  extra_attrs, background, out_color, out_others, out_extra, tracer_pairs,
+                                  (long long)tracer_capacity, tracer_count, binning_capacity);
 }
 
 int isr_backward(int P, int D, int M, int64_t num_rendered, int ED, int width, int height, int mode, unsigned grad_mask,

@@ -872,9 +872,5 @@ ISR_INST_FWD(ExactMath, 0, 256)
 ISR_INST_FWD(ExactMath, 8, 256)
 ISR_INST_FWD(ExactMath, 16, 256)
 ISR_INST_FWD(ExactMath, 32, 128)
-ISR_INST_FWD(FastMath, 0, 256)
-ISR_INST_FWD(FastMath, 8, 256)
-ISR_INST_FWD(FastMath, 16, 256)
-ISR_INST_FWD(FastMath, 32, 128)
 
 }  // namespace isr

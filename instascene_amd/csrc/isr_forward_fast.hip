@@ -1,0 +1,311 @@
+// K8 in FAST arithmetic (reference forward.cu:256-462): the per-tile front-to-back blend re-derived for the CDNA4
+// issue ports instead of the reference's operation order.  The EXACT kernel (isr_forward.hip: k_render_fwd<ExactMath>)
+// keeps the reference's order op for op; this one keeps its DECISIONS (which splats a pixel blends, in which order,
+// where it stops) and its results to 1e-4, and spends as few vector and scalar instructions per (wave, splat) pair as
+// the algebra allows - the kernel is issue-bound, not memory-bound:
+//
+//   * The ray-splat intersection  p = (px Tw - Tu) x (py Tw - Tv)  is AFFINE in the pixel: the px*py term is Tw x Tw = 0,
+//     so  p = px (Tv x Tw) + py (Tw x Tu) + Tu x Tv.  The two cross products and p at the tile's origin are computed
+//     once per staged (tile, splat) instance; a pixel needs 6 FMAs with its tile-relative coordinates (0..15: no large
+//     pixel coordinate enters the per-pixel arithmetic) instead of 12 multiply-subtracts.
+//   * The depth of the intersection,  s.x Tw.x + s.y Tw.y + Tw.z  with  s = p.xy / p.z,  is  <p, Tw> / p.z,  and
+//     <p, Tw> = det(Tu, Tv, Tw) for every pixel (both cross products above are orthogonal to Tw): one multiply with
+//     the reciprocal that s needs anyway.  Its reciprocal (for the distortion term's  near / depth)  is  p.z / det:
+//     no second v_rcp_f32.
+//   * Lane predicates never live in vector registers or in compiler-managed exec-mask stacks: every test is a v_cmp
+//     that writes a 64-bit lane mask, masks are combined on the scalar unit, and the single predicated region per
+//     splat takes its exec mask from the combined mask (inverse ballot).
+//   * The feature channels accumulate on the matrix cores exactly as before (two splats per pair of
+//     v_mfma_f32_32x32x2_f32); chunks narrower than 32 channels are zero-padded in LDS instead of taking a vector path.
+#include "isr_common.hpp"
+
+namespace isr {
+
+constexpr int FF_BATCH = 128;       // instances staged per round
+constexpr int FF_RS = 24;           // staged floats per instance (six float4)
+// staged record:  q0 = A.xyz, cx - X0              A = Tv x Tw
+//                 q1 = B.xyz, cy - Y0              B = Tw x Tu
+//                 q2 = C.xyz, skip                C = p at the tile origin (X0, Y0); skip: alpha < 1/255 for rho > skip
+//                 q3 = det, Tw.z, opacity, 1/det
+//                 q4 = 1/Tw.z, normal.xyz
+//                 q5 = rgb, unused
+
+template <bool FEAT, bool STATS>
+__global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
+    int W, int H, int ED, int ch_base, int first_pass, int gx, const uint32_t* __restrict__ tile_offset,
+    const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ cull,
+    const float* __restrict__ col_pre, const float* __restrict__ tm_pre, const float* __restrict__ extras,
+    const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+    float* __restrict__ out_others, float* __restrict__ out_extra, int32_t* __restrict__ tracer, long long tracer_cap,
+    int32_t* __restrict__ tracer_count, uint32_t* __restrict__ box4, int64_t capacity, unsigned long long* __restrict__ stats) {
+    constexpr int BATCH = FF_BATCH, RS = FF_RS, FCH = 32;
+    __shared__ __attribute__((aligned(16))) float s_rec[BATCH * RS];
+    __shared__ __attribute__((aligned(16))) float s_feat[FEAT ? BATCH * FCH : 4];
+    __shared__ int s_id[BATCH];
+    __shared__ __attribute__((aligned(16))) float4 s_box[BATCH];
+    __shared__ __attribute__((aligned(16))) float4 s_diag[BATCH];
+    constexpr int WCAP = 128;               // tracer pairs per wave region (see k_render_fwd)
+    __shared__ int s_trace[4 * 2 * WCAP];
+    int wcnt = 0;
+
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lxi = (wv & 1) * 8 + (lane & 7), lyi = (wv >> 1) * 8 + (lane >> 3);       // tile-relative pixel
+    const unsigned px = tx * TILE + lxi, py = ty * TILE + lyi;
+    const bool inside = px < (unsigned)W && py < (unsigned)H;
+    const size_t N = (size_t)W * H;
+    const size_t pix = (size_t)W * py + px;
+    const float lx = (float)lxi, ly = (float)lyi;
+    const float X0 = (float)(tx * TILE), Y0 = (float)(ty * TILE);
+
+    const int64_t r0 = tile_offset[tile];
+    int64_t r1 = tile_offset[tile + 1];
+    if (r1 > capacity) r1 = capacity;
+    const int nfeat = FEAT ? min(FCH, ED - ch_base) : 0;
+
+    unsigned long long m_done = __ballot(!inside);      // lanes that have stopped (or lie outside the image)
+    float T = 1.0f;
+    unsigned last_contributor = 0, median_contributor = 0;
+    float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, D = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
+    f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
+    float w_pend = 0.0f, f_pend = 0.0f;
+    bool pending = false;                    // wave-uniform
+    unsigned st_cull = 0, st_eval = 0, st_blend = 0, st_lanes = 0;      // STATS only
+    const float mscale = FAR_N / (FAR_N - NEAR_N);
+    const float bx0 = X0 + (float)((wv & 1) * 8), bx1 = bx0 + 7.0f;
+    const float by0 = Y0 + (float)((wv >> 1) * 8), by1 = by0 + 7.0f;
+
+    auto flush_trace = [&]() {
+        const int n = wcnt;
+        if (n > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int gb = 0;
+            if (lane == 0) gb = atomicAdd(tracer_count, n) + 1;        // counter starts at -1
+            gb = __builtin_amdgcn_readfirstlane(gb);
+            const int* src = s_trace + wv * 2 * WCAP;
+            for (int e = lane; e < n; e += 64)
+                if (gb + e < tracer_cap)
+                    *reinterpret_cast<int2*>(tracer + 2 * (size_t)(gb + e)) = make_int2(src[2 * e], src[2 * e + 1]);
+            __builtin_amdgcn_wave_barrier();
+            wcnt = 0;
+        }
+    };
+
+    const int my_inst = threadIdx.x & (BATCH - 1);
+    int nid = (threadIdx.x < BATCH && r0 + my_inst < r1) ? (int)point_list[r0 + my_inst] : 0;
+    for (int64_t base = r0; base < r1; base += BATCH) {
+        if (__syncthreads_and(m_done == ~0ull)) break;
+        const int nb = (int)min((int64_t)BATCH, r1 - base);
+        const int id = nid;
+        if (threadIdx.x < BATCH && base + BATCH + my_inst < r1) nid = (int)point_list[base + BATCH + my_inst];
+        if (threadIdx.x < nb) {
+            const int t = threadIdx.x;
+            s_id[t] = id;
+            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
+            float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3], e = r4[4];
+            if (tm_pre != nullptr) {
+                const float* tp = tm_pre + 9 * (size_t)id;
+                a = make_float4(tp[0], tp[1], tp[2], tp[3]);
+                b = make_float4(tp[4], tp[5], tp[6], tp[7]);
+                c.x = tp[8];
+            }
+            if (col_pre != nullptr) {
+                d.w = col_pre[3 * (size_t)id]; e.x = col_pre[3 * (size_t)id + 1]; e.y = col_pre[3 * (size_t)id + 2];
+            }
+            const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y}, Tw = {b.z, b.w, c.x};
+            const float opa = d.z;
+            float skip = __builtin_inff();      // opa * exp(-rho/2) < 1/255 for every rho > skip (1 % + 0.05 margin)
+            if (opa <= 1.0f) {
+                const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
+                skip = 2.0f * l * 1.01f + 0.05f;
+            }
+            // p(px, py) = (px - X0) A + (py - Y0) B + C,  C = (X0 Tw - Tu) x (Y0 Tw - Tv)
+            const F3 A = {__builtin_fmaf(Tv.y, Tw.z, -(Tv.z * Tw.y)), __builtin_fmaf(Tv.z, Tw.x, -(Tv.x * Tw.z)),
+                          __builtin_fmaf(Tv.x, Tw.y, -(Tv.y * Tw.x))};
+            const F3 B = {__builtin_fmaf(Tw.y, Tu.z, -(Tw.z * Tu.y)), __builtin_fmaf(Tw.z, Tu.x, -(Tw.x * Tu.z)),
+                          __builtin_fmaf(Tw.x, Tu.y, -(Tw.y * Tu.x))};
+            const F3 k0 = {__builtin_fmaf(X0, Tw.x, -Tu.x), __builtin_fmaf(X0, Tw.y, -Tu.y), __builtin_fmaf(X0, Tw.z, -Tu.z)};
+            const F3 l0 = {__builtin_fmaf(Y0, Tw.x, -Tv.x), __builtin_fmaf(Y0, Tw.y, -Tv.y), __builtin_fmaf(Y0, Tw.z, -Tv.z)};
+            const F3 C = {__builtin_fmaf(k0.y, l0.z, -(k0.z * l0.y)), __builtin_fmaf(k0.z, l0.x, -(k0.x * l0.z)),
+                          __builtin_fmaf(k0.x, l0.y, -(k0.y * l0.x))};
+            const float det = __builtin_fmaf(C.x, Tw.x, __builtin_fmaf(C.y, Tw.y, C.z * Tw.z));
+            float4* s4 = reinterpret_cast<float4*>(s_rec + t * RS);
+            s4[0] = make_float4(A.x, A.y, A.z, c.y - X0);
+            s4[1] = make_float4(B.x, B.y, B.z, c.z - Y0);
+            s4[2] = make_float4(C.x, C.y, C.z, skip);
+            s4[3] = make_float4(det, Tw.z, opa, __builtin_amdgcn_rcpf(det));
+            s4[4] = make_float4(__builtin_amdgcn_rcpf(Tw.z), c.w, d.x, d.y);
+            s4[5] = make_float4(d.w, e.x, e.y, 0.0f);
+            const float4 cb = reinterpret_cast<const float4*>(cull + (size_t)id * 8)[0];      // per-Gaussian bounds from K1
+            s_box[t] = cb;
+            s_diag[t] = reinterpret_cast<const float4*>(cull + (size_t)id * 8)[1];
+            if (first_pass) box4[base + t] = pack_box4(cb, X0, Y0);
+        }
+        __syncthreads();
+        if (FEAT) {
+            if ((ED & 3) == 0 && nfeat == FCH) {
+                for (int e = threadIdx.x; e < nb * (FCH / 4); e += 256) {
+                    const int inst = e / (FCH / 4), part = e - inst * (FCH / 4);
+                    reinterpret_cast<float4*>(s_feat)[e] =
+                        *reinterpret_cast<const float4*>(extras + (size_t)s_id[inst] * ED + ch_base + part * 4);
+                }
+            } else {                    // narrow or ragged chunk: zero-padded to 32 channels
+                for (int e = threadIdx.x; e < nb * FCH; e += 256) {
+                    const int inst = e / FCH, c = e - inst * FCH;
+                    s_feat[e] = c < nfeat ? extras[(size_t)s_id[inst] * ED + ch_base + c] : 0.0f;
+                }
+            }
+            __syncthreads();
+        }
+        const unsigned cbase = (unsigned)(base - r0) + 1u;
+        // ---- walk the batch: each wave visits only the splats whose cull bounds meet its 8x8 pixel block
+        for (int c0 = 0; c0 < nb; c0 += 64) {
+            const int jj = c0 + lane;
+            bool hit = false;
+            if (jj < nb) {
+                const float4 bb = s_box[jj], dg = s_diag[jj];
+                hit = !(bb.x > bx1) && !(bb.y < bx0) && !(bb.z > by1) && !(bb.w < by0) &&
+                      !(dg.x > bx1 + by1) && !(dg.y < bx0 + by0) && !(dg.z > bx1 - by0) && !(dg.w < bx0 - by1);
+            }
+            unsigned long long m = __ballot(hit);
+            if (STATS) st_cull += (unsigned)min(64, nb - c0);
+            while (m != 0ull) {
+                if (m_done == ~0ull) break;
+                const int j = c0 + __builtin_ctzll(m);
+                m &= m - 1ull;
+                if (STATS) st_eval++;
+                const float4* q = reinterpret_cast<const float4*>(s_rec + j * RS);
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+                const float p_x = __builtin_fmaf(lx, q0.x, __builtin_fmaf(ly, q1.x, q2.x));
+                const float p_y = __builtin_fmaf(lx, q0.y, __builtin_fmaf(ly, q1.y, q2.y));
+                const float p_z = __builtin_fmaf(lx, q0.z, __builtin_fmaf(ly, q1.z, q2.z));
+                const float dx = q0.w - lx, dy = q1.w - ly;
+                const float hh = __builtin_fmaf(dy, dy, dx * dx);
+                const float rho2d = hh + hh;                                  // FilterInvSquare = 2
+                const float rz = __builtin_amdgcn_rcpf(p_z);
+                const float sx = p_x * rz, sy = p_y * rz;
+                const float rho3d = __builtin_fmaf(sy, sy, sx * sx);
+                const float rho = fminf(rho3d, rho2d);
+                // beyond `skip` alpha < 1/255 is certain: when that holds for the whole wave nothing else is needed
+                const unsigned long long m_near = __ballot(rho <= q2.w) & __ballot(p_z != 0.0f) & ~m_done;
+                if (m_near == 0ull) continue;
+                const float4 q3 = q[3];
+                const bool use3d = rho3d <= rho2d;
+                const float depth = use3d ? q3.x * rz : q3.y;
+                const float alpha = fminf(0.99f, q3.z * __builtin_amdgcn_exp2f(rho * -0.72134752f));
+                const float test_T = __builtin_fmaf(-T, alpha, T);
+                const unsigned long long m_pass = m_near & __ballot(!(depth < NEAR_N)) & __ballot(!(alpha < 1.0f / 255.0f));
+                const unsigned long long m_stop = m_pass & __ballot(test_T < 0.0001f);
+                m_done |= m_stop;
+                const unsigned long long m_ok = m_pass & ~m_stop;
+                if (m_ok == 0ull) continue;
+                if (STATS) { st_blend++; st_lanes += (unsigned)__popcll(m_ok); }
+                float w_lane = 0.0f;
+                if (__builtin_amdgcn_inverse_ballot_w64(m_ok)) {
+                    const float w = alpha * T;
+                    w_lane = w;
+                    const unsigned contributor = cbase + (unsigned)j;
+                    if (first_pass) {
+                        const float4 q4 = q[4], q5 = q[5];
+                        const float inv_depth = use3d ? p_z * q3.w : q4.x;
+                        const float m_ = __builtin_fmaf(-(mscale * NEAR_N), inv_depth, mscale);
+                        const float mm = m_ * m_;
+                        const float A_ = 1.0f - T;
+                        const float t2 = __builtin_fmaf(-2.0f * m_, M1, __builtin_fmaf(mm, A_, M2));
+                        distortion = __builtin_fmaf(t2, w, distortion);
+                        D = __builtin_fmaf(depth, w, D);
+                        M1 = __builtin_fmaf(m_, w, M1);
+                        M2 = __builtin_fmaf(mm, w, M2);
+                        if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }
+                        N0 = __builtin_fmaf(q4.y, w, N0); N1 = __builtin_fmaf(q4.z, w, N1); N2 = __builtin_fmaf(q4.w, w, N2);
+                        C0 = __builtin_fmaf(q5.x, w, C0); C1 = __builtin_fmaf(q5.y, w, C1); C2 = __builtin_fmaf(q5.z, w, C2);
+                    }
+                    T = test_T;
+                    last_contributor = contributor;
+                }
+                if (tracer != nullptr && first_pass) {
+                    const unsigned long long m_tr = __ballot(w_lane >= 0.1f);     // (double)w > 0.1  <=>  w >= 0.1f
+                    if (m_tr != 0ull) {
+                        if (w_lane >= 0.1f) {
+                            const int slot = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_tr >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((unsigned)m_tr, 0u));
+                            int* dst = s_trace + wv * 2 * WCAP + 2 * slot;
+                            dst[0] = s_id[j];
+                            dst[1] = (int)pix;
+                        }
+                        wcnt += __popcll(m_tr);
+                        if (wcnt > WCAP - 64) flush_trace();
+                    }
+                }
+                if constexpr (FEAT) {
+                    // A[i = channel][k = splat]: lanes 0..31 carry the pending splat's channels, 32..63 this splat's;
+                    // B[k = splat][j = pixel]: v_permlane32_swap puts the two splats' weights of one half of the pixels
+                    // into the two halves of the wave.
+                    const float f_lane = s_feat[j * FCH + (lane & 31)];
+                    if (!pending) { w_pend = w_lane; f_pend = f_lane; pending = true; }
+                    else {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(w_pend), __float_as_uint(w_lane), false, false);
+                        const float a = lane < 32 ? f_pend : f_lane;
+                        accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[0]), accA, 0, 0, 0);
+                        accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[1]), accB, 0, 0, 0);
+                        pending = false;
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (FEAT) {
+        if (pending) {          // odd number of contributing splats: pair the last one with a zero
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(w_pend), 0u, false, false);
+            const float a = lane < 32 ? f_pend : 0.0f;
+            accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[0]), accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[1]), accB, 0, 0, 0);
+        }
+    }
+    if (tracer != nullptr && first_pass) flush_trace();
+    if (STATS) {
+        if (lane == 0 && first_pass) {
+            atomicAdd(stats + 0, (unsigned long long)st_cull);
+            atomicAdd(stats + 1, (unsigned long long)st_eval);
+            atomicAdd(stats + 2, (unsigned long long)st_blend);
+            atomicAdd(stats + 3, (unsigned long long)st_lanes);
+        }
+    }
+    if (inside && first_pass) {
+        final_T[pix] = T;
+        final_T[pix + N] = M1;
+        final_T[pix + 2 * N] = M2;
+        n_contrib[pix] = last_contributor;
+        n_contrib[pix + N] = median_contributor;
+        out_color[pix] = __builtin_fmaf(T, bg[0], C0);
+        out_color[N + pix] = __builtin_fmaf(T, bg[1], C1);
+        out_color[2 * N + pix] = __builtin_fmaf(T, bg[2], C2);
+        out_others[pix] = D;
+        out_others[N + pix] = 1 - T;
+        out_others[2 * N + pix] = N0;
+        out_others[3 * N + pix] = N1;
+        out_others[4 * N + pix] = N2;
+        out_others[5 * N + pix] = median_depth;
+        out_others[6 * N + pix] = distortion;
+    }
+    if constexpr (FEAT) {
+        // D[row = channel (r&3) + 8*(r>>2) + 4*(lane>>5)][col = pixel lane&31 of the group]
+#pragma unroll
+        for (int grp = 0; grp < 2; grp++) {
+            const int p = grp * 32 + (lane & 31);                       // pixel (wave lane numbering) held by this lane
+            const unsigned qx = tx * TILE + (wv & 1) * 8 + (p & 7), qy = ty * TILE + (wv >> 1) * 8 + (p >> 3);
+            if (qx < (unsigned)W && qy < (unsigned)H) {
+                const size_t qp = (size_t)W * qy + qx;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int ch = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (ch < nfeat) out_extra[(size_t)(ch_base + ch) * N + qp] = grp == 0 ? accA[r] : accB[r];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace isr

@@ -36,6 +36,22 @@ class PipelineParams:
     debug = False
 
 
+def splat_to_world(xyz, scaling, scaling_modifier, rotation):
+    """``GaussianModel.get_covariance`` (scene/gaussian_model.py:35-42,137-138): the 4x4 splat->world matrix of every
+    surfel in row-vector storage - rows = the two scaled tangent axes, the normal, the centre; the quaternion (w,x,y,z) is
+    normalised here like ``build_rotation`` does.  Only ``pipe.compute_cov3D_python`` reads it (render._precomputed_transforms)."""
+    from .densify import rotation_matrices
+    R = rotation_matrices(rotation)                              # [P,3,3], columns = local axes
+    s = scaling * scaling_modifier
+    out = xyz.new_zeros((xyz.shape[0], 4, 4))
+    out[:, 0, :3] = R[:, :, 0] * s[:, 0:1]
+    out[:, 1, :3] = R[:, :, 1] * s[:, 1:2]
+    out[:, 2, :3] = R[:, :, 2]
+    out[:, 3, :3] = xyz
+    out[:, 3, 3] = 1.0
+    return out
+
+
 class SegGaussianModel:
     """The subset of the reference ``GaussianModel`` that ``render()`` and the loop touch
     (getters scene/gaussian_model.py:109-138; ``_seg_feature`` is the only trainable tensor)."""
@@ -57,6 +73,9 @@ class SegGaussianModel:
         self._act_cache = {}
 
     get_xyz = property(lambda s: s._xyz)
+
+    def get_covariance(self, scaling_modifier=1):
+        return splat_to_world(self.get_xyz, self.get_scaling, scaling_modifier, self._rotation)
 
     def _frozen(self, name, src, fn):
         """Activation of a frozen parameter: loop-invariant in this stage, evaluated once (the reference re-runs
@@ -135,7 +154,7 @@ class SegTrainer:
             g = torch.Generator().manual_seed(seed + 17)
             class_feat = gram_schmidt(torch.rand(n_labels + 1, F, generator=g)).to(self.device)
         self.model = SegGaussianModel(scene, self.device, class_feat)
-        self.labels3d = scene.labels3d.to(self.device)
+        self.labels3d = scene.labels3d.to(self.device).to(torch.int64).contiguous()     # iso_sample_step reads int64
         self.cams = [c.to(self.device) for c in cameras]
         self.pipe = PipelineParams()
         self.bg = torch.zeros(3, dtype=torch.float32, device=self.device)
@@ -173,6 +192,12 @@ class SegTrainer:
             if c.segmap is None:
                 c.segmap = scenes.voronoi_labels(c.image_width, c.image_height, n_labels, 5000 + i, device=self.device)
                 c.sorted_segmap = c.segmap
+            # caller-supplied label maps come from image files (uint8 / int32, possibly strided views): the sampling kernel
+            # (iso_sample_step) and the loss read contiguous int64
+            same = c.sorted_segmap is c.segmap
+            c.segmap = c.segmap.to(self.device).to(torch.int64).contiguous()
+            c.sorted_segmap = c.segmap if (same or c.sorted_segmap is None) else \
+                c.sorted_segmap.to(self.device).to(torch.int64).contiguous()
             self.valid_idx[i] = torch.nonzero(c.segmap.reshape(-1) > 0).reshape(-1)
 
     def features_in_input_order(self) -> torch.Tensor:
@@ -264,6 +289,17 @@ class SegTrainer:
         return view_for(it, self.rank, self.world, len(self.cams))
 
     def step(self, it: int):
+        from .rasterizer import BinningOverflow
+        try:
+            return self._step_once(it)
+        except BinningOverflow:
+            # the view needed more tile instances than its estimate allowed (async binning): the library has corrected the
+            # estimate; nothing of this iteration has reached the parameters yet (the check precedes the backward kernels)
+            self.opt.zero_grad(set_to_none=True)
+            self.model._seg_cache = None
+            return self._step_once(it)
+
+    def _step_once(self, it: int):
         if not self.fused_tail:
             return self._step(it)
         # inside the step the normalised feature is a pair of autograd LEAVES (FeatureAdam.leaf_mode); outside it the
@@ -435,6 +471,9 @@ class RgbGaussianModel:
     get_opacity = property(lambda s: torch.sigmoid(s._opacity))
     get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
     get_seg_feature = property(lambda s: None)
+
+    def get_covariance(self, scaling_modifier=1):
+        return splat_to_world(self.get_xyz, self.get_scaling, scaling_modifier, self._rotation)
 
     def param_groups(self):
         return [{"params": [self._xyz], "lr": 0.00016, "name": "xyz"},

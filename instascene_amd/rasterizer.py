@@ -23,9 +23,16 @@ import torch.nn as nn
 from . import _lib
 from ._lib import GRAD_EXTRA, GRAD_GEOMETRY, MODE_EXACT, MODE_FAST, MODE_PREBINNED, check, lib
 
+_ENV_MODE = os.environ.get("ISR_MODE", "exact").lower()
 _CONFIG = {
-    # arithmetic mode of the per-pixel loops: "exact" (bit-identical to the CPU oracle) or "fast"
-    "mode": MODE_FAST if os.environ.get("ISR_MODE", "exact").lower() == "fast" else MODE_EXACT,
+    # arithmetic mode of the per-pixel loops: "exact" (bit-identical to the CPU oracle) or "fast" (contracted FMAs,
+    # v_rcp / v_exp).  Both keep the reference's tile rectangles, so radii, tiles_touched, point_list and ranges are
+    # bit-identical to the reference's in either mode.
+    "mode": MODE_FAST if _ENV_MODE in ("fast", "fast_tight") else MODE_EXACT,
+    # opt-in on top of "fast" (mode name "fast_tight", or ISR_TIGHT_RECTS=1): bin a splat only into the tiles its
+    # alpha >= 1/255 bound reaches (ISR_PREPARE_TIGHT_RECTS).  Tile lists are then order-preserving SUBSEQUENCES of the
+    # reference's - same images, but not the reference's point_list / ranges.
+    "tight_rects": _ENV_MODE == "fast_tight" or os.environ.get("ISR_TIGHT_RECTS", "0") == "1",
     # produce the (gaussian, pixel) tracer list like the reference does on every forward
     "tracer": os.environ.get("ISR_TRACER", "1") != "0",
     # size the binning workspace from the previous view's instance count (+25 %) instead of a blocking
@@ -34,19 +41,23 @@ _CONFIG = {
     "async_binning": os.environ.get("ISR_ASYNC_BINNING", "0") == "1",
 }
 _ASYNC_GROWTH, _ASYNC_SLACK = 1.25, 65536
-_R_ESTIMATE = {}      # (device, P, W, H) -> last verified instance count
-_PENDING = {}         # (device, P, W, H) -> (pinned int64 tensor, event, capacity, address of the geometry buffer)
+_R_ESTIMATE = {}      # (device, P, W, H, tight, view matrices' storage) -> verified instance count of THAT view
+_PENDING = {}         # address of a forward's geometry buffer -> (pinned int64 tensor, event, capacity, estimate key)
 
 
 LAST_NUM_RENDERED = 0   # instance count of the most recent forward (reporting only)
 
 
 def set_mode(mode: str):
-    _CONFIG["mode"] = {"exact": MODE_EXACT, "fast": MODE_FAST}[mode]
+    """"exact" | "fast" | "fast_tight" (see _CONFIG)."""
+    _CONFIG["mode"] = {"exact": MODE_EXACT, "fast": MODE_FAST, "fast_tight": MODE_FAST}[mode]
+    _CONFIG["tight_rects"] = mode == "fast_tight"
 
 
 def get_mode() -> str:
-    return "fast" if _CONFIG["mode"] == MODE_FAST else "exact"
+    if _CONFIG["mode"] != MODE_FAST:
+        return "exact"
+    return "fast_tight" if _CONFIG["tight_rects"] else "fast"
 
 
 def set_tracer(enabled: bool):
@@ -59,10 +70,10 @@ def set_async_binning(enabled: bool):
 
 class _ViewState:
     """Geometry pass + binning of one view, kept for the next render of the same view with the same inputs."""
-    __slots__ = ("radii", "geom", "img", "R", "binning", "nbytes", "busy", "__weakref__")
+    __slots__ = ("radii", "geom", "img", "R", "binning", "nbytes", "busy", "refs", "__weakref__")
 
-    def __init__(self, radii, geom, img, R, binning):
-        self.radii, self.geom, self.img, self.R, self.binning = radii, geom, img, R, binning
+    def __init__(self, radii, geom, img, R, binning, refs=()):
+        self.radii, self.geom, self.img, self.R, self.binning, self.refs = radii, geom, img, R, binning, refs
         self.nbytes = sum(t.numel() * t.element_size() for t in (radii, geom, img, binning))
         self.busy = 0           # forwards whose backward has not run yet: they still need this img / binning state
 
@@ -98,28 +109,51 @@ def _view_cache_put(sig, state):
 
 
 class BinningOverflow(RuntimeError):
-    pass
+    """A forward that sized its binning workspace from an estimate turned out to need more: its outputs are truncated.
+    The estimate of that view has been corrected; re-run the forward (``SegTrainer.step`` does)."""
 
 
-def _verify_pending(key, owner=None):
-    """Check an asynchronously read instance count against the capacity that forward ran with.  ``owner``: the geometry
-    buffer of the forward the caller is about to differentiate — a pending count that belongs to ANOTHER geometry pass
-    (the next view's, issued ahead on a side stream) is left alone instead of being waited for."""
-    pend = _PENDING.get(key)
-    if pend is None:
-        return
-    if owner is not None and pend[3] != owner:
-        return
-    del _PENDING[key]
-    pinned, event, capacity = pend[:3]
+def _view_id(viewmatrix, projmatrix):
+    """Identity of a camera for the size estimate: the storage of its two matrices (cameras are long-lived objects)."""
+    return (viewmatrix.data_ptr() if viewmatrix is not None else 0, projmatrix.data_ptr() if projmatrix is not None else 0)
+
+
+def _verify_entry(owner, pend):
+    pinned, event, capacity, ekey = pend
     event.synchronize()
     R = int(pinned.item())
-    _R_ESTIMATE[key] = R
+    _R_ESTIMATE[ekey] = R                 # the true count of THIS view: the next capacity is 1.25 R + 64 k
     if R > capacity:
-        _CONFIG["async_binning"] = False
         raise BinningOverflow(
-            f"rasterizer: {R} tile instances exceeded the async binning capacity {capacity}; the previous forward of "
-            "this view is invalid. async_binning has been switched off (exact, blocking sizing); re-run the step.")
+            f"rasterizer: {R} tile instances exceeded the async binning capacity {capacity} estimated for this view; the "
+            "outputs of that forward are truncated. The estimate has been corrected: re-run the forward.")
+
+
+_OVERFLOWED = {}      # geometry buffer address -> message: forwards found truncated before anybody asked about them
+
+
+def _verify_pending(owner):
+    """Check the asynchronously read instance count of the forward whose geometry buffer is ``owner`` against the
+    capacity it ran with (blocks until that forward's geometry pass has finished)."""
+    msg = _OVERFLOWED.pop(owner, None)
+    if msg is not None:
+        raise BinningOverflow(msg)
+    pend = _PENDING.pop(owner, None)
+    if pend is not None:
+        _verify_entry(owner, pend)
+
+
+def _reap_pending():
+    """Counts whose copy has completed are checked without blocking, so that entries of forwards whose backward never
+    runs do not pile up; a truncated one is remembered until somebody asks about that forward."""
+    for owner in [o for o, p in _PENDING.items() if p[1].query()]:
+        pend = _PENDING.pop(owner)
+        try:
+            _verify_entry(owner, pend)
+        except BinningOverflow as e:
+            if len(_OVERFLOWED) > 64:
+                _OVERFLOWED.clear()
+            _OVERFLOWED[owner] = str(e)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -142,110 +176,157 @@ def _f32c(t: Optional[torch.Tensor], name: str):
     return t.contiguous()
 
 
-# ISR_PREPARE_TIGHT_RECTS: FAST mode bins a splat only into tiles it can reach (ISR_TIGHT_RECTS=0 turns it off: A/B, debugging)
-_TIGHT_RECTS = 0x100 if os.environ.get("ISR_TIGHT_RECTS", "1") != "0" else 0
-_PREFETCHED = {}      # signature -> (signature, radii, geom, img, R, binning, done event): geometry pass + binning issued ahead of its forward
+_TIGHT_RECTS = 0x100  # ISR_PREPARE_TIGHT_RECTS
+_PREFETCHED = {}      # signature -> _Prefetched: geometry pass + binning issued ahead of its forward
 PREFETCH_HITS = 0     # forwards that found their geometry pass already issued (statistics / tests)
 
 
-def _geometry_signature(mode, P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered, tensors):
-    """Identity of everything the geometry pass reads: scalars + (address, version) of the tensors."""
-    return (int(mode), P, W, H, int(degree), M, float(scale_modifier), float(tan_fovx), float(tan_fovy),
+def _tight(mode, tight=None) -> bool:
+    return mode == MODE_FAST and bool(_CONFIG["tight_rects"] if tight is None else tight)
+
+
+def _geometry_signature(mode, tight, P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered, tensors):
+    """Identity of everything the geometry pass reads: scalars + (address, version, shape) of the CALLER's tensors.  An
+    address can be recycled once its tensor is freed, so a cache entry additionally holds weak references to those
+    tensors (:func:`_refs`) and is only honoured while every one of them is still the very same object."""
+    return (int(mode), bool(tight), P, W, H, int(degree), M, float(scale_modifier), float(tan_fovx), float(tan_fovy),
             bool(prefiltered)) + tuple(
-        None if t is None else (t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+        None if (t is None or t.numel() == 0) else (t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
 
 
-def _prepare(L, mode, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
-             transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img):
-    """K1 + tile scan (``isr_forward_prepare``) into ``radii / geom / img``; returns the instance count R, or — with
-    async binning — the capacity the binning workspace is sized with (the true count is verified later)."""
+def _refs(tensors):
+    return tuple(None if (t is None or t.numel() == 0) else weakref.ref(t) for t in tensors)
+
+
+def _same_objects(refs, tensors) -> bool:
+    for r, t in zip(refs, tensors):
+        if r is None:
+            if not (t is None or t.numel() == 0):
+                return False
+        elif r() is not t:
+            return False
+    return True
+
+
+class _Prefetched:
+    __slots__ = ("sig", "refs", "radii", "geom", "img", "R", "binning", "done", "inputs")
+
+    def __init__(self, sig, refs, radii, geom, img, R, binning, done, inputs):
+        self.sig, self.refs, self.radii, self.geom, self.img, self.R = sig, refs, radii, geom, img, R
+        self.binning, self.done, self.inputs = binning, done, inputs
+
+
+def _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
+             transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img, tight=None):
+    """K1 + tile scan (``isr_forward_prepare``) into ``radii / geom / img``; returns ``(R, is_capacity)``: the instance
+    count, or - with async binning and a verified count of THIS view ``(key, view)`` from an earlier forward - the
+    capacity the binning workspace is sized with (the true count is read back asynchronously and verified before the
+    backward, or at once when autograd is off)."""
     global LAST_NUM_RENDERED
     num_rendered = ctypes.c_int64(0)
-    use_async = _CONFIG["async_binning"]
-    if use_async:
-        _verify_pending(key)
-        use_async = key in _R_ESTIMATE and _CONFIG["async_binning"]
+    ekey = key + (bool(_tight(mode, tight)),) + tuple(view)
+    use_async = _CONFIG["async_binning"] and ekey in _R_ESTIMATE
+    if _PENDING:
+        _reap_pending()
     check(L.isr_forward_prepare(P, int(degree), M, W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
                                 _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(transMat_precomp),
                                 _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
-                                int(bool(prefiltered)) | (_TIGHT_RECTS if mode == MODE_FAST else 0), _ptr(radii),
+                                int(bool(prefiltered)) | (_TIGHT_RECTS if _tight(mode, tight) else 0), _ptr(radii),
                                 _ptr(geom), _ptr(img),
                                 None if use_async else ctypes.byref(num_rendered), st), "isr_forward_prepare")
     if use_async:
-        R = int(_R_ESTIMATE[key] * _ASYNC_GROWTH) + _ASYNC_SLACK            # capacity, not the count
+        R = int(_R_ESTIMATE[ekey] * _ASYNC_GROWTH) + _ASYNC_SLACK            # capacity, not the count
         pinned = torch.empty(1, dtype=torch.int64).pin_memory()
         pinned.copy_(geom[:8].view(torch.int64), non_blocking=True)   # header[0] = R
         ev = torch.cuda.Event()
         ev.record()
-        _PENDING[key] = (pinned, ev, R, geom.data_ptr())
-        LAST_NUM_RENDERED = _R_ESTIMATE[key]
+        _PENDING[geom.data_ptr()] = (pinned, ev, R, ekey)
+        _OVERFLOWED.pop(geom.data_ptr(), None)      # a recycled address
+        LAST_NUM_RENDERED = _R_ESTIMATE[ekey]
     else:
         R = int(num_rendered.value)
-        _R_ESTIMATE[key] = R
+        _R_ESTIMATE[ekey] = R
+        if len(_R_ESTIMATE) > 4096:
+            for k in list(_R_ESTIMATE)[:1024]:
+                del _R_ESTIMATE[k]
         LAST_NUM_RENDERED = R
-    return R
+    return R, use_async
 
 
 def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp, viewmatrix,
                       projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
                       stream=None, after=None) -> bool:
     """Issue the geometry pass (K1, tile counts, scan) and the binning (key scatter, tile sort) of a view NOW, for a
-    ``rasterize_gaussians`` call that will follow with exactly these inputs.  It reads no feature, so a trainer can
-    overlap it with the rest of the current step (small, latency-bound loss kernels, the bandwidth-bound per-Gaussian
-    tail, the all-reduce of the gradient): ``stream`` = a side ``torch.cuda.Stream`` to issue it on (default: the current
-    stream), ``after`` = an event that stream waits for first (default: everything enqueued on the current stream so
-    far).  The forward that consumes the entry waits for its completion event.  Needs async binning and a known size
-    estimate for this (P, W, H); returns False (and does nothing) otherwise.  An entry that is never consumed is simply
-    dropped."""
+    ``rasterize_gaussians`` call that will follow with exactly these inputs (the same tensor objects, unmodified).  It
+    reads no feature, so a trainer can overlap it with the rest of the current step (small, latency-bound loss kernels,
+    the bandwidth-bound per-Gaussian tail, the all-reduce of the gradient): ``stream`` = a side ``torch.cuda.Stream`` to
+    issue it on (default: the current stream), ``after`` = an event that stream waits for first (default: everything
+    enqueued on the current stream so far).  The forward that consumes the entry waits for its completion event.  Needs
+    async binning and a verified instance count of this view from an earlier forward; returns False (and does nothing)
+    otherwise.  An entry that is never consumed is simply dropped."""
     L = lib()
     dev = means3D.device
     P, H, W = means3D.shape[0], int(image_height), int(image_width)
     key = (dev.index, P, W, H)
-    if P == 0 or not _CONFIG["async_binning"] or key not in _R_ESTIMATE:
+    mode = _CONFIG["mode"]
+    view = _view_id(viewmatrix, projmatrix)
+    if P == 0 or not _CONFIG["async_binning"] or (key + (bool(_tight(mode)),) + view) not in _R_ESTIMATE:
         return False
+    originals = (means3D, sh, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix, campos)
+    M = sh.shape[1] if (sh is not None and sh.dim() == 3) else 0
+    sig = _geometry_signature(mode, _tight(mode), P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered, originals)
+    kept = _VIEW_CACHE.get(sig) if _CONFIG.get("view_cache_bytes", 0) > 0 else None
+    if kept is not None and kept.busy == 0 and _same_objects(kept.refs, originals):
+        return False                      # the view cache already holds this view's state
+    # fp32 / contiguous forms (made on the caller's stream; a non-contiguous reference Camera matrix gets a temporary)
     means3D = _f32c(means3D, "means3D")
     colors, opacity = _f32c(colors, "colors"), _f32c(opacity, "opacity")
     scales, rotations = _f32c(scales, "scales"), _f32c(rotations, "rotations")
     transMat_precomp = _f32c(transMat_precomp, "transMat_precomp")
     viewmatrix, projmatrix = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix")
     sh, campos = _f32c(sh, "sh"), _f32c(campos, "campos")
-    M = sh.shape[1] if (sh is not None and sh.dim() == 3) else 0
-    mode = _CONFIG["mode"]
-    sig = _geometry_signature(mode, P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered,
-                              (means3D, sh, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix,
-                               campos))
-    kept = _VIEW_CACHE.get(sig) if _CONFIG.get("view_cache_bytes", 0) > 0 else None
-    if kept is not None and kept.busy == 0:
-        return False                      # the view cache already holds this view's state
+    inputs = (means3D, sh, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix, campos)
     with torch.cuda.device(dev):
         done = None
         side = stream if (stream is not None and stream != torch.cuda.current_stream()) else None
-        if side is not None and after is not False:      # after=False: start at once (inputs are long-lived constants)
-            if after is None:
-                after = torch.cuda.Event()
-                after.record()
-            side.wait_event(after)
+        if side is not None:
+            if after is None or after is False:
+                # `after=False` used to mean "start at once"; temporaries made above on the caller's stream must be
+                # complete before the side stream reads them, so the side stream always waits at least for those
+                made_temporary = any(a is not b for a, b in zip(inputs, originals))
+                if after is None or made_temporary:
+                    after = torch.cuda.Event()
+                    after.record()
+            if after is not None and after is not False:
+                side.wait_event(after)
+            for t in inputs:              # read by kernels on the side stream: the allocator must not recycle them earlier
+                if t is not None:
+                    t.record_stream(side)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
             geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
             img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
             st = _stream()
-            R = _prepare(L, mode, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
-                         transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img)
+            R, _ = _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier,
+                            rotations, transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered,
+                            radii, geom, img)
             binning = torch.empty(L.isr_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
             check(L.isr_forward_bin(P, W, H, _ptr(geom), _ptr(binning), R, _ptr(img), st), "isr_forward_bin")
             if side is not None:
                 done = torch.cuda.Event()
                 done.record()
-    _PREFETCHED[sig] = (sig, radii, geom, img, R, binning, done)
+    # the entry keeps the converted inputs alive until it is consumed or dropped
+    _PREFETCHED[sig] = _Prefetched(sig, _refs(originals), radii, geom, img, R, binning, done, inputs)
     while len(_PREFETCHED) > 2:                 # entries nobody came for
-        _PREFETCHED.pop(next(iter(_PREFETCHED)))
+        old = _PREFETCHED.pop(next(iter(_PREFETCHED)))
+        _PENDING.pop(old.geom.data_ptr(), None)
     return True
 
 
 def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
                         extra_attrs, attr_degree, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
-                        image_width, sh, degree, campos, prefiltered, debug, *, tracer=None, mode=None, _state_out=None):
+                        image_width, sh, degree, campos, prefiltered, debug, *, tracer=None, mode=None, tight=None,
+                        _state_out=None):
     """Equivalent of ``_C.rasterize_gaussians`` (rasterize_points.cu:39-151).
 
     Returns ``(num_rendered, out_color, out_others, radii, out_extra, geomBuffer, binningBuffer, imgBuffer,
@@ -259,7 +340,12 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
     dev = means3D.device
     P, H, W, F = means3D.shape[0], int(image_height), int(image_width), int(attr_degree)
     mode = _CONFIG["mode"] if mode is None else mode
+    tight = _tight(mode, tight)
     tracer = _CONFIG["tracer"] if tracer is None else tracer
+    call_args = (bg, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp, extra_attrs, attr_degree,
+                 viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug)
+    originals = (means3D, sh, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix, campos)
+    view = _view_id(viewmatrix, projmatrix)
     means3D = _f32c(means3D, "means3D")
     bg = _f32c(bg, "background")
     colors, opacity = _f32c(colors, "colors"), _f32c(opacity, "opacity")
@@ -288,12 +374,17 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
     with torch.cuda.device(dev):
         st = _stream()
         key = (dev.index, P, W, H)
-        sig = _geometry_signature(mode, P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered,
-                                  (means3D, sh, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix,
-                                   campos))
+        sig = _geometry_signature(mode, tight, P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered, originals)
         ahead = _PREFETCHED.pop(sig, None)
+        if ahead is not None and not _same_objects(ahead.refs, originals):
+            _PENDING.pop(ahead.geom.data_ptr(), None)
+            ahead = None                  # a recycled address: not the tensors that geometry pass read
         prebinned = 0
+        sized_by_estimate = False
         kept = _VIEW_CACHE.get(sig) if _CONFIG.get("view_cache_bytes", 0) > 0 else None
+        if kept is not None and not _same_objects(kept.refs, originals):
+            _VIEW_CACHE.pop(sig, None)
+            kept = None
         if kept is not None and kept.busy == 0:
             radii, geom, img, R, binning = kept.radii, kept.geom, kept.img, kept.R, kept.binning
             prebinned = MODE_PREBINNED
@@ -302,22 +393,25 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
             VIEW_CACHE_HITS += 1
             if _state_out is not None:
                 _state_out.append(kept)
-        elif ahead is not None and ahead[0] == sig:
-            radii, geom, img, R, binning, done = ahead[1:]     # the geometry pass of this view was issued by prefetch_geometry()
+        elif ahead is not None:
+            # the geometry pass of this view was issued by prefetch_geometry()
+            radii, geom, img, R, binning, done = ahead.radii, ahead.geom, ahead.img, ahead.R, ahead.binning, ahead.done
             if done is not None:                # ... on a side stream: order this stream behind it, keep its buffers alive
                 cur = torch.cuda.current_stream()
                 cur.wait_event(done)
                 for t in (radii, geom, img, binning):
                     t.record_stream(cur)
             prebinned = MODE_PREBINNED
+            sized_by_estimate = geom.data_ptr() in _PENDING or geom.data_ptr() in _OVERFLOWED
             global PREFETCH_HITS
             PREFETCH_HITS += 1
         else:
             radii = torch.empty((P,), dtype=torch.int32, device=dev)      # K1 writes every entry
             geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
             img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
-            R = _prepare(L, mode, key, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
-                         transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img)
+            R, sized_by_estimate = _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales,
+                                            scale_modifier, rotations, transMat_precomp, viewmatrix, projmatrix, campos,
+                                            tan_fovx, tan_fovy, prefiltered, radii, geom, img, tight=tight)
             binning = torch.empty(L.isr_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
         if tracer:
             grp = torch.empty((H * W * 10, 2), dtype=torch.int32, device=dev)
@@ -328,8 +422,21 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
                                    _ptr(geom), _ptr(binning), R, _ptr(img), _ptr(out_color), _ptr(out_others),
                                    _ptr(out_extra), _ptr(grp), H * W * 10 if tracer else 0, _ptr(gcount), st),
               "isr_forward_render")
-    if _CONFIG.get("view_cache_bytes", 0) > 0 and kept is None and _state_out is not None:
-        st_new = _ViewState(radii, geom, img, R, binning)
+    if sized_by_estimate and not torch.is_grad_enabled():
+        # no backward will follow to verify the estimate (an eval / no_grad render): check it now, and if the view needed
+        # more than the estimate allowed, render it again with the exact, blocking sizing instead of returning a
+        # truncated image
+        try:
+            _verify_pending(geom.data_ptr())
+        except BinningOverflow:
+            was = _CONFIG["async_binning"]
+            _CONFIG["async_binning"] = False
+            try:
+                return rasterize_gaussians(*call_args, tracer=tracer, mode=mode, tight=tight, _state_out=_state_out)
+            finally:
+                _CONFIG["async_binning"] = was
+    if _CONFIG.get("view_cache_bytes", 0) > 0 and kept is None and _state_out is not None and not sized_by_estimate:
+        st_new = _ViewState(radii, geom, img, R, binning, _refs(originals))
         if st_new.nbytes <= _CONFIG["view_cache_bytes"]:
             _view_cache_put(sig, st_new)
             _state_out.append(st_new)
@@ -384,8 +491,7 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, 
     ge = new(P, F) if (grad_mask & GRAD_EXTRA) else None
     if P == 0 or grad_mask == 0:
         return g2, gc, go, g3, gt, gsh, gs, gr, (ge if F else torch.empty(0, device=dev))
-    if _CONFIG["async_binning"]:
-        _verify_pending((dev.index, P, W, H), owner=geomBuffer.data_ptr())
+    _verify_pending(geomBuffer.data_ptr())
     nbytes = L.isr_backward_scratch_bytes(int(R), F, grad_mask)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
@@ -453,8 +559,7 @@ def rasterize_gaussians_backward_sampled(P, F, W, H, R, pixels, dL_dsampled, tra
     L = lib()
     dev = geomBuffer.device
     mode = _CONFIG["mode"] if mode is None else mode
-    if _CONFIG["async_binning"]:
-        _verify_pending((dev.index, P, W, H), owner=geomBuffer.data_ptr())
+    _verify_pending(geomBuffer.data_ptr())
     pix = pixels.contiguous().to(torch.int64)
     g = dL_dsampled.contiguous().float()
     n = pix.shape[0]
@@ -537,7 +642,7 @@ class _Token:
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, extra_attrs,
-                raster_settings, sample_pixels=None):
+                raster_settings, sample_pixels=None, lazy_tracer=False):
         rs = raster_settings
         attr_degree = extra_attrs.shape[1] if extra_attrs.shape[0] != 0 else 0
         kept_state = []
@@ -551,7 +656,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             kept_state[0].busy += 1
             ctx.view_token = _Token()
             weakref.finalize(ctx.view_token, kept_state[0].release)
-        if gau_related_pixels.shape[0] and not _CONFIG.get("lazy_tracer", False):
+        if gau_related_pixels.shape[0] and not lazy_tracer:
             gau_related_pixels = gau_related_pixels[:(gau_pixel_indices + 1)]   # same slicing as the reference (:106)
         elif gau_related_pixels.shape[0]:
             # render() wraps the pair in a lazily sliced dict entry: slicing needs the count on the host (a sync)
@@ -591,7 +696,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             dense.index_add_(1, ctx.sample_pixels.to(torch.int64), grad_sampled.t().contiguous().float())
             grad_out_extra, grad_sampled = dense.reshape(Fm, Hm, Wm), None
         if mask == 0 or (grad_out_color is None and grad_depth is None and grad_out_extra is None and grad_sampled is None):
-            return (None,) * 11
+            return (None,) * 12
         if grad_sampled is not None and grad_out_color is None and grad_depth is None and grad_out_extra is None:
             # the common case of feature training: only sampled features carry gradient
             sink = _ROWS_SINK
@@ -600,11 +705,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                     means3D.shape[0], extra_attrs.shape[1], rs.image_width, rs.image_height, ctx.num_rendered,
                     ctx.sample_pixels, grad_sampled, cov3Ds_precomp, geomBuffer, binningBuffer, imgBuffer, mode=ctx.mode,
                     rows_only=True)
-                return (None,) * 11
+                return (None,) * 12
             ge = rasterize_gaussians_backward_sampled(means3D.shape[0], extra_attrs.shape[1], rs.image_width, rs.image_height,
                                                       ctx.num_rendered, ctx.sample_pixels, grad_sampled, cov3Ds_precomp,
                                                       geomBuffer, binningBuffer, imgBuffer, mode=ctx.mode)
-            return (None,) * 8 + (ge, None, None)
+            return (None,) * 8 + (ge, None, None, None)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_extra_attrs) = rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, extra_attrs, rs.scale_modifier, cov3Ds_precomp,
@@ -626,13 +731,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                 pick(3, grad_colors_precomp, colors_precomp), grad_opacities if need[4] else None,
                 pick(5, grad_scales, scales), pick(6, grad_rotations, rotations),
                 pick(7, grad_cov3Ds_precomp, cov3Ds_precomp),
-                grad_extra_attrs if (need[8] and extra_attrs.numel()) else None, None, None)
+                grad_extra_attrs if (need[8] and extra_attrs.numel()) else None, None, None, None)
 
 
 def rasterize_gaussians_autograd(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                 extra_attrs, raster_settings, sample_pixels=None):
+                                 extra_attrs, raster_settings, sample_pixels=None, lazy_tracer=False):
     out = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                    cov3Ds_precomp, extra_attrs, raster_settings, sample_pixels)
+                                    cov3Ds_precomp, extra_attrs, raster_settings, sample_pixels, lazy_tracer)
     return out if sample_pixels is not None else out[:5]
 
 
@@ -657,9 +762,11 @@ class GaussianRasterizer(nn.Module):
                                      rs.image_width, shs, rs.sh_degree, rs.campos, rs.prefiltered, stream=stream, after=after)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, extra_attrs=None, sample_pixels=None):
-        """Reference signature (:210-248).  Extension: ``sample_pixels`` (int64 ``y*W + x``, may repeat) appends a sixth
-        result, the feature map read at those pixels ``[n, F]``; its gradient is propagated without a dense map."""
+                cov3D_precomp=None, extra_attrs=None, sample_pixels=None, lazy_tracer=False):
+        """Reference signature (:210-248).  Extensions: ``sample_pixels`` (int64 ``y*W + x``, may repeat) appends a sixth
+        result, the feature map read at those pixels ``[n, F]``; its gradient is propagated without a dense map.
+        ``lazy_tracer``: return the whole tracer buffer with its count attached (``slice_tracer``) instead of slicing it
+        here, which needs the count on the host, i.e. a device sync (``render()`` slices on first access)."""
         rs = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -675,4 +782,4 @@ class GaussianRasterizer(nn.Module):
         cov3D_precomp = empty() if cov3D_precomp is None else cov3D_precomp
         extra_attrs = empty() if extra_attrs is None else extra_attrs
         return rasterize_gaussians_autograd(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                            cov3D_precomp, extra_attrs, rs, sample_pixels)
+                                            cov3D_precomp, extra_attrs, rs, sample_pixels, lazy_tracer)

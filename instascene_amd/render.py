@@ -1,8 +1,8 @@
 """``render()`` — mirror of the reference's ``gaussian_renderer.render``
 (gaussian_renderer/__init__.py:20-169): same signature, same returned dict
 (13 entries), built on the HIP rasterizer.  The post-processing of the 7-channel
-``allmap`` (:127-167) and ``depth_to_normal`` (utils/point_utils.py:10-40) are
-restated here in torch (thin elementwise work)."""
+``allmap`` (:127-167) incl. ``depth_to_normal`` (utils/point_utils.py:10-40) is
+``csrc/iso_post.hip`` (two kernels each way)."""
 from __future__ import annotations
 
 import ctypes
@@ -67,42 +67,35 @@ _ZEROS = {}
 
 
 def _camera_rays(view, device):
-    """Per-pixel ray directions and origin of utils/point_utils.py:10-27 (static per camera: cached)."""
+    """The camera's per-pixel ray table for ``iso_render_post_forward`` (what utils/point_utils.py:10-27 rebuilds on
+    every call; static per camera, so cached): ``rays_d[y*W + x]`` = world-space direction of the ray through pixel
+    ``(x, y)`` scaled to unit view depth, ``rays_o`` = camera centre, i.e. a surface point is ``depth * rays_d + rays_o``.
+
+    With the reference's row-vector storage (``p_view = p_world @ V``, ``p_clip = p_world @ VP``) the camera->clip map is
+    ``Pj = V^-1 VP`` and a camera-space point lands on the homogeneous pixel ``q = p_cam @ K`` with
+    ``K[:, 0] = W/2 (Pj[:3, 0] + Pj[:3, 3])``, ``K[:, 1] = H/2 (Pj[:3, 1] + Pj[:3, 3])``, ``K[:, 2] = Pj[:3, 3]``
+    (the reference's pixel mapping for this table has offset W/2, not (W-1)/2).  Hence
+    ``rays_d(x, y) = (x, y, 1) @ M`` with the single 3x3 matrix ``M = K^-1 (V^-1)[:3, :3]``: an affine function of the
+    pixel, evaluated by broadcasting instead of a meshgrid and two [N,3]x[3,3] products."""
     key = (id(view), str(device))
     hit = _RAY_CACHE.get(key)
     if hit is not None and hit[0] is view.world_view_transform:
         return hit[1], hit[2]
-    c2w = (view.world_view_transform.T).inverse()
-    W, H = view.image_width, view.image_height
-    ndc2pix = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], dtype=torch.float32,
-                           device=device).T
-    projection_matrix = c2w.T @ view.full_proj_transform
-    intrins = (projection_matrix @ ndc2pix)[:3, :3].T
-    grid_x, grid_y = torch.meshgrid(torch.arange(W, device=device).float(), torch.arange(H, device=device).float(),
-                                    indexing="xy")
-    points = torch.stack([grid_x, grid_y, torch.ones_like(grid_x)], dim=-1).reshape(-1, 3)
-    rays_d = points @ intrins.inverse().T @ c2w[:3, :3].T
-    rays_o = c2w[:3, 3]
+    W, H = int(view.image_width), int(view.image_height)
+    V = view.world_view_transform.to(device=device, dtype=torch.float64)
+    VP = view.full_proj_transform.to(device=device, dtype=torch.float64)
+    Vinv = torch.linalg.inv(V)
+    Pj = (Vinv @ VP)[:3]
+    K = torch.stack((0.5 * W * (Pj[:, 0] + Pj[:, 3]), 0.5 * H * (Pj[:, 1] + Pj[:, 3]), Pj[:, 3]), dim=1)
+    M = (torch.linalg.inv(K) @ Vinv[:3, :3]).to(torch.float32)
+    xs = torch.arange(W, device=device, dtype=torch.float32).view(1, W, 1)
+    ys = torch.arange(H, device=device, dtype=torch.float32).view(H, 1, 1)
+    rays_d = (xs * M[0] + ys * M[1] + M[2]).reshape(-1, 3).contiguous()
+    rays_o = Vinv[3, :3].to(torch.float32).contiguous()
     if len(_RAY_CACHE) > 256:
         _RAY_CACHE.clear()
     _RAY_CACHE[key] = (view.world_view_transform, rays_d, rays_o)
     return rays_d, rays_o
-
-
-def depths_to_points(view, depthmap):
-    """utils/point_utils.py:10-27"""
-    rays_d, rays_o = _camera_rays(view, depthmap.device)
-    return depthmap.reshape(-1, 1) * rays_d + rays_o
-
-
-def depth_to_normal(view, depth):
-    """utils/point_utils.py:30-40"""
-    points = depths_to_points(view, depth).reshape(*depth.shape[1:], 3)
-    output = torch.zeros_like(points)
-    dx = points[2:, 1:-1] - points[:-2, 1:-1]
-    dy = points[1:-1, 2:] - points[1:-1, :-2]
-    output[1:-1, 1:-1, :] = torch.nn.functional.normalize(torch.linalg.cross(dx, dy, dim=-1), dim=-1)
-    return output
 
 
 class _RenderPost(torch.autograd.Function):
@@ -155,30 +148,30 @@ def _stream():
 
 
 def post_process(viewpoint_camera, allmap, depth_ratio):
-    """gaussian_renderer/__init__.py:127-167.  CUDA tensors: two HIP kernels each way; the torch restatement below
-    serves host-side tensors (it is what tests/golden/render_post.npz pins)."""
-    if allmap.is_cuda:
-        rays_d, rays_o = _camera_rays(viewpoint_camera, allmap.device)
-        alpha, normal, dist, surf, snorm, depth, median = _RenderPost.apply(
-            allmap, viewpoint_camera.world_view_transform, rays_d.contiguous(), rays_o.contiguous(), float(depth_ratio))
-        return {'rend_alpha': alpha, 'rend_normal': normal, 'rend_dist': dist, 'surf_depth': surf,
-                'surf_normal': snorm, 'rend_depth': depth, 'rend_median_depth': median}
-    render_alpha = allmap[1:2]
-    render_normal = allmap[2:5]
-    # (n.permute(1,2,0) @ R^T).permute(2,0,1) of the reference (:132), written as three broadcast FMAs — a [N,3]x[3,3]
-    # product is a poor fit for a GEMM kernel
-    Rm = viewpoint_camera.world_view_transform[:3, :3]
-    render_normal = (render_normal[0:1] * Rm[:, 0].view(3, 1, 1) + render_normal[1:2] * Rm[:, 1].view(3, 1, 1)
-                     + render_normal[2:3] * Rm[:, 2].view(3, 1, 1))
-    render_depth_median = torch.nan_to_num(allmap[5:6], 0, 0)
-    render_depth_expected = torch.nan_to_num(allmap[0:1] / render_alpha, 0, 0)
-    render_dist = allmap[6:7]
-    surf_depth = render_depth_expected * (1 - depth_ratio) + depth_ratio * render_depth_median
-    surf_normal = depth_to_normal(viewpoint_camera, surf_depth).permute(2, 0, 1)
-    surf_normal = surf_normal * render_alpha.detach()
-    return {'rend_alpha': render_alpha, 'rend_normal': render_normal, 'rend_dist': render_dist,
-            'surf_depth': surf_depth, 'surf_normal': surf_normal, 'rend_depth': render_depth_expected,
-            'rend_median_depth': render_depth_median}
+    """The seven maps render() derives from the rasterizer's 7-channel ``allmap`` (gaussian_renderer/__init__.py:127-167,
+    utils/point_utils.py:10-40): two HIP kernels each way.  Device tensors only - there is no host path in the product
+    (the CPU restatement that tests/golden/render_post.npz pins lives in oracle/torch_ops.py)."""
+    if not allmap.is_cuda:
+        raise RuntimeError("instascene_amd.render.post_process: allmap must be a CUDA tensor (no CPU fallback)")
+    rays_d, rays_o = _camera_rays(viewpoint_camera, allmap.device)
+    alpha, normal, dist, surf, snorm, depth, median = _RenderPost.apply(
+        allmap, viewpoint_camera.world_view_transform, rays_d, rays_o, float(depth_ratio))
+    return {'rend_alpha': alpha, 'rend_normal': normal, 'rend_dist': dist, 'surf_depth': surf,
+            'surf_normal': snorm, 'rend_depth': depth, 'rend_median_depth': median}
+
+
+def _precomputed_transforms(viewpoint_camera, pc, scaling_modifier):
+    """``pipe.compute_cov3D_python`` (gaussian_renderer/__init__.py:69-82): the per-Gaussian 3x3 splat->pixel homography
+    built in torch from the model's 4x4 splat->world matrices (``pc.get_covariance``, scene/gaussian_model.py:35-42) and
+    handed to the rasterizer as ``cov3D_precomp [P,9]`` (rows Tu, Tv, Tw).  Only rows/columns (0, 1, 3) of the 4x4
+    factors take part - the splat has no third axis and the pixel has no depth row - so the NDC->pixel map is built as
+    the [4,3] matrix it is used as."""
+    W, H = float(viewpoint_camera.image_width), float(viewpoint_camera.image_height)
+    vp = viewpoint_camera.full_proj_transform
+    to_pixel = vp.new_tensor([[0.5 * W, 0.0, 0.0], [0.0, 0.5 * H, 0.0], [0.0, 0.0, 0.0], [0.5 * (W - 1.0), 0.5 * (H - 1.0), 1.0]])
+    world_to_pixel = vp @ to_pixel                                            # [4,3]
+    splat_rows = pc.get_covariance(scaling_modifier)[:, (0, 1, 3), :]         # [P,3,4]: tangent u, tangent v, centre
+    return torch.einsum("prk,kc->pcr", splat_rows, world_to_pixel).reshape(-1, 9)
 
 
 def _geometry_inputs(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color):
@@ -192,13 +185,7 @@ def _geometry_inputs(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, ove
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
     scales = rotations = cov3D_precomp = None
     if getattr(pipe, "compute_cov3D_python", False):
-        splat2world = pc.get_covariance(scaling_modifier)
-        W, H = viewpoint_camera.image_width, viewpoint_camera.image_height
-        near, far = viewpoint_camera.znear, viewpoint_camera.zfar
-        ndc2pix = torch.tensor([[W / 2, 0, 0, (W - 1) / 2], [0, H / 2, 0, (H - 1) / 2], [0, 0, far - near, near],
-                                [0, 0, 0, 1]], dtype=torch.float32, device=xyz.device).T
-        world2pix = viewpoint_camera.full_proj_transform @ ndc2pix
-        cov3D_precomp = (splat2world[:, [0, 1, 3]] @ world2pix[:, [0, 1, 3]]).permute(0, 2, 1).reshape(-1, 9)
+        cov3D_precomp = _precomputed_transforms(viewpoint_camera, pc, scaling_modifier)
     else:
         scales = pc.get_scaling
         rotations = pc.get_rotation
@@ -250,17 +237,16 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
                 _ZEROS.clear()
             screenspace_points = _ZEROS[zkey] = torch.zeros_like(xyz, requires_grad=False)
     rasterizer, geo = _geometry_inputs(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color)
-    _rz._CONFIG["lazy_tracer"] = True       # render() defers the tracer slice (and its host sync) to first access
 
     means2D = screenspace_points
     seg_feature = pc.get_seg_feature
     if seg_feature is not None and norm_seg_feat:
         seg_feature = row_normalize(seg_feature, 1e-9)      # reference :61-62
 
+    # lazy_tracer: the tracer list is sliced to its valid length (a host sync) on first access of the dict entry
     res = rasterizer(means2D=means2D, extra_attrs=seg_feature, sample_pixels=sample_pixels if seg_feature is not None else None,
-                     **geo)
+                     lazy_tracer=True, **geo)
     rendered_image, radii, allmap, extra_attrs, gau_related_pixels = res[:5]
-    _rz._CONFIG["lazy_tracer"] = False
 
     rets = RenderPackage({"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0,
                           "radii": radii, "seg_feature": extra_attrs, "gau_related_pixels": gau_related_pixels})

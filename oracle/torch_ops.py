@@ -52,11 +52,11 @@ def contrastive_loss(features, labels, predef_u=None, min_pixnum=0, temp_lambda=
 def depths_to_points(wvt, full_proj, W, H, depth):
     """utils/point_utils.py:10-27; wvt/full_proj in the reference's row-vector storage."""
     c2w = wvt.t().inverse()
-    n2p = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], dtype=torch.float32,
+    n2p = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], dtype=wvt.dtype,
                        device=depth.device).t()
     intr = ((c2w.t() @ full_proj) @ n2p)[:3, :3].t()
-    gx, gy = torch.meshgrid(torch.arange(W, device=depth.device).float(), torch.arange(H, device=depth.device).float(),
-                            indexing="xy")
+    gx, gy = torch.meshgrid(torch.arange(W, device=depth.device).to(wvt.dtype),
+                            torch.arange(H, device=depth.device).to(wvt.dtype), indexing="xy")
     pts = torch.stack([gx, gy, torch.ones_like(gx)], dim=-1).reshape(-1, 3)
     rays = pts @ intr.inverse().t() @ c2w[:3, :3].t()
     return depth.reshape(-1, 1) * rays + c2w[:3, 3]

@@ -19,7 +19,9 @@ import types
 import numpy as np
 import torch
 
-REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+_argv = [a for a in sys.argv[1:] if not a.startswith("--only=")]
+ONLY = set(sum((a[len("--only="):].split(",") for a in sys.argv[1:] if a.startswith("--only=")), []))   # e.g. --only=transmat.npz
+REF = _argv[0] if _argv else "/root/reference"
 OUT = os.path.dirname(os.path.abspath(__file__))
 if not os.path.isdir(REF):
     print("reference not present; nothing to do")
@@ -78,6 +80,8 @@ class FakeRasterizer(torch.nn.Module):
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, extra_attrs=None):
         FAKE["extra_in"] = None if extra_attrs is None else extra_attrs.detach().clone()
+        FAKE["cov3D_in"] = None if cov3D_precomp is None else cov3D_precomp.detach().clone()
+        FAKE["scales_in"], FAKE["rotations_in"] = scales, rotations
         return FAKE["color"], FAKE["radii"], FAKE["allmap"], FAKE["extra"], FAKE["grp"]
 
 
@@ -99,6 +103,9 @@ class CpuMode(TorchFunctionMode):
 
 
 def save(name, **arrs):
+    if ONLY and name not in ONLY:
+        print("skipped", name)
+        return
     arrs = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()}
     np.savez_compressed(os.path.join(OUT, name), **arrs)
     print("wrote", name, {k: v.shape for k, v in arrs.items()})
@@ -222,6 +229,41 @@ with CpuMode():
         rp[f"c{i}_settings"] = np.array([s.image_height, s.image_width, s.tanfovx, s.tanfovy, s.scale_modifier,
                                          s.sh_degree], dtype=np.float64)
     save("render_post.npz", **rp)
+
+    # ------------------------------------------------------------------ K1 homography by the reference's own Python
+    # pipe.compute_cov3D_python = True: render() builds transMat_precomp = cov3D_precomp itself
+    # (gaussian_renderer/__init__.py:69-82) from GaussianModel.get_covariance (scene/gaussian_model.py:35-42,137-138).
+    from scene.gaussian_model import GaussianModel as _RefGM
+
+    tm = {}
+    gen = torch.Generator().manual_seed(31337)
+    Ptm = 300
+    gm = _RefGM(3)
+    gm.active_sh_degree = 3
+    gm._xyz = torch.randn(Ptm, 3, generator=gen) * 1.2
+    gm._scaling = torch.log(0.01 + 0.3 * torch.rand(Ptm, 2, generator=gen))
+    gm._rotation = torch.randn(Ptm, 4, generator=gen) * (0.2 + 2.0 * torch.rand(Ptm, 1, generator=gen))   # NOT unit length
+    gm._opacity = torch.randn(Ptm, 1, generator=gen)
+    gm._features_dc = torch.randn(Ptm, 1, 3, generator=gen)
+    gm._features_rest = torch.randn(Ptm, 15, 3, generator=gen) * 0.1
+    gm._seg_feature = None
+    if not hasattr(gm, "covariance_activation"):
+        gm.setup_functions()
+    tm.update(xyz=gm._xyz, log_scaling=gm._scaling, rotation_raw=gm._rotation)
+    for i, cam in enumerate(cams[:4]):
+        H_, W_ = cam.image_height, cam.image_width
+        FAKE.update(color=torch.zeros(3, H_, W_), radii=torch.zeros(Ptm).int(), allmap=torch.ones(7, H_, W_),
+                    extra=torch.zeros(0), grp=torch.zeros(0, 2).int())
+        for mod in (1.0, 0.6, 1.7):
+            pipe = Pipe()
+            pipe.compute_cov3D_python = True
+            try:
+                gaussian_renderer.render(cam, gm, pipe, torch.zeros(3), scaling_modifier=mod)
+            except Exception as e:      # the post-processing after the rasterizer call is not what is captured here
+                print("render() after the rasterizer call:", repr(e))
+            assert FAKE["cov3D_in"] is not None and FAKE["scales_in"] is None and FAKE["rotations_in"] is None
+            tm[f"cam{i}_mod{mod:g}"] = FAKE["cov3D_in"]
+    save("transmat.npz", **tm)
 
     # ------------------------------------------------------------------ SH + rotation helpers
     from utils.sh_utils import eval_sh

@@ -23,7 +23,7 @@ def _dev(t):
 
 
 def hip_forward(inp, cam, bg=(0.0, 0.0, 0.0), sh_degree=3, mode=None, tracer=False, scale_modifier=1.0,
-                colors_precomp=None, transMat_precomp=None, use_sh=True, use_extra=True):
+                colors_precomp=None, transMat_precomp=None, use_sh=True, use_extra=True, tight=False):
     dev = "cuda"
     e = lambda: torch.empty(0, device=dev)
     extra = _dev(inp["extra"]) if (use_extra and inp.get("extra") is not None) else e()
@@ -39,7 +39,7 @@ def hip_forward(inp, cam, bg=(0.0, 0.0, 0.0), sh_degree=3, mode=None, tracer=Fal
                 projmatrix=cam.full_proj_transform.cuda(), tan_fovx=math.tan(cam.FoVx * 0.5),
                 tan_fovy=math.tan(cam.FoVy * 0.5), image_height=cam.image_height, image_width=cam.image_width, sh=sh,
                 degree=sh_degree, campos=cam.camera_center.cuda(), prefiltered=False, debug=False)
-    out = rz.rasterize_gaussians(**args, tracer=tracer, mode=mode)
+    out = rz.rasterize_gaussians(**args, tracer=tracer, mode=mode, tight=tight)
     return args, out
 
 
@@ -63,6 +63,19 @@ def check_forward_exact(st, args, out, tracer=False):
         got = {(int(a), int(b)) for a, b in grp[:n].cpu().numpy()}
         want = {(int(a), int(b)) for a, b in st["tracer"]}
         assert n == len(st["tracer"]) and got == want
+
+
+def check_binning_exact(st, out):
+    """Integer state of the geometry pass and the binning: radii, tiles_touched, point_list, ranges - bit-identical to
+    the oracle's (reference rasterizer_impl.cu:70-138, auxiliary.h:68-78) in EXACT and in FAST mode alike."""
+    R, radii, geom, binning, img = out[0], out[3], out[5], out[6], out[7]
+    assert R == st["R"]
+    np.testing.assert_array_equal(radii.cpu().numpy(), st["radii"])
+    dbg = rz.debug_state(st["P"], st["W"], st["H"], R, geom, binning, img)
+    np.testing.assert_array_equal(dbg["tiles_touched"], st["tiles_touched"])
+    np.testing.assert_array_equal(dbg["point_list"], st["point_list"])
+    np.testing.assert_array_equal(dbg["ranges"], st["ranges"])
+    return dbg
 
 
 @pytest.mark.parametrize("P,F,W,H,seed,bg", [
@@ -113,11 +126,13 @@ def test_tile_counter_aggregation_overflow_path():
     inp["scales"] = scales
     st = oracle_forward(inp, cams[0])
     assert int((st["tiles_touched"] >= 3000).sum()) >= 5
-    for mode in (MODE_EXACT, MODE_FAST):
-        args, out = hip_forward(inp, cams[0], mode=mode)
+    for mode, tight in ((MODE_EXACT, False), (MODE_FAST, False), (MODE_FAST, True)):
+        args, out = hip_forward(inp, cams[0], mode=mode, tight=tight)
         if mode == MODE_EXACT:
             check_forward_exact(st, args, out)
-        else:       # FAST: tight tile rectangles and rcp/exp arithmetic; isolated threshold-flip pixels allowed
+        else:       # FAST: rcp/exp arithmetic (and optionally tight tile rectangles); isolated threshold-flip pixels allowed
+            if not tight:
+                check_binning_exact(st, out)
             err = np.abs(out[1].cpu().numpy() - st["color"]).max(axis=0)
             assert (err <= 1e-4 * np.abs(st["color"]).max()).mean() > 0.999 and err.max() < 0.05
 
@@ -258,18 +273,46 @@ def test_backward_precomputed_paths():
         assert_close(t.cpu().numpy().reshape(want[name].shape), want[name], 1e-3, name)
 
 
+def _images_within_fast_tolerance(out, st):
+    R, color, others, radii, extra = out[:5]
+    for name, got, want in [("color", color, st["color"]), ("extra", extra, st["extra"]),
+                            ("alpha", others[1], st["others"][1]), ("depth", others[0], st["others"][0]),
+                            ("normal", others[2:5], st["others"][2:5])]:
+        if want.size == 0:
+            continue
+        got = got.cpu().numpy()
+        scale = np.abs(want).max()
+        bad = np.abs(got - want) > 1e-4 * scale
+        assert bad.mean() <= 1e-4, f"{name}: {bad.sum()} outlier pixels"
+        assert np.abs(got - want).max() <= 1e-2 * scale
+
+
+@pytest.mark.parametrize("P,F,W,H,seed", [(1500, 16, 100, 70, 41), (3000, 32, 160, 112, 42), (2000, 0, 128, 96, 43),
+                                          (2500, 40, 96, 80, 44)])
+def test_fast_mode_keeps_the_reference_binning_bit_for_bit(P, F, W, H, seed):
+    """The headline mode of bench.py: FAST arithmetic in the per-pixel loops (contracted FMAs, v_rcp / v_exp), the
+    reference's tile rectangles.  radii, tiles_touched, point_list and ranges are bit-identical to the oracle's;
+    images are within 1e-4 of the tensor's max except isolated pixels where a decision at the alpha = 1/255 or
+    T = 1e-4 threshold flips (those stay within one skipped contribution)."""
+    sc, cams, inp = small_scene(P=P, F=F, W=W, H=H, seed=seed, mu_s=math.log(0.05))
+    for cam in cams[:2]:
+        st = oracle_forward(inp, cam, bg=(0.1, 0.2, 0.3))
+        args, out = hip_forward(inp, cam, bg=(0.1, 0.2, 0.3), mode=MODE_FAST)
+        dbg = check_binning_exact(st, out)
+        _images_within_fast_tolerance(out, st)
+        # the last / median contributors may differ only where a threshold decision flipped
+        assert (dbg["n_contrib"] != st["n_contrib"]).mean() <= 2e-3
+
+
 @pytest.mark.parametrize("P,F,W,H,seed", [(1500, 16, 100, 70, 41), (3000, 32, 160, 112, 42)])
-def test_fast_mode_forward_within_tolerance(P, F, W, H, seed):
-    """FAST mode contracts FMAs and uses hardware rcp/exp: decisions at the alpha=1/255 and
-    T=1e-4 thresholds may flip for isolated pixels, so the comparison is max-norm 1e-4 on all
-    but a vanishing fraction of pixels, and those outliers stay within one skipped contribution."""
+def test_fast_tight_mode_forward_within_tolerance(P, F, W, H, seed):
+    """Opt-in "fast_tight": additionally bins a splat only into the tiles it can reach (alpha >= 1/255 somewhere):
+    every tile list is a subsequence, in the same order, of the reference's list; radii are untouched."""
     sc, cams, inp = small_scene(P=P, F=F, W=W, H=H, seed=seed, mu_s=math.log(0.05))
     st = oracle_forward(inp, cams[0], bg=(0.1, 0.2, 0.3))
-    args, out = hip_forward(inp, cams[0], bg=(0.1, 0.2, 0.3), mode=MODE_FAST)
+    args, out = hip_forward(inp, cams[0], bg=(0.1, 0.2, 0.3), mode=MODE_FAST, tight=True)
     R, color, others, radii, extra = out[:5]
-    # FAST mode bins a splat only into the tiles it can reach (alpha >= 1/255 somewhere): every tile list is a
-    # subsequence, in the same order, of the reference's list; radii are untouched
-    assert 0 < R <= st["R"]
+    assert 0 < R < st["R"]
     np.testing.assert_array_equal(radii.cpu().numpy(), st["radii"])
     dbg = rz.debug_state(P, W, H, R, out[5], out[6], out[7])
     ref_ranges = np.asarray(st["ranges"]).reshape(-1, 2)
@@ -278,13 +321,67 @@ def test_fast_mode_forward_within_tolerance(P, F, W, H, seed):
     for (a0, a1), (b0, b1) in zip(got_ranges, ref_ranges):
         it = iter(st["point_list"][b0:b1])
         assert all(any(g == r for r in it) for g in dbg["point_list"][a0:a1])
-    for name, got, want in [("color", color, st["color"]), ("extra", extra, st["extra"]),
-                            ("alpha", others[1], st["others"][1]), ("depth", others[0], st["others"][0])]:
-        got = got.cpu().numpy()
-        scale = np.abs(want).max()
-        bad = np.abs(got - want) > 1e-4 * scale
-        assert bad.mean() <= 1e-4, f"{name}: {bad.sum()} outlier pixels"
-        assert np.abs(got - want).max() <= 1e-2 * scale
+    _images_within_fast_tolerance(out, st)
+
+
+def test_homography_matches_the_reference_python(golden_dir):
+    """K1 pinned by the reference's own Python (tests/golden/transmat.npz = the transMat_precomp its render() builds with
+    pipe.compute_cov3D_python, gaussian_renderer/__init__.py:69-82): (i) the splat records k_preprocess writes hold the
+    same Tu, Tv, Tw to fp32 rounding; (ii) a forward FROM the reference's matrices is bit-identical to the oracle's forward
+    from them; (iii) render() with pipe.compute_cov3D_python takes that path end to end."""
+    import os
+    z = np.load(os.path.join(golden_dir, "transmat.npz"))
+    c = np.load(os.path.join(golden_dir, "cameras.npz"))
+    P = z["xyz"].shape[0]
+    for i in range(4):
+        Wc, Hc = (int(v) for v in c[f"wh{i}"])
+        cam = scenes.Camera(Wc, Hc, float(c[f"fov{i}"][0]), float(c[f"fov{i}"][1]), torch.tensor(c[f"wvt{i}"]),
+                            torch.tensor(c[f"proj{i}"]), torch.tensor(c[f"full{i}"]), torch.tensor(c[f"center{i}"]))
+        for mod in ("1", "0.6", "1.7"):
+            want = z[f"cam{i}_mod{mod}"]
+            inp = dict(means3D=torch.tensor(z["xyz"]), opacities=torch.full((P, 1), 0.5),
+                       scales=torch.exp(torch.tensor(z["log_scaling"])), rotations=torch.tensor(z["rotation_raw"]),
+                       shs=None, extra=None)
+            colors = np.full((P, 3), 0.5, np.float32)
+            args, out = hip_forward(inp, cam, mode=MODE_EXACT, scale_modifier=float(mod), colors_precomp=colors,
+                                    use_extra=False)
+            radii = out[3].cpu().numpy()
+            rec = rz.debug_state(P, Wc, Hc, out[0], out[5], out[6], out[7])["records"]
+            seen = radii > 0
+            if seen.sum():
+                scale = np.abs(want[seen]).max(axis=1, keepdims=True)
+                assert (np.abs(rec[seen, :9] - want[seen]) <= 2e-5 * scale).all(), (i, mod)
+            st = oracle_forward(inp, cam, scale_modifier=1.0, transMat_precomp=want, scales=None, rotations=None,
+                                colors_precomp=colors, shs=None)
+            args2, out2 = hip_forward(inp, cam, mode=MODE_EXACT, transMat_precomp=want, colors_precomp=colors,
+                                      use_extra=False)
+            check_forward_exact(st, args2, out2)
+    # (iii) through render(): the model's get_covariance -> _precomputed_transforms -> cov3D_precomp
+    from instascene_amd.harness import PipelineParams, splat_to_world
+    from instascene_amd.render import render
+
+    class PC:
+        active_sh_degree = 0
+        get_xyz = torch.tensor(z["xyz"]).cuda()
+        get_opacity = torch.full((P, 1), 0.5).cuda()
+        get_features = torch.rand(P, 1, 3, generator=torch.Generator().manual_seed(1)).cuda()
+        get_seg_feature = None
+
+        def get_covariance(self, m=1):
+            return splat_to_world(self.get_xyz, torch.exp(torch.tensor(z["log_scaling"])).cuda(), m,
+                                  torch.tensor(z["rotation_raw"]).cuda())
+
+    pipe = PipelineParams()
+    pipe.compute_cov3D_python = True
+    cam = scenes.Camera(*(int(v) for v in c["wh0"]), float(c["fov0"][0]), float(c["fov0"][1]), torch.tensor(c["wvt0"]),
+                        torch.tensor(c["proj0"]), torch.tensor(c["full0"]), torch.tensor(c["center0"])).to("cuda")
+    rz.set_mode("exact")
+    pkg = render(cam, PC(), pipe, torch.zeros(3).cuda(), scaling_modifier=0.6)
+    st = oracle.forward(z["xyz"], np.full((P, 1), 0.5, np.float32), c["wvt0"], c["full0"], c["center0"],
+                        np.zeros(3, np.float32), cam.image_width, cam.image_height, math.tan(cam.FoVx / 2),
+                        math.tan(cam.FoVy / 2), transMat_precomp=z["cam0_mod0.6"], shs=PC.get_features.cpu().numpy(),
+                        sh_degree=0)
+    assert_close(pkg["render"].cpu().numpy(), st["color"], 1e-4, "render() from precomputed transforms")
 
 
 def test_mark_visible():

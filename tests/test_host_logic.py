@@ -55,20 +55,38 @@ def test_product_package_never_imports_the_oracle():
         assert "oracle" not in open(os.path.join(ROOT, "dropin", f)).read()
 
 
-@pytest.mark.parametrize("i", range(3))
-@pytest.mark.parametrize("ratio", [0, 1])
-def test_render_post_processing_matches_reference(golden_dir, i, ratio):
+def test_render_post_processing_has_no_host_path(golden_dir):
+    """post_process is two HIP kernels each way; handing it host tensors must fail loudly instead of computing on the CPU
+    (the CPU restatement pinned by tests/golden/render_post.npz is oracle/torch_ops.render_post, test_goldens_oracle.py;
+    the HIP kernels are pinned by the same fixture in tests/test_gpu_ops.py)."""
     from instascene_amd.render import post_process
     from instascene_amd import scenes
-    from helpers import assert_close
-    z = np.load(os.path.join(golden_dir, "render_post.npz"))
     c = np.load(os.path.join(golden_dir, "cameras.npz"))
-    W, H = (int(v) for v in c[f"wh{i}"])
-    cam = scenes.Camera(W, H, float(c[f"fov{i}"][0]), float(c[f"fov{i}"][1]), torch.tensor(c[f"wvt{i}"]),
-                        torch.tensor(c[f"proj{i}"]), torch.tensor(c[f"full{i}"]), torch.tensor(c[f"center{i}"]))
-    out = post_process(cam, torch.tensor(z[f"c{i}_r{ratio}_allmap"]), float(ratio))
-    for k, v in out.items():
-        assert_close(v.numpy(), z[f"c{i}_r{ratio}_{k}"], 2e-5, k)
+    W, H = (int(v) for v in c["wh0"])
+    cam = scenes.Camera(W, H, float(c["fov0"][0]), float(c["fov0"][1]), torch.tensor(c["wvt0"]),
+                        torch.tensor(c["proj0"]), torch.tensor(c["full0"]), torch.tensor(c["center0"]))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        post_process(cam, torch.zeros(7, H, W), 1.0)
+
+
+def test_camera_ray_table_matches_the_reference_points(golden_dir):
+    """render._camera_rays (one 3x3 matrix, broadcast) against the reference's depth_to_normal fixture: the normals of
+    depth * rays_d + rays_o equal tests/golden/depth_to_normal.npz."""
+    from instascene_amd.render import _camera_rays
+    from instascene_amd import scenes
+    from helpers import assert_close
+    z = np.load(os.path.join(golden_dir, "depth_to_normal.npz"))
+    c = np.load(os.path.join(golden_dir, "cameras.npz"))
+    for i in range(2):
+        W, H = (int(v) for v in c[f"wh{i}"])
+        cam = scenes.Camera(W, H, float(c[f"fov{i}"][0]), float(c[f"fov{i}"][1]), torch.tensor(c[f"wvt{i}"]),
+                            torch.tensor(c[f"proj{i}"]), torch.tensor(c[f"full{i}"]), torch.tensor(c[f"center{i}"]))
+        rays_d, rays_o = _camera_rays(cam, "cpu")
+        pts = (torch.tensor(z[f"depth{i}"]).reshape(-1, 1) * rays_d + rays_o).reshape(H, W, 3)
+        n = torch.zeros_like(pts)
+        n[1:-1, 1:-1] = torch.nn.functional.normalize(
+            torch.linalg.cross(pts[2:, 1:-1] - pts[:-2, 1:-1], pts[1:-1, 2:] - pts[1:-1, :-2], dim=-1), dim=-1)
+        assert_close(n.numpy(), z[f"normal{i}"], 2e-5, "normal from the ray table")
 
 
 def test_rasterizer_argument_checks_mirror_reference():
@@ -93,11 +111,18 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.lib()
 
 
-def test_render_package_evaluates_derived_maps_on_first_access(golden_dir):
+def test_render_package_evaluates_derived_maps_on_first_access(golden_dir, monkeypatch):
     """The seven allmap-derived entries of render()'s dict are computed on first access, under the grad mode of the
-    render() call, and dict(pkg) / items() see real tensors."""
+    render() call, and dict(pkg) / items() see real tensors.  (Host tensors: the kernels are replaced by the oracle's
+    restatement for this test of the dict's laziness.)"""
     from instascene_amd import render as R
     from instascene_amd import scenes
+    from oracle import torch_ops
+
+    def _post(cam, allmap, ratio):
+        return torch_ops.render_post(allmap, cam.world_view_transform, cam.full_proj_transform, cam.image_width,
+                                     cam.image_height, ratio)
+    monkeypatch.setattr(R, "post_process", _post)
     z = np.load(os.path.join(golden_dir, "render_post.npz"))
     c = np.load(os.path.join(golden_dir, "cameras.npz"))
     W, H = (int(v) for v in c["wh0"])
@@ -111,7 +136,7 @@ def test_render_package_evaluates_derived_maps_on_first_access(golden_dir):
     with torch.no_grad():                       # accessed later under no_grad: still differentiable
         a = pkg["rend_alpha"]
     assert pkg._pending is None and a.requires_grad
-    want = R.post_process(cam, allmap, 0.0)
+    want = _post(cam, allmap, 0.0)
     for k in R._LAZY_KEYS:
         assert torch.equal(pkg[k], want[k])
     pkg2 = R.RenderPackage({"render": torch.zeros(3, 4, 4)})
