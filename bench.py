@@ -1,42 +1,65 @@
 #!/usr/bin/env python
-"""Benchmark of the hot path named by BASELINE.json: train-step views/s (render forward + backward,
-three contrastive losses, Adam on the [P,F] feature) on the synthetic C3 workload
-(1.5 M Gaussians, 1920x1080, 32-d feature, sample batch 8192) — SURVEY.md §8(d).
+"""Benchmark of the hot path named by BASELINE.json.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
-           --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C5|C2|C1] [--step seg|rgb] [--mode fast|exact|fast_tight]
 
-One rank per GPU; every rank renders a different view per step (weak scaling), the [P,F] gradient is
-summed with an RCCL all-reduce.  Rank 0 prints ONE JSON line.
+* ``--step seg`` (default, configs with a feature channel: C3 = the headline, C5): the train_semantic.py step - render
+  forward, two single-view contrastive losses on 8 192 sampled pixels each, the 3-D contrastive loss, backward, Adam on
+  the [P,F] feature.  ``--step rgb`` (C2 = BASELINE config 2, also C1 / C3): the train.py step - render, L1 + SSIM +
+  normal consistency, full geometry backward, Adam on the six parameter groups.
+* ``--mode fast`` (default, the headline): FAST arithmetic in the per-pixel loops with the REFERENCE's tile rectangles -
+  radii, tiles_touched, point_list and ranges bit-identical to the reference's, images within 1e-4, gradients within 1e-3.
+  At one GPU the same line also carries ``sub_records`` for ``exact`` (op-for-op IEEE, bit-identical images too) and
+  ``fast_tight`` (tighter tile rectangles: tile lists are subsequences of the reference's), timed the same way.
+* ``--gpus N`` > 1 without a launcher re-executes itself under ``torch.distributed.run`` (one rank per GPU, RCCL); under
+  a launcher (WORLD_SIZE set) it is a rank.  Every rank renders a different view per step (weak scaling); the parameter
+  gradients are summed across ranks.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes
 import json
 import math
 import os
+import socket
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md); measured copy peak ~6290 GB/s
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
 
 
-def algorithmic_bytes(P, V, R, N, F):
-    """algorithmic HBM bytes per view, per kernel group."""
-    fwd_blend = R * (64 + 12 + 4 * F) + N * (40 + 20 + 4 * F)          # K8: staged records/colours/features + per-pixel outputs
-    bwd_blend = N * (40 + 20 + 4 * F) + R * (64 + 12 + 4 * F) + R * 2 * 4 * F   # K9 (feature-only): grads+state, staging, one row write+read
-    pre = 12 * P + 307 * V + 8 * P
-    binning = R * (12 + 8 + 12)                                          # bucket write, sort read, list write (this design; reference: 164 B)
-    return dict(k_render_fwd=fwd_blend, k_render_bwd=bwd_blend, k_preprocess=pre, binning=binning)
+def _self_launch(n):
+    """``python bench.py --gpus N`` with no launcher: become ``torch.distributed.run`` with N ranks on this node."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("OMP_NUM_THREADS", "8")
+    os.execv(sys.executable, cmd)
+
+
+def byte_model(P, V, R, N, F, tiles):
+    """SURVEY.md 8(d) / DESIGN.md section 3: algorithmic HBM bytes per view, per kernel of this design."""
+    return {
+        "k_render_fwd": R * (64 + 12 + 4 * F) + N * (40 + 20 + 4 * F),      # K8: staged records/colours/features + per-pixel outputs
+        "k_render_bwd_dense": N * (40 + 20 + 4 * F) + R * (64 + 12 + 4 * F) + R * 2 * 4 * (16 + F),   # K9, dense upstream gradient
+        "k_preprocess": 12 * P + 220 * V + 92 * V + 20 * P + 32 * V,         # xyz; scale/rot/opacity/SH in; record, rect, counts, radii, cull out
+        "k_scatter": 16 * V + 8 * R,
+        "k_tile_sort": 12 * R,
+        "k_feature_rows_step": 8 * P + 7 * 4 * F * P,                        # mask/offsets + x, m, v in; x, m, v, z out (+ flagged rows)
+        "k_preprocess_bwd": 340 * V + 252 * P,
+        "pp_maps": (28 + 44) * N,
+        "pp_surf_normal": (20 + 12) * N,
+    }
 
 
 def profile_summary(L):
     buf = ctypes.create_string_buffer(1 << 16)
-    n = L.isr_profile_summary(buf, len(buf))
+    L.isr_profile_summary(buf, len(buf))
     out = {}
     for line in buf.value.decode().splitlines():
         name, cnt, tot = line.split()
@@ -44,18 +67,29 @@ def profile_summary(L):
     return out
 
 
-def cpu_baseline(cfg, seconds_budget=25.0):
-    """The CPU oracle (C++/OpenMP restatement of the reference kernels) timed on this box's host cores on a
-    bounded sample of the same workload: forward + full backward of one C3 view, at the largest scale
-    (1, 1/2 or 1/4 in each image dimension, P scaled alike) whose estimated time fits the budget."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, step, n_samples, seconds_budget=25.0):
+    """The CPU oracle (C++/OpenMP restatement of the reference kernels; the reference has no CPU path of its own) timed on
+    this box's host cores on a bounded sample of the same per-view work: forward + the reference's backward of one view, at
+    the largest scale (1, 1/2 or 1/4 in each image dimension, P scaled alike) whose estimated time fits the budget."""
     import numpy as np
     import oracle
     from instascene_amd import scenes
+    F = cfg["F"] if step == "seg" else 0
 
     def build(scale):
         P = int(cfg["P"] * scale * scale)
         W, H = int(cfg["W"] * scale), int(cfg["H"] * scale)
-        sc = scenes.synthetic_scene(P, cfg["F"], scenes.SEED_BASE + 3, cfg["mu_s"] - math.log(scale))
+        sc = scenes.synthetic_scene(P, F, scenes.SEED_BASE + cfg["index"], cfg["mu_s"] - math.log(scale))
         cam = scenes.ring_cameras(64, W, H)[0]
         a = {k: (None if v is None else v.numpy()) for k, v in scenes.activated_inputs(sc).items()}
         return P, W, H, cam, a
@@ -65,11 +99,17 @@ def cpu_baseline(cfg, seconds_budget=25.0):
                             cam.camera_center.numpy(), np.zeros(3, np.float32), W, H, math.tan(cam.FoVx / 2),
                             math.tan(cam.FoVy / 2), scales=a["scales"], rotations=a["rotations"], shs=a["shs"],
                             extra=a["extra"], sh_degree=3)
-        oracle.backward(st, np.zeros_like(st["color"]), np.zeros_like(st["others"]), np.ones_like(st["extra"]))
+        if step == "seg":
+            # the upstream gradient of this step: dL/dfeature on the sampled pixels only, nothing on colour / aux maps
+            dE = np.zeros_like(st["extra"]).reshape(F, -1)
+            pick = np.random.RandomState(0).randint(0, W * H, max(1, int(n_samples * W * H / (cfg["W"] * cfg["H"]))))
+            dE[:, pick] = 1.0
+            oracle.backward(st, np.zeros_like(st["color"]), np.zeros_like(st["others"]), dE.reshape(st["extra"].shape))
+        else:
+            oracle.backward(st, np.ones_like(st["color"]), np.ones_like(st["others"]), None)
         return st["R"]
 
-    # calibrate on the 1/4-scale view (splats enlarged by 1/scale in world units: same pixel footprint and depth complexity)
-    small = build(0.25)
+    small = build(0.25)     # splats enlarged by 1/scale in world units: same pixel footprint and depth complexity
     one(*small)
     t0 = time.time()
     one(*small)
@@ -90,10 +130,176 @@ def cpu_baseline(cfg, seconds_budget=25.0):
     dt = (time.time() - t0) / n
     P, W, H = args[0], args[1], args[2]
     frac = scale * scale
-    return {"value": frac / dt, "unit": "views/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": f"oracle forward + full backward of a C3 view at scale {scale:g} (P={P}, {W}x{H}, F={cfg['F']}, R={R}): "
-                      f"{n} view(s) in {dt * n:.1f} s" + ("" if scale == 1.0 else
-                      f"; value = measured {1.0 / dt:.3f} views/s x {frac:g} (work scales with P and pixels)")}
+    what = ("forward + the reference's backward walk over all pixels of one view with dL/dfeature on the sampled pixels only "
+            "(the reference does not exploit that sparsity, the GPU path does; the three losses and Adam are not in the sample)"
+            if step == "seg" else "forward + dense full backward (colour + aux maps) of one view (losses and Adam not in the sample)")
+    return {"value": frac / dt, "unit": "views/s", "cores": oracle.num_threads(), "cpu": cpu_model(), "kind": "port",
+            "sample": f"oracle {what}; {cfg['name']} at scale {scale:g} (P={P}, {W}x{H}, F={F}, R={R}): {n} view(s) in "
+                      f"{dt * n:.1f} s" + ("" if scale == 1.0 else f"; value = measured {1.0 / dt:.3f} views/s x {frac:g} "
+                                           "(work scales with P and pixels)")}
+
+
+def time_allreduce(numel, dev, world, reps=5):
+    import torch
+    import torch.distributed as dist
+    if world <= 1:
+        return None
+    t = torch.zeros(numel, dtype=torch.float32, device=dev)
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(t)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / reps
+
+
+def run(args, mode, rank, world, dev, detail):
+    """One timed measurement in ``mode``: W warm-up steps, then exactly K steps between barrier + synchronize on both
+    sides.  Returns the record (rank 0: with the kernel detail when ``detail``)."""
+    import torch
+    import torch.distributed as dist
+    from instascene_amd import scenes, rasterizer
+    from instascene_amd._lib import lib
+    from instascene_amd.harness import RgbTrainer, SegTrainer
+    from instascene_amd.render import render
+
+    rasterizer.set_mode(mode)
+    rasterizer.set_tracer(bool(args.tracer))
+    rasterizer.set_async_binning(bool(args.async_binning))
+    rasterizer.set_view_cache(args.view_cache_gb)
+    scene, cams, cfg = scenes.config_scene(args.config)
+    cfg["name"] = args.config
+    n_views = 16
+    if args.step == "seg":
+        trainer = SegTrainer(scene, cams[:n_views], device=dev, sample_batchsize=8192, use_class_feat=True, rank=rank, world=world,
+                             spatial_sort=bool(args.spatial_sort), fused_sampling=bool(args.fused_sampling))
+        trainer.split_tail = bool(args.split_tail)
+        trainer.pipe.lazy_maps = bool(args.lazy_maps)
+        trainer.warm_view_caches()       # per-view constants (ray tables, visible pools, instance counts): setup
+        trainer.prime()                  # code objects, allocator pools, side stream: two steps whose effect is undone
+        view_index = trainer.view_index
+    else:
+        scene.seg_feature = None
+        trainer = RgbTrainer(scene, cams[:n_views], [torch.zeros(3, 8, 8)] * n_views, device=dev, rank=rank, world=world,
+                             spatial_sort=bool(args.spatial_sort))
+        with torch.no_grad():            # targets: the initial renders plus noise (setup)
+            g = torch.Generator(device=dev).manual_seed(5)
+            trainer.targets = [(render(c, trainer.model, trainer.pipe, trainer.bg)["render"]
+                                + 0.05 * torch.randn(3, cfg["H"], cfg["W"], device=dev, generator=g)).clamp(0, 1)
+                               for c in trainer.cams]
+        from instascene_amd.dist_utils import view_for
+        view_index = lambda it: view_for(it, rank, world, n_views)
+    L = lib()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        trainer.step(it)
+    sync()
+    L.isr_profile_enable(2)          # HIP events around the forward blend kernel only inside the timed region
+    t0 = time.perf_counter()
+    for it in range(args.warmup, args.warmup + args.steps):
+        trainer.step(it)
+    sync()
+    dt = time.perf_counter() - t0
+    prof_dom = profile_summary(L)
+    L.isr_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    rec = {"value": round(world * args.steps / dt, 3), "ms_per_step": round(1e3 * dt / args.steps, 4), "arithmetic_mode": mode}
+    if rank == 0 and detail:
+        # every kernel of the library, over a few extra (untimed) steps, HIP events on the launch stream
+        L.isr_profile_enable(1)
+        extra_steps = min(5, args.steps)
+        it0 = args.warmup + args.steps
+        for it in range(it0, it0 + extra_steps):
+            trainer.step(it)
+        torch.cuda.synchronize()
+        prof_all = profile_summary(L)
+        L.isr_profile_enable(0)
+        # workload statistics + work counters of the blend kernel on the last timed view (one extra, untimed render)
+        counters = torch.zeros(4, dtype=torch.int64, device=dev)
+        with torch.no_grad():
+            was = rasterizer._CONFIG["async_binning"]
+            rasterizer.set_async_binning(False)             # exact instance count for the byte model
+            if mode != "exact":
+                L.isr_forward_set_counters(ctypes.c_void_p(counters.data_ptr()))
+            pkg = render(trainer.cams[view_index(it0 - 1)], trainer.model, trainer.pipe, trainer.bg)
+            V = int((pkg["radii"] > 0).sum().item())
+            R = int(rasterizer.LAST_NUM_RENDERED)
+            rasterizer.set_async_binning(was)
+        cull_tests, pairs_eval, pairs_blend, lane_pairs = (int(v) for v in counters.tolist())
+        P, N, F = cfg["P"], cfg["W"] * cfg["H"], (cfg["F"] if args.step == "seg" else 0)
+        tiles = ((cfg["W"] + 15) // 16) * ((cfg["H"] + 15) // 16)
+        bm = byte_model(P, V, R, N, F, tiles)
+        kern = {}
+        for k, (cnt, tot) in sorted(prof_all.items()):
+            ms = tot / cnt
+            key = "k_render_bwd_dense" if (k == "k_render_bwd" and args.step == "rgb") else k
+            e = {"ms_per_launch": round(ms, 4), "launches_per_view": round(cnt / float(extra_steps), 2)}
+            if key in bm:
+                per_launch = bm[key] / max(1.0, cnt / float(extra_steps)) if k != "k_render_fwd" else bm[key] / max(1.0, round(cnt / float(extra_steps)))
+                e["algorithmic_bytes"] = int(per_launch)
+                e["GB/s"] = round(per_launch / (ms * 1e-3) / 1e9, 1)
+                e["frac_hbm"] = round(per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            kern[k] = e
+        dom = "k_render_fwd" if args.step == "seg" else max(kern, key=lambda k: kern[k]["ms_per_launch"] * kern[k]["launches_per_view"])
+        dom_ms = kern[dom]["ms_per_launch"]
+        timing = "HIP events on the launch stream over %d extra untimed steps" % extra_steps
+        if dom in prof_dom:              # the dominant forward kernel: measured over the timed region itself
+            dom_ms = prof_dom[dom][1] / prof_dom[dom][0]
+            kern[dom]["ms_per_launch"] = round(dom_ms, 4)
+            timing = "HIP events on the launch stream: %s over the timed region, the other kernels over %d extra untimed steps" % (dom, extra_steps)
+        dom_key = "k_render_bwd_dense" if (dom == "k_render_bwd" and args.step == "rgb") else dom
+        launches = max(1, round(kern[dom]["launches_per_view"]))
+        dom_bytes = bm.get(dom_key, 0) / launches
+        gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
+        traffic, tsrc = None, None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(args.config + ":" + args.step + ":" + mode, {}).get(dom)
+                tsrc = tj.get("source")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
+                "avg_launch_ms": round(dom_ms, 4), "launches_per_view": launches,
+                "hbm": {"bytes": int(dom_bytes), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 5),
+                        "frac_of_measured_copy_peak_6290": round(gbs / 6290.0, 5)},
+                "note": "the blend kernels are VALU / LDS issue-bound, not HBM-bound (SURVEY 8d): see `valu`",
+                "timing": timing, "kernels": kern,
+                "workload": {"P": P, "V": V, "R": R, "N": N, "F": F, "tiles": tiles}}
+        if dom == "k_render_fwd" and pairs_eval:
+            per_pair, per_contrib = 40.0, 2.0 * (3 + 7 + F)
+            flops_eval = per_pair * 64 * pairs_eval + per_contrib * lane_pairs
+            flops_model = per_pair * 256.0 * R + per_contrib * lane_pairs
+            tf = flops_eval / (dom_ms * launches * 1e-3) / 1e12
+            roof["valu"] = {
+                "wave_splat_cull_tests": cull_tests, "wave_splat_pairs_evaluated": pairs_eval,
+                "wave_splat_pairs_blending": pairs_blend, "pixel_splat_pairs_evaluated": 64 * pairs_eval,
+                "pixel_splat_pairs_contributing": lane_pairs,
+                "lane_utilisation_of_blending_pairs": round(lane_pairs / max(1, 64 * pairs_blend), 4),
+                "flop_model": "SURVEY 8(d): 40 flop per evaluated (pixel, splat) pair + 2*(3+7+F) per contributing pair",
+                "flops": int(flops_eval), "flops_upper_bound_256R": int(flops_model),
+                "TFLOP/s": round(tf, 2), "peak_TFLOP/s": VALU_PEAK_TFLOPS, "frac": round(tf / VALU_PEAK_TFLOPS, 4),
+                "frac_with_256R_bound": round(flops_model / (dom_ms * launches * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}
+        rec["roofline"] = roof
+        rec["cfg"] = cfg
+    if world > 1 and args.step == "seg":
+        ms = time_allreduce(cfg["P"] * cfg["F"], dev, world)
+        rec["allreduce_ms"] = None if ms is None else round(ms, 3)
+    del trainer
+    torch.cuda.empty_cache()
+    return rec
 
 
 def main():
@@ -102,17 +308,22 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--mode", default=os.environ.get("ISR_MODE", "fast"))
+    ap.add_argument("--step", default=None, choices=[None, "seg", "rgb"],
+                    help="seg: train_semantic.py step (needs a feature channel: C3, C5); rgb: train.py step (C1, C2, C3)")
+    ap.add_argument("--mode", default=os.environ.get("ISR_MODE", "fast"), choices=["fast", "exact", "fast_tight"])
+    ap.add_argument("--submodes", default="exact,fast_tight",
+                    help="at one GPU: further modes timed the same way and reported as sub_records ('' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tracer", type=int, default=1, help="produce gau_related_pixels each forward like the reference")
     ap.add_argument("--async-binning", type=int, default=1,
-                    help="size the binning workspace from the previous view instead of a blocking read of R")
+                    help="size a view's binning workspace from its own verified count of an earlier forward instead of a "
+                         "blocking read of R")
     ap.add_argument("--view-cache-gb", type=float, default=0.0,
                     help="opt-in exploration, NOT the headline configuration: keep each view's geometry pass + binning "
                          "while the geometry is frozen (rasterizer.set_view_cache); 0 = recompute every step like the "
                          "reference")
     ap.add_argument("--lazy-maps", type=int, default=0,
-                    help="1: evaluate render()'s seven derived normal/depth maps on first access (this step never reads "
+                    help="1: evaluate render()'s seven derived normal/depth maps on first access (the seg step never reads "
                          "them) instead of inside render() like the reference (default 0 = reference behaviour)")
     ap.add_argument("--spatial-sort", type=int, default=1,
                     help="1 (default): the trainer stores the Gaussians in Z-order of their centres (sorted once at load, "
@@ -120,19 +331,23 @@ def main():
     ap.add_argument("--fused-sampling", type=int, default=1,
                     help="1 (default): one kernel draws every index of a step (iso_sample_step); 0: torch.randint + gathers")
     ap.add_argument("--split-tail", type=int, default=0,
-                    help="1: with one rank, take the multi-rank form of the per-Gaussian tail (dL/dx kernel, [no-op] "
-                         "all-reduce, Adam kernel) to measure what it costs next to the one-pass tail")
+                    help="1: with one rank, take the multi-rank form of the per-Gaussian tail to measure what it costs")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args.gpus)
+
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("launch with torch.distributed.run for --gpus > 1", file=sys.stderr)
-        sys.exit(2)
     # ISR_DIST_BACKEND=gloo (testing only): several ranks may then share one GPU, which RCCL does not allow
     backend = os.environ.get("ISR_DIST_BACKEND", "nccl")
-    local = local if backend == "nccl" else local % torch.cuda.device_count()
+    if backend == "nccl" and world > torch.cuda.device_count():
+        print(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s); RCCL needs one GPU per rank", file=sys.stderr)
+        sys.exit(2)
+    local = local if backend == "nccl" else local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -142,115 +357,81 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from instascene_amd import scenes, rasterizer
-    from instascene_amd._lib import lib
-    from instascene_amd.harness import SegTrainer
-
-    rasterizer.set_mode(args.mode)
-    rasterizer.set_tracer(bool(args.tracer))
-    rasterizer.set_async_binning(bool(args.async_binning))
-    rasterizer.set_view_cache(args.view_cache_gb)
-    scene, cams, cfg = scenes.config_scene(args.config)
-    if cfg["F"] == 0:
-        print("bench.py measures the feature-training step: the config needs F > 0 (C3, C5); the RGB + geometry step of "
-              "C1 / C2 is tools/bench_rgb.py", file=sys.stderr)
+    from instascene_amd import scenes
+    cfg0 = scenes.CONFIGS[args.config]
+    if args.step is None:
+        args.step = "seg" if cfg0["F"] > 0 else "rgb"
+    if args.step == "seg" and cfg0["F"] == 0:
+        print(f"bench.py: --step seg needs a feature channel; {args.config} has none (use --step rgb)", file=sys.stderr)
         sys.exit(2)
-    trainer = SegTrainer(scene, cams[:16], device=dev, sample_batchsize=8192, use_class_feat=True, rank=rank, world=world,
-                         spatial_sort=bool(args.spatial_sort), fused_sampling=bool(args.fused_sampling))
-    trainer.split_tail = bool(args.split_tail)
-    trainer.pipe.lazy_maps = bool(args.lazy_maps)
-    trainer.warm_view_caches()       # per-view constants (ray tables, visible pools): setup, like the label maps
-    trainer.prime()                  # code objects, allocator pools, side stream: two steps whose effect is undone
-    L = lib()
 
-    for it in range(args.warmup):
-        trainer.step(it)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    L.isr_profile_enable(2)          # HIP events around the dominant kernel only inside the timed region
-    t0 = time.perf_counter()
-    for it in range(args.warmup, args.warmup + args.steps):
-        trainer.step(it)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof_dom = profile_summary(L)
-    # every kernel of the library, over a few extra (untimed) steps: detail for the JSON line
-    L.isr_profile_enable(1)
-    extra_steps = min(5, args.steps)
-    for it in range(args.warmup + args.steps, args.warmup + args.steps + extra_steps):
-        trainer.step(it)
-    torch.cuda.synchronize()
-    prof_all = profile_summary(L)
-    L.isr_profile_enable(0)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    head = run(args, args.mode, rank, world, dev, detail=True)
+    subs = {}
+    if world == 1:
+        for m in [m for m in args.submodes.split(",") if m and m != args.mode]:
+            r = run(args, m, rank, world, dev, detail=True)
+            roof = r.pop("roofline", None) or {}
+            r.pop("cfg", None)
+            r["dominant_kernel_ms"] = roof.get("avg_launch_ms")
+            r["R"] = roof.get("workload", {}).get("R")
+            r["parity"] = {"exact": "radii / tiles_touched / point_list / ranges / n_contrib / images bit-identical to the CPU oracle",
+                           "fast_tight": "tile lists are order-preserving subsequences of the reference's; images 1e-4",
+                           "fast": "binning bit-identical; images 1e-4"}[m]
+            subs[m] = r
 
     if rank == 0:
-        # workload statistics of the last rendered view, for the byte model
-        from instascene_amd.render import render
-        with torch.no_grad():
-            vi = trainer.view_index(args.warmup + args.steps - 1)
-            pkg = render(trainer.cams[vi], trainer.model, trainer.pipe, trainer.bg)
-            V = int((pkg["radii"] > 0).sum().item())
-        P, N, F = cfg["P"], cfg["W"] * cfg["H"], cfg["F"]
-        ptr = ctypes.c_int64(0)
-        # R of that view: re-run prepare is not needed — total instances = sum of tiles touched == binning size
-        R = int(rasterizer.LAST_NUM_RENDERED) if hasattr(rasterizer, "LAST_NUM_RENDERED") else 0
-        ab = algorithmic_bytes(P, V, R, N, F)
-        kern_ms = {k: (tot / cnt) for k, (cnt, tot) in prof_all.items()}
-        dom = max(kern_ms, key=lambda k: kern_ms[k] * prof_all[k][0]) if kern_ms else None
-        if dom in prof_dom:             # measured over the timed region itself
-            prof, steps_prof = prof_dom, args.steps
-            kern_ms[dom] = prof_dom[dom][1] / prof_dom[dom][0]
+        cfg = head.pop("cfg")
+        roof = head.pop("roofline")
+        if args.step == "seg":
+            metric = "train-step views/sec (fwd+bwd) @1.5M Gaussians, 1080p, 32-d feat"
+            if args.config != "C3":
+                metric = f"train-step views/sec (fwd+bwd), {args.config}"
+            workload = (f"{args.config}: {cfg['P']} Gaussians, {cfg['W']}x{cfg['H']}, F={cfg['F']}, sample batch 8192, "
+                        "2 single-view + 1 3-D contrastive loss, Adam on [P,F] (train_semantic.py step)")
         else:
-            prof, steps_prof = prof_all, extra_steps
-        roof = None
-        if dom is not None:
-            per_launch_bytes = ab.get(dom, 0)
-            launches_per_view = prof[dom][0] / float(steps_prof)
-            achieved = per_launch_bytes / max(launches_per_view, 1e-9) / (kern_ms[dom] * 1e-3) / 1e9 if per_launch_bytes else 0.0
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(dom)
-                except Exception:
-                    traffic = None
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                    "avg_launch_ms": round(kern_ms[dom], 4), "launches_per_view": round(launches_per_view, 3),
-                    "algorithmic_bytes_per_view": int(per_launch_bytes),
-                    "note": "blend kernels are VALU/LDS-bound, not HBM-bound (SURVEY 8d); per-kernel ms below",
-                    "kernels_ms_per_launch": {k: round(v, 4) for k, v in sorted(kern_ms.items())},
-                    "kernels_launches_per_view": {k: round(prof_all[k][0] / float(extra_steps), 2) for k in sorted(prof_all)},
-                    "timing": "HIP events on the launch stream: dominant kernel over the timed region, the others "
-                              "over %d extra untimed steps" % extra_steps,
-                    "workload": {"P": P, "V": V, "R": R, "N": N, "F": F}}
-        out = {"metric": "train-step views/sec (fwd+bwd) @1.5M Gaussians, 1080p, 32-d feat",
-               "value": round(world * args.steps / dt, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{args.config}: {cfg['P']} Gaussians, {cfg['W']}x{cfg['H']}, F={cfg['F']}, "
-                                      f"sample batch 8192, 2 single-view + 1 3-D contrastive loss, Adam on [P,F]",
-                          "parallelism": f"dp{world} (one view per rank, RCCL all-reduce of the [P,F] gradient"
-                                         + (", overlapped with the next view's geometry pass)" if world > 1 else ")"),
-                          "arithmetic_mode": args.mode, "tracer": bool(args.tracer),
-                          "async_binning": bool(args.async_binning), "view_cache_gb": args.view_cache_gb,
+            metric = f"train-step views/sec (fwd+bwd), train.py step, {args.config}"
+            workload = (f"{args.config}: {cfg['P']} Gaussians, {cfg['W']}x{cfg['H']}, RGB + depth + normal, L1 + SSIM + normal "
+                        "consistency, full geometry backward, Adam on six parameter groups (train.py step)")
+        par = f"dp{world} (one view per rank"
+        if world > 1:
+            par += (", RCCL all-reduce of the [P,F] gradient in row ranges overlapped with the per-Gaussian tail and the next view's "
+                    "geometry pass)" if args.step == "seg" else ", all-reduce of the six parameter groups' gradients)")
+        else:
+            par += ")"
+        out = {"metric": metric, "value": head["value"], "unit": "views/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": workload, "parallelism": par, "arithmetic_mode": args.mode,
+                          "parity_of_this_mode": {"fast": "radii, tiles_touched, point_list, ranges bit-identical to the reference's; "
+                                                          "images within 1e-4, gradients within 1e-3 (tests/test_gpu_rasterizer.py, "
+                                                          "tests/test_gpu_fuzz.py)",
+                                                  "exact": "every forward output and all integer state bit-identical to the CPU oracle",
+                                                  "fast_tight": "tile lists are subsequences of the reference's (NOT its point_list)"}[args.mode],
+                          "tracer": bool(args.tracer), "async_binning": bool(args.async_binning),
+                          "view_cache_gb": args.view_cache_gb,
+                          "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
+                          "allreduce_ms_per_step_alone": head.get("allreduce_ms"),
                           "gaussian_order": "z-order of the centres, sorted once at load" if args.spatial_sort else "as generated (random)",
-                          "derived_render_maps": "on first access (never read by this step)" if args.lazy_maps else "inside render(), like the reference"},
+                          "derived_render_maps": "on first access (never read by the seg step)" if args.lazy_maps else "inside render(), like the reference",
+                          "view_order": "deterministic round-robin over 16 ring cameras (the reference pops a random view, "
+                                        "train_semantic.py:100): the next view is known, so its geometry pass + binning are issued "
+                                        "on a side stream during the current step",
+                          "hoisted_out_of_the_timed_region": (
+                              ["activations of the frozen parameters (exp / sigmoid / normalize, SH concat): evaluated once",
+                               "per-view pools of labelled pixels and of visible labelled Gaussians, the cameras' ray tables, each "
+                               "view's verified tile-instance count (SegTrainer.warm_view_caches: one untrained render per view)",
+                               "two priming steps whose effect on parameters / optimiser / RNG is undone (SegTrainer.prime)"]
+                              if args.step == "seg" else
+                              ["targets = initial renders + noise", "the cameras' ray tables, each view's verified tile-instance count"])},
                "roofline": roof}
+        if subs:
+            out["sub_records"] = subs
         if world > 1:
             out["cpu_baseline"] = None       # timed on rank 0 at N=1 only (task contract)
         elif not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg)
+                cfg["index"] = scenes.CONFIGS[args.config]["index"]
+                out["cpu_baseline"] = cpu_baseline(cfg, args.step, 16384)
             except Exception as e:   # the bench line must still be printed
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))

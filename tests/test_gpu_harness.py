@@ -57,7 +57,8 @@ def test_prefetched_geometry_pass_changes_nothing():
             sc, cams = _scene()
             tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=2048, n_labels=12, use_class_feat=True, seed=3,
                             prefetch_geometry=pf)
-            tr.step(0)                                   # first step: sizes the binning estimate (blocking)
+            tr.warm_view_caches()                        # every view rendered once: its verified instance count (blocking)
+            tr.step(0)
             hits0 = rz.PREFETCH_HITS
             losses = [float(tr.step(it)) for it in range(1, 8)]
             outs.append((losses, tr.model._seg_feature.detach().clone(), rz.PREFETCH_HITS - hits0))

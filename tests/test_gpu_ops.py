@@ -231,21 +231,26 @@ def test_contrastive_with_label_bound_and_dropped_samples():
 
 
 def test_async_binning_and_lazy_tracer_slice():
-    """Binning workspace sized from the previous view (no blocking read of R) gives identical results; the overflow
-    check fires when the estimate is too small; the tracer list is sliced only when accessed."""
+    """Binning workspace sized from THIS view's verified instance count of an earlier forward (no blocking read of R)
+    gives identical results; a view seen for the first time is sized exactly; when the estimate turns out too small an
+    eval render is redone with the exact size, a training forward raises BinningOverflow at its backward - and in both
+    cases the estimate is corrected and async binning stays on.  The tracer list is sliced only when accessed."""
     import copy
     from helpers import oracle_forward
     sc, cams, inp = small_scene(P=900, F=8, W=64, H=48, seed=77)
     pc = _PC(inp)
     rz.set_mode("exact")
     rz.set_tracer(True)
-    rz._R_ESTIMATE.clear(); rz._PENDING.clear()
+    rz._R_ESTIMATE.clear(); rz._PENDING.clear(); rz._OVERFLOWED.clear()
     try:
         rz.set_async_binning(True)
+        camg = [copy.deepcopy(cams[k]).to("cuda") for k in range(2)]       # long-lived cameras, like a trainer's
+        bg = torch.zeros(3, device="cuda")
         outs = []
-        for k in range(3):                       # first call sizes exactly (no estimate yet), later calls run async
-            camg = copy.deepcopy(cams[k % 2]).to("cuda")
-            outs.append(render(camg, pc, _Pipe(), torch.zeros(3, device="cuda")))
+        with torch.no_grad():
+            for k in range(4):                   # first visit of each view sizes exactly, revisits run async
+                outs.append(render(camg[k % 2], pc, _Pipe(), bg))
+        assert len(rz._R_ESTIMATE) == 2          # one verified count per view
         feat = __import__("instascene_amd.contrastive", fromlist=["row_normalize"]).row_normalize(inp["extra"].cuda(), 1e-9).cpu()
         st0 = oracle_forward(dict(inp, extra=feat), cams[0], tracer=True)
         np.testing.assert_array_equal(outs[2]["render"].cpu().numpy(), st0["color"])
@@ -253,23 +258,31 @@ def test_async_binning_and_lazy_tracer_slice():
         grp = outs[2]["gau_related_pixels"]       # lazily sliced here
         assert grp.shape[0] == len(st0["tracer"])
         assert {(int(a), int(b)) for a, b in grp.cpu().numpy()} == {(int(a), int(b)) for a, b in st0["tracer"]}
-        # force an overflow: pretend the last view had almost no instances
-        key = next(iter(rz._R_ESTIMATE))
-        rz._verify_pending(key)
-        rz._R_ESTIMATE[key] = 1
+        # force an overflow: pretend view 0 had almost no instances, then render it with much larger splats
+        key0 = next(k for k in rz._R_ESTIMATE if k[-2:] == rz._view_id(camg[0].world_view_transform, camg[0].full_proj_transform))
         slack, rz._ASYNC_SLACK = rz._ASYNC_SLACK, 0
         big = {k: (v.clone() if v is not None else None) for k, v in inp.items()}
-        big["scales"] = big["scales"] * 30.0        # far more tile instances than 1*1.25 + 65536
+        big["scales"] = big["scales"] * 30.0        # far more tile instances than 1 * 1.25
         pc2 = _PC(big)
-        camg = copy.deepcopy(cams[0]).to("cuda")
-        render(camg, pc2, _Pipe(), torch.zeros(3, device="cuda"))
+        st_big = oracle_forward(dict(big, extra=feat), cams[0])
+        rz._R_ESTIMATE[key0] = 1
+        with torch.no_grad():                       # eval render: verified at once, redone with the exact size
+            pkg = render(camg[0], pc2, _Pipe(), bg)
+        np.testing.assert_array_equal(pkg["render"].cpu().numpy(), st_big["color"])
+        assert rz._R_ESTIMATE[key0] == st_big["R"] and rz._CONFIG["async_binning"] is True
+        rz._R_ESTIMATE[key0] = 1
+        pc2._i["extra"].requires_grad_(True)        # training forward: the check fires before the backward kernels run
+        pkg = render(camg[0], pc2, _Pipe(), bg)
         with pytest.raises(rz.BinningOverflow):
-            rz._verify_pending(key)
-        assert rz._CONFIG["async_binning"] is False
+            pkg["seg_feature"].sum().backward()
+        assert rz._R_ESTIMATE[key0] == st_big["R"] and rz._CONFIG["async_binning"] is True
+        pkg = render(camg[0], pc2, _Pipe(), bg)     # re-run: sized by the corrected estimate, async again
+        pkg["seg_feature"].sum().backward()
+        np.testing.assert_array_equal(pkg["render"].detach().cpu().numpy(), st_big["color"])
     finally:
         rz.set_async_binning(False)
         rz._ASYNC_SLACK = 65536
-        rz._R_ESTIMATE.clear(); rz._PENDING.clear()
+        rz._R_ESTIMATE.clear(); rz._PENDING.clear(); rz._OVERFLOWED.clear()
 
 
 def _golden_cam(c, i):

@@ -273,18 +273,20 @@ def test_backward_precomputed_paths():
         assert_close(t.cpu().numpy().reshape(want[name].shape), want[name], 1e-3, name)
 
 
-def _images_within_fast_tolerance(out, st):
+def _images_within_fast_tolerance(out, st, frac=1e-4, floor=2):
+    """Within 1e-4 of the tensor's max on all but max(floor, frac * pixels) pixels; those within 1e-2."""
     R, color, others, radii, extra = out[:5]
     for name, got, want in [("color", color, st["color"]), ("extra", extra, st["extra"]),
                             ("alpha", others[1], st["others"][1]), ("depth", others[0], st["others"][0]),
                             ("normal", others[2:5], st["others"][2:5])]:
         if want.size == 0:
             continue
-        got = got.cpu().numpy()
+        got = got.cpu().numpy().reshape(-1, st["H"], st["W"])
+        want = want.reshape(got.shape)
         scale = np.abs(want).max()
-        bad = np.abs(got - want) > 1e-4 * scale
-        assert bad.mean() <= 1e-4, f"{name}: {bad.sum()} outlier pixels"
-        assert np.abs(got - want).max() <= 1e-2 * scale
+        bad = (np.abs(got - want) > 1e-4 * scale).any(axis=0)          # a flipped decision shows in all of a pixel's channels
+        assert bad.sum() <= max(floor, frac * bad.size), f"{name}: {bad.sum()} outlier pixels of {bad.size}"
+        assert np.abs(got - want).max() <= 1e-2 * scale, f"{name}: {np.abs(got - want).max() / scale:.3g} of max"
 
 
 @pytest.mark.parametrize("P,F,W,H,seed", [(1500, 16, 100, 70, 41), (3000, 32, 160, 112, 42), (2000, 0, 128, 96, 43),

@@ -79,9 +79,9 @@ def _opt(*x, **k):
 tr.opt.step = _opt
 _blocked = [0.0, 0]
 _orig_verify = rasterizer._verify_pending
-def _timed_verify(key):
+def _timed_verify(owner):
     t = time.perf_counter()
-    _orig_verify(key)
+    _orig_verify(owner)
     _blocked[0] += time.perf_counter() - t
     _blocked[1] += 1
 rasterizer._verify_pending = _timed_verify
@@ -105,6 +105,17 @@ ms1 = torch.cuda.memory_stats()
 for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "allocation.all.allocated", "segment.all.allocated"):
     print(k, ms1.get(k, 0) - ms0.get(k, 0))
 print("reserved GB %.2f allocated peak GB %.2f" % (ms1["reserved_bytes.all.current"] / 2**30, ms1["allocated_bytes.all.peak"] / 2**30))
+if os.environ.get("HOST_CPROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for it in range(5 + a.steps, 5 + 2 * a.steps):
+        tr.step(it)
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(30)
+    sys.exit(0)
 acc = {}
 for (t0_, e0), (t1_, e1) in zip(_ev[:-1], _ev[1:]):
     key = t1_ if t1_ != "start" else "between steps"
