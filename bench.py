@@ -214,16 +214,18 @@ def run(args, mode, rank, world, dev, detail):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     rec = {"value": round(world * args.steps / dt, 3), "ms_per_step": round(1e3 * dt / args.steps, 4), "arithmetic_mode": mode}
-    if rank == 0 and detail:
-        # every kernel of the library, over a few extra (untimed) steps, HIP events on the launch stream
+    extra_steps = min(5, args.steps)
+    it0 = args.warmup + args.steps
+    if detail:
+        # every kernel of the library, over a few extra (untimed) steps, HIP events on the launch stream (all ranks step:
+        # a step holds collectives)
         L.isr_profile_enable(1)
-        extra_steps = min(5, args.steps)
-        it0 = args.warmup + args.steps
         for it in range(it0, it0 + extra_steps):
             trainer.step(it)
-        torch.cuda.synchronize()
+        sync()
         prof_all = profile_summary(L)
         L.isr_profile_enable(0)
+    if rank == 0 and detail:
         # workload statistics + work counters of the blend kernel on the last timed view (one extra, untimed render)
         counters = torch.zeros(4, dtype=torch.int64, device=dev)
         with torch.no_grad():

@@ -326,7 +326,7 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
 def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
                         extra_attrs, attr_degree, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
                         image_width, sh, degree, campos, prefiltered, debug, *, tracer=None, mode=None, tight=None,
-                        _state_out=None):
+                        _state_out=None, _verify_at_backward=False):
     """Equivalent of ``_C.rasterize_gaussians`` (rasterize_points.cu:39-151).
 
     Returns ``(num_rendered, out_color, out_others, radii, out_extra, geomBuffer, binningBuffer, imgBuffer,
@@ -422,10 +422,10 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
                                    _ptr(geom), _ptr(binning), R, _ptr(img), _ptr(out_color), _ptr(out_others),
                                    _ptr(out_extra), _ptr(grp), H * W * 10 if tracer else 0, _ptr(gcount), st),
               "isr_forward_render")
-    if sized_by_estimate and not torch.is_grad_enabled():
-        # no backward will follow to verify the estimate (an eval / no_grad render): check it now, and if the view needed
-        # more than the estimate allowed, render it again with the exact, blocking sizing instead of returning a
-        # truncated image
+    if sized_by_estimate and not _verify_at_backward:
+        # no backward will follow to verify the estimate (an eval / no_grad render, or a direct call of this function):
+        # check it now, and if the view needed more than the estimate allowed, render it again with the exact, blocking
+        # sizing instead of returning a truncated image
         try:
             _verify_pending(geom.data_ptr())
         except BinningOverflow:
@@ -650,7 +650,8 @@ class _RasterizeGaussians(torch.autograd.Function):
          gau_pixel_indices) = rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             extra_attrs, attr_degree, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
-            rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, _state_out=kept_state)
+            rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, _state_out=kept_state,
+            _verify_at_backward=any(ctx.needs_input_grad))     # (grad mode is off inside Function.forward: ask the context)
         if kept_state and any(ctx.needs_input_grad):
             # the cached view state now backs a pending backward: not reusable until that has run (or the graph is freed)
             kept_state[0].busy += 1
