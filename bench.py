@@ -164,6 +164,8 @@ def run(args, mode, rank, world, dev, detail):
     from instascene_amd.harness import RgbTrainer, SegTrainer
     from instascene_amd.render import render
 
+    feature_only = mode.endswith("+feature_only")      # opt-in sub-record: the blend kernel skips colour / aux maps / tracer
+    mode = mode.split("+")[0]
     rasterizer.set_mode(mode)
     rasterizer.set_tracer(bool(args.tracer))
     rasterizer.set_async_binning(bool(args.async_binning))
@@ -176,6 +178,7 @@ def run(args, mode, rank, world, dev, detail):
                              spatial_sort=bool(args.spatial_sort), fused_sampling=bool(args.fused_sampling))
         trainer.split_tail = bool(args.split_tail)
         trainer.pipe.lazy_maps = bool(args.lazy_maps)
+        trainer.pipe.feature_only_forward = feature_only
         trainer.warm_view_caches()       # per-view constants (ray tables, visible pools, instance counts): setup
         trainer.prime()                  # code objects, allocator pools, side stream: two steps whose effect is undone
         view_index = trainer.view_index
@@ -213,7 +216,8 @@ def run(args, mode, rank, world, dev, detail):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    rec = {"value": round(world * args.steps / dt, 3), "ms_per_step": round(1e3 * dt / args.steps, 4), "arithmetic_mode": mode}
+    rec = {"value": round(world * args.steps / dt, 3), "ms_per_step": round(1e3 * dt / args.steps, 4),
+           "arithmetic_mode": mode + ("+feature_only" if feature_only else "")}
     extra_steps = min(5, args.steps)
     it0 = args.warmup + args.steps
     if detail:
@@ -233,6 +237,7 @@ def run(args, mode, rank, world, dev, detail):
             rasterizer.set_async_binning(False)             # exact instance count for the byte model
             if mode != "exact":
                 L.isr_forward_set_counters(ctypes.c_void_p(counters.data_ptr()))
+            trainer.pipe.feature_only_forward = False
             pkg = render(trainer.cams[view_index(it0 - 1)], trainer.model, trainer.pipe, trainer.bg)
             V = int((pkg["radii"] > 0).sum().item())
             R = int(rasterizer.LAST_NUM_RENDERED)
@@ -313,7 +318,7 @@ def main():
     ap.add_argument("--step", default=None, choices=[None, "seg", "rgb"],
                     help="seg: train_semantic.py step (needs a feature channel: C3, C5); rgb: train.py step (C1, C2, C3)")
     ap.add_argument("--mode", default=os.environ.get("ISR_MODE", "fast"), choices=["fast", "exact", "fast_tight"])
-    ap.add_argument("--submodes", default="exact,fast_tight",
+    ap.add_argument("--submodes", default="exact,fast_tight,fast+feature_only",
                     help="at one GPU: further modes timed the same way and reported as sub_records ('' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tracer", type=int, default=1, help="produce gau_related_pixels each forward like the reference")
@@ -371,6 +376,8 @@ def main():
     subs = {}
     if world == 1:
         for m in [m for m in args.submodes.split(",") if m and m != args.mode]:
+            if m.endswith("+feature_only") and args.step != "seg":
+                continue
             r = run(args, m, rank, world, dev, detail=True)
             roof = r.pop("roofline", None) or {}
             r.pop("cfg", None)
@@ -378,7 +385,10 @@ def main():
             r["R"] = roof.get("workload", {}).get("R")
             r["parity"] = {"exact": "radii / tiles_touched / point_list / ranges / n_contrib / images bit-identical to the CPU oracle",
                            "fast_tight": "tile lists are order-preserving subsequences of the reference's; images 1e-4",
-                           "fast": "binning bit-identical; images 1e-4"}[m]
+                           "fast": "binning bit-identical; images 1e-4",
+                           "fast+feature_only": "opt-in pipe.feature_only_forward (NOT the reference's behaviour: render() returns no colour / "
+                                                "depth / normal maps and no tracer list); feature map, binning and the step's parameters "
+                                                "bit-identical to `fast`"}[m]
             subs[m] = r
 
     if rank == 0:

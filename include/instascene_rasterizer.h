@@ -42,6 +42,9 @@ extern "C" {
 #define ISR_MODE_EXACT 0 /* op-for-op IEEE fp32, bit-identical to oracle/surfel_oracle.cpp */
 #define ISR_MODE_FAST 1  /* explicit FMA contraction + hardware rcp/exp in the per-pixel loops */
 #define ISR_MODE_PREBINNED 0x100 /* flag for isr_forward_render: isr_forward_bin already ran on these buffers */
+#define ISR_MODE_FEATURE_ONLY 0x200 /* opt-in flag for isr_forward_render (with ISR_MODE_FAST, ED > 0): only out_extra and the
+                                     * state the feature-only backward reads are produced; out_color / out_others (may be NULL)
+                                     * and the tracer list are left untouched.  The reference always renders everything. */
 
 /* which gradients isr_backward must produce (bit mask) */
 #define ISR_GRAD_EXTRA 1u    /* dL_dextra only needs the blend weights */

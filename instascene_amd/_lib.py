@@ -16,6 +16,7 @@ _lib = None
 
 MODE_EXACT, MODE_FAST = 0, 1
 MODE_PREBINNED = 0x100
+MODE_FEATURE_ONLY = 0x200
 GRAD_EXTRA, GRAD_GEOMETRY = 1, 2
 
 # every exported symbol and its signature (checked by tests/test_abi.py against include/*.h)

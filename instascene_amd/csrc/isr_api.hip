@@ -60,16 +60,21 @@ thread_local unsigned long long* g_fwd_counters = nullptr;    // isr_forward_set
 static int launch_render_fwd_fast(int tiles, hipStream_t s, int W, int H, int ED, int gx, const ImageView& iv,
                                   const BinView& bv, const float* rec, const float* cull, const float* col_pre, const float* tm_pre,
                                   const float* extras, const float* bg, float* out_color, float* out_others, float* out_extra,
-                                  int32_t* tracer, long long tcap, int32_t* tcount, int64_t capacity) {
+                                  int32_t* tracer, long long tcap, int32_t* tcount, int64_t capacity, bool aux) {
     unsigned long long* counters = g_fwd_counters;
     g_fwd_counters = nullptr;
     int ch = 0, first = 1;
     do {
         ProfScope ps_("k_render_fwd", s);
 #define ISR_GO(FEAT, STATS)                                                                                           \
-    hipLaunchKernelGGL((k_render_fwd_fast<FEAT, STATS>), dim3(tiles), dim3(256), 0, s, W, H, ED, ch, first, gx,        \
+    do { if (aux)                                                                                                     \
+    hipLaunchKernelGGL((k_render_fwd_fast<FEAT, STATS, true>), dim3(tiles), dim3(256), 0, s, W, H, ED, ch, first, gx,  \
                        iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,    \
-                       out_color, out_others, out_extra, tracer, tcap, tcount, bv.box4, capacity, counters)
+                       out_color, out_others, out_extra, tracer, tcap, tcount, bv.box4, capacity, counters);            \
+    else                                                                                                              \
+    hipLaunchKernelGGL((k_render_fwd_fast<FEAT, STATS, false>), dim3(tiles), dim3(256), 0, s, W, H, ED, ch, first, gx, \
+                       iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,    \
+                       out_color, out_others, out_extra, tracer, tcap, tcount, bv.box4, capacity, counters); } while (0)
         if (ED - ch <= 0) { if (counters) ISR_GO(false, true); else ISR_GO(false, false); }
         else { if (counters) ISR_GO(true, true); else ISR_GO(true, false); }
 #undef ISR_GO
@@ -242,11 +247,13 @@ int isr_forward_render(int P, int ED, int width, int height, int mode, const flo
                        float* out_color, float* out_others, float* out_extra, int32_t* tracer_pairs,
                        int64_t tracer_capacity, int32_t* tracer_count, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (!geom_buffer || !binning_buffer || !image_buffer || !out_color || !out_others || !background)
+    const bool prebinned = (mode & ISR_MODE_PREBINNED) != 0;
+    const bool feature_only = (mode & ISR_MODE_FEATURE_ONLY) != 0;
+    mode &= ~(ISR_MODE_PREBINNED | ISR_MODE_FEATURE_ONLY);
+    if (feature_only && (mode != ISR_MODE_FAST || ED <= 0)) return fail(ISR_EINVAL, "ISR_MODE_FEATURE_ONLY needs ISR_MODE_FAST and ED > 0");
+    if (!geom_buffer || !binning_buffer || !image_buffer || !background || (!feature_only && (!out_color || !out_others)))
         return fail(ISR_EINVAL, "null buffer");
     if (ED < 0 || (ED > 0 && (!extra_attrs || !out_extra))) return fail(ISR_EINVAL, "extra_attrs/out_extra required when ED>0");
-    const bool prebinned = (mode & ISR_MODE_PREBINNED) != 0;
-    mode &= ~ISR_MODE_PREBINNED;
     if (mode != ISR_MODE_EXACT && mode != ISR_MODE_FAST) return fail(ISR_EINVAL, "unknown mode %d", mode);
     if (tracer_pairs && !tracer_count) return fail(ISR_EINVAL, "tracer_count required with tracer_pairs");
     const int gx = tiles_x(width), gy = tiles_y(height), T = gx * gy;
@@ -263,8 +270,8 @@ int isr_forward_render(int P, int ED, int width, int height, int mode, const flo
                                             extra_attrs, background, out_color, out_others, out_extra, tracer_pairs,
                                             (long long)tracer_capacity, tracer_count, binning_capacity);
     return launch_render_fwd_fast(T, s, width, height, ED, gx, iv, bv, g.rec, g.cull, colors_precomp, transMat_precomp,
-                                  extra_attrs, background, out_color, out_others, out_extra, tracer_pairs,
-                                  (long long)tracer_capacity, tracer_count, binning_capacity);
+                                  extra_attrs, background, out_color, out_others, out_extra, feature_only ? nullptr : tracer_pairs,
+                                  (long long)tracer_capacity, tracer_count, binning_capacity, !feature_only);
 }
 
 int isr_backward(int P, int D, int M, int64_t num_rendered, int ED, int width, int height, int mode, unsigned grad_mask,

@@ -30,7 +30,10 @@ constexpr int FF_RS = 24;           // staged floats per instance (six float4)
 //                 q4 = 1/Tw.z, normal.xyz
 //                 q5 = rgb, unused
 
-template <bool FEAT, bool STATS>
+// AUX = false ("feature-only forward", opt-in ISR_MODE_FEATURE_ONLY): colour, the seven auxiliary maps, the median
+// contributor, the distortion moments and the tracer are not produced - only the feature map and the state the
+// feature-only backward reads (final T, last contributor).
+template <bool FEAT, bool STATS, bool AUX>
 __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
     int W, int H, int ED, int ch_base, int first_pass, int gx, const uint32_t* __restrict__ tile_offset,
     const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ cull,
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                     const float w = alpha * T;
                     w_lane = w;
                     const unsigned contributor = cbase + (unsigned)j;
-                    if (first_pass) {
+                    if (AUX && first_pass) {
                         const float4 q4 = q[4], q5 = q[5];
                         const float inv_depth = use3d ? p_z * q3.w : q4.x;
                         const float m_ = __builtin_fmaf(-(mscale * NEAR_N), inv_depth, mscale);
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                     T = test_T;
                     last_contributor = contributor;
                 }
-                if (tracer != nullptr && first_pass) {
+                if (AUX && tracer != nullptr && first_pass) {
                     const unsigned long long m_tr = __ballot(w_lane >= 0.1f);     // (double)w > 0.1  <=>  w >= 0.1f
                     if (m_tr != 0ull) {
                         if (w_lane >= 0.1f) {
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
             accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[1]), accB, 0, 0, 0);
         }
     }
-    if (tracer != nullptr && first_pass) flush_trace();
+    if (AUX && tracer != nullptr && first_pass) flush_trace();
     if (STATS) {
         if (lane == 0 && first_pass) {
             atomicAdd(stats + 0, (unsigned long long)st_cull);
@@ -273,7 +276,11 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
             atomicAdd(stats + 3, (unsigned long long)st_lanes);
         }
     }
-    if (inside && first_pass) {
+    if (!AUX && inside && first_pass) {
+        final_T[pix] = T;
+        n_contrib[pix] = last_contributor;
+    }
+    if (AUX && inside && first_pass) {
         final_T[pix] = T;
         final_T[pix + N] = M1;
         final_T[pix + 2 * N] = M2;

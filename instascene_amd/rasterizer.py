@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import GRAD_EXTRA, GRAD_GEOMETRY, MODE_EXACT, MODE_FAST, MODE_PREBINNED, check, lib
+from ._lib import GRAD_EXTRA, GRAD_GEOMETRY, MODE_EXACT, MODE_FAST, MODE_FEATURE_ONLY, MODE_PREBINNED, check, lib
 
 _ENV_MODE = os.environ.get("ISR_MODE", "exact").lower()
 _CONFIG = {
@@ -326,14 +326,17 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
 def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
                         extra_attrs, attr_degree, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
                         image_width, sh, degree, campos, prefiltered, debug, *, tracer=None, mode=None, tight=None,
-                        _state_out=None, _verify_at_backward=False):
+                        _state_out=None, _verify_at_backward=False, feature_only=False):
     """Equivalent of ``_C.rasterize_gaussians`` (rasterize_points.cu:39-151).
 
     Returns ``(num_rendered, out_color, out_others, radii, out_extra, geomBuffer, binningBuffer, imgBuffer,
     gau_related_pixels, gau_pixel_indices)``.  ``gau_related_pixels`` holds ``H*W*10`` rows (a pixel has at most 9
     entries with weight > 0.1) instead of the reference's ``H*W*100`` and is not pre-filled;
     ``gau_pixel_indices`` is the reference's *last valid index* (count - 1) so that
-    ``gau_related_pixels[:gau_pixel_indices + 1]`` is the list, as in the reference wrapper (:106)."""
+    ``gau_related_pixels[:gau_pixel_indices + 1]`` is the list, as in the reference wrapper (:106).
+
+    ``feature_only`` (opt-in extension, FAST mode with a feature channel): only ``out_extra`` and the state of a
+    feature-only backward are produced; ``out_color`` / ``out_others`` come back empty and there is no tracer list."""
     L = lib()
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -342,6 +345,9 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
     mode = _CONFIG["mode"] if mode is None else mode
     tight = _tight(mode, tight)
     tracer = _CONFIG["tracer"] if tracer is None else tracer
+    feature_only = bool(feature_only) and mode == MODE_FAST and int(attr_degree) > 0
+    if feature_only:
+        tracer = False
     call_args = (bg, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp, extra_attrs, attr_degree,
                  viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug)
     originals = (means3D, sh, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix, campos)
@@ -356,8 +362,8 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
     extra = _f32c(extra_attrs.to(dev) if (extra_attrs is not None and extra_attrs.numel() and not extra_attrs.is_cuda)
                   else extra_attrs, "extra_attrs") if F > 0 else None
 
-    out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-    out_others = torch.empty((7, H, W), dtype=torch.float32, device=dev)
+    out_color = torch.empty((0 if feature_only else 3, H, W), dtype=torch.float32, device=dev)
+    out_others = torch.empty((0 if feature_only else 7, H, W), dtype=torch.float32, device=dev)
     out_extra = torch.empty((F, H, W), dtype=torch.float32, device=dev) if F > 0 else torch.empty(0, device=dev)
     M = sh.shape[1] if (sh is not None and sh.dim() == 3) else 0
     if P == 0:
@@ -418,7 +424,7 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
             gcount = torch.empty((1,), dtype=torch.int32, device=dev)
         else:
             grp, gcount = None, None
-        check(L.isr_forward_render(P, F, W, H, int(mode) | prebinned, _ptr(bg), _ptr(colors), _ptr(transMat_precomp), _ptr(extra),
+        check(L.isr_forward_render(P, F, W, H, int(mode) | prebinned | (MODE_FEATURE_ONLY if feature_only else 0), _ptr(bg), _ptr(colors), _ptr(transMat_precomp), _ptr(extra),
                                    _ptr(geom), _ptr(binning), R, _ptr(img), _ptr(out_color), _ptr(out_others),
                                    _ptr(out_extra), _ptr(grp), H * W * 10 if tracer else 0, _ptr(gcount), st),
               "isr_forward_render")
@@ -432,7 +438,8 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
             was = _CONFIG["async_binning"]
             _CONFIG["async_binning"] = False
             try:
-                return rasterize_gaussians(*call_args, tracer=tracer, mode=mode, tight=tight, _state_out=_state_out)
+                return rasterize_gaussians(*call_args, tracer=tracer, mode=mode, tight=tight, _state_out=_state_out,
+                                           feature_only=feature_only)
             finally:
                 _CONFIG["async_binning"] = was
     if _CONFIG.get("view_cache_bytes", 0) > 0 and kept is None and _state_out is not None and not sized_by_estimate:
@@ -642,8 +649,10 @@ class _Token:
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, extra_attrs,
-                raster_settings, sample_pixels=None, lazy_tracer=False):
+                raster_settings, sample_pixels=None, lazy_tracer=False, feature_only=False):
         rs = raster_settings
+        if feature_only and any(ctx.needs_input_grad[i] for i in (0, 1, 2, 3, 4, 5, 6, 7)):
+            raise Exception("feature_only forward: only extra_attrs may require grad")
         attr_degree = extra_attrs.shape[1] if extra_attrs.shape[0] != 0 else 0
         kept_state = []
         (num_rendered, color, depth, radii, extra, geomBuffer, binningBuffer, imgBuffer, gau_related_pixels,
@@ -651,7 +660,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             extra_attrs, attr_degree, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
             rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, _state_out=kept_state,
-            _verify_at_backward=any(ctx.needs_input_grad))     # (grad mode is off inside Function.forward: ask the context)
+            _verify_at_backward=any(ctx.needs_input_grad),     # (grad mode is off inside Function.forward: ask the context)
+            feature_only=feature_only)
         if kept_state and any(ctx.needs_input_grad):
             # the cached view state now backs a pending backward: not reusable until that has run (or the graph is freed)
             kept_state[0].busy += 1
@@ -697,7 +707,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             dense.index_add_(1, ctx.sample_pixels.to(torch.int64), grad_sampled.t().contiguous().float())
             grad_out_extra, grad_sampled = dense.reshape(Fm, Hm, Wm), None
         if mask == 0 or (grad_out_color is None and grad_depth is None and grad_out_extra is None and grad_sampled is None):
-            return (None,) * 12
+            return (None,) * 13
         if grad_sampled is not None and grad_out_color is None and grad_depth is None and grad_out_extra is None:
             # the common case of feature training: only sampled features carry gradient
             sink = _ROWS_SINK
@@ -706,11 +716,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                     means3D.shape[0], extra_attrs.shape[1], rs.image_width, rs.image_height, ctx.num_rendered,
                     ctx.sample_pixels, grad_sampled, cov3Ds_precomp, geomBuffer, binningBuffer, imgBuffer, mode=ctx.mode,
                     rows_only=True)
-                return (None,) * 12
+                return (None,) * 13
             ge = rasterize_gaussians_backward_sampled(means3D.shape[0], extra_attrs.shape[1], rs.image_width, rs.image_height,
                                                       ctx.num_rendered, ctx.sample_pixels, grad_sampled, cov3Ds_precomp,
                                                       geomBuffer, binningBuffer, imgBuffer, mode=ctx.mode)
-            return (None,) * 8 + (ge, None, None, None)
+            return (None,) * 8 + (ge, None, None, None, None)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_extra_attrs) = rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, extra_attrs, rs.scale_modifier, cov3Ds_precomp,
@@ -732,13 +742,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                 pick(3, grad_colors_precomp, colors_precomp), grad_opacities if need[4] else None,
                 pick(5, grad_scales, scales), pick(6, grad_rotations, rotations),
                 pick(7, grad_cov3Ds_precomp, cov3Ds_precomp),
-                grad_extra_attrs if (need[8] and extra_attrs.numel()) else None, None, None, None)
+                grad_extra_attrs if (need[8] and extra_attrs.numel()) else None, None, None, None, None)
 
 
 def rasterize_gaussians_autograd(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                 extra_attrs, raster_settings, sample_pixels=None, lazy_tracer=False):
+                                 extra_attrs, raster_settings, sample_pixels=None, lazy_tracer=False, feature_only=False):
     out = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                    cov3Ds_precomp, extra_attrs, raster_settings, sample_pixels, lazy_tracer)
+                                    cov3Ds_precomp, extra_attrs, raster_settings, sample_pixels, lazy_tracer, feature_only)
     return out if sample_pixels is not None else out[:5]
 
 
@@ -763,11 +773,12 @@ class GaussianRasterizer(nn.Module):
                                      rs.image_width, shs, rs.sh_degree, rs.campos, rs.prefiltered, stream=stream, after=after)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, extra_attrs=None, sample_pixels=None, lazy_tracer=False):
+                cov3D_precomp=None, extra_attrs=None, sample_pixels=None, lazy_tracer=False, feature_only=False):
         """Reference signature (:210-248).  Extensions: ``sample_pixels`` (int64 ``y*W + x``, may repeat) appends a sixth
         result, the feature map read at those pixels ``[n, F]``; its gradient is propagated without a dense map.
         ``lazy_tracer``: return the whole tracer buffer with its count attached (``slice_tracer``) instead of slicing it
-        here, which needs the count on the host, i.e. a device sync (``render()`` slices on first access)."""
+        here, which needs the count on the host, i.e. a device sync (``render()`` slices on first access).
+        ``feature_only``: see :func:`rasterize_gaussians` (colour / allmap / tracer come back empty)."""
         rs = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -783,4 +794,4 @@ class GaussianRasterizer(nn.Module):
         cov3D_precomp = empty() if cov3D_precomp is None else cov3D_precomp
         extra_attrs = empty() if extra_attrs is None else extra_attrs
         return rasterize_gaussians_autograd(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                            cov3D_precomp, extra_attrs, rs, sample_pixels, lazy_tracer)
+                                            cov3D_precomp, extra_attrs, rs, sample_pixels, lazy_tracer, feature_only)

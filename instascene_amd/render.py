@@ -243,10 +243,22 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if seg_feature is not None and norm_seg_feat:
         seg_feature = row_normalize(seg_feature, 1e-9)      # reference :61-62
 
+    # opt-in (pipe.feature_only_forward, like lazy_maps): a trainer that reads nothing but the feature map - the whole of
+    # train_semantic.py's loss - lets the blend kernel skip colour, the seven auxiliary maps and the tracer.  The dict keeps
+    # all 13 keys; the skipped ones are None.  Never the default: the reference renders everything on every call.
+    feature_only = (bool(getattr(pipe, "feature_only_forward", False)) and seg_feature is not None and not need_geom_grad
+                    and _rz._CONFIG["mode"] == _lib.MODE_FAST and seg_feature.shape[1] > 0)
     # lazy_tracer: the tracer list is sliced to its valid length (a host sync) on first access of the dict entry
     res = rasterizer(means2D=means2D, extra_attrs=seg_feature, sample_pixels=sample_pixels if seg_feature is not None else None,
-                     lazy_tracer=True, **geo)
+                     lazy_tracer=True, feature_only=feature_only, **geo)
     rendered_image, radii, allmap, extra_attrs, gau_related_pixels = res[:5]
+    if feature_only:
+        rets = RenderPackage({"render": None, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii,
+                              "seg_feature": extra_attrs, "gau_related_pixels": None})
+        if len(res) > 5:
+            rets["sampled_seg_feature"] = res[5]
+        dict.update(rets, dict.fromkeys(_LAZY_KEYS))
+        return rets
 
     rets = RenderPackage({"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0,
                           "radii": radii, "seg_feature": extra_attrs, "gau_related_pixels": gau_related_pixels})

@@ -320,3 +320,30 @@ def test_prime_leaves_no_trace():
         rz.set_async_binning(False)
         rz.set_mode("exact")
         rz.set_tracer(True)
+
+
+def test_feature_only_forward_changes_no_parameter():
+    """Opt-in pipe.feature_only_forward: the blend kernel skips colour, the auxiliary maps and the tracer.  The feature map
+    and everything the step trains on are computed by the same instructions, so losses and parameters are bit-identical
+    to the full forward's; the skipped dict entries are None."""
+    from instascene_amd.render import render
+    rz.set_mode("fast")
+    rz.set_tracer(True)
+    try:
+        outs = []
+        for fo in (False, True):
+            sc, cams = _scene()
+            tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=2048, n_labels=12, use_class_feat=True, seed=3)
+            tr.pipe.feature_only_forward = fo
+            losses = [float(tr.step(it)) for it in range(6)]
+            with torch.no_grad():
+                pkg = render(tr.cams[1], tr.model, tr.pipe, tr.bg)
+            outs.append((losses, tr.model._seg_feature.detach().clone(), pkg))
+        assert outs[0][0] == outs[1][0]
+        assert torch.equal(outs[0][1], outs[1][1])
+        full, fo = outs[0][2], outs[1][2]
+        assert torch.equal(full["seg_feature"], fo["seg_feature"]) and torch.equal(full["radii"], fo["radii"])
+        assert fo["render"] is None and fo["rend_normal"] is None and fo["gau_related_pixels"] is None
+        assert set(fo.keys()) >= set(full.keys())
+    finally:
+        rz.set_mode("exact")
