@@ -204,6 +204,7 @@ def run(args, mode, rank, world, dev, detail):
     for it in range(args.warmup):
         trainer.step(it)
     sync()
+    dbg0 = (rasterizer.PREFETCH_HITS, torch.cuda.memory_stats().get("num_device_alloc", 0), len(rasterizer._R_ESTIMATE))
     L.isr_profile_enable(2)          # HIP events around the forward blend kernel only inside the timed region
     t0 = time.perf_counter()
     for it in range(args.warmup, args.warmup + args.steps):
@@ -212,6 +213,10 @@ def run(args, mode, rank, world, dev, detail):
     dt = time.perf_counter() - t0
     prof_dom = profile_summary(L)
     L.isr_profile_enable(0)
+    if os.environ.get("ISR_BENCH_DEBUG"):
+        print(f"[bench debug] mode={mode} prefetch hits {rasterizer.PREFETCH_HITS - dbg0[0]} / {args.steps} steps, device allocs "
+              f"{torch.cuda.memory_stats().get('num_device_alloc', 0) - dbg0[1]}, estimates {dbg0[2]} -> {len(rasterizer._R_ESTIMATE)}, "
+              f"pending {len(rasterizer._PENDING)}, reserved {torch.cuda.memory_reserved() / 2**30:.2f} GB", file=sys.stderr)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -29,6 +29,22 @@ from .rasterizer import DeferredFeatureRows
 from .render import prefetch, render
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """ONE side stream per device for the whole process.  HIP multiplexes streams onto a handful of hardware queues; a
+    process that keeps creating streams (a trainer per benchmark mode, say) sooner or later gets one that shares the
+    current stream's queue, and work issued on it then serialises with the main chain instead of overlapping it
+    (measured: the third trainer of a process ran 1.5x slower per step until its side stream was shared)."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 class PipelineParams:
     compute_cov3D_python = False
     convert_SHs_python = False
@@ -449,7 +465,7 @@ class SegTrainer:
             prefetch(self.cams[self.view_index(it + 1)], self.model, self.pipe, self.bg)
             return
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = side_stream(self.device)
         prefetch(self.cams[self.view_index(it + 1)], self.model, self.pipe, self.bg, stream=self._side)
 
 
