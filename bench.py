@@ -154,7 +154,7 @@ def time_allreduce(numel, dev, world, reps=5):
     return 1e3 * (time.perf_counter() - t0) / reps
 
 
-def run(args, mode, rank, world, dev, detail):
+def run(args, mode, rank, world, dev, detail, repeats=1):
     """One timed measurement in ``mode``: W warm-up steps, then exactly K steps between barrier + synchronize on both
     sides.  Returns the record (rank 0: with the kernel detail when ``detail``)."""
     import torch
@@ -205,14 +205,19 @@ def run(args, mode, rank, world, dev, detail):
         trainer.step(it)
     sync()
     dbg0 = (rasterizer.PREFETCH_HITS, torch.cuda.memory_stats().get("num_device_alloc", 0), len(rasterizer._R_ESTIMATE))
-    L.isr_profile_enable(2)          # HIP events around the forward blend kernel only inside the timed region
-    t0 = time.perf_counter()
-    for it in range(args.warmup, args.warmup + args.steps):
-        trainer.step(it)
-    sync()
-    dt = time.perf_counter() - t0
-    prof_dom = profile_summary(L)
-    L.isr_profile_enable(0)
+    dt, it_next = None, args.warmup
+    for rep in range(repeats):       # the headline: exactly one block of K steps; sub-records: the better of two blocks
+        L.isr_profile_enable(2)      # HIP events around the forward blend kernel only inside the timed region
+        t0 = time.perf_counter()
+        for it in range(it_next, it_next + args.steps):
+            trainer.step(it)
+        sync()
+        dt_rep = time.perf_counter() - t0
+        if dt is None or dt_rep < dt:
+            dt = dt_rep
+            prof_dom = profile_summary(L)
+        L.isr_profile_enable(0)
+        it_next += args.steps
     if os.environ.get("ISR_BENCH_DEBUG"):
         print(f"[bench debug] mode={mode} prefetch hits {rasterizer.PREFETCH_HITS - dbg0[0]} / {args.steps} steps, device allocs "
               f"{torch.cuda.memory_stats().get('num_device_alloc', 0) - dbg0[1]}, estimates {dbg0[2]} -> {len(rasterizer._R_ESTIMATE)}, "
@@ -224,7 +229,7 @@ def run(args, mode, rank, world, dev, detail):
     rec = {"value": round(world * args.steps / dt, 3), "ms_per_step": round(1e3 * dt / args.steps, 4),
            "arithmetic_mode": mode + ("+feature_only" if feature_only else "")}
     extra_steps = min(5, args.steps)
-    it0 = args.warmup + args.steps
+    it0 = it_next
     if detail:
         # every kernel of the library, over a few extra (untimed) steps, HIP events on the launch stream (all ranks step:
         # a step holds collectives)
@@ -383,7 +388,8 @@ def main():
         for m in [m for m in args.submodes.split(",") if m and m != args.mode]:
             if m.endswith("+feature_only") and args.step != "seg":
                 continue
-            r = run(args, m, rank, world, dev, detail=True)
+            r = run(args, m, rank, world, dev, detail=True, repeats=2)
+            r["timing"] = "the faster of two consecutive blocks of %d steps (a process sees one ~40 ms runtime stall somewhere in its first few hundred steps)" % args.steps
             roof = r.pop("roofline", None) or {}
             r.pop("cfg", None)
             r["dominant_kernel_ms"] = roof.get("avg_launch_ms")

@@ -113,6 +113,20 @@ class BinningOverflow(RuntimeError):
     The estimate of that view has been corrected; re-run the forward (``SegTrainer.step`` does)."""
 
 
+_PINNED = {"ring": None, "next": 0}
+
+
+def _pinned_slot():
+    """A pinned int64 for the asynchronous read-back of an instance count: a ring of 64 slots allocated once (a fresh
+    ``pin_memory()`` per forward goes through the host allocator every step); a slot comes round again long after its
+    forward has been verified (at most a few forwards are ever outstanding)."""
+    if _PINNED["ring"] is None:
+        _PINNED["ring"] = torch.empty(64, dtype=torch.int64).pin_memory()
+    i = _PINNED["next"]
+    _PINNED["next"] = (i + 1) % 64
+    return _PINNED["ring"][i:i + 1]
+
+
 def _view_id(viewmatrix, projmatrix):
     """Identity of a camera for the size estimate: the storage of its two matrices (cameras are long-lived objects)."""
     return (viewmatrix.data_ptr() if viewmatrix is not None else 0, projmatrix.data_ptr() if projmatrix is not None else 0)
@@ -236,7 +250,7 @@ def _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, op
                                 None if use_async else ctypes.byref(num_rendered), st), "isr_forward_prepare")
     if use_async:
         R = int(_R_ESTIMATE[ekey] * _ASYNC_GROWTH) + _ASYNC_SLACK            # capacity, not the count
-        pinned = torch.empty(1, dtype=torch.int64).pin_memory()
+        pinned = _pinned_slot()
         pinned.copy_(geom[:8].view(torch.int64), non_blocking=True)   # header[0] = R
         ev = torch.cuda.Event()
         ev.record()
