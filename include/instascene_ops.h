@@ -131,6 +131,19 @@ int iso_adam_rownorm2(long long N, int F, double lr, double beta1, double beta2,
 int iso_rows_compact(int n, int F, long long P, const long long* idx, const float* vals, int* slot /*[P]*/,
                      float* merged /*[n,F]*/, void* stream);
 
+/* The optimiser step of the train.py loop (scene/gaussian_model.py:206-253: torch.optim.Adam(lr = 0, eps = 1e-15) over six
+ * parameter groups; train.py:153-156) as ONE pass, with the chain rule in front of it and the next forward's activations
+ * behind it.  Tables of six device pointers in the order xyz [P,3], f_dc [P,3] (the reference's [P,1,3]), f_rest
+ * [P, 3(M-1)] (its [P,M-1,3]), opacity [P,1], scaling [P,2], rotation [P,4]; lr[6] likewise (per group, host doubles).
+ * g_*: gradients with respect to the ACTIVATED tensors the rasterizer consumed - xyz, shs = cat(f_dc, f_rest) [P,M,3],
+ * sigmoid(opacity), exp(scaling), normalize(rotation) (scene/gaussian_model.py:109-138) - a NULL one leaves its group(s)
+ * untouched, like a parameter without .grad.  a_*: the same activations of the UPDATED parameters (any may be NULL).
+ * Dense torch.optim.Adam arithmetic (no weight decay, no amsgrad; `step` counts from 1, shared by the groups). */
+int iso_gaussian_adam_step(int P, int M, float* const params[6], float* const exp_avg[6], float* const exp_avg_sq[6],
+                           const double lr[6], double beta1, double beta2, double eps, long long step, const float* g_xyz,
+                           const float* g_shs, const float* g_opacity, const float* g_scale, const float* g_rotation,
+                           float* a_shs, float* a_opacity, float* a_scale, float* a_rotation, void* stream);
+
 /* out[i, :] = x[idx[i], :] / (|x[idx[i], :]|_2 + eps), i < n: rows of the normalised feature (scene/gaussian_model.py:122-125)
  * gathered straight from the raw parameter x[P, F] - bit-identical to gathering them from iso_rownorm2's / iso_adam_rownorm2's
  * `y`, which a trainer that only ever reads a few thousand rows of it (train_semantic.py:183-190) need not store.

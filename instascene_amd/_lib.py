@@ -67,6 +67,8 @@ SIGNATURES = {
     "iso_ssim_forward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "iso_ssim_backward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "iso_densify_stats": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "iso_gaussian_adam_step": (c_int, [c_int, c_int, _P, _P, _P, _P, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                       ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "iso_gather_rownorm": (c_int, [c_int, c_int, ctypes.c_longlong, c_float, _P, _P, _P, _P]),
     "iso_sample_step": (c_int, [ctypes.c_ulonglong, ctypes.c_ulonglong, c_int, ctypes.c_longlong, _P, _P, _P, ctypes.c_longlong, _P,
                                 _P, _P, _P, _P, _P, _P, _P]),

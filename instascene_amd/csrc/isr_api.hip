@@ -10,6 +10,7 @@
 #include "iso_contrastive.hip"
 #include "iso_post.hip"
 #include "iso_ssim.hip"
+#include "iso_optim.hip"
 #include "../../include/instascene_rasterizer.h"
 #include "../../include/instascene_ops.h"
 
@@ -680,6 +681,33 @@ int iso_adam_rownorm2(long long N, int F, double lr, double beta1, double beta2,
                        (float)beta2, (float)(1.0 - beta2), (float)(1.0 / sqrt(bc2)), (float)eps, eps1, eps2, param, grad,
                        exp_avg, exp_avg_sq, y, z);
     ISR_LAUNCH_CHECK("iso_adam_rownorm2");
+    return ISR_OK;
+}
+
+int iso_gaussian_adam_step(int P, int M, float* const params[6], float* const exp_avg[6], float* const exp_avg_sq[6],
+                           const double lr[6], double beta1, double beta2, double eps, long long step, const float* g_xyz,
+                           const float* g_shs, const float* g_opacity, const float* g_scale, const float* g_rotation,
+                           float* a_shs, float* a_opacity, float* a_scale, float* a_rotation, void* stream) {
+    if (P < 0 || M < 1 || M > 64) return fail(ISR_EINVAL, "gaussian_adam_step: bad sizes P=%d M=%d", P, M);
+    if (step < 1) return fail(ISR_EINVAL, "gaussian_adam_step: step counts from 1");
+    if (P == 0) return ISR_OK;
+    if (!params || !exp_avg || !exp_avg_sq || !lr) return fail(ISR_EINVAL, "gaussian_adam_step: null table");
+    iso::GaussAdamArgs a = {};
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    for (int g = 0; g < 6; g++) {
+        if (g == 2 && M == 1) continue;                     // no higher-order coefficients
+        if (!params[g] || !exp_avg[g] || !exp_avg_sq[g]) return fail(ISR_EINVAL, "gaussian_adam_step: group %d has a null tensor", g);
+        a.p[g] = params[g]; a.m[g] = exp_avg[g]; a.v[g] = exp_avg_sq[g];
+        a.lr_over_bc1[g] = (float)(lr[g] / bc1);
+    }
+    a.g_xyz = g_xyz; a.g_shs = g_shs; a.g_opa = g_opacity; a.g_scale = g_scale; a.g_rot = g_rotation;
+    a.a_shs = a_shs; a.a_opa = a_opacity; a.a_scale = a_scale; a.a_rot = a_rotation;
+    a.om1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.om2 = (float)(1.0 - beta2);
+    a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)); a.eps = (float)eps;
+    a.P = P; a.M = M;
+    const long long threads = (long long)P * (3 + 3LL * M + 1 + 2 + 1);
+    hipLaunchKernelGGL(iso::gaussian_adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    ISR_LAUNCH_CHECK("iso_gaussian_adam_step");
     return ISR_OK;
 }
 

@@ -24,7 +24,8 @@ import torch.nn as nn
 
 from . import scenes
 from .contrastive import contrastive_loss, contrastive_loss_batch, gather_rows, row_normalize_chain
-from .dist_utils import allreduce_grads, allreduce_grads_async, allreduce_rows_async, row_ranges, view_for, wait_all
+from .dist_utils import (allreduce_bucket, allreduce_grads, allreduce_grads_async, allreduce_rows_async, row_ranges, view_for,
+                         wait_all)
 from .rasterizer import DeferredFeatureRows
 from .render import prefetch, render
 
@@ -480,12 +481,13 @@ class RgbGaussianModel:
         self._opacity, self._features_dc, self._features_rest = mk(s.opacity_logit), mk(s.features_dc), mk(s.features_rest)
         self.active_sh_degree = 3
         self.max_sh_degree = 3
+        self._leaves = None      # optim.GaussianAdam.begin(): the activated tensors as leaves for the duration of a step
 
     get_xyz = property(lambda s: s._xyz)
-    get_scaling = property(lambda s: torch.exp(s._scaling))
-    get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation))
-    get_opacity = property(lambda s: torch.sigmoid(s._opacity))
-    get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
+    get_scaling = property(lambda s: s._leaves["scaling"] if s._leaves else torch.exp(s._scaling))
+    get_rotation = property(lambda s: s._leaves["rotation"] if s._leaves else torch.nn.functional.normalize(s._rotation))
+    get_opacity = property(lambda s: s._leaves["opacity"] if s._leaves else torch.sigmoid(s._opacity))
+    get_features = property(lambda s: s._leaves["shs"] if s._leaves else torch.cat((s._features_dc, s._features_rest), dim=1))
     get_seg_feature = property(lambda s: None)
 
     def get_covariance(self, scaling_modifier=1):
@@ -505,7 +507,7 @@ class RgbTrainer:
     lambda_normal*(1 - <rend_normal, surf_normal>) -> backward (full geometry gradients) -> Adam."""
 
     def __init__(self, scene, cameras, targets, device="cuda", lambda_dssim=0.2, lambda_normal=0.05, lambda_dist=0.0,
-                 rank=0, world=1, densify=None, scene_extent=None, spatial_sort=True):
+                 rank=0, world=1, densify=None, scene_extent=None, spatial_sort=True, fused_update=None):
         """``spatial_sort``: store the Gaussians in Z-order of their centres (a row permutation, once, here; rows that the
         density control appends later go to the end).  ``densify``: None (off) or a dict overriding the reference's schedule (arguments/__init__.py:106-125):
         ``from_iter=500, until_iter=15000, interval=100, opacity_reset_interval=3000, grad_threshold=0.0002,
@@ -524,7 +526,18 @@ class RgbTrainer:
         self.bg = torch.zeros(3, dtype=torch.float32, device=self.device)
         self.ld, self.ln, self.ldist = lambda_dssim, lambda_normal, lambda_dist
         self.rank, self.world = rank, world
-        self.opt = torch.optim.Adam(self.model.param_groups(), lr=0.0, eps=1e-15, fused=self.device.type == "cuda")
+        # chain rule of the getters + Adam on the six groups + the next activations in one kernel (optim.GaussianAdam);
+        # the density control edits optimiser rows through torch's state dict, so it keeps torch.optim.Adam
+        if fused_update is None:
+            fused_update = self.device.type == "cuda" and densify is None
+        if fused_update and densify is not None:
+            raise ValueError("fused_update does not support the density control")
+        self.fused_update = bool(fused_update)
+        if self.fused_update:
+            from .optim import GaussianAdam
+            self.opt = GaussianAdam(self.model, {g["name"]: g["lr"] for g in self.model.param_groups()}, eps=1e-15)
+        else:
+            self.opt = torch.optim.Adam(self.model.param_groups(), lr=0.0, eps=1e-15, fused=self.device.type == "cuda")
         self.densify_cfg = None
         if densify is not None:
             from .densify import Densifier
@@ -555,14 +568,32 @@ class RgbTrainer:
         if iteration % cfg["opacity_reset_interval"] == 0:
             d.reset_opacity()
 
-    def step(self, it: int):
-        vi = view_for(it, self.rank, self.world, len(self.cams))
-        pkg = render(self.cams[vi], self.model, self.pipe, self.bg)
+    def _loss(self, pkg, vi):
         image, gt = pkg["render"], self.targets[vi]
         loss = (1.0 - self.ld) * self.l1(image, gt) + self.ld * (1.0 - self.ssim(image, gt))
-        loss = loss + self.ldist * pkg["rend_dist"].mean()
+        if self.ldist != 0.0:
+            loss = loss + self.ldist * pkg["rend_dist"].mean()
         normal_error = (1 - (pkg["rend_normal"] * pkg["surf_normal"]).sum(dim=0))[None]
-        loss = loss + self.ln * normal_error.mean()
+        return loss + self.ln * normal_error.mean()
+
+    def step(self, it: int):
+        vi = view_for(it, self.rank, self.world, len(self.cams))
+        if self.fused_update:
+            self.model._leaves = self.opt.begin()
+            try:
+                pkg = render(self.cams[vi], self.model, self.pipe, self.bg)
+                loss = self._loss(pkg, vi)
+                loss.backward()
+            finally:
+                self.model._leaves = None
+            # one flat collective for all six groups' gradients (they are final only after the per-Gaussian backward pass)
+            lv = self.opt.leaves
+            self.opt.step(allreduce_bucket(self.opt.leaf_grads(), self.world,
+                                           like=[lv["xyz"], lv["shs"], lv["opacity"], lv["scaling"], lv["rotation"]]))
+            self.opt.zero_grad(set_to_none=True)
+            return loss.detach(), pkg
+        pkg = render(self.cams[vi], self.model, self.pipe, self.bg)
+        loss = self._loss(pkg, vi)
         loss.backward()
         allreduce_grads([p for gr in self.opt.param_groups for p in gr["params"]], self.world)
         if self.densify_cfg is not None:
