@@ -263,3 +263,89 @@ def test_c5_two_feature_passes_adjoint_and_trainer():
         rz.set_async_binning(False)
         rz.set_mode("exact")
         rz.set_tracer(True)
+
+
+# ---- BASELINE config 2 at full size (300 k Gaussians, 779 x 519, RGB + depth + normal): the dense backward WITH geometry
+def _c2():
+    if "c2" not in _CACHE:
+        scene, cams, cfg = scenes.config_scene("C2")
+        inp = {k: (None if v is None else v.cuda()) for k, v in scenes.activated_inputs(scene).items()}
+        _CACHE["c2"] = (scene, cams, cfg, inp)
+    return _CACHE["c2"]
+
+
+def _render_c2(inp, cam, cfg, mode, colors=None, over=None):
+    from instascene_amd._lib import GRAD_GEOMETRY  # noqa: F401
+    e = torch.empty(0, device="cuda")
+    v = dict(inp)
+    if over:
+        v.update(over)
+    args = (torch.tensor([0.2, 0.1, 0.3], device="cuda"), v["means3D"], e if colors is None else colors, v["opacities"],
+            v["scales"], v["rotations"], 1.0, e, e, 0, cam.world_view_transform.cuda(), cam.full_proj_transform.cuda(),
+            math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), cfg["H"], cfg["W"], v["shs"] if colors is None else e, 3,
+            cam.camera_center.cuda(), False, False)
+    return args, rz.rasterize_gaussians(*args, mode=mode, tracer=False)
+
+
+def _backward_c2(args, out, dC, dO, mode):
+    from instascene_amd._lib import GRAD_GEOMETRY
+    R, color, others, radii, extra, geom, binning, img = out[:8]
+    e = torch.empty(0, device="cuda")
+    return rz.rasterize_gaussians_backward(args[0], args[1], radii, args[2], args[4], args[5], e, 1.0, e, args[10], args[11],
+                                           args[12], args[13], dC, dO, e, args[16], 3, args[18], geom, R, binning, img, False,
+                                           grad_mask=GRAD_GEOMETRY, mode=mode)
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_c2_geometry_backward_adjoint_and_oracle_parity_at_full_size(mode):
+    """Full-size C2 through the dense backward with GRAD_GEOMETRY (k_render_bwd<GEOM> + k_preprocess_bwd):
+    (i) the colour image is LINEAR in per-Gaussian colours and dL/dcolors is its adjoint: <render(c) - render(0), G> ==
+    <c, dL/dcolors(G)>; (ii) forward and all gradients against the CPU oracle on the full-size view."""
+    scene, cams, cfg, inp = _c2()
+    md = MODE_EXACT if mode == "exact" else MODE_FAST
+    P, W, H = cfg["P"], cfg["W"], cfg["H"]
+    cam = cams[5]
+    g = torch.Generator(device="cuda").manual_seed(21)
+    # (i) colours
+    c1 = torch.rand(P, 3, device="cuda", generator=g)
+    a1, o1 = _render_c2(inp, cam, cfg, md, colors=c1)
+    a0, o0 = _render_c2(inp, cam, cfg, md, colors=torch.zeros(P, 3, device="cuda"))
+    G = torch.randn(3, H, W, device="cuda", generator=g)
+    lhs = float(((o1[1] - o0[1]).double() * G.double()).sum())
+    grads = _backward_c2(a1, o1, G, torch.zeros(7, H, W, device="cuda"), md)
+    rhs = float((c1.double() * grads[1].double()).sum())
+    assert abs(lhs - rhs) <= 2e-5 * float(((o1[1] - o0[1]).double().abs() * G.double().abs()).sum())
+    # (ii) against the CPU oracle at FULL C2 size (0.7 s per view on the test box's cores): the forward in EXACT mode is
+    # bit-identical, every gradient of the dense geometry backward is within 1e-3 of the tensor's maximum; in FAST mode
+    # the binning is bit-identical and at most 1e-4 of the rows may sit outside 1e-3 (threshold decisions, see
+    # tests/test_gpu_fuzz.py).  (A finite-difference check is useless at this size: the render is a sum over 4 * 10^5
+    # pixels of terms that jump at the alpha = 1/255 and T = 1e-4 thresholds, and the jumps crossed inside any usable step
+    # are as large as the derivative itself - measured: central differences at two step sizes disagree by 20-100 %.)
+    import oracle
+    import test_gpu_rasterizer as TR
+    from helpers import oracle_forward
+    cpu = {k: (None if v is None else v.cpu()) for k, v in inp.items()}
+    st = oracle_forward(cpu, cam, bg=(0.2, 0.1, 0.3))
+    a, o = _render_c2(inp, cam, cfg, md)
+    if mode == "exact":
+        assert o[0] == st["R"]
+        np.testing.assert_array_equal(o[1].cpu().numpy(), st["color"])
+        np.testing.assert_array_equal(o[2].cpu().numpy(), st["others"])
+        np.testing.assert_array_equal(o[3].cpu().numpy(), st["radii"])
+    dbg = rz.debug_state(P, W, H, o[0], o[5], o[6], o[7])
+    np.testing.assert_array_equal(dbg["point_list"], st["point_list"])
+    np.testing.assert_array_equal(dbg["ranges"], st["ranges"])
+    rng = np.random.RandomState(3)
+    dC = rng.randn(3, H, W).astype(np.float32)
+    dO = rng.randn(7, H, W).astype(np.float32)
+    want = oracle.backward(st, dC, dO, None)
+    got = _backward_c2(a, o, torch.tensor(dC).cuda(), torch.tensor(dO).cuda(), md)
+    for name, t in zip(TR.GRAD_NAMES, got):
+        if t is None or name not in want or want[name].size == 0:
+            continue
+        w = want[name].reshape(P, -1)
+        dev = np.abs(t.cpu().numpy().reshape(w.shape) - w).max(axis=1) / (np.abs(w).max() + 1e-30)
+        if mode == "exact":
+            assert dev.max() <= 1e-3, (name, float(dev.max()))
+        else:
+            assert (dev > 1e-3).sum() <= 1e-4 * P and dev.max() <= 0.25, (name, int((dev > 1e-3).sum()), float(dev.max()))
