@@ -109,6 +109,14 @@ int iso_ssim_forward(int C, int H, int W, const float* img1, const float* img2, 
 int iso_ssim_backward(int C, int H, int W, const float* img1, const float* img2, const float* dmaps, const float* g_mean,
                       float* dL_dimg1, void* stream);
 
+/* The whole photometric term of train.py:91 in the same two kernels: additionally *l1_mean = mean |img1 - img2|
+ * (utils/loss_utils.py:18-19) in the forward, and  g_l1 * sign(img1 - img2) / (C H W)  added to dL_dimg1 in the backward
+ * (g_l1 = dL/d l1_mean, device scalar; NULL = SSIM only).  l1_mean NULL: exactly iso_ssim_forward. */
+int iso_photometric_forward(int C, int H, int W, const float* img1, const float* img2, float* ssim_mean, float* l1_mean,
+                            float* dmaps, void* scratch, size_t scratch_bytes, void* stream);
+int iso_photometric_backward(int C, int H, int W, const float* img1, const float* img2, const float* dmaps,
+                             const float* g_ssim, const float* g_l1, float* dL_dimg1, void* stream);
+
 /* Densification statistics of one iteration (train.py:140-142; scene/gaussian_model.py:601-604): for every Gaussian i
  * with visible[i] != 0:  grad_accum[i] += |viewspace_grad[i, 0:C]|_2,  denom[i] += 1,
  * max_radii[i] = max(max_radii[i], radii[i]). */

@@ -44,6 +44,9 @@ __device__ __forceinline__ void tile_blur(const float* __restrict__ in, float* _
 
 // grid (ceil(W/32), ceil(H/8), C).  map_part[block] = sum of the SSIM map over the block's pixels.
 // dmaps (optional) [3][C][H][W]: d map / d mu1, d map / d E[a^2], d map / d E[ab].
+// L1: also map_part[nblocks + block] = sum of |img1 - img2| over the block's pixels (the other half of train.py's
+// photometric loss, utils/loss_utils.py:18-19: the images are in LDS already).
+template <bool L1>
 __global__ __launch_bounds__(256) void ssim_fwd(int C, int H, int W, SsimTaps tp, const float* __restrict__ img1,
                                                 const float* __restrict__ img2, float* __restrict__ map_part,
                                                 float* __restrict__ dmaps) {
@@ -69,8 +72,12 @@ __global__ __launch_bounds__(256) void ssim_fwd(int C, int H, int W, SsimTaps tp
     tile_blur<5>(s_in, s_h, tp, m);
     const int tx = threadIdx.x & (SS_TW - 1), ty = threadIdx.x >> 5;
     const int x = blockIdx.x * SS_TW + tx, y = blockIdx.y * SS_TH + ty;
-    float val = 0.0f;
+    float val = 0.0f, l1v = 0.0f;
     if (x < W && y < H) {
+        if (L1) {
+            const int ce = (ty + SS_R) * SS_IW + tx + SS_R;
+            l1v = fabsf(s_in[ce] - s_in[SS_IH * SS_IW + ce]);
+        }
         const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
         const float mu1 = m[0], mu2 = m[1];
         const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
@@ -96,13 +103,25 @@ __global__ __launch_bounds__(256) void ssim_fwd(int C, int H, int W, SsimTaps tp
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0)
-        map_part[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0) map_part[blk] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (L1) {
+        __syncthreads();
+        float u = l1v;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) u += __shfl_xor(u, o);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = u;
+        __syncthreads();
+        if (threadIdx.x == 0) map_part[gridDim.x * gridDim.y * gridDim.z + blk] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
 }
 
+// block b sums part[b * n .. (b + 1) * n) into out_b (b = 0: SSIM map, b = 1: |a - b|)
 __global__ __launch_bounds__(256) void ssim_sum_parts(int n, const float* __restrict__ part, float inv_count,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out0, float* __restrict__ out1) {
     __shared__ float s_red[4];
+    part += (size_t)blockIdx.x * n;
+    float* out = blockIdx.x == 0 ? out0 : out1;
     float a = 0.0f;
     for (int i = threadIdx.x; i < n; i += 256) a += part[i];
 #pragma unroll
@@ -113,10 +132,11 @@ __global__ __launch_bounds__(256) void ssim_sum_parts(int n, const float* __rest
 }
 
 // dL/dimg1 = g * ( blur(dm1) + 2 a blur(dm2) + b blur(dm3) ),  g = dL/d(mean) / (C H W)
+//            [+ g_l1 / (C H W) * sign(a - b): the L1 term's gradient, when g_l1 is given]
 __global__ __launch_bounds__(256) void ssim_bwd(int C, int H, int W, SsimTaps tp, const float* __restrict__ img1,
                                                 const float* __restrict__ img2, const float* __restrict__ dmaps,
-                                                const float* __restrict__ g_mean, float inv_count,
-                                                float* __restrict__ dimg1) {
+                                                const float* __restrict__ g_mean, const float* __restrict__ g_l1,
+                                                float inv_count, float* __restrict__ dimg1) {
     __shared__ float s_in[3 * SS_IH * SS_IW];
     __shared__ float s_h[3 * SS_IH * SS_TW];
     const int ch = blockIdx.z;
@@ -140,7 +160,12 @@ __global__ __launch_bounds__(256) void ssim_bwd(int C, int H, int W, SsimTaps tp
     if (x < W && y < H) {
         const size_t o = ch * plane + (size_t)y * W + x;
         const float a = img1[o], b = img2[o];
-        dimg1[o] = (g_mean[0] * inv_count) * (m[0] + 2.0f * a * m[1] + b * m[2]);
+        float v = (g_mean[0] * inv_count) * (m[0] + 2.0f * a * m[1] + b * m[2]);
+        if (g_l1 != nullptr) {
+            const float df = a - b;
+            v += (g_l1[0] * inv_count) * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));     // torch: sign(0) = 0
+        }
+        dimg1[o] = v;
     }
 }
 

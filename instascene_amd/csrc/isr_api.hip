@@ -622,34 +622,45 @@ static iso::SsimTaps ssim_taps() {
 
 size_t iso_ssim_scratch_bytes(int C, int H, int W) {
     const size_t nb = (size_t)((W + iso::SS_TW - 1) / iso::SS_TW) * ((H + iso::SS_TH - 1) / iso::SS_TH) * (size_t)(C > 0 ? C : 1);
-    return nb * sizeof(float) + 256;
+    return 2 * nb * sizeof(float) + 256;        // SSIM-map and |a - b| block sums
 }
 
-int iso_ssim_forward(int C, int H, int W, const float* img1, const float* img2, float* ssim_mean, float* dmaps,
-                     void* scratch, size_t scratch_bytes, void* stream) {
+int iso_photometric_forward(int C, int H, int W, const float* img1, const float* img2, float* ssim_mean, float* l1_mean,
+                            float* dmaps, void* scratch, size_t scratch_bytes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !ssim_mean || !scratch) return fail(ISR_EINVAL, "bad ssim arguments");
     if (scratch_bytes < iso_ssim_scratch_bytes(C, H, W)) return fail(ISR_EINVAL, "ssim scratch too small");
     const dim3 grid((W + iso::SS_TW - 1) / iso::SS_TW, (H + iso::SS_TH - 1) / iso::SS_TH, C);
     const int nb = (int)(grid.x * grid.y * grid.z);
     { ProfScope ps_("ssim_fwd", s);
-    hipLaunchKernelGGL(iso::ssim_fwd, grid, dim3(256), 0, s, C, H, W, ssim_taps(), img1, img2, (float*)scratch, dmaps); }
-    hipLaunchKernelGGL(iso::ssim_sum_parts, dim3(1), dim3(256), 0, s, nb, (const float*)scratch,
-                       (float)(1.0 / ((double)C * H * W)), ssim_mean);
-    ISR_LAUNCH_CHECK("iso_ssim_forward");
+    if (l1_mean) hipLaunchKernelGGL(iso::ssim_fwd<true>, grid, dim3(256), 0, s, C, H, W, ssim_taps(), img1, img2, (float*)scratch, dmaps);
+    else hipLaunchKernelGGL(iso::ssim_fwd<false>, grid, dim3(256), 0, s, C, H, W, ssim_taps(), img1, img2, (float*)scratch, dmaps); }
+    hipLaunchKernelGGL(iso::ssim_sum_parts, dim3(l1_mean ? 2 : 1), dim3(256), 0, s, nb, (const float*)scratch,
+                       (float)(1.0 / ((double)C * H * W)), ssim_mean, l1_mean);
+    ISR_LAUNCH_CHECK("iso_photometric_forward");
+    return ISR_OK;
+}
+
+int iso_ssim_forward(int C, int H, int W, const float* img1, const float* img2, float* ssim_mean, float* dmaps,
+                     void* scratch, size_t scratch_bytes, void* stream) {
+    return iso_photometric_forward(C, H, W, img1, img2, ssim_mean, nullptr, dmaps, scratch, scratch_bytes, stream);
+}
+
+int iso_photometric_backward(int C, int H, int W, const float* img1, const float* img2, const float* dmaps,
+                             const float* g_ssim, const float* g_l1, float* dL_dimg1, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dmaps || !g_ssim || !dL_dimg1) return fail(ISR_EINVAL, "bad ssim arguments");
+    const dim3 grid((W + iso::SS_TW - 1) / iso::SS_TW, (H + iso::SS_TH - 1) / iso::SS_TH, C);
+    { ProfScope ps_("ssim_bwd", s);
+    hipLaunchKernelGGL(iso::ssim_bwd, grid, dim3(256), 0, s, C, H, W, ssim_taps(), img1, img2, dmaps, g_ssim, g_l1,
+                       (float)(1.0 / ((double)C * H * W)), dL_dimg1); }
+    ISR_LAUNCH_CHECK("iso_photometric_backward");
     return ISR_OK;
 }
 
 int iso_ssim_backward(int C, int H, int W, const float* img1, const float* img2, const float* dmaps, const float* g_mean,
                       float* dL_dimg1, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dmaps || !g_mean || !dL_dimg1) return fail(ISR_EINVAL, "bad ssim arguments");
-    const dim3 grid((W + iso::SS_TW - 1) / iso::SS_TW, (H + iso::SS_TH - 1) / iso::SS_TH, C);
-    { ProfScope ps_("ssim_bwd", s);
-    hipLaunchKernelGGL(iso::ssim_bwd, grid, dim3(256), 0, s, C, H, W, ssim_taps(), img1, img2, dmaps, g_mean,
-                       (float)(1.0 / ((double)C * H * W)), dL_dimg1); }
-    ISR_LAUNCH_CHECK("iso_ssim_backward");
-    return ISR_OK;
+    return iso_photometric_backward(C, H, W, img1, img2, dmaps, g_mean, nullptr, dL_dimg1, stream);
 }
 
 int iso_densify_stats(int P, int C, const float* viewspace_grad, const unsigned char* visible, const int* radii,

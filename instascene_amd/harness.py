@@ -512,8 +512,8 @@ class RgbTrainer:
         density control appends later go to the end).  ``densify``: None (off) or a dict overriding the reference's schedule (arguments/__init__.py:106-125):
         ``from_iter=500, until_iter=15000, interval=100, opacity_reset_interval=3000, grad_threshold=0.0002,
         opacity_cull=0.05, percent_dense=0.01``; ``scene_extent`` = the reference's ``cameras_extent``."""
-        from .losses import l1_loss, ssim
-        self.l1, self.ssim = l1_loss, ssim
+        from .losses import l1_loss, photometric_loss, ssim
+        self.l1, self.ssim, self.photometric = l1_loss, ssim, photometric_loss
         self.device = torch.device(device)
         self.order = None
         if spatial_sort:
@@ -570,7 +570,7 @@ class RgbTrainer:
 
     def _loss(self, pkg, vi):
         image, gt = pkg["render"], self.targets[vi]
-        loss = (1.0 - self.ld) * self.l1(image, gt) + self.ld * (1.0 - self.ssim(image, gt))
+        loss = self.photometric(image, gt, self.ld)       # (1 - l) L1 + l (1 - SSIM), one pair of kernels on the GPU
         if self.ldist != 0.0:
             loss = loss + self.ldist * pkg["rend_dist"].mean()
         normal_error = (1 - (pkg["rend_normal"] * pkg["surf_normal"]).sum(dim=0))[None]

@@ -74,6 +74,56 @@ class _SsimHip(torch.autograd.Function):
         return out, None
 
 
+class _PhotometricHip(torch.autograd.Function):
+    """``(1 - lambda) * L1 + lambda * (1 - SSIM)`` of two [C,H,W] CUDA images (train.py:89-91) in the SSIM kernels
+    (``iso_photometric_forward/backward``): the images are in LDS anyway, so the L1 mean and its sign gradient cost no pass.
+    Returns ``(loss, l1, ssim)``; gradients flow to the first image."""
+
+    @staticmethod
+    def forward(ctx, img1, img2, lambda_dssim):
+        from ._lib import check, lib
+        L = lib()
+        a, b = img1.contiguous().float(), img2.detach().contiguous().float()
+        C, H, W = a.shape
+        out = torch.empty(2, dtype=torch.float32, device=a.device)       # ssim mean, l1 mean
+        need = img1.requires_grad
+        dmaps = torch.empty((3, C, H, W), dtype=torch.float32, device=a.device) if need else None
+        nbytes = L.iso_ssim_scratch_bytes(C, H, W)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+        with torch.cuda.device(a.device):
+            check(L.iso_photometric_forward(C, H, W, _ptr(a), _ptr(b), _ptr(out[0:1]), _ptr(out[1:2]), _ptr(dmaps),
+                                            _ptr(scratch), nbytes, _stream()), "iso_photometric_forward")
+        ctx.save_for_backward(a, b, dmaps)
+        ctx.lam = float(lambda_dssim)
+        ssim_v, l1_v = out[0], out[1]
+        loss = (1.0 - ctx.lam) * l1_v + ctx.lam * (1.0 - ssim_v)
+        ctx.mark_non_differentiable(l1_v, ssim_v)
+        return loss, l1_v, ssim_v
+
+    @staticmethod
+    def backward(ctx, g, _g_l1, _g_ssim):
+        from ._lib import check, lib
+        a, b, dmaps = ctx.saved_tensors
+        if dmaps is None or g is None:
+            return None, None, None
+        C, H, W = a.shape
+        gg = g.reshape(1).float()
+        gs = torch.stack(((-ctx.lam) * gg[0], (1.0 - ctx.lam) * gg[0]))   # dL/d ssim_mean, dL/d l1_mean
+        out = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            check(lib().iso_photometric_backward(C, H, W, _ptr(a), _ptr(b), _ptr(dmaps), _ptr(gs[0:1]), _ptr(gs[1:2]),
+                                                 _ptr(out), _stream()), "iso_photometric_backward")
+        return out, None, None
+
+
+def photometric_loss(image, gt, lambda_dssim: float = 0.2):
+    """``(1 - lambda_dssim) * l1_loss + lambda_dssim * (1 - ssim)`` (train.py:89-91).  CUDA [C,H,W] images: one fused pair of
+    kernels; otherwise composed from :func:`l1_loss` and :func:`ssim`."""
+    if image.is_cuda and image.dim() == 3 and gt.shape == image.shape and not gt.requires_grad:
+        return _PhotometricHip.apply(image, gt, float(lambda_dssim))[0]
+    return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))
+
+
 def _ptr(t):
     import ctypes
     return None if t is None else ctypes.c_void_p(t.data_ptr())

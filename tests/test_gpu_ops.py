@@ -366,6 +366,13 @@ def test_hip_ssim_matches_torch_restatement_and_golden(golden_dir, C, H, W):
     assert abs(float(ss.detach()) - float(z["ssim"])) < 1e-5
     (0.8 * l1 + 0.2 * (1.0 - ss)).backward()
     assert_close(img.grad.cpu().numpy(), z["grad"], 1e-4, "loss grad vs reference")
+    # the fused photometric term (L1 inside the SSIM kernels) against the same reference outputs
+    img2 = torch.tensor(z["img"]).cuda().requires_grad_(True)
+    loss = losses.photometric_loss(img2, gt, 0.2)
+    want_loss = 0.8 * float(z["l1"]) + 0.2 * (1.0 - float(z["ssim"]))
+    assert abs(float(loss.detach()) - want_loss) < 2e-6
+    loss.backward()
+    assert_close(img2.grad.cpu().numpy(), z["grad"], 1e-4, "fused photometric grad vs reference")
 
 
 def test_feature_adam_matches_torch_adam_and_emits_the_normalisation_chain():
