@@ -32,13 +32,16 @@ __host__ __device__ inline int row_floats(int ED, unsigned mask) {
     return ((mask & 2u) ? GEOM_ROW : 0) + ((mask & 1u) ? feat_row(ED) : 0);
 }
 __host__ __device__ inline int n_passes(int ED, unsigned mask) { return ((mask & 1u) && ED > 32) ? (ED + 31) / 32 : 1; }
+// geometry-only backward without a feature channel: room for the splat-major kernel's row per (tile, Gaussian, 8x8 block)
+// (isr_backward_geo.hip; four slots per instance, of which ~1.2 are written)
+__host__ __device__ inline int rows_per_instance(int ED, unsigned mask) { return ((mask & 3u) == 2u && ED == 0) ? 4 : 1; }
 inline size_t rows_bytes(int64_t R, int ED, unsigned mask) {
-    return align_up((size_t)(R > 0 ? R : 1) * row_floats(ED, mask) * sizeof(float), 256);
+    return align_up((size_t)(R > 0 ? R : 1) * rows_per_instance(ED, mask) * row_floats(ED, mask) * sizeof(float), 256);
 }
 // rows[R][stride] followed by one validity byte per (pass, row): a row is written (and flagged) only when some
 // wave actually evaluated that (tile, splat) instance — everything else is skipped by the reductions.
 size_t backward_scratch_bytes(int64_t R, int ED, unsigned mask) {
-    return rows_bytes(R, ED, mask) + align_up((size_t)(R > 0 ? R : 1) * n_passes(ED, mask), 256) + 256;
+    return rows_bytes(R, ED, mask) + align_up((size_t)(R > 0 ? R : 1) * rows_per_instance(ED, mask) * n_passes(ED, mask), 256) + 256;
 }
 
 __global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D,
@@ -1275,6 +1278,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ tm_pre,
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos, int Wd, int Hd,
     GeomView g, const float* __restrict__ partial, const uint8_t* __restrict__ row_flags, int row_stride, int geom_off,
+    int rpi /* partial rows per tile instance: 1, or 4 (one per 8x8 block: k_render_bwd_geo) */,
     float* __restrict__ dL_dmean2D,
     float* __restrict__ dL_dnormal, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
     float* __restrict__ dL_dmean3D, float* __restrict__ dL_dtransMat, float* __restrict__ dL_dsh,
@@ -1291,10 +1295,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     float gs[18];
 #pragma unroll
     for (int q = 0; q < 18; q++) gs[q] = 0.0f;
-    const uint32_t nt = g.tiles_touched[i];
+    const uint32_t nt = g.tiles_touched[i] * (uint32_t)rpi;
     if (nt > 0) {
-        const float* src = partial + (size_t)g.point_offsets[i] * row_stride + geom_off;
-        const uint8_t* fl = row_flags + g.point_offsets[i];
+        const float* src = partial + (size_t)g.point_offsets[i] * rpi * row_stride + geom_off;
+        const uint8_t* fl = row_flags + (size_t)g.point_offsets[i] * rpi;
         for (uint32_t r = 0; r < nt; r++) {
             if (!fl[r]) continue;
             const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)r * row_stride);
@@ -1467,6 +1471,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
 }
 
 // ----------------------------------------------------------------------------
+}  // namespace isr
+#include "isr_backward_geo.hip"
+namespace isr {
+
 #define ISR_CHECK_LAUNCH_B(name)                                                  \
     do {                                                                          \
         hipError_t e_ = hipGetLastError();                                        \
@@ -1476,6 +1484,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
 // ISR_SPARSE_BWD=0 disables the pixel-major kernel (A/B measurements)
 static bool sparse_path_enabled() {
     static const bool on = [] { const char* e = getenv("ISR_SPARSE_BWD"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// ISR_GEO_SPLAT=0 keeps the pixel-major kernel for the geometry-only FAST backward (A/B measurements)
+static bool geo_splat_enabled() {
+    static const bool on = [] { const char* e = getenv("ISR_GEO_SPLAT"); return !(e && e[0] == '0'); }();
     return on;
 }
 
@@ -1500,7 +1514,17 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
     uint8_t* flags = (uint8_t*)scratch + rows_bytes(R, ED, eff_mask);
     const int npass = n_passes(ED, eff_mask);
     if (P == 0) return 0;
-    if (R > 0) {
+    // FAST arithmetic, geometry only, no feature channel (the train.py step): splat-major kernel, a row per 8x8 block
+    const bool geo_splat = Math::fast && geomg && !featg && ED == 0 && geo_splat_enabled();
+    const int rpi = geo_splat ? rows_per_instance(ED, eff_mask) : 1;
+    if (R > 0 && geo_splat) {
+        if (hipMemsetAsync(flags, 0, (size_t)R * rpi, s) != hipSuccess) return -2;
+        ProfScope ps_("k_render_bwd", s);
+        hipLaunchKernelGGL(k_render_bwd_geo, dim3(T * 4), dim3(64), 0, s, W, H, gx, iv.tile_offset, bv.point_list, bv.box4, g.rec,
+                           col_pre, tm_pre, bg, iv.final_T, iv.n_contrib, dC, dO, g.point_offsets, g.rect, partial, flags, stride,
+                           geom_off, R);
+        ISR_CHECK_LAUNCH_B("k_render_bwd_geo");
+    } else if (R > 0) {
         if (hipMemsetAsync(flags, 0, (size_t)R * npass, s) != hipSuccess) return -2;
         int pass = 0;
         bool first = true;
@@ -1552,7 +1576,7 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
         const int Wd = (int)(focal_x * tan_fovx * 2), Hd = (int)(focal_y * tan_fovy * 2);   // backward.cu:633-634
         ProfScope ps_("k_preprocess_bwd", s);
         hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, shs, scales, rots,
-                           tm_pre, view, proj, campos, Wd, Hd, g, partial, flags, stride, geom_off, dL_dmean2D, dL_dnormal,
+                           tm_pre, view, proj, campos, Wd, Hd, g, partial, flags, stride, geom_off, rpi, dL_dmean2D, dL_dnormal,
                            dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot);
         ISR_CHECK_LAUNCH_B("k_preprocess_bwd");
     }

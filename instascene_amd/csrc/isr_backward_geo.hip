@@ -1,0 +1,268 @@
+// K9 for the train.py step (reference backward.cu:143-466) in FAST arithmetic, geometry only (no feature channel), dense
+// upstream gradient - the kernel BASELINE config 2 lives on.  "Splat-major": a lane owns a SPLAT, not a pixel.
+//
+// The pixel-major kernel (isr_backward.hip: k_render_bwd<GEOM>) evaluates a splat on the 64 pixels of a wave and then has
+// to sum twelve non-linear terms and the blend weights over those pixels - a packed butterfly, LDS partials of four
+// waves, two MFMA phases, three workgroup barriers per 32 instances; ~220 vector instructions per (wave, splat) pair at
+// 3 waves/SIMD.  Here one wave owns an 8x8 pixel block of a tile and walks the block's culled splat list BACK TO FRONT, 64
+// splats at a time, a lane per splat, pixel after pixel:
+//   * what the reference carries along the list for one pixel - the transmittance in front of a splat and the
+//     "accumulated behind it" recurrences - are PREFIX SCANS over the lanes: a product scan of (1 - alpha) and a sum scan
+//     of  w S  (S = the pixel's combined upstream gradient, one scalar for colour, depth, alpha, normal and distortion
+//     weight: they all follow the same linear recurrence).  DPP row shifts + row broadcasts, no LDS;
+//   * every gradient of a (block, splat) pair accumulates in the registers of the lane that owns the splat while the 64
+//     pixels go by: no cross-lane reduction, no partials, no barrier, and the finished 18-value row is stored once.
+// Each of a tile's four blocks writes its own row per splat (slot 4 s + block of the partial-row scratch; only pairs that
+// were evaluated are flagged - 1.17 rows per tile instance on the C3 scene), and k_preprocess_bwd sums a Gaussian's rows
+// in slot order as before: still no atomics, bit-reproducible.
+#include "isr_common.hpp"
+
+namespace isr {
+
+constexpr int GEO_SEG = 256;        // tile-list entries culled per round (four per lane)
+constexpr int GEO_QCAP = 512;       // queue capacity (entries that touch the block, waiting for their chunk of 64)
+constexpr int GEO_BLOCKS = 4;       // 8x8 blocks per tile = rows per (tile, Gaussian) instance
+
+__device__ __forceinline__ float wave_scan_add(float v) {      // inclusive sum scan over the 64 lanes
+    v += dpp_fetch<0x111, 0xF>(v, 0.0f);     // row_shr:1
+    v += dpp_fetch<0x112, 0xF>(v, 0.0f);     // row_shr:2
+    v += dpp_fetch<0x114, 0xF>(v, 0.0f);     // row_shr:4
+    v += dpp_fetch<0x118, 0xF>(v, 0.0f);     // row_shr:8
+    v += dpp_fetch<0x142, 0xA>(v, 0.0f);     // row_bcast:15 into rows 1 and 3
+    v += dpp_fetch<0x143, 0xC>(v, 0.0f);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+__global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
+    int W, int H, int gx, const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ point_list,
+    const uint32_t* __restrict__ box4, const float* __restrict__ rec, const float* __restrict__ col_pre,
+    const float* __restrict__ tm_pre, const float* __restrict__ bg, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dC, const float* __restrict__ dO,
+    const uint32_t* __restrict__ point_offsets, const Rect16* __restrict__ rects, float* __restrict__ partial,
+    uint8_t* __restrict__ row_flags, int row_stride, int geom_off, int64_t capacity) {
+    __shared__ __attribute__((aligned(16))) float s_pix[64 * 16];
+    __shared__ int s_q[GEO_QCAP];
+
+    const int tile = blockIdx.x >> 2, blk = blockIdx.x & 3;
+    const int tx = tile % gx, ty = tile / gx;
+    const int lane = threadIdx.x;
+    const int bxo = (blk & 1) * 8, byo = (blk >> 1) * 8;            // block origin inside the tile
+    const int64_t r0 = tile_offset[tile];
+    int64_t r1 = tile_offset[tile + 1];
+    if (r1 > capacity) r1 = capacity;
+    const int len = (int)(r1 - r0);
+    if (len <= 0) return;
+    const size_t N = (size_t)W * H;
+    // ---- the block's pixels: lane p loads pixel p, LDS hands them to everybody (wave-uniform reads in the pixel loop)
+    unsigned mylast = 0u;
+    {
+        const unsigned px = tx * TILE + bxo + (lane & 7), py = ty * TILE + byo + (lane >> 3);
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = 0.0f;
+        if (px < (unsigned)W && py < (unsigned)H) {
+            const size_t pix = (size_t)W * py + px;
+            if (dC) { v[0] = dC[pix]; v[1] = dC[N + pix]; v[2] = dC[2 * N + pix]; }
+            if (dO) {
+#pragma unroll
+                for (int k = 0; k < 7; k++) v[3 + k] = dO[(size_t)k * N + pix];
+            }
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 10; k++) any = any || (v[k] != 0.0f);
+            v[10] = final_T[pix]; v[11] = final_T[pix + N]; v[12] = final_T[pix + 2 * N];
+            mylast = any ? n_contrib[pix] : 0u;          // a pixel without upstream gradient contributes exact zeros
+            v[13] = __uint_as_float(mylast);
+            v[14] = __uint_as_float(n_contrib[pix + N]);
+            v[15] = (bg[0] * v[0] + bg[1] * v[1]) + bg[2] * v[2];
+        }
+        float4* dst = reinterpret_cast<float4*>(s_pix + lane * 16);
+        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+        dst[2] = make_float4(v[8], v[9], v[10], v[11]);
+        dst[3] = make_float4(v[12], v[13], v[14], v[15]);
+    }
+    unsigned block_last = mylast;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) block_last = max(block_last, (unsigned)__shfl_xor((int)block_last, o));
+    if (block_last == 0u) return;
+    wave_lds_sync();
+    const int len_eff = min(len, (int)block_last);
+    const float mscale = FAR_N / (FAR_N - NEAR_N);
+    const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
+    float carryT = 0.0f, carryR = 0.0f;      // lane p: transmittance behind / sum of w S behind the splats walked so far, pixel p
+    carryT = s_pix[lane * 16 + 10];
+
+    int n_q = 0;                    // queued entries (uniform); s_q holds tile-list positions in DESCENDING order
+    int seg_hi = len_eff;           // entries [0, seg_hi) are still to be culled
+    while (seg_hi > 0 || n_q > 0) {
+        while (seg_hi > 0 && n_q <= GEO_QCAP - GEO_SEG) {
+            const int seg_lo = max(0, seg_hi - GEO_SEG);
+#pragma unroll
+            for (int u = 0; u < GEO_SEG / 64; u++) {
+                const int i = seg_hi - 1 - (64 * u + lane);
+                bool hit = false;
+                if (i >= seg_lo) {
+                    const unsigned bx = box4[r0 + i];
+                    const int xl = (int)(signed char)(bx & 255u), xh = (int)(signed char)((bx >> 8) & 255u);
+                    const int yl = (int)(signed char)((bx >> 16) & 255u), yh = (int)(signed char)(bx >> 24);
+                    hit = xl <= bxo + 7 && xh >= bxo && yl <= byo + 7 && yh >= byo;
+                }
+                const unsigned long long b = __ballot(hit);
+                if (hit) s_q[n_q + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))] = i;
+                n_q += __popcll(b);
+            }
+            seg_hi = seg_lo;
+        }
+        wave_lds_sync();
+        const bool drained = seg_hi == 0;
+        int done = 0;
+        while (n_q - done >= 64 || (drained && done < n_q)) {
+            const int li = done + lane < n_q ? s_q[done + lane] : -1;       // this lane's splat: position in the tile's list
+            done += 64;
+            // ---- the splat (one per lane; lane order = back to front)
+            F3 Tu = {0, 0, 0}, Tv = {0, 0, 0}, Tw = {0, 0, 1}, nrm = {0, 0, 0}, col = {0, 0, 0};
+            float cx = 0, cy = 0, opa = 0, skip = 0;
+            int bxl = 127, bxh = -128, byl = 127, byh = -128;           // empty box: a lane without a splat touches no pixel
+            unsigned slot = 0;
+            if (li >= 0) {
+                const int id = (int)point_list[r0 + li];
+                const unsigned bx = box4[r0 + li];
+                bxl = (int)(signed char)(bx & 255u); bxh = (int)(signed char)((bx >> 8) & 255u);
+                byl = (int)(signed char)((bx >> 16) & 255u); byh = (int)(signed char)(bx >> 24);
+                const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
+                float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3], e = r4[4];
+                if (tm_pre != nullptr) {
+                    const float* tp = tm_pre + 9 * (size_t)id;
+                    a = make_float4(tp[0], tp[1], tp[2], tp[3]);
+                    b = make_float4(tp[4], tp[5], tp[6], tp[7]);
+                    c.x = tp[8];
+                }
+                if (col_pre != nullptr) {
+                    d.w = col_pre[3 * (size_t)id]; e.x = col_pre[3 * (size_t)id + 1]; e.y = col_pre[3 * (size_t)id + 2];
+                }
+                Tu = {a.x, a.y, a.z}; Tv = {a.w, b.x, b.y}; Tw = {b.z, b.w, c.x};
+                cx = c.y; cy = c.z; nrm = {c.w, d.x, d.y}; opa = d.z; col = {d.w, e.x, e.y};
+                skip = __builtin_inff();
+                if (opa <= 1.0f) {
+                    const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
+                    skip = 2.0f * l * 1.01f + 0.05f;
+                }
+                const Rect16 rc = rects[id];
+                slot = point_offsets[id] + (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
+            }
+            float acc[18];
+#pragma unroll
+            for (int k = 0; k < 18; k++) acc[k] = 0.0f;
+            bool touched = false;
+            for (int p = 0; p < 64; p++) {
+                const float4* pq = reinterpret_cast<const float4*>(s_pix + p * 16);
+                const float4 q3 = pq[3];
+                const unsigned last_p = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q3.y));
+                if (last_p == 0u) continue;
+                const int lx = bxo + (p & 7), ly = byo + (p >> 3);
+                bool act = li >= 0 && (unsigned)li < last_p && bxl <= lx && bxh >= lx && byl <= ly && byh >= ly;
+                if (__ballot(act) == 0ull) continue;
+                const float pxf = tile_x0 + (float)lx, pyf = tile_y0 + (float)ly;
+                const F3 kk = {__builtin_fmaf(pxf, Tw.x, -Tu.x), __builtin_fmaf(pxf, Tw.y, -Tu.y), __builtin_fmaf(pxf, Tw.z, -Tu.z)};
+                const F3 ll = {__builtin_fmaf(pyf, Tw.x, -Tv.x), __builtin_fmaf(pyf, Tw.y, -Tv.y), __builtin_fmaf(pyf, Tw.z, -Tv.z)};
+                const F3 pp = {__builtin_fmaf(kk.y, ll.z, -(kk.z * ll.y)), __builtin_fmaf(kk.z, ll.x, -(kk.x * ll.z)),
+                               __builtin_fmaf(kk.x, ll.y, -(kk.y * ll.x))};
+                const float dx = cx - pxf, dy = cy - pyf;
+                const float rho2d = FILTER_INV_SQ * __builtin_fmaf(dy, dy, dx * dx);
+                const float rz = __builtin_amdgcn_rcpf(pp.z);
+                const float sx = pp.x * rz, sy = pp.y * rz;
+                const float rho3d = __builtin_fmaf(sy, sy, sx * sx);
+                const float rho = fminf(rho3d, rho2d);
+                const bool use3d = rho3d <= rho2d;
+                const float c_d = use3d ? __builtin_fmaf(sy, Tw.y, sx * Tw.x) + Tw.z : Tw.z;
+                const float G = __builtin_amdgcn_exp2f(rho * -0.72134752f);
+                const float alpha = fminf(0.99f, opa * G);
+                act = act && (rho <= skip) && (pp.z != 0.0f) && !(c_d < NEAR_N) && !(alpha < 1.0f / 255.0f);
+                if (__ballot(act) == 0ull) continue;
+                const float4 q0 = pq[0], q1 = pq[1], q2 = pq[2];
+                // q0 = dC.rgb, d_depth   q1 = d_accum, dN.xyz   q2 = d_median, d_reg, T_final, final_D   q3 = final_D2, last, median, bg_dot
+                const float om = act ? 1.0f - alpha : 1.0f;
+                const float Pinc = wave_scan_mul(om);
+                const float cT = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(carryT), p));
+                const float cR = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(carryR), p));
+                const float Tb = cT * __builtin_amdgcn_rcpf(Pinc);                  // transmittance in front of this lane's splat
+                const float w = act ? alpha * Tb : 0.0f;
+                const float T_final = q2.z, final_A = 1.0f - q2.z, final_D = q2.w, final_D2 = q3.x, dL_dreg = q2.y;
+                float dL_dweight = 0.0f, m_d = 0.0f, inv_cd = 0.0f;
+                if (dL_dreg != 0.0f) {          // uniform: the pixel's distortion gradient
+                    inv_cd = __builtin_amdgcn_rcpf(c_d);
+                    m_d = mscale * (1.0f - NEAR_N * inv_cd);
+                    dL_dweight = (__builtin_fmaf(m_d * m_d, final_A, final_D2) - 2.0f * m_d * final_D) * dL_dreg;
+                }
+                float S = col.x * q0.x;
+                S = __builtin_fmaf(col.y, q0.y, S); S = __builtin_fmaf(col.z, q0.z, S);
+                S = __builtin_fmaf(c_d, q0.w, S); S += q1.x;
+                S = __builtin_fmaf(nrm.x, q1.y, S); S = __builtin_fmaf(nrm.y, q1.z, S); S = __builtin_fmaf(nrm.z, q1.w, S);
+                S += dL_dweight;
+                const float wS = w * S;
+                const float incl = wave_scan_add(wS);
+                const float Rl = cR + (incl - wS);                                   // sum of w S over the splats behind this one
+                {
+                    const float Ptot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Pinc), 63));
+                    const float Stot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+                    if (lane == p) { carryT = cT * __builtin_amdgcn_rcpf(Ptot); carryR = cR + Stot; }
+                }
+                if (act) {
+                    touched = true;
+                    const float inv_om = __builtin_amdgcn_rcpf(om);
+                    float dL_dalpha = __builtin_fmaf(Tb, S, -(Rl * inv_om));
+                    dL_dalpha = __builtin_fmaf(-T_final * inv_om, q3.w, dL_dalpha);
+                    float dL_dz = w * q0.w;
+                    const unsigned median_p = __float_as_uint(q3.z);
+                    if ((unsigned)li == median_p - 1u) dL_dz += q2.x;
+                    if (dL_dreg != 0.0f) {
+                        const float dmd_dd = (FAR_N * NEAR_N / (FAR_N - NEAR_N)) * inv_cd * inv_cd;
+                        dL_dz = __builtin_fmaf(2.0f * w * (m_d * final_A - final_D) * dL_dreg, dmd_dd, dL_dz);
+                    }
+                    const float dL_dG = opa * dL_dalpha;
+                    if (use3d) {
+                        const float dsx = __builtin_fmaf(dL_dG * -G, sx, dL_dz * Tw.x);
+                        const float dsy = __builtin_fmaf(dL_dG * -G, sy, dL_dz * Tw.y);
+                        const float dsx_pz = dsx * rz, dsy_pz = dsy * rz;
+                        const F3 dL_dp = {dsx_pz, dsy_pz, -(dsx_pz * sx + dsy_pz * sy)};
+                        const F3 dL_dk = cross3(ll, dL_dp);
+                        const F3 dL_dl = cross3(dL_dp, kk);
+                        acc[0] -= dL_dk.x; acc[1] -= dL_dk.y; acc[2] -= dL_dk.z;
+                        acc[3] -= dL_dl.x; acc[4] -= dL_dl.y; acc[5] -= dL_dl.z;
+                        acc[6] += __builtin_fmaf(pxf, dL_dk.x, __builtin_fmaf(pyf, dL_dl.x, dL_dz * sx));
+                        acc[7] += __builtin_fmaf(pxf, dL_dk.y, __builtin_fmaf(pyf, dL_dl.y, dL_dz * sy));
+                        acc[8] += __builtin_fmaf(pxf, dL_dk.z, __builtin_fmaf(pyf, dL_dl.z, dL_dz));
+                    } else {
+                        acc[9] = __builtin_fmaf(dL_dG, -G * FILTER_INV_SQ * dx, acc[9]);
+                        acc[10] = __builtin_fmaf(dL_dG, -G * FILTER_INV_SQ * dy, acc[10]);
+                        acc[8] += dL_dz;
+                    }
+                    acc[11] = __builtin_fmaf(w, q1.y, acc[11]); acc[12] = __builtin_fmaf(w, q1.z, acc[12]);
+                    acc[13] = __builtin_fmaf(w, q1.w, acc[13]);
+                    acc[14] = __builtin_fmaf(G, dL_dalpha, acc[14]);
+                    acc[15] = __builtin_fmaf(w, q0.x, acc[15]); acc[16] = __builtin_fmaf(w, q0.y, acc[16]);
+                    acc[17] = __builtin_fmaf(w, q0.z, acc[17]);
+                }
+            }
+            if (touched) {
+                float4* o4 = reinterpret_cast<float4*>(partial + ((size_t)slot * GEO_BLOCKS + blk) * row_stride + geom_off);
+                o4[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                o4[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                o4[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
+                o4[3] = make_float4(acc[12], acc[13], acc[14], acc[15]);
+                o4[4] = make_float4(acc[16], acc[17], 0.0f, 0.0f);
+                row_flags[(size_t)slot * GEO_BLOCKS + blk] = 1;
+            }
+        }
+        // what is left (less than a chunk, unless the list is drained) moves to the front of the queue
+        const int rem = n_q - done;                    // < 64
+        const int keep = lane < rem ? s_q[done + lane] : 0;
+        wave_lds_sync();
+        if (lane < rem) s_q[lane] = keep;
+        n_q = rem > 0 ? rem : 0;
+        wave_lds_sync();
+    }
+}
+
+}  // namespace isr
