@@ -151,107 +151,127 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
                 const Rect16 rc = rects[id];
                 slot = point_offsets[id] + (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
             }
-            float acc[18];
-#pragma unroll
-            for (int k = 0; k < 18; k++) acc[k] = 0.0f;
+            // The ray-splat intersection is affine in the pixel (see isr_forward_fast.hip): p = lx A + ly B + C with tile-relative
+            // pixel coordinates, and so is its adjoint: dL/dA = sum lx dL/dp, dL/dB = sum ly dL/dp, dL/dC = sum dL/dp.  The pixel
+            // loop accumulates those nine sums (instead of two cross products and nine FMAs per pair for dL/dTu, dL/dTv, dL/dTw);
+            // they are turned into the gradient of the three rows once per (block, splat), after the loop.
+            const F3 A = {__builtin_fmaf(Tv.y, Tw.z, -(Tv.z * Tw.y)), __builtin_fmaf(Tv.z, Tw.x, -(Tv.x * Tw.z)),
+                          __builtin_fmaf(Tv.x, Tw.y, -(Tv.y * Tw.x))};
+            const F3 B = {__builtin_fmaf(Tw.y, Tu.z, -(Tw.z * Tu.y)), __builtin_fmaf(Tw.z, Tu.x, -(Tw.x * Tu.z)),
+                          __builtin_fmaf(Tw.x, Tu.y, -(Tw.y * Tu.x))};
+            const F3 k0 = {__builtin_fmaf(tile_x0, Tw.x, -Tu.x), __builtin_fmaf(tile_x0, Tw.y, -Tu.y), __builtin_fmaf(tile_x0, Tw.z, -Tu.z)};
+            const F3 l0 = {__builtin_fmaf(tile_y0, Tw.x, -Tv.x), __builtin_fmaf(tile_y0, Tw.y, -Tv.y), __builtin_fmaf(tile_y0, Tw.z, -Tv.z)};
+            const F3 C = {__builtin_fmaf(k0.y, l0.z, -(k0.z * l0.y)), __builtin_fmaf(k0.z, l0.x, -(k0.x * l0.z)),
+                          __builtin_fmaf(k0.x, l0.y, -(k0.y * l0.x))};
+            const float cxr = cx - tile_x0, cyr = cy - tile_y0;
+            float aP0 = 0, aP1 = 0, aP2 = 0, aX0 = 0, aX1 = 0, aX2 = 0, aY0 = 0, aY1 = 0, aY2 = 0;     // sum dL/dp, sum lx dL/dp, sum ly dL/dp
+            float aZ0 = 0, aZ1 = 0, aZ2 = 0;            // sum dL/dz (sx, sy, 1)
+            float aC0 = 0, aC1 = 0;                     // dL/dcentre (low-pass branch)
+            float aN0 = 0, aN1 = 0, aN2 = 0, aO = 0, aR = 0, aG = 0, aB = 0;
             bool touched = false;
             for (int p = 0; p < 64; p++) {
                 const float4* pq = reinterpret_cast<const float4*>(s_pix + p * 16);
                 const float4 q3 = pq[3];
                 const unsigned last_p = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q3.y));
-                if (last_p == 0u) continue;
-                const int lx = bxo + (p & 7), ly = byo + (p >> 3);
-                bool act = li >= 0 && (unsigned)li < last_p && bxl <= lx && bxh >= lx && byl <= ly && byh >= ly;
-                if (__ballot(act) == 0ull) continue;
-                const float pxf = tile_x0 + (float)lx, pyf = tile_y0 + (float)ly;
-                const F3 kk = {__builtin_fmaf(pxf, Tw.x, -Tu.x), __builtin_fmaf(pxf, Tw.y, -Tu.y), __builtin_fmaf(pxf, Tw.z, -Tu.z)};
-                const F3 ll = {__builtin_fmaf(pyf, Tw.x, -Tv.x), __builtin_fmaf(pyf, Tw.y, -Tv.y), __builtin_fmaf(pyf, Tw.z, -Tv.z)};
-                const F3 pp = {__builtin_fmaf(kk.y, ll.z, -(kk.z * ll.y)), __builtin_fmaf(kk.z, ll.x, -(kk.x * ll.z)),
-                               __builtin_fmaf(kk.x, ll.y, -(kk.y * ll.x))};
-                const float dx = cx - pxf, dy = cy - pyf;
-                const float rho2d = FILTER_INV_SQ * __builtin_fmaf(dy, dy, dx * dx);
-                const float rz = __builtin_amdgcn_rcpf(pp.z);
-                const float sx = pp.x * rz, sy = pp.y * rz;
-                const float rho3d = __builtin_fmaf(sy, sy, sx * sx);
-                const float rho = fminf(rho3d, rho2d);
-                const bool use3d = rho3d <= rho2d;
-                const float c_d = use3d ? __builtin_fmaf(sy, Tw.y, sx * Tw.x) + Tw.z : Tw.z;
-                const float G = __builtin_amdgcn_exp2f(rho * -0.72134752f);
-                const float alpha = fminf(0.99f, opa * G);
-                act = act && (rho <= skip) && (pp.z != 0.0f) && !(c_d < NEAR_N) && !(alpha < 1.0f / 255.0f);
-                if (__ballot(act) == 0ull) continue;
-                const float4 q0 = pq[0], q1 = pq[1], q2 = pq[2];
-                // q0 = dC.rgb, d_depth   q1 = d_accum, dN.xyz   q2 = d_median, d_reg, T_final, final_D   q3 = final_D2, last, median, bg_dot
-                const float om = act ? 1.0f - alpha : 1.0f;
-                const float Pinc = wave_scan_mul(om);
-                const float cT = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(carryT), p));
-                const float cR = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(carryR), p));
-                const float Tb = cT * __builtin_amdgcn_rcpf(Pinc);                  // transmittance in front of this lane's splat
-                const float w = act ? alpha * Tb : 0.0f;
-                const float T_final = q2.z, final_A = 1.0f - q2.z, final_D = q2.w, final_D2 = q3.x, dL_dreg = q2.y;
-                float dL_dweight = 0.0f, m_d = 0.0f, inv_cd = 0.0f;
-                if (dL_dreg != 0.0f) {          // uniform: the pixel's distortion gradient
-                    inv_cd = __builtin_amdgcn_rcpf(c_d);
-                    m_d = mscale * (1.0f - NEAR_N * inv_cd);
-                    dL_dweight = (__builtin_fmaf(m_d * m_d, final_A, final_D2) - 2.0f * m_d * final_D) * dL_dreg;
-                }
-                float S = col.x * q0.x;
-                S = __builtin_fmaf(col.y, q0.y, S); S = __builtin_fmaf(col.z, q0.z, S);
-                S = __builtin_fmaf(c_d, q0.w, S); S += q1.x;
-                S = __builtin_fmaf(nrm.x, q1.y, S); S = __builtin_fmaf(nrm.y, q1.z, S); S = __builtin_fmaf(nrm.z, q1.w, S);
-                S += dL_dweight;
-                const float wS = w * S;
-                const float incl = wave_scan_add(wS);
-                const float Rl = cR + (incl - wS);                                   // sum of w S over the splats behind this one
-                {
-                    const float Ptot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Pinc), 63));
-                    const float Stot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
-                    if (lane == p) { carryT = cT * __builtin_amdgcn_rcpf(Ptot); carryR = cR + Stot; }
-                }
-                if (act) {
-                    touched = true;
-                    const float inv_om = __builtin_amdgcn_rcpf(om);
-                    float dL_dalpha = __builtin_fmaf(Tb, S, -(Rl * inv_om));
-                    dL_dalpha = __builtin_fmaf(-T_final * inv_om, q3.w, dL_dalpha);
-                    float dL_dz = w * q0.w;
-                    const unsigned median_p = __float_as_uint(q3.z);
-                    if ((unsigned)li == median_p - 1u) dL_dz += q2.x;
-                    if (dL_dreg != 0.0f) {
-                        const float dmd_dd = (FAR_N * NEAR_N / (FAR_N - NEAR_N)) * inv_cd * inv_cd;
-                        dL_dz = __builtin_fmaf(2.0f * w * (m_d * final_A - final_D) * dL_dreg, dmd_dd, dL_dz);
+                const int lxi = bxo + (p & 7), lyi = byo + (p >> 3);
+                const bool cand = li >= 0 && (unsigned)li < last_p && bxl <= lxi && bxh >= lxi && byl <= lyi && byh >= lyi;
+                if (__ballot(cand) != 0ull) {       // (one latch for the loop: `continue`s here made the compiler rotate the accumulators)
+                    const float lx = (float)lxi, ly = (float)lyi;
+                    const float p_x = __builtin_fmaf(lx, A.x, __builtin_fmaf(ly, B.x, C.x));
+                    const float p_y = __builtin_fmaf(lx, A.y, __builtin_fmaf(ly, B.y, C.y));
+                    const float p_z = __builtin_fmaf(lx, A.z, __builtin_fmaf(ly, B.z, C.z));
+                    const float dx = cxr - lx, dy = cyr - ly;
+                    const float rho2d = FILTER_INV_SQ * __builtin_fmaf(dy, dy, dx * dx);
+                    const float rz = __builtin_amdgcn_rcpf(p_z);
+                    const float sx = p_x * rz, sy = p_y * rz;
+                    const float rho3d = __builtin_fmaf(sy, sy, sx * sx);
+                    const float rho = fminf(rho3d, rho2d);
+                    const bool use3d = rho3d <= rho2d;
+                    const float c_d = use3d ? __builtin_fmaf(sy, Tw.y, sx * Tw.x) + Tw.z : Tw.z;
+                    const float G = __builtin_amdgcn_exp2f(rho * -0.72134752f);
+                    const float alpha = fminf(0.99f, opa * G);
+                    const bool act = cand && (rho <= skip) && (p_z != 0.0f) && !(c_d < NEAR_N) && !(alpha < 1.0f / 255.0f);
+                    if (__ballot(act) != 0ull) {
+                        const float4 q0 = pq[0], q1 = pq[1], q2 = pq[2];
+                        // q0 = dC.rgb, d_depth   q1 = d_accum, dN.xyz   q2 = d_median, d_reg, T_final, final_D   q3 = final_D2, last, median, bg_dot
+                        const float om = act ? 1.0f - alpha : 1.0f;
+                        // transmittance in front of this lane's splat: carry / prod_{lanes <= l} (1 - alpha), the product
+                        // as a SUM scan of logarithms (6 fused DPP adds + v_log + v_exp instead of 18 instructions)
+                        const float lg = __builtin_amdgcn_logf(om);                      // log2, <= 0
+                        const float Linc = wave_scan_add(lg);
+                        const float cT = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(carryT), p));
+                        const float cR = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(carryR), p));
+                        const float Tb = cT * __builtin_amdgcn_exp2f(-Linc);
+                        const float w = act ? alpha * Tb : 0.0f;
+                        const float T_final = q2.z, final_A = 1.0f - q2.z, final_D = q2.w, final_D2 = q3.x;
+                        const float dL_dreg = q2.y;
+                        const bool has_reg = __builtin_amdgcn_readfirstlane((int)__float_as_uint(dL_dreg)) != 0;    // uniform
+                        float dL_dweight = 0.0f, dz_reg = 0.0f;
+                        if (has_reg) {          // the pixel's distortion gradient (lambda_dist = 0: never)
+                            const float inv_cd = __builtin_amdgcn_rcpf(c_d);
+                            const float m_d = mscale * (1.0f - NEAR_N * inv_cd);
+                            dL_dweight = (__builtin_fmaf(m_d * m_d, final_A, final_D2) - 2.0f * m_d * final_D) * dL_dreg;
+                            dz_reg = 2.0f * w * (m_d * final_A - final_D) * dL_dreg * ((FAR_N * NEAR_N / (FAR_N - NEAR_N)) * inv_cd * inv_cd);
+                        }
+                        float S = col.x * q0.x;
+                        S = __builtin_fmaf(col.y, q0.y, S); S = __builtin_fmaf(col.z, q0.z, S);
+                        S = __builtin_fmaf(c_d, q0.w, S); S += q1.x;
+                        S = __builtin_fmaf(nrm.x, q1.y, S); S = __builtin_fmaf(nrm.y, q1.z, S); S = __builtin_fmaf(nrm.z, q1.w, S);
+                        S += dL_dweight;
+                        const float wS = w * S;             // (0 for an inactive lane: w is)
+                        const float incl = wave_scan_add(wS);
+                        const float Rl = cR + (incl - wS);                               // sum of w S over the splats behind this one
+                        const float Tfront = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tb), 63));
+                        const float Stot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+                        const bool mine = lane == p;
+                        carryT = mine ? Tfront : carryT;     // (lane 63 is the chunk's front-most splat: its T_before is what the next chunk sees behind it)
+                        carryR = mine ? cR + Stot : carryR;
+                        touched = touched || act;
+                        // every addend below is selected to zero for an inactive lane (its inputs may be inf / NaN)
+                        const float inv_om = __builtin_amdgcn_exp2f(-lg);                // 1 / (1 - alpha)
+                        float dL_dalpha = __builtin_fmaf(Tb, S, -(Rl * inv_om));
+                        dL_dalpha = __builtin_fmaf(-T_final * inv_om, q3.w, dL_dalpha);
+                        dL_dalpha = act ? dL_dalpha : 0.0f;
+                        float dL_dz = __builtin_fmaf(w, q0.w, dz_reg);
+                        const unsigned median_p = __float_as_uint(q3.z);
+                        dL_dz += ((unsigned)li == median_p - 1u) ? q2.x : 0.0f;
+                        dL_dz = act ? dL_dz : 0.0f;
+                        const float gG = (opa * dL_dalpha) * -G;
+                        const bool a3 = act && use3d;
+                        const float dsx = __builtin_fmaf(gG, sx, dL_dz * Tw.x);
+                        const float dsy = __builtin_fmaf(gG, sy, dL_dz * Tw.y);
+                        const float ssx = a3 ? sx : 0.0f, ssy = a3 ? sy : 0.0f;
+                        const float dpx_ = a3 ? dsx * rz : 0.0f, dpy_ = a3 ? dsy * rz : 0.0f;
+                        const float dpz_ = -__builtin_fmaf(dpx_, ssx, dpy_ * ssy);
+                        aP0 += dpx_; aP1 += dpy_; aP2 += dpz_;
+                        aX0 = __builtin_fmaf(lx, dpx_, aX0); aX1 = __builtin_fmaf(lx, dpy_, aX1); aX2 = __builtin_fmaf(lx, dpz_, aX2);
+                        aY0 = __builtin_fmaf(ly, dpx_, aY0); aY1 = __builtin_fmaf(ly, dpy_, aY1); aY2 = __builtin_fmaf(ly, dpz_, aY2);
+                        const float dz3 = a3 ? dL_dz : 0.0f;
+                        aZ0 = __builtin_fmaf(dz3, ssx, aZ0); aZ1 = __builtin_fmaf(dz3, ssy, aZ1); aZ2 += dL_dz;
+                        const float g2 = (act && !use3d) ? gG * FILTER_INV_SQ : 0.0f;
+                        aC0 = __builtin_fmaf(g2, dx, aC0); aC1 = __builtin_fmaf(g2, dy, aC1);
+                        aN0 = __builtin_fmaf(w, q1.y, aN0); aN1 = __builtin_fmaf(w, q1.z, aN1); aN2 = __builtin_fmaf(w, q1.w, aN2);
+                        aO = __builtin_fmaf(G, dL_dalpha, aO);
+                        aR = __builtin_fmaf(w, q0.x, aR); aG = __builtin_fmaf(w, q0.y, aG); aB = __builtin_fmaf(w, q0.z, aB);
                     }
-                    const float dL_dG = opa * dL_dalpha;
-                    if (use3d) {
-                        const float dsx = __builtin_fmaf(dL_dG * -G, sx, dL_dz * Tw.x);
-                        const float dsy = __builtin_fmaf(dL_dG * -G, sy, dL_dz * Tw.y);
-                        const float dsx_pz = dsx * rz, dsy_pz = dsy * rz;
-                        const F3 dL_dp = {dsx_pz, dsy_pz, -(dsx_pz * sx + dsy_pz * sy)};
-                        const F3 dL_dk = cross3(ll, dL_dp);
-                        const F3 dL_dl = cross3(dL_dp, kk);
-                        acc[0] -= dL_dk.x; acc[1] -= dL_dk.y; acc[2] -= dL_dk.z;
-                        acc[3] -= dL_dl.x; acc[4] -= dL_dl.y; acc[5] -= dL_dl.z;
-                        acc[6] += __builtin_fmaf(pxf, dL_dk.x, __builtin_fmaf(pyf, dL_dl.x, dL_dz * sx));
-                        acc[7] += __builtin_fmaf(pxf, dL_dk.y, __builtin_fmaf(pyf, dL_dl.y, dL_dz * sy));
-                        acc[8] += __builtin_fmaf(pxf, dL_dk.z, __builtin_fmaf(pyf, dL_dl.z, dL_dz));
-                    } else {
-                        acc[9] = __builtin_fmaf(dL_dG, -G * FILTER_INV_SQ * dx, acc[9]);
-                        acc[10] = __builtin_fmaf(dL_dG, -G * FILTER_INV_SQ * dy, acc[10]);
-                        acc[8] += dL_dz;
-                    }
-                    acc[11] = __builtin_fmaf(w, q1.y, acc[11]); acc[12] = __builtin_fmaf(w, q1.z, acc[12]);
-                    acc[13] = __builtin_fmaf(w, q1.w, acc[13]);
-                    acc[14] = __builtin_fmaf(G, dL_dalpha, acc[14]);
-                    acc[15] = __builtin_fmaf(w, q0.x, acc[15]); acc[16] = __builtin_fmaf(w, q0.y, acc[16]);
-                    acc[17] = __builtin_fmaf(w, q0.z, acc[17]);
                 }
             }
             if (touched) {
+                // adjoint of  A = Tv x Tw,  B = Tw x Tu,  C = (X0 Tw - Tu) x (Y0 Tw - Tv),  with the pixel sums taken to absolute
+                // coordinates:  SP = sum dL/dp,  SX = sum px dL/dp,  SY = sum py dL/dp:
+                //   dL/dTu = Tv x SP - Tw x SY,   dL/dTv = SP x Tu - SX x Tw,   dL/dTw = SX x Tv + Tu x SY + sum dL/dz (sx, sy, 1)
+                const F3 SP = {aP0, aP1, aP2};
+                const F3 SX = {__builtin_fmaf(tile_x0, aP0, aX0), __builtin_fmaf(tile_x0, aP1, aX1), __builtin_fmaf(tile_x0, aP2, aX2)};
+                const F3 SY = {__builtin_fmaf(tile_y0, aP0, aY0), __builtin_fmaf(tile_y0, aP1, aY1), __builtin_fmaf(tile_y0, aP2, aY2)};
+                const F3 dTu = cross3(Tv, SP) - cross3(Tw, SY);
+                const F3 dTv = cross3(SP, Tu) - cross3(SX, Tw);
+                const F3 dTw = cross3(SX, Tv) + cross3(Tu, SY);
                 float4* o4 = reinterpret_cast<float4*>(partial + ((size_t)slot * GEO_BLOCKS + blk) * row_stride + geom_off);
-                o4[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                o4[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-                o4[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
-                o4[3] = make_float4(acc[12], acc[13], acc[14], acc[15]);
-                o4[4] = make_float4(acc[16], acc[17], 0.0f, 0.0f);
+                o4[0] = make_float4(dTu.x, dTu.y, dTu.z, dTv.x);
+                o4[1] = make_float4(dTv.y, dTv.z, dTw.x + aZ0, dTw.y + aZ1);
+                o4[2] = make_float4(dTw.z + aZ2, aC0, aC1, aN0);
+                o4[3] = make_float4(aN1, aN2, aO, aR);
+                o4[4] = make_float4(aG, aB, 0.0f, 0.0f);
                 row_flags[(size_t)slot * GEO_BLOCKS + blk] = 1;
             }
         }
