@@ -84,3 +84,37 @@ def test_view_sharding_is_a_partition():
         views = [view_for(step, r, world, n_views) for r in range(world)]
         assert len(set(views)) == world
     assert sorted(view_for(s, r, world, n_views) for s in range(2) for r in range(world)) == list(range(16))
+
+
+def _bucket_worker(rank, world, port, out):
+    from instascene_amd.dist_utils import allreduce_bucket
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7 + rank)
+    shapes = [(50, 3), (50, 16, 3), (50, 1), (50, 2), (50, 4)]           # the five gradients of a train.py-style step
+    ts = [torch.randn(s, generator=g) for s in shapes]
+    if rank == 1:
+        ts[2] = None                                                     # a rank without a gradient for one tensor
+    like = [torch.empty(s) for s in shapes]
+    summed = allreduce_bucket(ts, world, like=like)
+    torch.save({"sum": [t.clone() for t in summed], "mine": [None if t is None else t.clone() for t in ts]},
+               os.path.join(out, f"b{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_flat_bucket_allreduce_equals_the_sum_of_the_tensors(tmp_path):
+    """RgbTrainer's exchange: the six parameter groups' gradients as ONE flat collective; a missing gradient counts as
+    zeros; every rank receives identical sums."""
+    world = 2
+    mp.spawn(_bucket_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = torch.load(tmp_path / "b0.pt"), torch.load(tmp_path / "b1.pt")
+    for i in range(5):
+        want = a["mine"][i] + (b["mine"][i] if b["mine"][i] is not None else 0)
+        assert torch.equal(a["sum"][i], b["sum"][i])
+        assert torch.equal(a["sum"][i], want)
+    # one rank: the input comes back untouched
+    from instascene_amd.dist_utils import allreduce_bucket
+    t = [torch.ones(3), None]
+    assert allreduce_bucket(t, 1) == t

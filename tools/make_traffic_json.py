@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""profiles/roofline_traffic.json from the PMC passes of tools/refresh_profiles.sh: HBM bytes per launch and kernel,
+(2 * FETCH_SIZE + WRITE_SIZE) * 1024 - FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for gfx950
+(calibrated in round 1 on torch copy / add kernels over a 192 MB tensor: WRITE_SIZE = 1.00 x bytes, FETCH_SIZE = 0.50 x).
+usage: make_traffic_json.py gpurun_out/prof_TAG [tag-for-the-source-note]"""
+import json, os, re, sys
+d = sys.argv[1]
+tag = sys.argv[2] if len(sys.argv) > 2 else os.path.basename(d.rstrip("/"))
+out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `python bench.py --config C --step S --steps 3 "
+                 f"--warmup 2 --submodes ''` (tools/refresh_profiles.sh {tag}); bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024; "
+                 f"raw counters: profiles/{tag}_pmc_FETCH_SIZE_*.txt, profiles/{tag}_pmc_WRITE_SIZE_*.txt"}
+short = {"k_render_fwd_fast": "k_render_fwd", "k_render_fwd": "k_render_fwd", "k_render_bwd_geo": "k_render_bwd",
+         "k_render_bwd_sparse": "k_render_bwd_sparse", "k_render_bwd": "k_render_bwd", "k_preprocess_bwd": "k_preprocess_bwd",
+         "k_preprocess": "k_preprocess", "k_scatter": "k_scatter", "k_tile_sort": "k_tile_sort",
+         "k_feature_rows_step": "k_feature_rows_step", "gaussian_adam_kernel": "gaussian_adam_kernel", "ssim_fwd": "ssim_fwd",
+         "ssim_bwd": "ssim_bwd", "pp_maps": "pp_maps", "pp_surf_normal": "pp_surf_normal"}
+for cfg, step in (("C3", "seg"), ("C2", "rgb")):
+    vals = {}
+    for k in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = os.path.join(d, f"pmc_{k}_{cfg}_{step}.txt")
+        if not os.path.exists(f):
+            continue
+        for line in open(f):
+            if "|" not in line:
+                continue
+            name, rest = line.split("|", 1)
+            m = re.search(k + r"=([0-9.e+]+)", rest)
+            if not m:
+                continue
+            base = re.sub(r"^(void )?(isr|iso)::", "", name.strip())
+            base = re.split(r"[<(]", base)[0]
+            key = short.get(base)
+            if key is None:
+                continue
+            vals.setdefault(key, {})[k] = float(m.group(1))
+    rec = {k: int((2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024) for k, v in vals.items()}
+    if rec:
+        out[f"{cfg}:{step}:fast"] = rec
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "roofline_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:2000])
