@@ -423,7 +423,14 @@ int iso_dist2_3nn(int P, const float* points, float* mean_dist2, void* scratch, 
     hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, v.sums);
     hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, ccap, v.offset, v.sums);
     hipLaunchKernelGGL(iso::kk_scatter, dim3(pb), dim3(256), 0, s, P, points, v.grid, v.offset, v.cursor, v.sorted);
-    hipLaunchKernelGGL(iso::kk_query, dim3(pb), dim3(256), 0, s, P, v.grid, v.offset, v.count, v.sorted, mean_dist2);
+    // ISO_KNN_LDS=1: the LDS-bucketed query (built as north_star names it, measured 0.8-8x SLOWER than the ring walk from
+    // global memory - profiles/r02_knn_timing.json - because the cell-sorted points are L2-resident anyway and a clustered
+    // cloud overflows any fixed LDS budget; kept for A/B)
+    static const bool lds_query = [] { const char* e = getenv("ISO_KNN_LDS"); return e && e[0] == '1'; }();
+    if (lds_query)      // a fixed grid strides over the (segment, row) work items: the grid's dimensions live on the device
+        hipLaunchKernelGGL(iso::kk_query_lds, dim3(16384), dim3(256), 0, s, P, v.grid, v.offset, v.count, v.sorted, mean_dist2);
+    else
+        hipLaunchKernelGGL(iso::kk_query, dim3(pb), dim3(256), 0, s, P, v.grid, v.offset, v.count, v.sorted, mean_dist2);
     ISR_LAUNCH_CHECK("iso_dist2_3nn");
     return ISR_OK;
 }

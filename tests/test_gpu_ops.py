@@ -508,3 +508,33 @@ def test_contrastive_batch_variants(nb, consider_negative, min_pixnum):
     assert float(got.detach()) == float(want.detach())
     for x, y in zip(a, b):
         assert torch.equal(x.grad, y.grad)
+
+
+def test_dist2_3nn_lds_bucketed_query_matches_brute_force():
+    """The opt-in LDS-bucketed query (ISO_KNN_LDS=1, read once per process: hence a child process) gives the same bits
+    as the brute-force oracle on uniform, clustered (dense cells beyond the LDS budget -> global fallback), planar and
+    duplicated clouds."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle
+from instascene_amd.knn import distCUDA2
+for P, kind in [(5000, "uniform"), (20000, "clustered"), (3000, "planar"), (4000, "dup"), (3, "uniform"), (70000, "uniform")]:
+    g = np.random.RandomState(P)
+    if kind == "uniform": pts = g.rand(P, 3).astype(np.float32) * 3 - 1.5
+    elif kind == "clustered":
+        c = g.randn(8, 3) * 2
+        pts = (c[g.randint(0, 8, P)] + g.randn(P, 3) * 0.02).astype(np.float32); pts[:5] += 50.0
+    elif kind == "planar": pts = np.concatenate([g.rand(P, 2), np.zeros((P, 1))], 1).astype(np.float32)
+    else:
+        pts = g.rand(P // 2, 3).astype(np.float32); pts = np.concatenate([pts, pts], 0)
+    want = oracle.dist2_3nn(pts)
+    got = distCUDA2(torch.tensor(pts).cuda()).cpu().numpy()
+    assert np.array_equal(got, want), (P, kind, np.abs(got - want).max())
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, ISO_KNN_LDS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
