@@ -3,6 +3,8 @@ fixtures) and vs the torch oracle on seeded inputs; HIP 3-NN vs brute force; ren
 import math
 import os
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 import numpy as np
 import pytest
 import torch
