@@ -594,8 +594,10 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
     if (r1 > capacity) r1 = capacity;
     const int nfeat = FCH > 0 ? min(FCH, ED - ch_base) : 0;
 
-    bool done = !inside;
-    unsigned long long m_done = __ballot(!inside);      // the same predicate as a wave-uniform lane mask
+    // Lane predicates live in 64-bit masks on the scalar unit (every test is a v_cmp into a mask; the one predicated region
+    // per splat takes its exec mask from the combined mask): arithmetic-neutral, half the scalar instructions of the
+    // compiler's exec-mask stacks for per-lane bools (see isr_forward_fast.hip).
+    unsigned long long m_done = __ballot(!inside);      // lanes that have stopped (or lie outside the image)
     float T = 1.0f;
     unsigned contributor = 0, last_contributor = 0, median_contributor = 0;
     float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, D = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
     const int my_inst = threadIdx.x & (BATCH - 1);
     int nid = (threadIdx.x < BATCH && r0 + my_inst < r1) ? (int)point_list[r0 + my_inst] : 0;
     for (int64_t base = r0; base < r1; base += BATCH) {
-        if (__syncthreads_and(done)) break;
+        if (__syncthreads_and(m_done == ~0ull)) break;
         const int nb = (int)min((int64_t)BATCH, r1 - base);
         const int id = nid;
         if (threadIdx.x < BATCH && base + BATCH + my_inst < r1) nid = (int)point_list[base + BATCH + my_inst];
@@ -724,7 +726,6 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
                 const bool nz = p.z != 0.0f;
                 const unsigned long long m_cand = ~m_done & ~(__ballot(far_a) & __ballot(far_b)) & __ballot(nz);
                 if (m_cand == 0ull) continue;
-                const bool cand = !done & !(far_a & far_b) & nz;
                 const float sx = Math::div(p.x, p.z), sy = Math::div(p.y, p.z);
                 const float rho3d = Math::mad(sy, sy, sx * sx);
                 const float rho = fminf(rho3d, rho2d);
@@ -737,13 +738,10 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
                 const unsigned long long m_pass = m_cand & __ballot(t_near) & __ballot(t_pow) & __ballot(t_alpha);
                 const unsigned long long m_stop = m_pass & __ballot(t_stop);
                 m_done |= m_stop;
-                const bool pass = cand & t_near & t_pow & t_alpha;
-                const bool stop = pass & t_stop;
-                done = done | stop;
-                const bool ok = pass & !stop;
-                if ((m_pass & ~m_stop) == 0ull) continue;
+                const unsigned long long m_ok = m_pass & ~m_stop;
+                if (m_ok == 0ull) continue;
                 float w_lane = 0.0f;
-                if (ok) {
+                if (__builtin_amdgcn_inverse_ballot_w64(m_ok)) {
                     const float w = alpha * T;
                     w_lane = w;
                     contributor = (unsigned)(base - r0) + (unsigned)j + 1u;
