@@ -236,7 +236,19 @@ int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binni
                            bv.keys, binning_capacity); }
         ISR_LAUNCH_CHECK("k_scatter");
         { ProfScope ps_("k_tile_sort", s);
-        hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity); }
+        // dense scenes (more than ~1 500 instances per tile on average): buckets beyond the 4 096-key LDS budget get their
+        // own launch with 128 KB of LDS instead of the global-memory network
+        const int big = (binning_capacity / (T > 0 ? T : 1)) > 1500 ? 1 : 0;
+        hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity, big);
+        if (big) {
+            static const bool attr_ok = [] {
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           SORT_BIG_KEYS * (int)sizeof(unsigned long long)) == hipSuccess;
+            }();
+            if (!attr_ok) return fail(ISR_EHIP, "k_tile_sort_big: cannot reserve %d bytes of LDS", SORT_BIG_KEYS * 8);
+            hipLaunchKernelGGL(k_tile_sort_big, dim3(T), dim3(1024), SORT_BIG_KEYS * sizeof(unsigned long long), s, iv.tile_offset,
+                               bv.keys, bv.point_list, binning_capacity);
+        } }
         ISR_LAUNCH_CHECK("k_tile_sort");
     }
     return ISR_OK;

@@ -530,8 +530,27 @@ __device__ __forceinline__ void bitonic_flip_sort_lds(unsigned long long* a, int
 }
 #undef ISR_CMPX
 
+// Buckets of SORT_LDS_KEYS < n <= SORT_BIG_KEYS keys (dense scenes: C5 averages 3 100 instances per tile) are sorted by
+// k_tile_sort_big - 1024 threads, 128 KB of dynamic LDS, one workgroup per CU - instead of the in-place network in global
+// memory (a barrier and a round trip to L2 per pass: 2.1 ms of C5's side stream).  big_follows: this launch leaves them alone.
+constexpr int SORT_BIG_KEYS = 16384;
+__global__ __launch_bounds__(1024) void k_tile_sort_big(const uint32_t* __restrict__ tile_offset, unsigned long long* keys,
+                                                        uint32_t* __restrict__ point_list, int64_t capacity) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_big[];
+    const uint32_t t = blockIdx.x;
+    const int64_t r0 = tile_offset[t];
+    int64_t r1 = tile_offset[t + 1];
+    if (r1 > capacity) r1 = capacity;
+    const int n = (int)(r1 - r0);
+    if (n <= SORT_LDS_KEYS || n > SORT_BIG_KEYS) return;
+    unsigned long long* seg = keys + r0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s_big[i] = seg[i];
+    bitonic_flip_sort_lds(s_big, n);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) point_list[r0 + i] = (uint32_t)s_big[i];
+}
+
 __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ tile_offset, unsigned long long* keys,
-                                                   uint32_t* __restrict__ point_list, int64_t capacity) {
+                                                   uint32_t* __restrict__ point_list, int64_t capacity, int big_follows) {
     __shared__ unsigned long long s_keys[SORT_LDS_KEYS];
     const uint32_t t = blockIdx.x;
     const int64_t r0 = tile_offset[t];
@@ -539,6 +558,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
     if (r1 > capacity) r1 = capacity;
     const int n = (int)(r1 - r0);
     if (n <= 0) return;
+    if (big_follows && n > SORT_LDS_KEYS && n <= SORT_BIG_KEYS) return;
     unsigned long long* seg = keys + r0;
     if (n <= SORT_LDS_KEYS) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) s_keys[i] = seg[i];

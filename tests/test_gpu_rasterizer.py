@@ -105,11 +105,14 @@ def test_forward_large_splats_and_long_tile_lists():
     check_forward_exact(st, args, out)
 
 
-def test_forward_bucket_larger_than_lds_sort_budget():
-    sc, cams, inp = small_scene(P=9000, F=0, W=32, H=32, seed=12, mu_s=math.log(0.4))
+@pytest.mark.parametrize("P,lo,hi", [(9000, 4096, 16384), (60000, 16384, 10 ** 9)])
+def test_forward_bucket_larger_than_lds_sort_budget(P, lo, hi):
+    """Tile lists beyond the 4 096-key LDS sort: 4 096 < n <= 16 384 go to k_tile_sort_big (128 KB of LDS), longer ones to
+    the in-place network in global memory; both orders are the oracle's bit for bit."""
+    sc, cams, inp = small_scene(P=P, F=0, W=32, H=32, seed=12, mu_s=math.log(0.4))
     st = oracle_forward(inp, cams[0])
     lens = st["ranges"][:, 1].astype(np.int64) - st["ranges"][:, 0]
-    assert lens.max() > 4096          # SORT_LDS_KEYS: global-memory fallback path
+    assert lo < lens.max() <= hi
     args, out = hip_forward(inp, cams[0], mode=MODE_EXACT)
     check_forward_exact(st, args, out)
 
