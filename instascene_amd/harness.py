@@ -46,6 +46,19 @@ def side_stream(device) -> "torch.cuda.Stream":
     return st
 
 
+_MAIN_STREAMS = {}
+
+
+def main_stream(device) -> "torch.cuda.Stream":
+    """ONE high-priority stream per device (see SegTrainer.high_priority_main)."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _MAIN_STREAMS.get(key)
+    if st is None:
+        st = _MAIN_STREAMS[key] = torch.cuda.Stream(device=dev, priority=-1)
+    return st
+
+
 class PipelineParams:
     compute_cov3D_python = False
     convert_SHs_python = False
@@ -168,6 +181,7 @@ class SegTrainer:
         # backward and the bandwidth-bound tail)
         import os as _os
         self.prefetch_early = _os.environ.get("ISR_PREFETCH_EARLY", "1") == "1"     # measured: 2.092 -> 2.066 ms per C3 step
+        self.high_priority_main = _os.environ.get("ISR_MAIN_PRIORITY", "1") == "1"     # measured: 2.03 -> 1.995 ms per C3 step
         self.split_tail = False      # tests: take the multi-rank form of the tail (dL/dx, all-reduce, Adam) with one rank
         self.tail_chunks = 4         # row ranges of that form (all-reduce of one overlaps the kernels of the others)
         F = scene.seg_feature.shape[1]
@@ -311,6 +325,18 @@ class SegTrainer:
         return view_for(it, self.rank, self.world, len(self.cams))
 
     def step(self, it: int):
+        if self.high_priority_main and self.device.type == "cuda":
+            # the step's own chain on a high-priority stream: the hardware favours its workgroups over those of the side
+            # stream (the next view's binning), whose kernels otherwise slow the small loss kernels 2-3x
+            ms, cur = main_stream(self.device), torch.cuda.current_stream(self.device)
+            ms.wait_stream(cur)
+            with torch.cuda.stream(ms):
+                out = self._step_guarded(it)
+            cur.wait_stream(ms)
+            return out
+        return self._step_guarded(it)
+
+    def _step_guarded(self, it: int):
         from .rasterizer import BinningOverflow
         try:
             return self._step_once(it)
@@ -360,7 +386,7 @@ class SegTrainer:
         # than it hides: measured.)
         if not self.prefetch_early:
             self._prefetch_next(it)
-        seg_feature, vis = pkg["seg_feature"], pkg["visibility_filter"]
+        seg_feature = pkg["seg_feature"]
         # the step's prototype-contrastive losses, as (features, labels, predefined prototypes, weight)
         problems = []
         if merged:
@@ -381,7 +407,7 @@ class SegTrainer:
             # visible & labelled Gaussians first and gathering only the batch rows draws from the same distribution
             pool = self.vis_pool.get(vi)
             if pool is None:
-                pool = torch.nonzero(vis & (self.labels3d > 0)).reshape(-1)
+                pool = torch.nonzero(pkg["visibility_filter"] & (self.labels3d > 0)).reshape(-1)
                 self.vis_pool[vi] = pool
             if pool.numel() > 0:
                 if drawn is not None and drawn[3] is not None:

@@ -43,6 +43,11 @@ class RenderPackage(dict):
         if self._pending is not None and k in _LAZY_KEYS:
             self._materialize()
         v = dict.__getitem__(self, k)
+        if v is None and k == "visibility_filter":
+            # `radii > 0` (reference :110) on first access: the same values, one elementwise kernel over P Gaussians that a
+            # loop which never reads it (a warmed-up SegTrainer) does not wait for between the forward and its losses
+            v = dict.__getitem__(self, "radii") > 0
+            dict.__setitem__(self, k, v)
         if k == "gau_related_pixels" and getattr(v, "_isr_last_index", None) is not None:
             v = _rz.slice_tracer(v)
             dict.__setitem__(self, k, v)
@@ -53,6 +58,8 @@ class RenderPackage(dict):
 
     def __iter__(self):          # also routes dict(pkg) / {**pkg} through __getitem__
         self._materialize()
+        if dict.get(self, "visibility_filter", 0) is None:
+            self["visibility_filter"]
         return dict.__iter__(self)
 
     def items(self):
@@ -253,14 +260,14 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
                      lazy_tracer=True, feature_only=feature_only, **geo)
     rendered_image, radii, allmap, extra_attrs, gau_related_pixels = res[:5]
     if feature_only:
-        rets = RenderPackage({"render": None, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii,
+        rets = RenderPackage({"render": None, "viewspace_points": means2D, "visibility_filter": None, "radii": radii,
                               "seg_feature": extra_attrs, "gau_related_pixels": None})
         if len(res) > 5:
             rets["sampled_seg_feature"] = res[5]
         dict.update(rets, dict.fromkeys(_LAZY_KEYS))
         return rets
 
-    rets = RenderPackage({"render": rendered_image, "viewspace_points": means2D, "visibility_filter": radii > 0,
+    rets = RenderPackage({"render": rendered_image, "viewspace_points": means2D, "visibility_filter": None,
                           "radii": radii, "seg_feature": extra_attrs, "gau_related_pixels": gau_related_pixels})
     if len(res) > 5:
         # extension: ``seg_feature.reshape(F, -1)[:, sample_pixels].T`` without a dense gradient map in the backward
