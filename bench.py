@@ -241,7 +241,7 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
         L.isr_profile_enable(0)
     if rank == 0 and detail:
         # workload statistics + work counters of the blend kernel on the last timed view (one extra, untimed render)
-        counters = torch.zeros(4, dtype=torch.int64, device=dev)
+        counters = torch.zeros(8, dtype=torch.int64, device=dev)
         with torch.no_grad():
             was = rasterizer._CONFIG["async_binning"]
             rasterizer.set_async_binning(False)             # exact instance count for the byte model
@@ -252,7 +252,7 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
             V = int((pkg["radii"] > 0).sum().item())
             R = int(rasterizer.LAST_NUM_RENDERED)
             rasterizer.set_async_binning(was)
-        cull_tests, pairs_eval, pairs_blend, lane_pairs = (int(v) for v in counters.tolist())
+        cull_tests, pairs_eval, pairs_blend, lane_pairs, pairs_mergeable = (int(v) for v in counters.tolist()[:5])
         P, N, F = cfg["P"], cfg["W"] * cfg["H"], (cfg["F"] if args.step == "seg" else 0)
         tiles = ((cfg["W"] + 15) // 16) * ((cfg["H"] + 15) // 16)
         bm = byte_model(P, V, R, N, F, tiles)
@@ -302,7 +302,8 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
             tf = flops_eval / (dom_ms * launches * 1e-3) / 1e12
             roof["valu"] = {
                 "wave_splat_cull_tests": cull_tests, "wave_splat_pairs_evaluated": pairs_eval,
-                "wave_splat_pairs_blending": pairs_blend, "pixel_splat_pairs_evaluated": 64 * pairs_eval,
+                "wave_splat_pairs_blending": pairs_blend,
+                "consecutive_pairs_with_disjoint_pixel_bounds": pairs_mergeable, "pixel_splat_pairs_evaluated": 64 * pairs_eval,
                 "pixel_splat_pairs_contributing": lane_pairs,
                 "lane_utilisation_of_blending_pairs": round(lane_pairs / max(1, 64 * pairs_blend), 4),
                 "flop_model": "SURVEY 8(d): 40 flop per evaluated (pixel, splat) pair + 2*(3+7+F) per contributing pair",

@@ -59,8 +59,9 @@ int isr_version(void);
  * "kernel_name launches total_ms" line per kernel into buf (returns bytes written). */
 void isr_profile_enable(int on);
 /* Work counters of the forward blend kernel (bench.py's `roofline.valu`): the NEXT isr_forward_render call of this host
- * thread in ISR_MODE_FAST also adds, into device_counters[0..3] (u64, device memory, zeroed by the caller): (wave, splat)
- * cull tests, (wave, splat) pairs evaluated, pairs with at least one blending lane, and blending (pixel, splat) pairs.
+ * thread in ISR_MODE_FAST also adds, into device_counters[0..4] (u64[8], device memory, zeroed by the caller): (wave, splat)
+ * cull tests, (wave, splat) pairs evaluated, pairs with at least one blending lane, blending (pixel, splat) pairs, and
+ * consecutive evaluated pairs whose alpha >= 1/255 bounds share no pixel of the wave's block (greedy).
  * One extra atomic per wave; not meant for timed runs. */
 void isr_forward_set_counters(unsigned long long* device_counters);
 size_t isr_profile_summary(char* buf, size_t len);

@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
     f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
     float w_pend = 0.0f, f_pend = 0.0f;
     bool pending = false;                    // wave-uniform
-    unsigned st_cull = 0, st_eval = 0, st_blend = 0, st_lanes = 0;      // STATS only
+    unsigned st_cull = 0, st_eval = 0, st_blend = 0, st_lanes = 0, st_merge = 0;      // STATS only
+    bool st_skip_next = false;
     const float mscale = FAR_N / (FAR_N - NEAR_N);
     const float bx0 = X0 + (float)((wv & 1) * 8), bx1 = bx0 + 7.0f;
     const float by0 = Y0 + (float)((wv >> 1) * 8), by1 = by0 + 7.0f;
@@ -178,7 +179,20 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                 if (m_done == ~0ull) break;
                 const int j = c0 + __builtin_ctzll(m);
                 m &= m - 1ull;
-                if (STATS) st_eval++;
+                if (STATS) {
+                    st_eval++;
+                    // how often could this splat and the next one of the wave's list share ONE evaluation (their alpha >= 1/255
+                    // bounds touch disjoint pixels of the block)?  greedy pairs
+                    if (st_skip_next) st_skip_next = false;
+                    else if (m != 0ull) {
+                        const int j2 = c0 + __builtin_ctzll(m);
+                        const float fx = X0 + lx, fy = Y0 + ly;
+                        const float4 b1 = s_box[j], d1 = s_diag[j], b2 = s_box[j2], d2 = s_diag[j2];
+                        const bool in1 = fx >= b1.x && fx <= b1.y && fy >= b1.z && fy <= b1.w && fx + fy >= d1.x && fx + fy <= d1.y && fx - fy >= d1.z && fx - fy <= d1.w;
+                        const bool in2 = fx >= b2.x && fx <= b2.y && fy >= b2.z && fy <= b2.w && fx + fy >= d2.x && fx + fy <= d2.y && fx - fy >= d2.z && fx - fy <= d2.w;
+                        if (__ballot(in1 && in2) == 0ull) { st_merge++; st_skip_next = true; }
+                    }
+                }
                 const float4* q = reinterpret_cast<const float4*>(s_rec + j * RS);
                 const float4 q0 = q[0], q1 = q[1], q2 = q[2];
                 const float p_x = __builtin_fmaf(lx, q0.x, __builtin_fmaf(ly, q1.x, q2.x));
@@ -274,6 +288,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
             atomicAdd(stats + 1, (unsigned long long)st_eval);
             atomicAdd(stats + 2, (unsigned long long)st_blend);
             atomicAdd(stats + 3, (unsigned long long)st_lanes);
+            atomicAdd(stats + 4, (unsigned long long)st_merge);
         }
     }
     if (!AUX && inside && first_pass) {
