@@ -180,6 +180,30 @@ def backward(st, dL_dcolor, dL_dothers, dL_dextra=None):
     return g
 
 
+def preprocess_backward(st, dL_dtransMat, dL_dnormal=None, dL_dcolors=None, dL_dmeans2D=None):
+    """K10 alone (backward.cu:469-656) on the state of :func:`forward`: per-Gaussian gradients
+    ``(dL_dmeans3D, dL_dscales, dL_drotations, dL_dsh)`` from given ``dL/dtransMat [P,9]`` (+ optional ``dL/dnormal [P,3]``,
+    ``dL/dcolor [P,3]``, ``dL/dmean2D [P,3]``) - what tests/golden/kten_backward.npz pins against the reference's autograd."""
+    L = lib()
+    P, M = st["P"], st["M"]
+    inp = st["inputs"]
+    z = lambda *s: np.zeros(s, np.float32)
+    g = dict(dL_dtransMat=_f32(dL_dtransMat).copy(), dL_dnormal=z(P, 3) if dL_dnormal is None else _f32(dL_dnormal).copy(),
+             dL_dcolors=z(P, 3) if dL_dcolors is None else _f32(dL_dcolors).copy(), dL_dsh=z(P, M, 3),
+             dL_dmeans2D=z(P, 3) if dL_dmeans2D is None else _f32(dL_dmeans2D).copy(), dL_dmeans3D=z(P, 3),
+             dL_dscales=z(P, 2), dL_drotations=z(P, 4))
+    focal_y = np.float32(st["H"]) / (np.float32(2.0) * np.float32(st["tanfovy"]))
+    focal_x = np.float32(st["W"]) / (np.float32(2.0) * np.float32(st["tanfovx"]))
+    L.so_preprocess_bwd(c_int(P), c_int(st["sh_degree"]), c_int(M), _p(inp["means3D"]), _p(st["tm_used"]),
+                        _p(st["radii"]), _p(inp["shs"]), _p(st["clamped"]), _p(inp["scales"]),
+                        _p(inp["rotations"]), c_float(st["scale_modifier"]), _p(inp["view"]), _p(inp["proj"]),
+                        c_float(focal_x), c_float(focal_y), c_float(st["tanfovx"]), c_float(st["tanfovy"]),
+                        _p(inp["campos"]), _p(g["dL_dtransMat"]), _p(g["dL_dnormal"]), _p(g["dL_dcolors"]),
+                        _p(g["dL_dsh"]), _p(g["dL_dmeans2D"]), _p(g["dL_dmeans3D"]), _p(g["dL_dscales"]),
+                        _p(g["dL_drotations"]))
+    return g
+
+
 def test_quat_to_rot(q):
     q = _f32(q)
     out = np.zeros((q.shape[0], 3, 3), np.float32)

@@ -81,6 +81,7 @@ class FakeRasterizer(torch.nn.Module):
                 cov3D_precomp=None, extra_attrs=None):
         FAKE["extra_in"] = None if extra_attrs is None else extra_attrs.detach().clone()
         FAKE["cov3D_in"] = None if cov3D_precomp is None else cov3D_precomp.detach().clone()
+        FAKE["cov3D_graph"] = cov3D_precomp         # still attached to the model's parameters
         FAKE["scales_in"], FAKE["rotations_in"] = scales, rotations
         return FAKE["color"], FAKE["radii"], FAKE["allmap"], FAKE["extra"], FAKE["grp"]
 
@@ -264,6 +265,53 @@ with CpuMode():
             assert FAKE["cov3D_in"] is not None and FAKE["scales_in"] is None and FAKE["rotations_in"] is None
             tm[f"cam{i}_mod{mod:g}"] = FAKE["cov3D_in"]
     save("transmat.npz", **tm)
+
+    # ------------------------------------------------------------------ K10 by the reference's own autograd
+    # (a) dL/dtransMat -> dL/d(xyz, log-scaling, raw rotation): autograd through render()'s compute_cov3D_python graph
+    #     (gaussian_renderer/__init__.py:69-82, scene/gaussian_model.py:35-42, utils/general_utils.py build_rotation);
+    # (b) dL/dcolor -> dL/d(SH, xyz): autograd through the reference's own eval_sh (utils/sh_utils.py:57-117) composed as the
+    #     convert_SHs_python branch of render() composes it (:92-97: direction, eval_sh, + 0.5, clamp_min 0).
+    from utils.sh_utils import eval_sh as _eval_sh
+    kb = {}
+    gen = torch.Generator().manual_seed(424242)
+    for i, cam in enumerate(cams[:4]):
+        for prm in (gm._xyz, gm._scaling, gm._rotation):
+            prm.requires_grad_(True)
+            prm.grad = None
+        H_, W_ = cam.image_height, cam.image_width
+        FAKE.update(color=torch.zeros(3, H_, W_), radii=torch.zeros(Ptm).int(), allmap=torch.ones(7, H_, W_),
+                    extra=torch.zeros(0), grp=torch.zeros(0, 2).int())
+        pipe = Pipe()
+        pipe.compute_cov3D_python = True
+        try:
+            gaussian_renderer.render(cam, gm, pipe, torch.zeros(3), scaling_modifier=1.0)
+        except Exception as e:
+            print("render() after the rasterizer call:", repr(e))
+        dT = torch.randn(Ptm, 9, generator=gen)
+        (FAKE["cov3D_graph"] * dT).sum().backward()
+        kb[f"cam{i}_dL_dtransMat"] = dT
+        kb[f"cam{i}_grad_xyz"] = gm._xyz.grad.clone()
+        kb[f"cam{i}_grad_log_scaling"] = gm._scaling.grad.clone()
+        kb[f"cam{i}_grad_rotation_raw"] = gm._rotation.grad.clone()
+        # (b)
+        shs = torch.cat((gm._features_dc, gm._features_rest), dim=1).detach().clone().requires_grad_(True)      # [P,16,3]
+        xyz2 = gm._xyz.detach().clone().requires_grad_(True)
+        for deg in (1, 3):
+            shs.grad = None; xyz2.grad = None
+            shs_view = shs.transpose(1, 2).view(-1, 3, 16)
+            dir_pp = xyz2 - cam.camera_center.repeat(Ptm, 1)
+            dirn = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+            col = torch.clamp_min(_eval_sh(deg, shs_view, dirn) + 0.5, 0.0)
+            dC_ = torch.randn(Ptm, 3, generator=gen)
+            (col * dC_).sum().backward()
+            kb[f"cam{i}_deg{deg}_dL_dcolor"] = dC_
+            kb[f"cam{i}_deg{deg}_color"] = col.detach().clone()
+            kb[f"cam{i}_deg{deg}_grad_shs"] = shs.grad.clone()
+            kb[f"cam{i}_deg{deg}_grad_xyz"] = xyz2.grad.clone()
+    kb["shs"] = torch.cat((gm._features_dc, gm._features_rest), dim=1).detach()
+    for prm in (gm._xyz, gm._scaling, gm._rotation):
+        prm.requires_grad_(False)
+    save("kten_backward.npz", **kb)
 
     # ------------------------------------------------------------------ SH + rotation helpers
     from utils.sh_utils import eval_sh
