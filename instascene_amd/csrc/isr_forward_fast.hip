@@ -77,6 +77,11 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
     unsigned st_cull = 0, st_eval = 0, st_blend = 0, st_lanes = 0, st_merge = 0;      // STATS only
     bool st_skip_next = false;
     const float mscale = FAR_N / (FAR_N - NEAR_N);
+    // The distortion map  sum_i w_i (m_i^2 A_i - 2 m_i M1_i + M2_i)  (A, M1, M2: the sums over the splats in front of i) is
+    // 1/2 sum_ij w_i w_j (m_i - m_j)^2 = A M2 - M1^2 of the FINAL sums: the loop keeps only the two moments, of  m - m_ref
+    // with a workgroup-uniform m_ref near the tile's depth (the identity is shift-invariant; the shift keeps the final
+    // subtraction from cancelling), and the epilogue forms the map and un-shifts the moments the backward reads.
+    float m_ref = 0.9f, mshift = mscale - 0.9f;       // set from the first staged splat's depth (scalar registers)
     const float bx0 = X0 + (float)((wv & 1) * 8), bx1 = bx0 + 7.0f;
     const float by0 = Y0 + (float)((wv >> 1) * 8), by1 = by0 + 7.0f;
 
@@ -163,6 +168,12 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
             }
             __syncthreads();
         }
+        if (AUX && base == r0) {
+            const float z0 = s_rec[13];                  // Tw.z of the tile's nearest splat
+            const float mr = fminf(1.0f, fmaxf(0.0f, mscale - mscale * NEAR_N * __builtin_amdgcn_rcpf(z0)));
+            m_ref = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mr)));
+            mshift = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mscale - mr)));
+        }
         const unsigned cbase = (unsigned)(base - r0) + 1u;
         // ---- walk the batch: each wave visits only the splats whose cull bounds meet its 8x8 pixel block
         for (int c0 = 0; c0 < nb; c0 += 64) {
@@ -227,14 +238,11 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                     if (AUX && first_pass) {
                         const float4 q4 = q[4], q5 = q[5];
                         const float inv_depth = use3d ? p_z * q3.w : q4.x;
-                        const float m_ = __builtin_fmaf(-(mscale * NEAR_N), inv_depth, mscale);
-                        const float mm = m_ * m_;
-                        const float A_ = 1.0f - T;
-                        const float t2 = __builtin_fmaf(-2.0f * m_, M1, __builtin_fmaf(mm, A_, M2));
-                        distortion = __builtin_fmaf(t2, w, distortion);
+                        const float m_ = __builtin_fmaf(-(mscale * NEAR_N), inv_depth, mshift);      // m - m_ref
+                        const float mw = m_ * w;
                         D = __builtin_fmaf(depth, w, D);
-                        M1 = __builtin_fmaf(m_, w, M1);
-                        M2 = __builtin_fmaf(mm, w, M2);
+                        M1 += mw;
+                        M2 = __builtin_fmaf(m_, mw, M2);
                         if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }
                         N0 = __builtin_fmaf(q4.y, w, N0); N1 = __builtin_fmaf(q4.z, w, N1); N2 = __builtin_fmaf(q4.w, w, N2);
                         C0 = __builtin_fmaf(q5.x, w, C0); C1 = __builtin_fmaf(q5.y, w, C1); C2 = __builtin_fmaf(q5.z, w, C2);
@@ -296,9 +304,11 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
         n_contrib[pix] = last_contributor;
     }
     if (AUX && inside && first_pass) {
+        const float A_ = 1.0f - T;
+        distortion = __builtin_fmaf(A_, M2, -(M1 * M1));
         final_T[pix] = T;
-        final_T[pix + N] = M1;
-        final_T[pix + 2 * N] = M2;
+        final_T[pix + N] = __builtin_fmaf(m_ref, A_, M1);
+        final_T[pix + 2 * N] = __builtin_fmaf(m_ref, __builtin_fmaf(m_ref, A_, M1 + M1), M2);
         n_contrib[pix] = last_contributor;
         n_contrib[pix + N] = median_contributor;
         out_color[pix] = __builtin_fmaf(T, bg[0], C0);
