@@ -239,7 +239,12 @@ int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binni
         // dense scenes (more than ~1 500 instances per tile on average): buckets beyond the 4 096-key LDS budget get their
         // own launch with 128 KB of LDS instead of the global-memory network
         const int big = (binning_capacity / (T > 0 ? T : 1)) > 1500 ? 1 : 0;
-        hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity, big);
+        static const bool wave_sort = [] { const char* e = getenv("ISR_WAVE_SORT"); return !(e && e[0] == '0'); }();
+        // buckets of up to 2 048 keys: one wave each, in registers; the LDS network takes the rest
+        if (wave_sort)
+            hipLaunchKernelGGL(k_tile_sort_wave, dim3(T), dim3(64), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity);
+        hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity,
+                           big | (wave_sort ? 2 : 0));
         if (big) {
             static const bool attr_ok = [] {
                 return hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -549,6 +549,117 @@ __global__ __launch_bounds__(1024) void k_tile_sort_big(const uint32_t* __restri
     for (int i = threadIdx.x; i < n; i += blockDim.x) point_list[r0 + i] = (uint32_t)s_big[i];
 }
 
+// Buckets of up to SORT_WAVE_KEYS keys (all but the densest tiles of a 1080p view) are sorted by ONE WAVE in registers:
+// lane l holds K consecutive elements of the (virtual) array, so the network's strides below K are compare-exchanges between
+// a lane's own registers and the strides of K and more are exchanges with lane l ^ (stride / K) (two ds_bpermute per key) -
+// no LDS allocation, no barrier, a third of the LDS network's instructions, 6-8 waves per SIMD.  The input order is
+// irrelevant to a sort, so the bucket is read striped (coalesced) and only the sorted ids are written lane-contiguous.
+constexpr int SORT_WAVE_KEYS = 2048;
+struct __attribute__((packed, aligned(4))) Ids4 { uint32_t x, y, z, w; };
+
+template <int K>
+__device__ __forceinline__ void wave_cmpx(unsigned long long& a, unsigned long long& b, bool desc) {
+    const bool sw = (a > b) != desc;
+    const unsigned long long lo = sw ? b : a, hi = sw ? a : b;
+    a = lo; b = hi;
+}
+
+// in-register half-cleaner cascade: strides J, J/2, .. 1 over the K registers of every lane, one direction per lane
+template <int K, int J>
+__device__ __forceinline__ void wave_merge_regs(unsigned long long (&v)[K], bool desc) {
+    if constexpr (J >= 1) {
+#pragma unroll
+        for (int r = 0; r < K; r++)
+            if ((r & J) == 0) wave_cmpx<K>(v[r], v[r | J], desc);
+        wave_merge_regs<K, J / 2>(v, desc);
+    }
+}
+
+// phases k = 2 .. K of the network (strides inside a lane): direction of element i = l K + r is bit k of i
+template <int K, int KK>
+__device__ __forceinline__ void wave_sort_regs(unsigned long long (&v)[K], int lane) {
+    if constexpr (KK <= K) {
+        if constexpr (KK > 2) wave_sort_regs<K, KK / 2>(v, lane);
+        // stride KK/2 .. 1 with per-register directions (bit KK of r; for KK == K: bit 0 of the lane)
+#pragma unroll
+        for (int j = KK / 2; j >= 1; j >>= 1) {
+#pragma unroll
+            for (int r = 0; r < K; r++)
+                if ((r & j) == 0) {
+                    const bool desc = KK < K ? (r & KK) != 0 : (lane & 1) != 0;
+                    wave_cmpx<K>(v[r], v[r | j], desc);
+                }
+        }
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&v)[K], int lane) {
+    if constexpr (K > 1) wave_sort_regs<K, K>(v, lane);
+    // phases k = 2 K .. 64 K: lane-level bitonic merge (m = stride / K) followed by the in-register cascade
+    for (int kk = 2; kk <= 64; kk <<= 1) {
+        const bool desc = (lane & kk) != 0;                  // kk == 64: ascending everywhere
+        for (int m = kk >> 1; m >= 1; m >>= 1) {
+            const bool keep_min = ((lane & m) == 0) != desc;
+            const int src = (lane ^ m) << 2;
+#pragma unroll
+            for (int r = 0; r < K; r++) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)v[r]);
+                const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(v[r] >> 32));
+                const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+                v[r] = ((o < v[r]) == keep_min) ? o : v[r];
+            }
+        }
+        if constexpr (K > 1) wave_merge_regs<K, K / 2>(v, desc);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void wave_sort_bucket(const unsigned long long* __restrict__ seg, uint32_t* __restrict__ out, int n,
+                                                 int lane) {
+    unsigned long long v[K];
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        const int i = r * 64 + lane;
+        v[r] = i < n ? seg[i] : ~0ull;
+    }
+    wave_bitonic_sort<K>(v, lane);
+    const int base = lane * K;
+    if constexpr (K >= 4) {
+        if (base + K <= n) {        // (dword-aligned 16-byte stores: the bucket's start is any multiple of 4 bytes)
+#pragma unroll
+            for (int r = 0; r < K; r += 4) {
+                Ids4 q = {(uint32_t)v[r], (uint32_t)v[r + 1], (uint32_t)v[r + 2], (uint32_t)v[r + 3]};
+                *reinterpret_cast<Ids4*>(out + base + r) = q;
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < K; r++)
+        if (base + r < n) out[base + r] = (uint32_t)v[r];
+}
+
+__global__ __launch_bounds__(64) void k_tile_sort_wave(const uint32_t* __restrict__ tile_offset,
+                                                       const unsigned long long* __restrict__ keys,
+                                                       uint32_t* __restrict__ point_list, int64_t capacity) {
+    const uint32_t t = blockIdx.x;
+    const int64_t r0 = tile_offset[t];
+    int64_t r1 = tile_offset[t + 1];
+    if (r1 > capacity) r1 = capacity;
+    const int n = (int)(r1 - r0);
+    if (n <= 0 || n > SORT_WAVE_KEYS) return;
+    const unsigned long long* seg = keys + r0;
+    uint32_t* out = point_list + r0;
+    const int lane = threadIdx.x;
+    if (n <= 64) wave_sort_bucket<1>(seg, out, n, lane);
+    else if (n <= 128) wave_sort_bucket<2>(seg, out, n, lane);
+    else if (n <= 256) wave_sort_bucket<4>(seg, out, n, lane);
+    else if (n <= 512) wave_sort_bucket<8>(seg, out, n, lane);
+    else if (n <= 1024) wave_sort_bucket<16>(seg, out, n, lane);
+    else wave_sort_bucket<32>(seg, out, n, lane);
+}
+
 __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ tile_offset, unsigned long long* keys,
                                                    uint32_t* __restrict__ point_list, int64_t capacity, int big_follows) {
     __shared__ unsigned long long s_keys[SORT_LDS_KEYS];
@@ -558,7 +669,8 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
     if (r1 > capacity) r1 = capacity;
     const int n = (int)(r1 - r0);
     if (n <= 0) return;
-    if (big_follows && n > SORT_LDS_KEYS && n <= SORT_BIG_KEYS) return;
+    if ((big_follows & 1) && n > SORT_LDS_KEYS && n <= SORT_BIG_KEYS) return;
+    if ((big_follows & 2) && n <= SORT_WAVE_KEYS) return;         // k_tile_sort_wave's
     unsigned long long* seg = keys + r0;
     if (n <= SORT_LDS_KEYS) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) s_keys[i] = seg[i];
