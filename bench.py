@@ -201,16 +201,21 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for it in range(args.warmup):
-        trainer.step(it)
+    import contextlib
+    step_scope = trainer.stream_scope if (hasattr(trainer, "stream_scope") and os.environ.get("ISR_BENCH_SCOPE", "1") == "1") \
+        else contextlib.nullcontext
+    with step_scope():
+        for it in range(args.warmup):
+            trainer.step(it)
     sync()
     dbg0 = (rasterizer.PREFETCH_HITS, torch.cuda.memory_stats().get("num_device_alloc", 0), len(rasterizer._R_ESTIMATE))
     dt, it_next = None, args.warmup
     for rep in range(repeats):       # the headline: exactly one block of K steps; sub-records: the better of two blocks
         L.isr_profile_enable(2)      # HIP events around the forward blend kernel only inside the timed region
         t0 = time.perf_counter()
-        for it in range(it_next, it_next + args.steps):
-            trainer.step(it)
+        with step_scope():           # the trainer's own stream for the whole block (SegTrainer.stream_scope)
+            for it in range(it_next, it_next + args.steps):
+                trainer.step(it)
         sync()
         dt_rep = time.perf_counter() - t0
         if dt is None or dt_rep < dt:

@@ -30,13 +30,6 @@ class RenderPackage(dict):
       (``train_semantic`` never reads them).  Default: inside ``render()`` like the reference."""
 
     _pending = None
-    _maps_done = None        # event on the auxiliary stream that computed the seven maps (see _post_process_beside)
-
-    def _join_maps(self):
-        ev = self._maps_done
-        if ev is not None:
-            # the maps were computed beside whatever followed render() on the caller's stream: the reader's stream waits here
-            torch.cuda.current_stream().wait_event(ev)
 
     def _materialize(self):
         job = self._pending
@@ -47,10 +40,8 @@ class RenderPackage(dict):
                 dict.update(self, post_process(cam, allmap, depth_ratio))
 
     def __getitem__(self, k):
-        if k in _LAZY_KEYS:
-            if self._pending is not None:
-                self._materialize()
-            self._join_maps()
+        if self._pending is not None and k in _LAZY_KEYS:
+            self._materialize()
         v = dict.__getitem__(self, k)
         if v is None and k == "visibility_filter":
             # `radii > 0` (reference :110) on first access: the same values, one elementwise kernel over P Gaussians that a
@@ -67,7 +58,6 @@ class RenderPackage(dict):
 
     def __iter__(self):          # also routes dict(pkg) / {**pkg} through __getitem__
         self._materialize()
-        self._join_maps()
         if dict.get(self, "visibility_filter", 0) is None:
             self["visibility_filter"]
         return dict.__iter__(self)
@@ -175,30 +165,6 @@ def post_process(viewpoint_camera, allmap, depth_ratio):
         allmap, viewpoint_camera.world_view_transform, rays_d, rays_o, float(depth_ratio))
     return {'rend_alpha': alpha, 'rend_normal': normal, 'rend_dist': dist, 'surf_depth': surf,
             'surf_normal': snorm, 'rend_depth': depth, 'rend_median_depth': median}
-
-
-_AUX_STREAMS = {}
-
-
-def _post_process_beside(rets, viewpoint_camera, allmap, depth_ratio):
-    """``post_process`` on an auxiliary stream that waits for the forward just issued: when nothing differentiates through
-    the maps (frozen geometry: train_semantic.py), they are not on the path from the forward to the loss, and their two
-    kernels + launch gaps (~70 us at 1080p) run beside the loss kernels instead of in front of them.  Same values, computed
-    inside ``render()``; the first read of any of the seven entries makes the reader's stream wait for them."""
-    dev = allmap.device
-    cur = torch.cuda.current_stream(dev)
-    aux = _AUX_STREAMS.get(dev.index)
-    if aux is None:
-        aux = _AUX_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
-    aux.wait_stream(cur)
-    allmap.record_stream(aux)
-    with torch.cuda.stream(aux):
-        maps = post_process(viewpoint_camera, allmap, depth_ratio)
-        done = aux.record_event()
-    for t in maps.values():
-        t.record_stream(cur)           # allocated in the auxiliary stream's pool, consumed (and freed) on the caller's
-    dict.update(rets, maps)
-    rets._maps_done = done
 
 
 def _precomputed_transforms(viewpoint_camera, pc, scaling_modifier):
@@ -309,9 +275,6 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if getattr(pipe, "lazy_maps", False) or os.environ.get("ISR_LAZY_MAPS", "0") == "1":
         dict.update(rets, dict.fromkeys(_LAZY_KEYS))
         rets._pending = (viewpoint_camera, allmap, pipe.depth_ratio, torch.is_grad_enabled())
-    elif (allmap.is_cuda and not (torch.is_grad_enabled() and allmap.requires_grad)
-          and os.environ.get("ISR_MAPS_BESIDE", "1") != "0"):
-        _post_process_beside(rets, viewpoint_camera, allmap, pipe.depth_ratio)
     else:
         rets.update(post_process(viewpoint_camera, allmap, pipe.depth_ratio))
     return rets
