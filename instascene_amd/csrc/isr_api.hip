@@ -241,10 +241,17 @@ int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binni
         const int big = (binning_capacity / (T > 0 ? T : 1)) > 1500 ? 1 : 0;
         static const bool wave_sort = [] { const char* e = getenv("ISR_WAVE_SORT"); return !(e && e[0] == '0'); }();
         // buckets of up to 2 048 keys: one wave each, in registers; the LDS network takes the rest
-        if (wave_sort)
-            hipLaunchKernelGGL(k_tile_sort_wave, dim3(T), dim3(64), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity);
+        static const int wave_max = [] { const char* e = getenv("ISR_WAVE_SORT_MAX"); return e ? atoi(e) : 128; }();
+        const int wk = !wave_sort ? 0 : (!big ? 32 : wave_max);           // keys per lane of the widest variant launched
+        const int wflags = wk == 0 ? 0 : wk == 32 ? 2 : wk == 64 ? 6 : 14;
+        if (wk == 128)
+            hipLaunchKernelGGL(k_tile_sort_wave<128>, dim3(T), dim3(64), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity);
+        else if (wk == 64)
+            hipLaunchKernelGGL(k_tile_sort_wave<64>, dim3(T), dim3(64), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity);
+        else if (wk == 32)
+            hipLaunchKernelGGL(k_tile_sort_wave<32>, dim3(T), dim3(64), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity);
         hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity,
-                           big | (wave_sort ? 2 : 0));
+                           big | wflags);
         if (big) {
             static const bool attr_ok = [] {
                 return hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -252,7 +259,7 @@ int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binni
             }();
             if (!attr_ok) return fail(ISR_EHIP, "k_tile_sort_big: cannot reserve %d bytes of LDS", SORT_BIG_KEYS * 8);
             hipLaunchKernelGGL(k_tile_sort_big, dim3(T), dim3(1024), SORT_BIG_KEYS * sizeof(unsigned long long), s, iv.tile_offset,
-                               bv.keys, bv.point_list, binning_capacity);
+                               bv.keys, bv.point_list, binning_capacity, wk > 64 ? wk * 64 : SORT_LDS_KEYS);
         } }
         ISR_LAUNCH_CHECK("k_tile_sort");
     }

@@ -535,14 +535,14 @@ __device__ __forceinline__ void bitonic_flip_sort_lds(unsigned long long* a, int
 // memory (a barrier and a round trip to L2 per pass: 2.1 ms of C5's side stream).  big_follows: this launch leaves them alone.
 constexpr int SORT_BIG_KEYS = 16384;
 __global__ __launch_bounds__(1024) void k_tile_sort_big(const uint32_t* __restrict__ tile_offset, unsigned long long* keys,
-                                                        uint32_t* __restrict__ point_list, int64_t capacity) {
+                                                        uint32_t* __restrict__ point_list, int64_t capacity, int min_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_big[];
     const uint32_t t = blockIdx.x;
     const int64_t r0 = tile_offset[t];
     int64_t r1 = tile_offset[t + 1];
     if (r1 > capacity) r1 = capacity;
     const int n = (int)(r1 - r0);
-    if (n <= SORT_LDS_KEYS || n > SORT_BIG_KEYS) return;
+    if (n <= min_n || n > SORT_BIG_KEYS) return;
     unsigned long long* seg = keys + r0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) s_big[i] = seg[i];
     bitonic_flip_sort_lds(s_big, n);
@@ -640,6 +640,7 @@ __device__ __forceinline__ void wave_sort_bucket(const unsigned long long* __res
         if (base + r < n) out[base + r] = (uint32_t)v[r];
 }
 
+template <int MAXK>      // 32: buckets of up to 2 048 keys; 64 (dense scenes): up to 4 096, at half the waves per SIMD
 __global__ __launch_bounds__(64) void k_tile_sort_wave(const uint32_t* __restrict__ tile_offset,
                                                        const unsigned long long* __restrict__ keys,
                                                        uint32_t* __restrict__ point_list, int64_t capacity) {
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(64) void k_tile_sort_wave(const uint32_t* __restric
     int64_t r1 = tile_offset[t + 1];
     if (r1 > capacity) r1 = capacity;
     const int n = (int)(r1 - r0);
-    if (n <= 0 || n > SORT_WAVE_KEYS) return;
+    if (n <= 0 || n > 64 * MAXK) return;
     const unsigned long long* seg = keys + r0;
     uint32_t* out = point_list + r0;
     const int lane = threadIdx.x;
@@ -657,7 +658,9 @@ __global__ __launch_bounds__(64) void k_tile_sort_wave(const uint32_t* __restric
     else if (n <= 256) wave_sort_bucket<4>(seg, out, n, lane);
     else if (n <= 512) wave_sort_bucket<8>(seg, out, n, lane);
     else if (n <= 1024) wave_sort_bucket<16>(seg, out, n, lane);
-    else wave_sort_bucket<32>(seg, out, n, lane);
+    else if (MAXK == 32 || n <= 2048) wave_sort_bucket<32>(seg, out, n, lane);
+    else if (MAXK == 64 || n <= 4096) wave_sort_bucket<64>(seg, out, n, lane);
+    else wave_sort_bucket<128>(seg, out, n, lane);
 }
 
 __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ tile_offset, unsigned long long* keys,
@@ -671,6 +674,8 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
     if (n <= 0) return;
     if ((big_follows & 1) && n > SORT_LDS_KEYS && n <= SORT_BIG_KEYS) return;
     if ((big_follows & 2) && n <= SORT_WAVE_KEYS) return;         // k_tile_sort_wave's
+    if ((big_follows & 4) && n <= 2 * SORT_WAVE_KEYS) return;     // k_tile_sort_wave<64>'s
+    if ((big_follows & 8) && n <= 4 * SORT_WAVE_KEYS) return;     // k_tile_sort_wave<128>'s
     unsigned long long* seg = keys + r0;
     if (n <= SORT_LDS_KEYS) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) s_keys[i] = seg[i];
