@@ -284,6 +284,7 @@ class FeatureAdam:
         if not param.is_cuda or param.dim() != 2 or (param.shape[1] & 3) or param.shape[1] > 256:
             raise ValueError("FeatureAdam needs a CUDA [P,F] parameter with F % 4 == 0 and F <= 256")
         self.param, self.lr, self.betas, self.eps, self.norm_eps = param, float(lr), betas, float(eps), norm_eps
+        self._zero1 = None
         self.exp_avg = torch.zeros_like(param, memory_format=torch.contiguous_format)
         self.exp_avg_sq = torch.zeros_like(param, memory_format=torch.contiguous_format)
         self.step_count = 0
@@ -431,7 +432,9 @@ class FeatureAdam:
             else:
                 # y was not stored (store_y = False): a zero-stride placeholder of the right shape that knows where its rows
                 # come from (gather_rows reads them from the parameter); nothing else may read its values
-                y_leaf = torch.zeros(1, dtype=p.dtype, device=p.device, requires_grad=True)
+                if self._zero1 is None or self._zero1.device != p.device or self._zero1.dtype != p.dtype:
+                    self._zero1 = torch.zeros(1, dtype=p.dtype, device=p.device)
+                y_leaf = self._zero1.detach().requires_grad_(True)       # (a fresh leaf without a fill kernel per step)
                 y = y_leaf.expand(p.shape[0], p.shape[1])
                 setattr(y, _ROW_SOURCE_ATTR, (p.detach(), float(self.norm_eps[0])))
             setattr(y, _MEMO_ATTR, (float(self.norm_eps[1]), z, y._version))
