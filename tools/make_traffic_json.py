@@ -11,7 +11,7 @@ out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over
                  f"raw counters: profiles/{tag}_pmc_FETCH_SIZE_*.txt, profiles/{tag}_pmc_WRITE_SIZE_*.txt"}
 short = {"k_render_fwd_fast": "k_render_fwd", "k_render_fwd": "k_render_fwd", "k_render_bwd_geo": "k_render_bwd",
          "k_render_bwd_sparse": "k_render_bwd_sparse", "k_render_bwd": "k_render_bwd", "k_preprocess_bwd": "k_preprocess_bwd",
-         "k_preprocess": "k_preprocess", "k_scatter": "k_scatter", "k_tile_sort": "k_tile_sort",
+         "k_preprocess": "k_preprocess", "k_scatter": "k_scatter", "k_tile_sort": "k_tile_sort", "k_tile_sort_wave": "k_tile_sort_wave",
          "k_feature_rows_step": "k_feature_rows_step", "gaussian_adam_kernel": "gaussian_adam_kernel", "ssim_fwd": "ssim_fwd",
          "ssim_bwd": "ssim_bwd", "pp_maps": "pp_maps", "pp_surf_normal": "pp_surf_normal"}
 for cfg, step in (("C3", "seg"), ("C2", "rgb")):
