@@ -102,6 +102,7 @@ class _ProtoNCEBatch(torch.autograd.Function):
         ctx.save_for_backward(state)
         ctx.dims = (nb, N, F, K, one * nb, [p is not None for p in pres], [float(x) for x in weights])
         ctx.mark_non_differentiable(loss)
+        ctx.set_materialize_grads(False)      # (no zero-filled gradient for the non-differentiable second output)
         return loss[nb], loss
 
     @staticmethod
@@ -109,6 +110,8 @@ class _ProtoNCEBatch(torch.autograd.Function):
         L = lib()
         (state,) = ctx.saved_tensors
         nb, N, F, K, nbytes, has_pre, weights = ctx.dims
+        if grad_total is None:
+            return (None,) * (7 + nb)
         g = grad_total.reshape(1).contiguous().float()
         outs = [torch.empty((N, F), dtype=torch.float32, device=state.device) for _ in range(nb)]
         flags = (ctypes.c_int * nb)(*[int(h) for h in has_pre])

@@ -336,6 +336,13 @@ class SegTrainer:
 
         return _Scope()
 
+    def _unit_grad(self, loss):
+        """dL/dL = 1 from a cached tensor (autograd otherwise fills a fresh one every step: one more launch in the chain)."""
+        one = getattr(self, "_one", None)
+        if one is None or one.shape != loss.shape or one.device != loss.device or one.dtype != loss.dtype:
+            one = self._one = torch.ones_like(loss)
+        return one
+
     def _step_guarded(self, it: int):
         from .rasterizer import BinningOverflow
         try:
@@ -445,7 +452,7 @@ class SegTrainer:
                                            num_labels=self.n_labels + 1) * self.lmv
         if self.fused_tail:
             with DeferredFeatureRows() as sink:
-                loss.backward()
+                loss.backward(self._unit_grad(loss))
             if self.world == 1 and not self.split_tail:
                 self.opt.step_rows(sink.rows, row_grads=sink.row_grads)
                 m._seg_cache = None
