@@ -442,6 +442,8 @@ def main():
                           "allreduce_ms_per_step_alone": head.get("allreduce_ms"),
                           "gaussian_order": "z-order of the centres, sorted once at load" if args.spatial_sort else "as generated (random)",
                           "derived_render_maps": "on first access (never read by the seg step)" if args.lazy_maps else "inside render(), like the reference",
+                          "step_loop_stream": "the trainer's own high-priority HIP stream for the whole block of steps (SegTrainer.stream_scope); "
+                                              "the next view's geometry pass + binning on one side stream",
                           "view_order": "deterministic round-robin over 16 ring cameras (the reference pops a random view, "
                                         "train_semantic.py:100): the next view is known, so its geometry pass + binning are issued "
                                         "on a side stream during the current step",
