@@ -117,6 +117,22 @@ int iso_photometric_forward(int C, int H, int W, const float* img1, const float*
 int iso_photometric_backward(int C, int H, int W, const float* img1, const float* img2, const float* dmaps,
                              const float* g_ssim, const float* g_l1, float* dL_dimg1, void* stream);
 
+/* The whole loss of a train.py iteration (train.py:89-103) in the same two kernels + one single-workgroup sum:
+ *   total = ((1 - l) L1(image, gt) + l (1 - SSIM(image, gt))) + lambda_dist mean(rend_dist)
+ *           + lambda_normal mean(1 - sum_c rend_normal[c] surf_normal[c])
+ * image, gt [C,H,W]; rend_normal, surf_normal [3,H,W] (both or neither); rend_dist [H,W] or NULL.
+ * out5 = total, L1 mean, SSIM mean, normal-error mean, distortion mean.  dmaps [3,C,H,W] as for iso_ssim_forward.
+ * backward: g_total = device scalar dL/dtotal; writes dL/dimage and (where the pointers are given) the regularisers'
+ * gradients  -lambda_normal g surf_normal / (H W),  -lambda_normal g rend_normal / (H W),  lambda_dist g / (H W). */
+size_t iso_train_loss_scratch_bytes(int C, int H, int W);
+int iso_train_loss_forward(int C, int H, int W, const float* image, const float* gt, float lambda_dssim,
+                           const float* rend_normal, const float* surf_normal, float lambda_normal, const float* rend_dist,
+                           float lambda_dist, float* out5, float* dmaps, void* scratch, size_t scratch_bytes, void* stream);
+int iso_train_loss_backward(int C, int H, int W, const float* image, const float* gt, const float* dmaps, float lambda_dssim,
+                            const float* rend_normal, const float* surf_normal, float lambda_normal, float lambda_dist,
+                            const float* g_total, float* dL_dimage, float* dL_drend_normal, float* dL_dsurf_normal,
+                            float* dL_drend_dist, void* stream);
+
 /* Densification statistics of one iteration (train.py:140-142; scene/gaussian_model.py:601-604): for every Gaussian i
  * with visible[i] != 0:  grad_accum[i] += |viewspace_grad[i, 0:C]|_2,  denom[i] += 1,
  * max_radii[i] = max(max_radii[i], radii[i]). */

@@ -68,6 +68,9 @@ SIGNATURES = {
     "iso_ssim_backward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "iso_photometric_forward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "iso_photometric_backward": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "iso_train_loss_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "iso_train_loss_forward": (c_int, [c_int, c_int, c_int, _P, _P, c_float, _P, _P, c_float, _P, c_float, _P, _P, _P, c_size_t, _P]),
+    "iso_train_loss_backward": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "iso_densify_stats": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "iso_gaussian_adam_step": (c_int, [c_int, c_int, _P, _P, _P, _P, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                        ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

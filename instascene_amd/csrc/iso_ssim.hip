@@ -46,10 +46,14 @@ __device__ __forceinline__ void tile_blur(const float* __restrict__ in, float* _
 // dmaps (optional) [3][C][H][W]: d map / d mu1, d map / d E[a^2], d map / d E[ab].
 // L1: also map_part[nblocks + block] = sum of |img1 - img2| over the block's pixels (the other half of train.py's
 // photometric loss, utils/loss_utils.py:18-19: the images are in LDS already).
-template <bool L1>
+// REG (train.py:93-103, the geometric regularisers of the same step): the workgroups of channel 0 also sum
+// 1 - <rend_normal, surf_normal> and rend_dist over their tile: map_part[2 nblocks + tile] and [2 nblocks + tiles + tile]
+// (either pair of pointers may be NULL: that term is zero).
+struct TrainReg { const float* rend_normal; const float* surf_normal; const float* rend_dist; };
+template <bool L1, bool REG>
 __global__ __launch_bounds__(256) void ssim_fwd(int C, int H, int W, SsimTaps tp, const float* __restrict__ img1,
                                                 const float* __restrict__ img2, float* __restrict__ map_part,
-                                                float* __restrict__ dmaps) {
+                                                float* __restrict__ dmaps, TrainReg reg) {
     __shared__ float s_in[5 * SS_IH * SS_IW];      // a, b, a*a, b*b, a*b  (15.1 KB)
     __shared__ float s_h[5 * SS_IH * SS_TW];       // (11.5 KB)
     __shared__ float s_red[4];
@@ -114,6 +118,58 @@ __global__ __launch_bounds__(256) void ssim_fwd(int C, int H, int W, SsimTaps tp
         __syncthreads();
         if (threadIdx.x == 0) map_part[gridDim.x * gridDim.y * gridDim.z + blk] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
     }
+    if (REG && ch == 0) {
+        float ne = 0.0f, dv = 0.0f;
+        if (x < W && y < H) {
+            const size_t o = (size_t)y * W + x;
+            if (reg.rend_normal != nullptr) {
+                const float dot = (reg.rend_normal[o] * reg.surf_normal[o] + reg.rend_normal[plane + o] * reg.surf_normal[plane + o]) +
+                                  reg.rend_normal[2 * plane + o] * reg.surf_normal[2 * plane + o];
+                ne = 1.0f - dot;
+            }
+            if (reg.rend_dist != nullptr) dv = reg.rend_dist[o];
+        }
+        const int tiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+        float* rp = map_part + 2 * (size_t)tiles * gridDim.z;
+#pragma unroll
+        for (int which = 0; which < 2; which++) {
+            __syncthreads();
+            float u = which == 0 ? ne : dv;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) u += __shfl_xor(u, o);
+            if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = u;
+            __syncthreads();
+            if (threadIdx.x == 0) rp[which * tiles + tile] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        }
+    }
+}
+
+// ONE workgroup: the four partial-sum arrays of ssim_fwd<true, true> -> out[0] = the loss of train.py:91-103,
+//   ((1 - l) L1 + l (1 - SSIM)) + lambda_dist mean(rend_dist) + lambda_normal mean(1 - <n, n'>),
+// out[1..4] = L1 mean, SSIM mean, normal-error mean, distortion mean.  Fixed summation order.
+__global__ __launch_bounds__(256) void train_loss_sum(int nblk, int tiles, const float* __restrict__ part, float inv_chw,
+                                                      float inv_hw, float lam, float ln, float ldist, float* __restrict__ out) {
+    __shared__ float s_red[4];
+    float tot[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const float* p = part + (a == 0 ? 0 : a == 1 ? nblk : a == 2 ? 2 * nblk : 2 * nblk + tiles);
+        const int n = a < 2 ? nblk : tiles;
+        float v = 0.0f;
+        for (int i = threadIdx.x; i < n; i += 256) v += p[i];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        tot[a] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
+    if (threadIdx.x == 0) {
+        const float ssim = tot[0] * inv_chw, l1 = tot[1] * inv_chw, ne = tot[2] * inv_hw, dm = tot[3] * inv_hw;
+        const float photo = (1.0f - lam) * l1 + lam * (1.0f - ssim);
+        out[0] = (photo + ldist * dm) + ln * ne;
+        out[1] = l1; out[2] = ssim; out[3] = ne; out[4] = dm;
+    }
 }
 
 // block b sums part[b * n .. (b + 1) * n) into out_b (b = 0: SSIM map, b = 1: |a - b|)
@@ -136,7 +192,12 @@ __global__ __launch_bounds__(256) void ssim_sum_parts(int n, const float* __rest
 __global__ __launch_bounds__(256) void ssim_bwd(int C, int H, int W, SsimTaps tp, const float* __restrict__ img1,
                                                 const float* __restrict__ img2, const float* __restrict__ dmaps,
                                                 const float* __restrict__ g_mean, const float* __restrict__ g_l1,
-                                                float inv_count, float* __restrict__ dimg1) {
+                                                float inv_count, float* __restrict__ dimg1, float k_ssim, float k_l1,
+                                                TrainReg reg, float k_normal, float k_dist, float* __restrict__ d_rn,
+                                                float* __restrict__ d_sn, float* __restrict__ d_dist) {
+    // k_ssim / k_l1 scale the two upstream scalars (train loss: both point at dL/dtotal, k = -lambda and 1 - lambda).
+    // Channel-0 workgroups also write the regularisers' gradients of their tile (when the outputs are given):
+    //   d rend_normal = -k_normal g sn,  d surf_normal = -k_normal g rn,  d rend_dist = k_dist g      (k = lambda / (H W))
     __shared__ float s_in[3 * SS_IH * SS_IW];
     __shared__ float s_h[3 * SS_IH * SS_TW];
     const int ch = blockIdx.z;
@@ -160,12 +221,25 @@ __global__ __launch_bounds__(256) void ssim_bwd(int C, int H, int W, SsimTaps tp
     if (x < W && y < H) {
         const size_t o = ch * plane + (size_t)y * W + x;
         const float a = img1[o], b = img2[o];
-        float v = (g_mean[0] * inv_count) * (m[0] + 2.0f * a * m[1] + b * m[2]);
+        float v = (g_mean[0] * k_ssim * inv_count) * (m[0] + 2.0f * a * m[1] + b * m[2]);
         if (g_l1 != nullptr) {
             const float df = a - b;
-            v += (g_l1[0] * inv_count) * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));     // torch: sign(0) = 0
+            v += (g_l1[0] * k_l1 * inv_count) * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));     // torch: sign(0) = 0
         }
         dimg1[o] = v;
+        if (ch == 0) {
+            const size_t q = (size_t)y * W + x;
+            const float g = g_mean[0];
+            if (d_rn != nullptr) {
+                const float k = -(k_normal * g);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    d_rn[c * plane + q] = k * reg.surf_normal[c * plane + q];
+                    d_sn[c * plane + q] = k * reg.rend_normal[c * plane + q];
+                }
+            }
+            if (d_dist != nullptr) d_dist[q] = k_dist * g;
+        }
     }
 }
 

@@ -664,8 +664,9 @@ int iso_photometric_forward(int C, int H, int W, const float* img1, const float*
     const dim3 grid((W + iso::SS_TW - 1) / iso::SS_TW, (H + iso::SS_TH - 1) / iso::SS_TH, C);
     const int nb = (int)(grid.x * grid.y * grid.z);
     { ProfScope ps_("ssim_fwd", s);
-    if (l1_mean) hipLaunchKernelGGL(iso::ssim_fwd<true>, grid, dim3(256), 0, s, C, H, W, ssim_taps(), img1, img2, (float*)scratch, dmaps);
-    else hipLaunchKernelGGL(iso::ssim_fwd<false>, grid, dim3(256), 0, s, C, H, W, ssim_taps(), img1, img2, (float*)scratch, dmaps); }
+    const iso::TrainReg no_reg = {nullptr, nullptr, nullptr};
+    if (l1_mean) hipLaunchKernelGGL((iso::ssim_fwd<true, false>), grid, dim3(256), 0, s, C, H, W, ssim_taps(), img1, img2, (float*)scratch, dmaps, no_reg);
+    else hipLaunchKernelGGL((iso::ssim_fwd<false, false>), grid, dim3(256), 0, s, C, H, W, ssim_taps(), img1, img2, (float*)scratch, dmaps, no_reg); }
     hipLaunchKernelGGL(iso::ssim_sum_parts, dim3(l1_mean ? 2 : 1), dim3(256), 0, s, nb, (const float*)scratch,
                        (float)(1.0 / ((double)C * H * W)), ssim_mean, l1_mean);
     ISR_LAUNCH_CHECK("iso_photometric_forward");
@@ -683,9 +684,54 @@ int iso_photometric_backward(int C, int H, int W, const float* img1, const float
     if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dmaps || !g_ssim || !dL_dimg1) return fail(ISR_EINVAL, "bad ssim arguments");
     const dim3 grid((W + iso::SS_TW - 1) / iso::SS_TW, (H + iso::SS_TH - 1) / iso::SS_TH, C);
     { ProfScope ps_("ssim_bwd", s);
+    const iso::TrainReg no_reg = {nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(iso::ssim_bwd, grid, dim3(256), 0, s, C, H, W, ssim_taps(), img1, img2, dmaps, g_ssim, g_l1,
-                       (float)(1.0 / ((double)C * H * W)), dL_dimg1); }
+                       (float)(1.0 / ((double)C * H * W)), dL_dimg1, 1.0f, 1.0f, no_reg, 0.0f, 0.0f, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr); }
     ISR_LAUNCH_CHECK("iso_photometric_backward");
+    return ISR_OK;
+}
+
+size_t iso_train_loss_scratch_bytes(int C, int H, int W) {
+    const size_t tiles = (size_t)((W + iso::SS_TW - 1) / iso::SS_TW) * ((H + iso::SS_TH - 1) / iso::SS_TH);
+    return (2 * tiles * (size_t)(C > 0 ? C : 1) + 2 * tiles) * sizeof(float) + 256;
+}
+
+int iso_train_loss_forward(int C, int H, int W, const float* image, const float* gt, float lambda_dssim,
+                           const float* rend_normal, const float* surf_normal, float lambda_normal, const float* rend_dist,
+                           float lambda_dist, float* out5, float* dmaps, void* scratch, size_t scratch_bytes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 0 || H <= 0 || W <= 0 || !image || !gt || !out5 || !scratch) return fail(ISR_EINVAL, "bad train_loss arguments");
+    if ((rend_normal != nullptr) != (surf_normal != nullptr)) return fail(ISR_EINVAL, "train_loss: rend_normal and surf_normal come together");
+    if (scratch_bytes < iso_train_loss_scratch_bytes(C, H, W)) return fail(ISR_EINVAL, "train_loss scratch too small");
+    const dim3 grid((W + iso::SS_TW - 1) / iso::SS_TW, (H + iso::SS_TH - 1) / iso::SS_TH, C);
+    const int tiles = (int)(grid.x * grid.y), nb = tiles * C;
+    const iso::TrainReg reg = {rend_normal, surf_normal, rend_dist};
+    { ProfScope ps_("ssim_fwd", s);
+    hipLaunchKernelGGL((iso::ssim_fwd<true, true>), grid, dim3(256), 0, s, C, H, W, ssim_taps(), image, gt, (float*)scratch, dmaps, reg); }
+    hipLaunchKernelGGL(iso::train_loss_sum, dim3(1), dim3(256), 0, s, nb, tiles, (const float*)scratch,
+                       (float)(1.0 / ((double)C * H * W)), (float)(1.0 / ((double)H * W)), lambda_dssim,
+                       rend_normal ? lambda_normal : 0.0f, rend_dist ? lambda_dist : 0.0f, out5);
+    ISR_LAUNCH_CHECK("iso_train_loss_forward");
+    return ISR_OK;
+}
+
+int iso_train_loss_backward(int C, int H, int W, const float* image, const float* gt, const float* dmaps, float lambda_dssim,
+                            const float* rend_normal, const float* surf_normal, float lambda_normal, float lambda_dist,
+                            const float* g_total, float* dL_dimage, float* dL_drend_normal, float* dL_dsurf_normal,
+                            float* dL_drend_dist, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 0 || H <= 0 || W <= 0 || !image || !gt || !dmaps || !g_total || !dL_dimage) return fail(ISR_EINVAL, "bad train_loss arguments");
+    if ((dL_drend_normal != nullptr) != (dL_dsurf_normal != nullptr)) return fail(ISR_EINVAL, "train_loss: both normal gradients or none");
+    if (dL_drend_normal && (!rend_normal || !surf_normal)) return fail(ISR_EINVAL, "train_loss: normal maps required for their gradients");
+    const dim3 grid((W + iso::SS_TW - 1) / iso::SS_TW, (H + iso::SS_TH - 1) / iso::SS_TH, C);
+    const iso::TrainReg reg = {rend_normal, surf_normal, nullptr};
+    const float inv_hw = (float)(1.0 / ((double)H * W));
+    { ProfScope ps_("ssim_bwd", s);
+    hipLaunchKernelGGL(iso::ssim_bwd, grid, dim3(256), 0, s, C, H, W, ssim_taps(), image, gt, dmaps, g_total, g_total,
+                       (float)(1.0 / ((double)C * H * W)), dL_dimage, -lambda_dssim, 1.0f - lambda_dssim, reg,
+                       lambda_normal * inv_hw, lambda_dist * inv_hw, dL_drend_normal, dL_dsurf_normal, dL_drend_dist); }
+    ISR_LAUNCH_CHECK("iso_train_loss_backward");
     return ISR_OK;
 }
 

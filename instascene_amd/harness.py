@@ -553,8 +553,8 @@ class RgbTrainer:
         density control appends later go to the end).  ``densify``: None (off) or a dict overriding the reference's schedule (arguments/__init__.py:106-125):
         ``from_iter=500, until_iter=15000, interval=100, opacity_reset_interval=3000, grad_threshold=0.0002,
         opacity_cull=0.05, percent_dense=0.01``; ``scene_extent`` = the reference's ``cameras_extent``."""
-        from .losses import l1_loss, photometric_loss, ssim
-        self.l1, self.ssim, self.photometric = l1_loss, ssim, photometric_loss
+        from .losses import l1_loss, photometric_loss, ssim, train_loss
+        self.l1, self.ssim, self.photometric, self.train_loss = l1_loss, ssim, photometric_loss, train_loss
         self.device = torch.device(device)
         self.order = None
         if spatial_sort:
@@ -566,6 +566,7 @@ class RgbTrainer:
         self.pipe = PipelineParams()
         self.bg = torch.zeros(3, dtype=torch.float32, device=self.device)
         self.ld, self.ln, self.ldist = lambda_dssim, lambda_normal, lambda_dist
+        self.fused_loss = self.device.type == "cuda"        # tests switch it off to compare with the composed form
         self.rank, self.world = rank, world
         # chain rule of the getters + Adam on the six groups + the next activations in one kernel (optim.GaussianAdam);
         # the density control edits optimiser rows through torch's state dict, so it keeps torch.optim.Adam
@@ -611,6 +612,10 @@ class RgbTrainer:
 
     def _loss(self, pkg, vi):
         image, gt = pkg["render"], self.targets[vi]
+        if self.fused_loss:
+            # photometric term + both regularisers: three launches forward, one backward (losses.train_loss)
+            return self.train_loss(image, gt, self.ld, pkg["rend_normal"], pkg["surf_normal"], self.ln,
+                                   pkg["rend_dist"] if self.ldist != 0.0 else None, self.ldist)
         loss = self.photometric(image, gt, self.ld)       # (1 - l) L1 + l (1 - SSIM), one pair of kernels on the GPU
         if self.ldist != 0.0:
             loss = loss + self.ldist * pkg["rend_dist"].mean()
@@ -624,7 +629,7 @@ class RgbTrainer:
             try:
                 pkg = render(self.cams[vi], self.model, self.pipe, self.bg)
                 loss = self._loss(pkg, vi)
-                loss.backward()
+                loss.backward(SegTrainer._unit_grad(self, loss))
             finally:
                 self.model._leaves = None
             # one flat collective for all six groups' gradients (they are final only after the per-Gaussian backward pass)

@@ -124,6 +124,77 @@ def photometric_loss(image, gt, lambda_dssim: float = 0.2):
     return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))
 
 
+class _TrainLossHip(torch.autograd.Function):
+    """The loss of one ``train.py`` iteration (train.py:89-103) - photometric term, distortion and normal-consistency
+    regularisers - in three launches forward and one backward (``iso_train_loss_forward/backward``) instead of ~25 torch
+    kernels around the SSIM pair.  Returns ``(total, parts[5])`` with ``parts = total, L1, SSIM, normal error, distortion``
+    (means); gradients flow to ``image``, ``rend_normal``, ``surf_normal`` and ``rend_dist``."""
+
+    @staticmethod
+    def forward(ctx, image, gt, lambda_dssim, rend_normal, surf_normal, lambda_normal, rend_dist, lambda_dist):
+        from ._lib import check, lib
+        L = lib()
+        a, b = image.contiguous().float(), gt.detach().contiguous().float()
+        C, H, W = a.shape
+        use_n = rend_normal is not None and surf_normal is not None and float(lambda_normal) != 0.0
+        use_d = rend_dist is not None and float(lambda_dist) != 0.0
+        rn = rend_normal.contiguous().float() if use_n else None
+        sn = surf_normal.contiguous().float() if use_n else None
+        rd = rend_dist.contiguous().float() if use_d else None
+        if use_n and (tuple(rn.shape) != (3, H, W) or tuple(sn.shape) != (3, H, W)):
+            raise ValueError("train_loss: rend_normal / surf_normal must be [3,H,W] of the image's size")
+        if use_d and rd.numel() != H * W:
+            raise ValueError("train_loss: rend_dist must hold H*W values")
+        out = torch.empty(5, dtype=torch.float32, device=a.device)
+        dmaps = torch.empty((3, C, H, W), dtype=torch.float32, device=a.device)
+        nbytes = L.iso_train_loss_scratch_bytes(C, H, W)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+        with torch.cuda.device(a.device):
+            check(L.iso_train_loss_forward(C, H, W, _ptr(a), _ptr(b), float(lambda_dssim), _ptr(rn), _ptr(sn),
+                                           float(lambda_normal), _ptr(rd), float(lambda_dist), _ptr(out), _ptr(dmaps),
+                                           _ptr(scratch), nbytes, _stream()), "iso_train_loss_forward")
+        ctx.save_for_backward(a, b, dmaps, rn, sn)
+        ctx.cfg = (float(lambda_dssim), float(lambda_normal) if use_n else 0.0, float(lambda_dist) if use_d else 0.0,
+                   None if rend_dist is None else tuple(rend_dist.shape), use_d)
+        ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g, _g_parts):
+        from ._lib import check, lib
+        a, b, dmaps, rn, sn = ctx.saved_tensors
+        if g is None:
+            return (None,) * 8
+        lam, ln, ldist, dist_shape, use_d = ctx.cfg
+        C, H, W = a.shape
+        gg = g.reshape(1).contiguous().float()
+        d_img = torch.empty_like(a)
+        d_rn = torch.empty_like(rn) if (rn is not None and ctx.needs_input_grad[3]) else None
+        d_sn = torch.empty_like(sn) if d_rn is not None else None
+        d_rd = torch.empty(dist_shape, dtype=torch.float32, device=a.device) if (use_d and ctx.needs_input_grad[6]) else None
+        with torch.cuda.device(a.device):
+            check(lib().iso_train_loss_backward(C, H, W, _ptr(a), _ptr(b), _ptr(dmaps), lam, _ptr(rn), _ptr(sn), ln, ldist,
+                                                _ptr(gg), _ptr(d_img), _ptr(d_rn), _ptr(d_sn), _ptr(d_rd), _stream()),
+                  "iso_train_loss_backward")
+        return d_img, None, None, d_rn, d_sn, None, d_rd, None
+
+
+def train_loss(image, gt, lambda_dssim, rend_normal=None, surf_normal=None, lambda_normal=0.0, rend_dist=None,
+               lambda_dist=0.0):
+    """``(1 - l) L1 + l (1 - SSIM) + lambda_dist * rend_dist.mean() + lambda_normal * (1 - (rend_normal * surf_normal).sum(0)).mean()``
+    - the total loss of train.py:89-103.  CUDA images: ``iso_train_loss_forward/backward``; otherwise composed in torch."""
+    if image.is_cuda and image.dim() == 3 and gt.shape == image.shape and not gt.requires_grad:
+        return _TrainLossHip.apply(image, gt, float(lambda_dssim), rend_normal, surf_normal, float(lambda_normal), rend_dist,
+                                   float(lambda_dist))[0]
+    loss = (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))
+    if rend_dist is not None and lambda_dist != 0.0:
+        loss = loss + lambda_dist * rend_dist.mean()
+    if rend_normal is not None and lambda_normal != 0.0:
+        loss = loss + lambda_normal * (1 - (rend_normal * surf_normal).sum(dim=0))[None].mean()
+    return loss
+
+
 def _ptr(t):
     import ctypes
     return None if t is None else ctypes.c_void_p(t.data_ptr())

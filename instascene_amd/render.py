@@ -229,20 +229,16 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     # train.py's densification; when the geometry is frozen (train_semantic) nothing reads it, so the
     # carrier follows xyz and the rasterizer can run its feature-only backward.
     need_geom_grad = bool(xyz.requires_grad) or bool(getattr(pipe, "force_viewspace_grad", False))
+    # a constant: one zero tensor per (shape, device) instead of a fill per call (nothing reads or writes its values; with
+    # geometry gradients each call gets its own LEAF over that storage, whose .grad the rasterizer's backward fills)
+    zkey = (tuple(xyz.shape), xyz.dtype, str(xyz.device))
+    screenspace_points = _ZEROS.get(zkey)
+    if screenspace_points is None:
+        if len(_ZEROS) > 8:
+            _ZEROS.clear()
+        screenspace_points = _ZEROS[zkey] = torch.zeros_like(xyz, requires_grad=False)
     if need_geom_grad:
-        screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
-        try:
-            screenspace_points.retain_grad()
-        except Exception:
-            pass
-    else:
-        # a constant: one zero tensor per (shape, device) instead of an 18 MB fill per call
-        zkey = (tuple(xyz.shape), xyz.dtype, str(xyz.device))
-        screenspace_points = _ZEROS.get(zkey)
-        if screenspace_points is None:
-            if len(_ZEROS) > 8:
-                _ZEROS.clear()
-            screenspace_points = _ZEROS[zkey] = torch.zeros_like(xyz, requires_grad=False)
+        screenspace_points = screenspace_points.detach().requires_grad_(True)
     rasterizer, geo = _geometry_inputs(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color)
 
     means2D = screenspace_points

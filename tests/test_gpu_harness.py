@@ -391,3 +391,29 @@ def test_gaussian_adam_matches_torch_adam():
             ref, got = sa[k][j], sb[k][j].reshape(sa[k][j].shape)
             assert (ref - got).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-20, (k, j)
     rz.set_tracer(True)
+
+
+@pytest.mark.gpu
+def test_rgb_trainer_fused_loss_equals_the_composed_loss():
+    """RgbTrainer's one-op loss (losses.train_loss: photometric + distortion + normal consistency) against the same
+    step with the loss composed from torch ops: same loss values and parameters to fp32 rounding after a few steps."""
+    from instascene_amd.harness import RgbTrainer
+    rz.set_mode("exact")
+    rz.set_tracer(False)
+    res = []
+    for fused in (False, True):
+        sc = scenes.synthetic_scene(3000, 0, 7, math.log(0.05))
+        sc.seg_feature = None
+        cams = scenes.ring_cameras(4, 96, 64)
+        g = torch.Generator().manual_seed(1)
+        targets = [torch.rand(3, 64, 96, generator=g) for _ in cams]
+        tr = RgbTrainer(sc, cams, targets, device="cuda", lambda_dist=100.0)
+        tr.fused_loss = fused
+        losses = [float(tr.step(it)[0]) for it in range(6)]
+        res.append((losses, tr.model._xyz.detach().clone(), tr.model._scaling.detach().clone()))
+    (la, xa, sa), (lb, xb, sb) = res
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 2e-5 * abs(x), (la, lb)
+    assert (xa - xb).abs().max().item() <= 0.02 * 0.00016 * 6
+    assert (sa - sb).abs().max().item() <= 0.02 * 0.005 * 6
+    rz.set_tracer(True)

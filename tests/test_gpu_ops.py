@@ -377,6 +377,52 @@ def test_hip_ssim_matches_torch_restatement_and_golden(golden_dir, C, H, W):
     assert_close(img2.grad.cpu().numpy(), z["grad"], 1e-4, "fused photometric grad vs reference")
 
 
+@pytest.mark.parametrize("H,W,ln,ldist", [(70, 101, 0.05, 100.0), (64, 96, 0.05, 0.0), (33, 17, 0.0, 10.0)])
+def test_train_loss_matches_the_composed_form(golden_dir, H, W, ln, ldist):
+    """iso_train_loss_forward/backward (train.py:89-103 in three + one launches) against the same expression composed from
+    torch ops in float64: value and the gradients of image, rend_normal, surf_normal, rend_dist; and the photometric part
+    against the reference's golden."""
+    from instascene_amd import losses
+    g = torch.Generator().manual_seed(7 * H + W)
+    img = torch.rand(3, H, W, generator=g)
+    gt = (img + 0.2 * torch.randn(3, H, W, generator=g)).clamp(0, 1)
+    rn = torch.nn.functional.normalize(torch.randn(3, H, W, generator=g), dim=0) * torch.rand(1, H, W, generator=g)
+    sn = torch.nn.functional.normalize(torch.randn(3, H, W, generator=g), dim=0)
+    rd = torch.rand(1, H, W, generator=g) * 0.01
+
+    def composed(i, a, b, d):
+        loss = 0.8 * (i - gt.to(i)).abs().mean() + 0.2 * (1.0 - losses.ssim(i, gt.to(i)))
+        loss = loss + ldist * d.mean()
+        return loss + ln * (1 - (a * b).sum(dim=0))[None].mean()
+
+    ref = [t.double().requires_grad_(True) for t in (img, rn, sn, rd)]
+    want = composed(*ref)
+    (want * 1.7).backward()
+    dev = [t.cuda().requires_grad_(True) for t in (img, rn, sn, rd)]
+    got = losses.train_loss(dev[0], gt.cuda(), 0.2, dev[1], dev[2], ln, dev[3], ldist)
+    (got * 1.7).backward()
+    assert abs(float(got.detach()) - float(want.detach())) < 3e-6 * max(1.0, abs(float(want.detach())))
+    assert_close(dev[0].grad.cpu().numpy(), ref[0].grad.float().numpy(), 1e-4, "dL/dimage")
+    if ln != 0.0:
+        assert_close(dev[1].grad.cpu().numpy(), ref[1].grad.float().numpy(), 1e-5, "dL/drend_normal")
+        assert_close(dev[2].grad.cpu().numpy(), ref[2].grad.float().numpy(), 1e-5, "dL/dsurf_normal")
+    else:
+        assert dev[1].grad is None and dev[2].grad is None
+    if ldist != 0.0:
+        assert_close(dev[3].grad.cpu().numpy(), ref[3].grad.float().numpy(), 1e-5, "dL/drend_dist")
+    else:
+        assert dev[3].grad is None
+    again = losses.train_loss(img.cuda(), gt.cuda(), 0.2, rn.cuda(), sn.cuda(), ln, rd.cuda(), ldist)
+    assert float(again) == float(got.detach())              # deterministic
+    # the photometric part alone == the reference's golden (value and gradient of 0.8*L1 + 0.2*(1 - SSIM))
+    z = np.load(os.path.join(golden_dir, "losses.npz"))
+    gi = torch.tensor(z["img"]).cuda().requires_grad_(True)
+    loss = losses.train_loss(gi, torch.tensor(z["gt"]).cuda(), 0.2)
+    assert abs(float(loss.detach()) - (0.8 * float(z["l1"]) + 0.2 * (1.0 - float(z["ssim"])))) < 2e-6
+    loss.backward()
+    assert_close(gi.grad.cpu().numpy(), z["grad"], 1e-4, "train_loss photometric grad vs reference")
+
+
 def test_feature_adam_matches_torch_adam_and_emits_the_normalisation_chain():
     """iso_adam_rownorm2: parameters / moments like torch.optim.Adam(lr .025, eps 1e-15) over several steps, and the
     emitted (y, z) bit-identical to row_normalize_chain of the updated parameter; the chain stays differentiable."""
