@@ -64,20 +64,21 @@ static int launch_render_fwd_fast(int tiles, hipStream_t s, int W, int H, int ED
                                   int32_t* tracer, long long tcap, int32_t* tcount, int64_t capacity, bool aux) {
     unsigned long long* counters = g_fwd_counters;
     g_fwd_counters = nullptr;
+    static const int order_below = [] { const char* e = getenv("ISR_FWD_ORDER_BELOW"); return e ? atoi(e) : 4096; }();
+    const uint32_t* order = tiles < order_below ? iv.tile_order : nullptr;
     int ch = 0, first = 1;
     do {
         ProfScope ps_("k_render_fwd", s);
+#define ISR_GO2(FEAT, STATS, AUX_, ORD)                                                                                   \
+    hipLaunchKernelGGL((k_render_fwd_fast<FEAT, STATS, AUX_, ORD>), dim3(tiles), dim3(256), 0, s, W, H, ED, ch, first, gx, \
+                       iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,    \
+                       out_color, out_others, out_extra, tracer, tcap, tcount, bv.box4, capacity, counters, order)
 #define ISR_GO(FEAT, STATS)                                                                                           \
-    do { if (aux)                                                                                                     \
-    hipLaunchKernelGGL((k_render_fwd_fast<FEAT, STATS, true>), dim3(tiles), dim3(256), 0, s, W, H, ED, ch, first, gx,  \
-                       iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,    \
-                       out_color, out_others, out_extra, tracer, tcap, tcount, bv.box4, capacity, counters);            \
-    else                                                                                                              \
-    hipLaunchKernelGGL((k_render_fwd_fast<FEAT, STATS, false>), dim3(tiles), dim3(256), 0, s, W, H, ED, ch, first, gx, \
-                       iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,    \
-                       out_color, out_others, out_extra, tracer, tcap, tcount, bv.box4, capacity, counters); } while (0)
+    do { if (aux) { if (order) ISR_GO2(FEAT, STATS, true, true); else ISR_GO2(FEAT, STATS, true, false); }            \
+         else { if (order) ISR_GO2(FEAT, STATS, false, true); else ISR_GO2(FEAT, STATS, false, false); } } while (0)
         if (ED - ch <= 0) { if (counters) ISR_GO(false, true); else ISR_GO(false, false); }
         else { if (counters) ISR_GO(true, true); else ISR_GO(true, false); }
+#undef ISR_GO2
 #undef ISR_GO
         ISR_LAUNCH_CHECK("k_render_fwd_fast");
         ch += MAX_FCHUNK;
@@ -208,7 +209,7 @@ int isr_forward_prepare(int P, int D, int M, int width, int height, const float*
     }
     { ProfScope ps3_("k_tile_scan", s);
     hipLaunchKernelGGL(k_gather_counts, dim3((T * CNT_SUB + 255) / 256), dim3(256), 0, s, T * CNT_SUB, iv.tile_count, iv.sub_offset, iv.tile_cursor);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, iv.sub_offset, iv.tile_offset, g.header); }
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, iv.sub_offset, iv.tile_offset, g.header, iv.tile_order); }
     ISR_LAUNCH_CHECK("k_tile_scan");
     if (num_rendered_host) return isr_read_num_rendered(geom_buffer, num_rendered_host, stream);
     return ISR_OK;

@@ -763,7 +763,7 @@ __global__ __launch_bounds__(64, 3) void k_render_bwd_sparse(
     unsigned* const s_seg_in = s_q;                    // (the queue is empty whenever the samples are ranked)
     static_assert(2 * SPARSE_QUEUE >= SEG_SORT, "the sample ranking borrows the queue");
 
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x;       // (longest lists first - as k_render_bwd_geo - changes nothing here: measured)
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
     const size_t N = (size_t)W * H;
@@ -1493,6 +1493,11 @@ static bool geo_splat_enabled() {
     return on;
 }
 
+static bool geo_heavy_first() {
+    static const bool on = [] { const char* e = getenv("ISR_GEO_ORDER"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 template <class Math>
 static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int H, unsigned mask, const float* bg,
                              const float* means3D, const float* shs, const float* col_pre, const float* scales,
@@ -1522,7 +1527,7 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
         ProfScope ps_("k_render_bwd", s);
         hipLaunchKernelGGL(k_render_bwd_geo, dim3(T * 4), dim3(64), 0, s, W, H, gx, iv.tile_offset, bv.point_list, bv.box4, g.rec,
                            col_pre, tm_pre, bg, iv.final_T, iv.n_contrib, dC, dO, g.point_offsets, g.rect, partial, flags, stride,
-                           geom_off, R);
+                           geom_off, R, geo_heavy_first() ? iv.tile_order : (const uint32_t*)nullptr);
         ISR_CHECK_LAUNCH_B("k_render_bwd_geo");
     } else if (R > 0) {
         if (hipMemsetAsync(flags, 0, (size_t)R * npass, s) != hipSuccess) return -2;

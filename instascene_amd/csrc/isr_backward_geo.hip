@@ -39,11 +39,11 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
     const float* __restrict__ tm_pre, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dC, const float* __restrict__ dO,
     const uint32_t* __restrict__ point_offsets, const Rect16* __restrict__ rects, float* __restrict__ partial,
-    uint8_t* __restrict__ row_flags, int row_stride, int geom_off, int64_t capacity) {
+    uint8_t* __restrict__ row_flags, int row_stride, int geom_off, int64_t capacity, const uint32_t* __restrict__ tile_order) {
     __shared__ __attribute__((aligned(16))) float s_pix[64 * 16];
     __shared__ int s_q[GEO_QCAP];
 
-    const int tile = blockIdx.x >> 2, blk = blockIdx.x & 3;
+    const int tile = tile_order != nullptr ? (int)tile_order[blockIdx.x >> 2] : (int)(blockIdx.x >> 2), blk = blockIdx.x & 3;
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
     const int bxo = (blk & 1) * 8, byo = (blk >> 1) * 8;            // block origin inside the tile

@@ -51,6 +51,7 @@ struct ImageView {
     uint32_t* sub_offset;  // [tiles * CNT_SUB] start of every sub-bucket
     uint8_t* tile_mode;    // [tiles] backward only: live pixels of the tile (0 none, 255 = dense K9 kernel)
     uint32_t* live_list;   // [tiles, 32, 2] backward only: (x | y << 8, last contributor) of the live pixels
+    uint32_t* tile_order;  // [tiles] tile ids by descending instance count (k_tile_scan): launch order of k_render_bwd_geo
 };
 
 struct BinView {
@@ -103,11 +104,12 @@ inline ImageView image_view(void* buf, int W, int H) {
     v.sub_offset = carve<uint32_t>(p, T * CNT_SUB);
     v.tile_mode = carve<uint8_t>(p, T);
     v.live_list = carve<uint32_t>(p, T * 64);
+    v.tile_order = carve<uint32_t>(p, T);
     return v;
 }
 inline size_t image_bytes(int W, int H) {
     ImageView v = image_view((void*)0, W, H);
-    return (size_t)(v.live_list + (size_t)tiles_x(W) * tiles_y(H) * 64) + 256;
+    return (size_t)(v.tile_order + (size_t)tiles_x(W) * tiles_y(H)) + 256;
 }
 inline BinView bin_view(void* buf, int64_t R) {
     char* p = (char*)buf;

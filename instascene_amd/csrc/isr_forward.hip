@@ -302,7 +302,8 @@ __global__ __launch_bounds__(256) void k_gather_counts(int E, const uint32_t* __
 }
 
 __global__ __launch_bounds__(1024) void k_tile_scan(int T, uint32_t* __restrict__ sub_offset /* in: counts, out: offsets */,
-                                                    uint32_t* __restrict__ offset, int64_t* header) {
+                                                    uint32_t* __restrict__ offset, int64_t* header,
+                                                    uint32_t* __restrict__ tile_order) {
     // one workgroup; every thread owns a contiguous run of elements (serial prefix in registers, 16-byte accesses) and
     // the 1024 run totals are scanned once — instead of E / 1024 dependent workgroup scans
     __shared__ uint32_t s_warp[32];
@@ -338,6 +339,38 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int T, uint32_t* __restrict_
     if (threadIdx.x == 0) {
         offset[T] = carry;
         header[0] = (int64_t)carry;
+    }
+    // Launch order for kernels whose grid is only a few waves per SIMD (k_render_bwd_geo at 779x519: 1.6): heaviest tiles
+    // first (counting sort by instances / 16, 256 classes), so that the long lists start at once and the short ones fill in
+    // behind them.  Which tile of a class comes first is left to the atomics: it changes no result.
+    __shared__ uint32_t s_class[256];
+    if (threadIdx.x < 256) s_class[threadIdx.x] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 1024) {
+        const uint32_t n = offset[t + 1] - offset[t];
+        atomicAdd(&s_class[255u - min(255u, n >> 4)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                  // exclusive scan of the 256 class sizes: four per lane + a wave scan
+        uint32_t c[4], run = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { c[u] = s_class[threadIdx.x * 4 + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t x = c[u]; c[u] = run; run += x; }
+        uint32_t inc = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if ((int)threadIdx.x >= d) inc += o;
+        }
+        const uint32_t ex = inc - run;
+#pragma unroll
+        for (int u = 0; u < 4; u++) s_class[threadIdx.x * 4 + u] = ex + c[u];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 1024) {
+        const uint32_t n = offset[t + 1] - offset[t];
+        tile_order[atomicAdd(&s_class[255u - min(255u, n >> 4)], 1u)] = (uint32_t)t;
     }
 }
 

@@ -33,14 +33,15 @@ constexpr int FF_RS = 24;           // staged floats per instance (six float4)
 // AUX = false ("feature-only forward", opt-in ISR_MODE_FEATURE_ONLY): colour, the seven auxiliary maps, the median
 // contributor, the distortion moments and the tracer are not produced - only the feature map and the state the
 // feature-only backward reads (final T, last contributor).
-template <bool FEAT, bool STATS, bool AUX>
+template <bool FEAT, bool STATS, bool AUX, bool ORDER>
 __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
     int W, int H, int ED, int ch_base, int first_pass, int gx, const uint32_t* __restrict__ tile_offset,
     const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ cull,
     const float* __restrict__ col_pre, const float* __restrict__ tm_pre, const float* __restrict__ extras,
     const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_others, float* __restrict__ out_extra, int32_t* __restrict__ tracer, long long tracer_cap,
-    int32_t* __restrict__ tracer_count, uint32_t* __restrict__ box4, int64_t capacity, unsigned long long* __restrict__ stats) {
+    int32_t* __restrict__ tracer_count, uint32_t* __restrict__ box4, int64_t capacity, unsigned long long* __restrict__ stats,
+    const uint32_t* __restrict__ tile_order) {
     constexpr int BATCH = FF_BATCH, RS = FF_RS, FCH = 32;
     __shared__ __attribute__((aligned(16))) float s_rec[BATCH * RS];
     __shared__ __attribute__((aligned(16))) float s_feat[FEAT ? BATCH * FCH : 4];
@@ -51,7 +52,9 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
     __shared__ int s_trace[4 * 2 * WCAP];
     int wcnt = 0;
 
-    const int tile = blockIdx.x;
+    // small grids (a 779x519 view is 1.6 workgroups per slot of the chip): longest lists first; large ones keep the row-major
+    // order (heaviest-first costs 4 % at 1080p: measured)
+    const int tile = ORDER ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;      // (a template flag: the large-grid build is unchanged)
     const int tx = tile % gx, ty = tile / gx;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lxi = (wv & 1) * 8 + (lane & 7), lyi = (wv >> 1) * 8 + (lane >> 3);       // tile-relative pixel
