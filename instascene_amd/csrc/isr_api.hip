@@ -207,9 +207,10 @@ int isr_forward_prepare(int P, int D, int M, int width, int height, const float*
         hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, P, g.point_offsets, g.scan_tmp);
         ISR_LAUNCH_CHECK("k_scan");
     }
+    static const int order_classes = [] { const char* e = getenv("ISR_ORDER_CLASSES"); return e ? atoi(e) : 16; }();
     { ProfScope ps3_("k_tile_scan", s);
     hipLaunchKernelGGL(k_gather_counts, dim3((T * CNT_SUB + 255) / 256), dim3(256), 0, s, T * CNT_SUB, iv.tile_count, iv.sub_offset, iv.tile_cursor);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, iv.sub_offset, iv.tile_offset, g.header, iv.tile_order); }
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, iv.sub_offset, iv.tile_offset, g.header, iv.tile_order, order_classes); }
     ISR_LAUNCH_CHECK("k_tile_scan");
     if (num_rendered_host) return isr_read_num_rendered(geom_buffer, num_rendered_host, stream);
     return ISR_OK;

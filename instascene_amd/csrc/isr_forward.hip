@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void k_gather_counts(int E, const uint32_t* __
 
 __global__ __launch_bounds__(1024) void k_tile_scan(int T, uint32_t* __restrict__ sub_offset /* in: counts, out: offsets */,
                                                     uint32_t* __restrict__ offset, int64_t* header,
-                                                    uint32_t* __restrict__ tile_order) {
+                                                    uint32_t* __restrict__ tile_order, int order_classes) {
     // one workgroup; every thread owns a contiguous run of elements (serial prefix in registers, 16-byte accesses) and
     // the 1024 run totals are scanned once — instead of E / 1024 dependent workgroup scans
     __shared__ uint32_t s_warp[32];
@@ -341,36 +341,43 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int T, uint32_t* __restrict_
         header[0] = (int64_t)carry;
     }
     // Launch order for kernels whose grid is only a few waves per SIMD (k_render_bwd_geo at 779x519: 1.6): heaviest tiles
-    // first (counting sort by instances / 16, 256 classes), so that the long lists start at once and the short ones fill in
-    // behind them.  Which tile of a class comes first is left to the atomics: it changes no result.
-    __shared__ uint32_t s_class[256];
-    if (threadIdx.x < 256) s_class[threadIdx.x] = 0;
-    __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 1024) {
-        const uint32_t n = offset[t + 1] - offset[t];
-        atomicAdd(&s_class[255u - min(255u, n >> 4)], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {                  // exclusive scan of the 256 class sizes: four per lane + a wave scan
-        uint32_t c[4], run = 0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) { c[u] = s_class[threadIdx.x * 4 + u]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t x = c[u]; c[u] = run; run += x; }
-        uint32_t inc = run;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(inc, d, 64);
-            if ((int)threadIdx.x >= d) inc += o;
+    // first, so that the long lists start at once and the short ones fill in behind them.  A STABLE counting sort into
+    // `ncls` classes of the tile sizes relative to the largest one (tiles of a class keep their row-major order, i.e.
+    // neighbours - which share splats - still run close in time): thread i owns tiles [8 i, 8 i + 8).
+    {
+        __shared__ uint32_t s_cls[16 * 1024];                 // [class][thread] counts, then offsets
+        __shared__ uint32_t s_max[1];
+        const int ncls = order_classes < 1 ? 1 : (order_classes > 16 ? 16 : order_classes);
+        if (threadIdx.x == 0) s_max[0] = 1;
+        for (int e = threadIdx.x; e < ncls * 1024; e += 1024) s_cls[e] = 0;
+        __syncthreads();
+        const int per = (T + 1023) / 1024;
+        const int t0 = threadIdx.x * per, t1 = min(T, t0 + per);
+        uint32_t mx = 0;
+        for (int t = t0; t < t1; t++) mx = max(mx, offset[t + 1] - offset[t]);
+        atomicMax(&s_max[0], mx);
+        __syncthreads();
+        const uint32_t top = s_max[0];
+        auto cls_of = [&](uint32_t n) { return (int)min((uint32_t)(ncls - 1), (uint32_t)(((unsigned long long)(top - n) * ncls) / (top + 1u))); };
+        for (int t = t0; t < t1; t++) s_cls[cls_of(offset[t + 1] - offset[t]) * 1024 + threadIdx.x]++;
+        __syncthreads();
+        // exclusive scan over (class, thread): ncls * 1024 counters, ncls per thread + one block scan
+        uint32_t mine[16], run = 0;
+        for (int k = 0; k < ncls; k++) { const int e = threadIdx.x * ncls + k; mine[k] = s_cls[e]; }
+        for (int k = 0; k < ncls; k++) { const uint32_t x = mine[k]; mine[k] = run; run += x; }
+        uint32_t total;
+        __syncthreads();
+        const uint32_t ex = block_exclusive_scan_1024(run, s_warp, total);
+        for (int k = 0; k < ncls; k++) s_cls[threadIdx.x * ncls + k] = ex + mine[k];
+        __syncthreads();
+        uint32_t cur[16];
+        for (int k = 0; k < ncls; k++) cur[k] = s_cls[k * 1024 + threadIdx.x];
+        for (int t = t0; t < t1; t++) {
+            const int c = cls_of(offset[t + 1] - offset[t]);
+            uint32_t at = 0;
+            for (int k = 0; k < ncls; k++) if (k == c) at = cur[k]++;
+            tile_order[at] = (uint32_t)t;
         }
-        const uint32_t ex = inc - run;
-#pragma unroll
-        for (int u = 0; u < 4; u++) s_class[threadIdx.x * 4 + u] = ex + c[u];
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 1024) {
-        const uint32_t n = offset[t + 1] - offset[t];
-        tile_order[atomicAdd(&s_class[255u - min(255u, n >> 4)], 1u)] = (uint32_t)t;
     }
 }
 
