@@ -154,6 +154,7 @@ class SegTrainer:
         # kernel, which is issue-bound and leaves the memory system idle) instead of behind it (beside the loss kernels, the
         # backward and the bandwidth-bound tail)
         import os as _os
+        self.draw_ahead = _os.environ.get("ISR_DRAW_AHEAD", "1") == "1"
         self.prefetch_early = _os.environ.get("ISR_PREFETCH_EARLY", "1") == "1"     # measured: 2.092 -> 2.066 ms per C3 step
         self.high_priority_main = _os.environ.get("ISR_MAIN_PRIORITY", "1") == "1"     # measured: 2.03 -> 1.995 ms per C3 step
         self.split_tail = False      # tests: take the multi-rank form of the tail (dL/dx, all-reduce, Adam) with one rank
@@ -377,7 +378,11 @@ class SegTrainer:
         drawn = None
         if merged and self.fused_sampling:
             # every index this step needs, from one kernel (iso_sample_step): pixels + their labels, 3-D picks + theirs
-            drawn = self._draw_samples(it, vi)
+            ahead = getattr(self, "_drawn_ahead", None)
+            self._drawn_ahead = None
+            # (drawn one step early, behind the previous forward: the draw is a function of (seed, it, view) alone, so it
+            # need not sit between the previous step's tail and this forward)
+            drawn = ahead[2] if (ahead is not None and ahead[0] == it and ahead[1] == vi) else self._draw_samples(it, vi)
             pix = drawn[0]
         elif merged:
             # the pixels do not depend on the render: choose them first and let the rasterizer hand back the features at
@@ -393,6 +398,10 @@ class SegTrainer:
         # than it hides: measured.)
         if not self.prefetch_early:
             self._prefetch_next(it)
+        if merged and self.fused_sampling and self.draw_ahead:
+            vn = self.view_index(it + 1)
+            if self.valid_idx[vn].numel() > 0 and (self.l3d <= 0 or self.vis_pool.get(vn) is not None):
+                self._drawn_ahead = (it + 1, vn, self._draw_samples(it + 1, vn))
         seg_feature = pkg["seg_feature"]
         # the step's prototype-contrastive losses, as (features, labels, predefined prototypes, weight)
         problems = []
