@@ -10,7 +10,11 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $ROOT/bench.py 2>$OUT/bench_c3.err | tail -1 > $OUT/bench_c3.json
+# (the 779x519 train.py step is host-bound - 1.05 ms of enqueue work for 0.95 ms of kernels - and each bench ends with a
+# 128-thread CPU baseline: let the host cores cool down, or the next headline block runs at 1.25 ms per step)
+sleep 45
 python $ROOT/bench.py --config C2 2>$OUT/bench_c2.err | tail -1 > $OUT/bench_c2_rgb.json
+sleep 45
 python $ROOT/bench.py --config C3 --step rgb --no-cpu-baseline --submodes exact 2>/dev/null | tail -1 > $OUT/bench_c3_rgb.json
 python $ROOT/bench.py --config C5 --no-cpu-baseline --submodes "" 2>/dev/null | tail -1 > $OUT/bench_c5.json
 for CFG in "C3:seg" "C2:rgb"; do
