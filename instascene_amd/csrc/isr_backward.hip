@@ -1273,6 +1273,11 @@ __device__ __forceinline__ F3 dnorm_dv(F3 v, F3 dv) {
     return r;
 }
 
+// STAGE_SH (degree-3 colours, M = 16): the workgroup's 256 SH rows and its 256 rows of dL/dSH are contiguous 48 KB pieces of
+// their tensors; a lane walking its own 192-byte row touches 64 cache lines per instruction (and the gradient row was
+// written twice: zeros, then values).  Both now go through LDS - coalesced 16-byte loads in, the lane's coefficients copied
+// to registers, the gradient row assembled in the same LDS row, coalesced 16-byte stores out - as K1 does for its input.
+template <bool STAGE_SH>
 __global__ __launch_bounds__(256) void k_preprocess_bwd(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ tm_pre,
@@ -1289,14 +1294,68 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     constexpr float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                              -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    constexpr int SH_STRIDE = 52;           // floats per staged row: 48 + 4 (16-byte aligned, spreads the LDS banks)
+    __shared__ __attribute__((aligned(16))) float s_sh[STAGE_SH ? 256 * SH_STRIDE : 4];
+    float creg[STAGE_SH ? 48 : 1];
+    if constexpr (STAGE_SH) {
+        const int i0 = blockIdx.x * 256;
+        const int nq = min(256, P - i0) * 12;                      // float4s to move
+        const float4* src = reinterpret_cast<const float4*>(shs + (size_t)i0 * 48);
+        float4 v[12];
+#pragma unroll
+        for (int u = 0; u < 12; u++) v[u] = src[min((int)threadIdx.x + u * 256, nq - 1)];
+#pragma unroll
+        for (int u = 0; u < 12; u++) {
+            const int e = (int)threadIdx.x + u * 256;
+            if (e < nq) { const int r = e / 12, k = e - r * 12; *reinterpret_cast<float4*>(s_sh + r * SH_STRIDE + 4 * k) = v[u]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const float4 q = *reinterpret_cast<const float4*>(s_sh + threadIdx.x * SH_STRIDE + 4 * k);
+            creg[4 * k] = q.x; creg[4 * k + 1] = q.y; creg[4 * k + 2] = q.z; creg[4 * k + 3] = q.w;
+        }
+    }
     const size_t I = (size_t)i;
+    if (i < P) {
     // every output row is fully written (no zero-initialisation by the caller)
     float gs[18];
 #pragma unroll
     for (int q = 0; q < 18; q++) gs[q] = 0.0f;
     const uint32_t nt = g.tiles_touched[i] * (uint32_t)rpi;
-    if (nt > 0) {
+    if (nt > 0 && rpi == 4) {
+        // four rows per tile instance (k_render_bwd_geo): the instance's four flags are one aligned word, and the flagged rows
+        // of an instance are requested together - a quarter of the dependent memory round trips of the row-by-row walk
+        // (the kernel is bound by that chain, not by bytes).  Same summation order: instance by instance, block 0..3.
+        const float* src = partial + (size_t)g.point_offsets[i] * 4 * row_stride + geom_off;
+        const uint32_t* fw = reinterpret_cast<const uint32_t*>(row_flags + (size_t)g.point_offsets[i] * 4);
+        const uint32_t ni = nt >> 2;
+        uint32_t f_next = fw[0];
+        for (uint32_t t = 0; t < ni; t++) {
+            const uint32_t f4 = f_next;
+            if (t + 1 < ni) f_next = fw[t + 1];
+            if (f4 == 0u) continue;
+            float4 rw[4][5];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const bool on = ((f4 >> (8 * b)) & 0xffu) != 0u;
+                const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)(4 * t + b) * row_stride);
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    rw[b][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (on) rw[b][k] = s4[k];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if (((f4 >> (8 * b)) & 0xffu) == 0u) continue;      // (an unflagged row adds nothing, not even +0)
+                const float4 a = rw[b][0], bq = rw[b][1], c = rw[b][2], d = rw[b][3], e = rw[b][4];
+                gs[0] += a.x; gs[1] += a.y; gs[2] += a.z; gs[3] += a.w; gs[4] += bq.x; gs[5] += bq.y; gs[6] += bq.z; gs[7] += bq.w;
+                gs[8] += c.x; gs[9] += c.y; gs[10] += c.z; gs[11] += c.w; gs[12] += d.x; gs[13] += d.y; gs[14] += d.z;
+                gs[15] += d.w; gs[16] += e.x; gs[17] += e.y;
+            }
+        }
+    } else if (nt > 0) {
         const float* src = partial + (size_t)g.point_offsets[i] * rpi * row_stride + geom_off;
         const uint8_t* fl = row_flags + (size_t)g.point_offsets[i] * rpi;
         for (uint32_t r = 0; r < nt; r++) {
@@ -1317,8 +1376,9 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     float m2x = 0, m2y = 0;
     const bool vis = g.radii[i] > 0;
     const bool precomp = (tm_pre != nullptr);
-    if (dL_dsh != nullptr)
-        for (int k = 0; k < M * 3; k++) dL_dsh[I * M * 3 + k] = 0.0f;
+    float* const sh_out = STAGE_SH ? s_sh + threadIdx.x * SH_STRIDE : (dL_dsh != nullptr ? dL_dsh + I * M * 3 : nullptr);
+    if (sh_out != nullptr)
+        for (int k = 0; k < M * 3; k++) sh_out[k] = 0.0f;
     if (vis) {
         const float* rec = g.rec + I * REC;
         F3 Tu, Tv, Tw, normal = {0, 0, 0}, R0 = {0, 0, 0}, R1 = {0, 0, 0}, R2 = {0, 0, 0};
@@ -1412,14 +1472,14 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
             const F3 dir_orig = pos - F3{campos[0], campos[1], campos[2]};
             const float len = __builtin_sqrtf(dot3(dir_orig, dir_orig));
             const F3 dir = {dir_orig.x / len, dir_orig.y / len, dir_orig.z / len};
-            const float* shp = shs + I * M * 3;
+            const float* shp = STAGE_SH ? creg : shs + I * M * 3;
             auto sh = [&](int k) { return F3{shp[3 * k], shp[3 * k + 1], shp[3 * k + 2]}; };
             const unsigned cm = g.clamped[i];
             F3 dRGB = {gs[15], gs[16], gs[17]};
             dRGB.x *= (cm & 1u) ? 0.f : 1.f; dRGB.y *= (cm & 2u) ? 0.f : 1.f; dRGB.z *= (cm & 4u) ? 0.f : 1.f;
             F3 ddx = {0, 0, 0}, ddy = {0, 0, 0}, ddz = {0, 0, 0};
             const float x = dir.x, y = dir.y, z = dir.z;
-            float* out = dL_dsh + I * M * 3;
+            float* out = sh_out;
             auto put = [&](int k, float c) { out[3 * k] = c * dRGB.x; out[3 * k + 1] = c * dRGB.y; out[3 * k + 2] = c * dRGB.z; };
             put(0, C0);
             if (D > 0) {
@@ -1468,6 +1528,18 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     dL_dmean3D[3 * I] = m3x; dL_dmean3D[3 * I + 1] = m3y; dL_dmean3D[3 * I + 2] = m3z;
     dL_dscale[2 * I] = dsc0; dL_dscale[2 * I + 1] = dsc1;
     dL_drot[4 * I] = dq[0]; dL_drot[4 * I + 1] = dq[1]; dL_drot[4 * I + 2] = dq[2]; dL_drot[4 * I + 3] = dq[3];
+    }
+    if constexpr (STAGE_SH) {
+        __syncthreads();
+        const int i0 = blockIdx.x * 256;
+        const int nq = min(256, P - i0) * 12;
+        float4* dst = reinterpret_cast<float4*>(dL_dsh + (size_t)i0 * 48);
+#pragma unroll
+        for (int u = 0; u < 12; u++) {
+            const int e = (int)threadIdx.x + u * 256;
+            if (e < nq) { const int r = e / 12, k = e - r * 12; dst[e] = *reinterpret_cast<const float4*>(s_sh + r * SH_STRIDE + 4 * k); }
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -1580,9 +1652,14 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
         const float focal_y = H / (2.0f * tan_fovy), focal_x = W / (2.0f * tan_fovx);
         const int Wd = (int)(focal_x * tan_fovx * 2), Hd = (int)(focal_y * tan_fovy * 2);   // backward.cu:633-634
         ProfScope ps_("k_preprocess_bwd", s);
-        hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, shs, scales, rots,
-                           tm_pre, view, proj, campos, Wd, Hd, g, partial, flags, stride, geom_off, rpi, dL_dmean2D, dL_dnormal,
-                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot);
+        if (shs != nullptr && dL_dsh != nullptr && M == 16)
+            hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, shs, scales, rots,
+                               tm_pre, view, proj, campos, Wd, Hd, g, partial, flags, stride, geom_off, rpi, dL_dmean2D, dL_dnormal,
+                               dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot);
+        else
+            hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, shs, scales, rots,
+                               tm_pre, view, proj, campos, Wd, Hd, g, partial, flags, stride, geom_off, rpi, dL_dmean2D, dL_dnormal,
+                               dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot);
         ISR_CHECK_LAUNCH_B("k_preprocess_bwd");
     }
     return 0;
