@@ -149,23 +149,22 @@ __global__ __launch_bounds__(256) void ssim_fwd(int C, int H, int W, SsimTaps tp
 // out[1..4] = L1 mean, SSIM mean, normal-error mean, distortion mean.  Fixed summation order.
 __global__ __launch_bounds__(256) void train_loss_sum(int nblk, int tiles, const float* __restrict__ part, float inv_chw,
                                                       float inv_hw, float lam, float ln, float ldist, float* __restrict__ out) {
-    __shared__ float s_red[4];
-    float tot[4];
+    __shared__ float s_tot[4];
+    // wave a sums array a (fixed order: 64 strided partial sums, then the butterfly)
+    const int a = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* p = part + (a == 0 ? 0 : a == 1 ? nblk : a == 2 ? 2 * nblk : 2 * nblk + tiles);
+    const int n = a < 2 ? nblk : tiles;
+    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+    int i = lane;
+    for (; i + 192 < n; i += 256) { v0 += p[i]; v1 += p[i + 64]; v2 += p[i + 128]; v3 += p[i + 192]; }
+    for (; i < n; i += 64) v0 += p[i];
+    float v = (v0 + v1) + (v2 + v3);
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
-        const float* p = part + (a == 0 ? 0 : a == 1 ? nblk : a == 2 ? 2 * nblk : 2 * nblk + tiles);
-        const int n = a < 2 ? nblk : tiles;
-        float v = 0.0f;
-        for (int i = threadIdx.x; i < n; i += 256) v += p[i];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-        __syncthreads();
-        tot[a] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-    }
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) s_tot[a] = v;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const float ssim = tot[0] * inv_chw, l1 = tot[1] * inv_chw, ne = tot[2] * inv_hw, dm = tot[3] * inv_hw;
+        const float ssim = s_tot[0] * inv_chw, l1 = s_tot[1] * inv_chw, ne = s_tot[2] * inv_hw, dm = s_tot[3] * inv_hw;
         const float photo = (1.0f - lam) * l1 + lam * (1.0f - ssim);
         out[0] = (photo + ldist * dm) + ln * ne;
         out[1] = l1; out[2] = ssim; out[3] = ne; out[4] = dm;

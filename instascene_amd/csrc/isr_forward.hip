@@ -344,8 +344,39 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int T, uint32_t* __restrict_
     // first, so that the long lists start at once and the short ones fill in behind them.  A STABLE counting sort into
     // `ncls` classes of the tile sizes relative to the largest one (tiles of a class keep their row-major order, i.e.
     // neighbours - which share splats - still run close in time): thread i owns tiles [8 i, 8 i + 8).
-    {
-        __shared__ uint32_t s_cls[16 * 1024];                 // [class][thread] counts, then offsets
+    __shared__ uint32_t s_cls[16 * 1024];                 // [class][thread] counts, then offsets
+    if (T < 4096) {
+        // small views (where this kernel sits in the step's chain): 256 classes of 16 instances, LDS atomics - which tile of a
+        // class comes first is left to the atomics (it changes no result)
+        if (threadIdx.x < 256) s_cls[threadIdx.x] = 0;
+        __syncthreads();
+        for (int t = threadIdx.x; t < T; t += 1024) {
+            const uint32_t n = offset[t + 1] - offset[t];
+            atomicAdd(&s_cls[255u - min(255u, n >> 4)], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {                  // exclusive scan of the 256 class sizes: four per lane + a wave scan
+            uint32_t c[4], run = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) { c[u] = s_cls[threadIdx.x * 4 + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t x = c[u]; c[u] = run; run += x; }
+            uint32_t inc = run;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(inc, d, 64);
+                if ((int)threadIdx.x >= d) inc += o;
+            }
+            const uint32_t ex = inc - run;
+#pragma unroll
+            for (int u = 0; u < 4; u++) s_cls[threadIdx.x * 4 + u] = ex + c[u];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < T; t += 1024) {
+            const uint32_t n = offset[t + 1] - offset[t];
+            tile_order[atomicAdd(&s_cls[255u - min(255u, n >> 4)], 1u)] = (uint32_t)t;
+        }
+    } else {
         __shared__ uint32_t s_max[1];
         const int ncls = order_classes < 1 ? 1 : (order_classes > 16 ? 16 : order_classes);
         if (threadIdx.x == 0) s_max[0] = 1;
