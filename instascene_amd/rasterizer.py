@@ -230,6 +230,16 @@ class _Prefetched:
         self.binning, self.done, self.inputs = binning, done, inputs
 
 
+def _round_capacity(r: int) -> int:
+    """Capacities in steps of 1/32 of their magnitude: the views of a scene then ask the caching allocator for a handful of
+    distinct workspace sizes instead of one per view, and its pools stop growing (a hipMalloc of hundreds of MB in the middle
+    of a training loop) after the first few steps rather than after the first visit of every view."""
+    if r <= 0:
+        return r
+    g = 1 << max(0, r.bit_length() - 6)
+    return (r + g - 1) // g * g
+
+
 def _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
              transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img, tight=None):
     """K1 + tile scan (``isr_forward_prepare``) into ``radii / geom / img``; returns ``(R, is_capacity)``: the instance
@@ -249,7 +259,7 @@ def _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, op
                                 _ptr(geom), _ptr(img),
                                 None if use_async else ctypes.byref(num_rendered), st), "isr_forward_prepare")
     if use_async:
-        R = int(_R_ESTIMATE[ekey] * _ASYNC_GROWTH) + _ASYNC_SLACK            # capacity, not the count
+        R = _round_capacity(int(_R_ESTIMATE[ekey] * _ASYNC_GROWTH) + _ASYNC_SLACK)      # capacity, not the count
         pinned = _pinned_slot()
         pinned.copy_(geom[:8].view(torch.int64), non_blocking=True)   # header[0] = R
         ev = torch.cuda.Event()
