@@ -177,6 +177,8 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
         trainer = SegTrainer(scene, cams[:n_views], device=dev, sample_batchsize=8192, use_class_feat=True, rank=rank, world=world,
                              spatial_sort=bool(args.spatial_sort), fused_sampling=bool(args.fused_sampling))
         trainer.split_tail = bool(args.split_tail)
+        if args.sharded_tail is not None:
+            trainer.sharded_tail = bool(args.sharded_tail)
         trainer.pipe.lazy_maps = bool(args.lazy_maps)
         trainer.pipe.feature_only_forward = feature_only
         trainer.warm_view_caches()       # per-view constants (ray tables, visible pools, instance counts): setup
@@ -232,7 +234,8 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     rec = {"value": round(world * args.steps / dt, 3), "ms_per_step": round(1e3 * dt / args.steps, 4),
-           "arithmetic_mode": mode + ("+feature_only" if feature_only else "")}
+           "arithmetic_mode": mode + ("+feature_only" if feature_only else ""),
+           "sharded_tail": bool(getattr(trainer, "sharded_tail", False))}
     extra_steps = min(5, args.steps)
     it0 = it_next
     if detail:
@@ -353,6 +356,9 @@ def main():
                          "before the timed region; a pure relabelling of rows); 0: keep the generator's random order")
     ap.add_argument("--fused-sampling", type=int, default=1,
                     help="1 (default): one kernel draws every index of a step (iso_sample_step); 0: torch.randint + gathers")
+    ap.add_argument("--sharded-tail", type=int, default=None,
+                    help="1: several ranks exchange dL/dparam by reduce-scatter, run Adam on their shard of the rows and all-gather "
+                         "the parameter rows (SegTrainer.sharded_tail; default: ISR_SHARDED_TAIL or off)")
     ap.add_argument("--split-tail", type=int, default=0,
                     help="1: with one rank, take the multi-rank form of the per-Gaussian tail to measure what it costs")
     args = ap.parse_args()
@@ -442,6 +448,9 @@ def main():
                           "allreduce_ms_per_step_alone": head.get("allreduce_ms"),
                           "gaussian_order": "z-order of the centres, sorted once at load" if args.spatial_sort else "as generated (random)",
                           "derived_render_maps": "on first access (never read by the seg step)" if args.lazy_maps else "inside render(), like the reference",
+                          "multi_rank_tail": ("sharded: reduce-scatter, owner-only Adam, all-gather of the parameter rows"
+                                              if head.get("sharded_tail") else
+                                              "replicated: row-range pipelined all-reduce, Adam on every rank") if world > 1 else "n/a (one rank)",
                           "step_loop_stream": "the trainer's own high-priority HIP stream for the whole block of steps (SegTrainer.stream_scope); "
                                               "the next view's geometry pass + binning on one side stream",
                           "view_order": "deterministic round-robin over 16 ring cameras (the reference pops a random view, "

@@ -394,8 +394,25 @@ class FeatureAdam:
         self.step_count += 1
         self._pending_yz = (torch.empty_like(p.data) if self.store_y else None, torch.empty_like(p.data))
 
-    def step_range(self, r0: int, r1: int):
-        """Adam + the two normalisations on rows ``[r0, r1)`` from ``param.grad`` (``iso_adam_rownorm2`` on the slice)."""
+    def step_range(self, r0: int, r1: int, grad_rows=None):
+        """Adam + the two normalisations on rows ``[r0, r1)`` from ``param.grad`` (``iso_adam_rownorm2`` on the slice), or
+        from ``grad_rows [r1 - r0, F]`` when the summed gradient of those rows lives elsewhere (a reduce-scatter's shard)."""
+        p = self.param
+        if r1 <= r0:
+            return
+        F = p.shape[1]
+        y, z = self._pending_yz
+        at = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr() + 4 * F * int(r0))
+        g = at(p.grad) if grad_rows is None else _p(grad_rows.contiguous())
+        with torch.cuda.device(p.device):
+            check(lib().iso_adam_rownorm2(int(r1 - r0), F, self.lr, float(self.betas[0]), float(self.betas[1]), self.eps,
+                                          self.step_count, float(self.norm_eps[0]), float(self.norm_eps[1]), at(p.data),
+                                          g, at(self.exp_avg), at(self.exp_avg_sq), at(y), at(z), _stream()),
+                  "iso_adam_rownorm2")
+
+    def renormalize_range(self, r0: int, r1: int):
+        """The two normalisations of rows ``[r0, r1)`` of the CURRENT parameter into the pending outputs (``iso_rownorm2``):
+        for rows whose Adam step ran on another rank and arrived by all-gather (SegTrainer's sharded tail)."""
         p = self.param
         if r1 <= r0:
             return
@@ -403,10 +420,8 @@ class FeatureAdam:
         y, z = self._pending_yz
         at = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr() + 4 * F * int(r0))
         with torch.cuda.device(p.device):
-            check(lib().iso_adam_rownorm2(int(r1 - r0), F, self.lr, float(self.betas[0]), float(self.betas[1]), self.eps,
-                                          self.step_count, float(self.norm_eps[0]), float(self.norm_eps[1]), at(p.data),
-                                          at(p.grad), at(self.exp_avg), at(self.exp_avg_sq), at(y), at(z), _stream()),
-                  "iso_adam_rownorm2")
+            check(lib().iso_rownorm2(int(r1 - r0), F, float(self.norm_eps[0]), float(self.norm_eps[1]), 0, at(p.data), None, None,
+                                     at(y), at(z), _stream()), "iso_rownorm2")
 
     def end_step(self):
         p = self.param

@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void rn2_kernel(long long N, int F, float eps1
         for (int o = lpr >> 1; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
         const float r2 = 1.0f / (__builtin_sqrtf(s2) + eps2);
         if (ok) {
-            *reinterpret_cast<float4*>(out1 + off) = y;
+            if (out1 != nullptr) *reinterpret_cast<float4*>(out1 + off) = y;        // (y is optional: a sharded tail wants z only)
             *reinterpret_cast<float4*>(out2 + off) = make_float4(y.x * r2, y.y * r2, y.z * r2, y.w * r2);
         }
     } else {

@@ -845,7 +845,7 @@ int iso_rownorm2(long long N, int F, float eps1, float eps2, int backward, const
                  const float* gz, float* out1, float* out2, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (N < 0 || F <= 0 || (F & 3) != 0 || F > 256) return fail(ISR_EINVAL, "rownorm2 needs F % 4 == 0 and F <= 256");
-    if (N > 0 && (!x || !out1 || (!backward && !out2))) return fail(ISR_EINVAL, "bad rownorm2 arguments");
+    if (N > 0 && (!x || (backward && !out1) || (!backward && !out2))) return fail(ISR_EINVAL, "bad rownorm2 arguments");
     if (N == 0) return ISR_OK;
     int q = F >> 2, lpr = 1;
     while (lpr < q) lpr <<= 1;

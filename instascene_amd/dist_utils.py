@@ -82,6 +82,37 @@ def allreduce_rows_async(t: torch.Tensor, r0: int, r1: int, world: int):
     return dist.all_reduce(t[r0:r1], op=dist.ReduceOp.SUM, async_op=True)
 
 
+def shard_rows(n_rows: int, rank: int, world: int):
+    """Rows ``[r0, r1)`` owned by ``rank`` when ``n_rows`` (a multiple of ``world``) are dealt out in contiguous shards."""
+    per = n_rows // world
+    return rank * per, (rank + 1) * per
+
+
+def reduce_scatter_rows(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Sum the contiguous ``[P, ...]`` tensor ``t`` over the ranks and return THIS rank's shard of the sum (rows
+    ``shard_rows(P, rank, world)``) - half the traffic of an all-reduce.  RCCL: one ``reduce_scatter_tensor``; gloo (the CPU /
+    one-GPU tests) has no reduce-scatter: all-reduce and slice, the same values."""
+    r0, r1 = shard_rows(t.shape[0], rank, world)
+    if dist.get_backend() == "nccl":
+        out = torch.empty_like(t[r0:r1])
+        dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM)
+        return out
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t[r0:r1]
+
+
+def all_gather_rows(t: torch.Tensor, rank: int, world: int) -> None:
+    """Every rank holds valid rows ``shard_rows(P, rank, world)`` of the contiguous ``t``; afterwards all of ``t`` is valid
+    everywhere (the other half of an all-reduce's traffic)."""
+    r0, r1 = shard_rows(t.shape[0], rank, world)
+    mine = t[r0:r1].clone()
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(t, mine)
+        return
+    per = r1 - r0
+    dist.all_gather([t[k * per:(k + 1) * per] for k in range(world)], mine)
+
+
 def wait_all(works) -> None:
     for w in works:
         if w is not None:

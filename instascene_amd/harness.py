@@ -157,6 +157,7 @@ class SegTrainer:
         self.draw_ahead = _os.environ.get("ISR_DRAW_AHEAD", "1") == "1"
         self.prefetch_early = _os.environ.get("ISR_PREFETCH_EARLY", "1") == "1"     # measured: 2.092 -> 2.066 ms per C3 step
         self.high_priority_main = _os.environ.get("ISR_MAIN_PRIORITY", "1") == "1"     # measured: 2.03 -> 1.995 ms per C3 step
+        self.sharded_tail = _os.environ.get("ISR_SHARDED_TAIL", "0") == "1"    # opt-in (unmeasured on hardware): _tail_sharded
         self.split_tail = False      # tests: take the multi-rank form of the tail (dL/dx, all-reduce, Adam) with one rank
         self.tail_chunks = 4         # row ranges of that form (all-reduce of one overlaps the kernels of the others)
         F = scene.seg_feature.shape[1]
@@ -466,7 +467,10 @@ class SegTrainer:
                 self.opt.step_rows(sink.rows, row_grads=sink.row_grads)
                 m._seg_cache = None
                 return loss.detach()
-            self._tail_with_allreduce(sink)
+            if self.sharded_tail and m._seg_feature.shape[0] % self.world == 0:
+                self._tail_sharded(sink)
+            else:
+                self._tail_with_allreduce(sink)
             m._seg_cache = None
             return loss.detach()
         loss.backward()
@@ -478,6 +482,30 @@ class SegTrainer:
         self.opt.zero_grad(set_to_none=True)
         m._seg_cache = None          # the graph of this step is gone
         return loss.detach()
+
+    def _tail_sharded(self, sink):
+        """Several ranks, opt-in (``sharded_tail``; P divisible by the world size): reduce-scatter of dL/dparam, Adam on THIS
+        rank's contiguous shard of the rows only, all-gather of the updated parameter rows, local re-normalisation of the rows
+        that arrived.  The same bytes on the links as the all-reduce (its two halves), but each rank runs the optimiser pass on
+        1/W of the table (and needs the Adam moments of its shard only): per rank ~5 of the 8 [P,F] streams of the replicated
+        tail disappear.  Replicas stay bit-identical (every row is computed once, by its owner)."""
+        from .dist_utils import all_gather_rows, reduce_scatter_rows, shard_rows
+        opt, p = self.opt, self.model._seg_feature
+        P = p.shape[0]
+        tail = opt.begin_tail(sink.rows, sink.row_grads)
+        if tail is None:
+            p.grad = torch.zeros_like(p.data)
+        else:
+            opt.tail_gradient(tail, 0, P)
+        r0, r1 = shard_rows(P, self.rank, self.world)
+        mine = reduce_scatter_rows(p.grad, self.rank, self.world)
+        opt.begin_step()
+        opt.step_range(r0, r1, grad_rows=mine)
+        all_gather_rows(p.data, self.rank, self.world)
+        opt.renormalize_range(0, r0)
+        opt.renormalize_range(r1, P)
+        opt.end_step()
+        opt.zero_grad(set_to_none=True)
 
     def _tail_with_allreduce(self, sink):
         """Several ranks: dL/dparam must be summed before Adam.  The [P,F] table is walked in ``tail_chunks`` row ranges:

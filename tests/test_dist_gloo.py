@@ -118,3 +118,36 @@ def test_flat_bucket_allreduce_equals_the_sum_of_the_tensors(tmp_path):
     from instascene_amd.dist_utils import allreduce_bucket
     t = [torch.ones(3), None]
     assert allreduce_bucket(t, 1) == t
+
+
+def _shard_worker(rank, world, port, out):
+    from instascene_amd.dist_utils import all_gather_rows, reduce_scatter_rows, shard_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(11 + rank)
+    t = torch.randn(12, 8, generator=g)
+    mine0 = t.clone()
+    r0, r1 = shard_rows(12, rank, world)
+    shard = reduce_scatter_rows(t, rank, world).clone()            # the sum over ranks of rows [r0, r1)
+    table = torch.full((12, 8), float("nan"))
+    table[r0:r1] = shard * 2.0                                     # "the owner's update of its rows"
+    all_gather_rows(table, rank, world)
+    torch.save({"mine": mine0, "shard": shard, "table": table, "rows": (r0, r1)}, os.path.join(out, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_reduce_scatter_and_all_gather_of_row_shards(tmp_path):
+    """The two halves of the sharded tail's exchange (dist_utils.reduce_scatter_rows / all_gather_rows; gloo has no
+    reduce-scatter, so the helper all-reduces and slices): a rank's shard is the sum of those rows over the ranks, and after the
+    gather every rank holds every owner's rows."""
+    world = 3
+    mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f"s{r}.pt") for r in range(world)]
+    total = sum(r["mine"] for r in rs)
+    owners = torch.cat([r["shard"] for r in rs])                   # every row as its owner received it
+    torch.testing.assert_close(owners, total, rtol=0, atol=1e-6)   # (the collective's order of additions is its own)
+    for r in rs:
+        assert torch.equal(r["table"], owners * 2.0)               # ... and exactly those rows everywhere after the gather
+    assert [r["rows"] for r in rs] == [(0, 4), (4, 8), (8, 12)]

@@ -34,7 +34,7 @@ def _trainer(rank, world):
                       world=world)
 
 
-def _worker(rank, world, port, steps, out):
+def _worker(rank, world, port, steps, out, sharded=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -42,6 +42,7 @@ def _worker(rank, world, port, steps, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from instascene_amd.dist_utils import replicas_in_sync
     tr = _trainer(rank, world)
+    tr.sharded_tail = bool(sharded)
     tr.warm_view_caches()
     tr.prime()
     grads = []
@@ -67,6 +68,29 @@ def test_two_ranks_share_a_gpu_and_stay_in_sync(tmp_path):
         rz.set_async_binning(False)
         rz.set_mode("exact")
         rz.set_tracer(True)
+
+
+@pytest.mark.timeout(300)
+def test_sharded_tail_equals_the_all_reduce_tail(tmp_path):
+    """Opt-in SegTrainer.sharded_tail (reduce-scatter, Adam on the rank's shard of the rows, all-gather of the parameter rows,
+    local re-normalisation) against the replicated tail: same parameters bit for bit on both ranks (under gloo the
+    reduce-scatter is an all-reduce + slice, so the sums are the same sums), and each rank's Adam moments are those of the
+    replicated run on ITS shard and untouched elsewhere."""
+    world, steps = 2, 4
+    a, b = tmp_path / "ar", tmp_path / "sh"
+    a.mkdir(); b.mkdir()
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(a), False), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(b), True), nprocs=world, join=True)
+    ar = [torch.load(a / f"r{r}.pt") for r in range(world)]
+    sh = [torch.load(b / f"r{r}.pt") for r in range(world)]
+    assert torch.equal(sh[0]["p"], sh[1]["p"])
+    assert torch.equal(sh[0]["p"], ar[0]["p"])
+    P = ar[0]["p"].shape[0]
+    for r in range(world):
+        r0, r1 = r * (P // world), (r + 1) * (P // world)
+        assert torch.equal(sh[r]["m"][r0:r1], ar[r]["m"][r0:r1])
+        other = torch.cat([sh[r]["m"][:r0], sh[r]["m"][r1:]])
+        assert float(other.abs().max()) == 0.0            # the shard owner is the only rank that keeps those moments
 
 
 def _single_process_reference(world, steps, r0):
@@ -115,6 +139,48 @@ def _gradient_of_step(tr, it):
         tr.opt.leaf_mode = False
         tr.opt.leaves = None
         tr.model._seg_cache = None
+
+
+def _one_rank_sharded_worker(_, backend, port, steps, out, sharded):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    tr = _trainer(0, 1)
+    tr.split_tail = True                # one rank takes the multi-rank form of the tail
+    tr.sharded_tail = bool(sharded)
+    tr.warm_view_caches()
+    tr.prime()
+    for it in range(steps):
+        tr.step(it)
+    torch.cuda.synchronize()
+    torch.save({"p": tr.model._seg_feature.detach().cpu(), "m": tr.opt.exp_avg.cpu(), "v": tr.opt.exp_avg_sq.cpu()},
+               os.path.join(out, f"{backend}_{int(sharded)}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_reduce_scatter_and_all_gather_of_the_sharded_tail(tmp_path):
+    """The sharded tail's collectives on a real ``nccl`` group (one rank: the shard is the whole table):
+    ``reduce_scatter_tensor`` + ``all_gather_into_tensor`` between the library's kernels must give the bits of the gloo run and
+    of the all-reduce tail."""
+    steps = 3
+    try:
+        for backend, sharded in (("nccl", True), ("gloo", True), ("nccl", False)):
+            mp.spawn(_one_rank_sharded_worker, args=(backend, _free_port(), steps, str(tmp_path), sharded), nprocs=1, join=True)
+    finally:
+        from instascene_amd import rasterizer as rz
+        rz.set_async_binning(False)
+        rz.set_mode("exact")
+        rz.set_tracer(True)
+    a, b, c = torch.load(tmp_path / "nccl_1.pt"), torch.load(tmp_path / "gloo_1.pt"), torch.load(tmp_path / "nccl_0.pt")
+    for k in ("p", "m", "v"):
+        assert torch.equal(a[k], b[k]), k
+        assert torch.equal(a[k], c[k]), k
 
 
 def _one_rank_group_worker(_, backend, port, steps, out):
@@ -180,3 +246,11 @@ def test_bench_launches_itself_for_several_ranks():
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0
     assert rec["config"]["rccl_world_size"] == 2 and rec["config"]["allreduce_ms_per_step_alone"] is not None
     assert rec["roofline"]["kernel"] == "k_render_fwd" and rec["cpu_baseline"] is None
+    assert rec["config"]["multi_rank_tail"].startswith("replicated")
+    # ... and the same flow with the opt-in sharded tail
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--submodes", "", "--sharded-tail", "1"], env=env, capture_output=True, text=True,
+                       timeout=560, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["multi_rank_tail"].startswith("sharded")
