@@ -16,13 +16,16 @@
 // nvcc, no CUDA headers, no NVIDIA GPU), so this restatement is pinned by
 //   * closed-form known-answer cases derived from the reference source
 //     (tests/test_oracle_kat.py),
-//   * the reference's own importable Python (utils/sh_utils.eval_sh,
-//     utils/general_utils.build_rotation, scene/cameras.Camera) through
-//     committed fixtures (tests/golden/),
+//   * the reference's own importable Python through committed fixtures
+//     (tests/golden/, generator tests/golden/make_goldens.py): utils/sh_utils.eval_sh,
+//     utils/general_utils.build_rotation, scene/cameras.Camera; K1's homography as
+//     render() builds it with pipe.compute_cov3D_python (transmat.npz); K10's
+//     per-Gaussian backward and the SH backward as torch autograd through that
+//     same Python (kten_backward.npz),
 //   * an independent differentiable PyTorch restatement + finite differences
 //     for every gradient (oracle/torch_surfel.py, tests/test_oracle_grad.py).
-// The per-pixel CUDA loops themselves are "parity unpinned" by any reference
-// golden vector — the reference ships none.
+// The per-pixel CUDA loops themselves (K7 blend forward, K9 blend backward) are
+// "parity unpinned" by any reference golden vector — the reference ships none.
 //
 // Semantics notes that differ from a naive reading:
 //   * float -> uint32 conversion of the never-set median contributor (-1.0f)
