@@ -70,6 +70,7 @@ __device__ __forceinline__ F3 sh_to_rgb(int deg, F3 pos, F3 cam, const float* sh
 // integer LDS atomics) and each distinct tile costs ONE global atomic.  A tile that finds no slot within TH_PROBES steps
 // falls back to the direct global atomic, consistently in every phase (slots never become free again).
 constexpr int TH_SIZE = 2048, TH_BITS = 11, TH_PROBES = 32;
+constexpr int BIG_RECT = 128;            // tiles: rectangles beyond this are walked by the workgroup, not by the splat's own lane
 constexpr uint32_t TH_EMPTY = 0xffffffffu;
 __device__ __forceinline__ int th_find_or_insert(uint32_t* keys, uint32_t tile) {
     uint32_t h = (tile * 2654435761u) >> (32 - TH_BITS);
@@ -247,17 +248,38 @@ __global__ __launch_bounds__(256) void k_preprocess(
         g.rect[i] = rc;
     }
     // ---- tile counts: merged per workgroup in LDS, one global atomic per distinct tile ----
+    __shared__ int s_nbig;
+    __shared__ uint32_t s_bigx[256], s_bigy[256];
+    if (threadIdx.x == 0) s_nbig = 0;
     __syncthreads();                        // every lane is done with its staged SH row: the area becomes the hash table
     for (int e = threadIdx.x; e < TH_SIZE; e += 256) { th_key[e] = TH_EMPTY; th_cnt[e] = 0u; }
+    // A splat that reaches more than BIG_RECT tiles (a background surfel grown over the whole view: 1 617 tiles at 779x519)
+    // is not walked by its own lane - one lane looping while its workgroup waits at the barrier; a few such splats made this
+    // kernel 5x and k_scatter 30x slower late in a train.py run - but by the whole workgroup, a tile per thread.
+    const bool big = (unsigned)(rc.x1 - rc.x0) * (unsigned)(rc.y1 - rc.y0) > (unsigned)BIG_RECT;
+    if (big) {
+        const int k = atomicAdd(&s_nbig, 1);
+        s_bigx[k] = (uint32_t)rc.x0 | ((uint32_t)rc.x1 << 16);
+        s_bigy[k] = (uint32_t)rc.y0 | ((uint32_t)rc.y1 << 16);
+    }
     __syncthreads();
     const int sub = counter_sub(blockIdx.x);
-    for (int y = rc.y0; y < rc.y1; y++)
-        for (int x = rc.x0; x < rc.x1; x++) {
-            const uint32_t tile = (uint32_t)y * gx + x;
-            const int slot = th_find_or_insert(th_key, tile);
-            if (slot >= 0) atomicAdd(&th_cnt[slot], 1u);
-            else atomicAdd(tile_count + ((size_t)tile * CNT_SUB + sub) * CNT_STRIDE, 1u);
+    if (!big)
+        for (int y = rc.y0; y < rc.y1; y++)
+            for (int x = rc.x0; x < rc.x1; x++) {
+                const uint32_t tile = (uint32_t)y * gx + x;
+                const int slot = th_find_or_insert(th_key, tile);
+                if (slot >= 0) atomicAdd(&th_cnt[slot], 1u);
+                else atomicAdd(tile_count + ((size_t)tile * CNT_SUB + sub) * CNT_STRIDE, 1u);
+            }
+    for (int b = 0; b < s_nbig; b++) {
+        const int bx0 = (int)(s_bigx[b] & 0xffffu), bx1 = (int)(s_bigx[b] >> 16), by0 = (int)(s_bigy[b] & 0xffffu), by1 = (int)(s_bigy[b] >> 16);
+        const int w = bx1 - bx0, area = w * (by1 - by0);
+        for (int e = threadIdx.x; e < area; e += 256) {
+            const uint32_t tile = (uint32_t)(by0 + e / w) * gx + (uint32_t)(bx0 + e % w);
+            atomicAdd(tile_count + ((size_t)tile * CNT_SUB + sub) * CNT_STRIDE, 1u);
         }
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < TH_SIZE; e += 256)
         if (th_key[e] != TH_EMPTY) atomicAdd(tile_count + ((size_t)th_key[e] * CNT_SUB + sub) * CNT_STRIDE, th_cnt[e]);
@@ -457,13 +479,37 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, GeomView g, cons
         rc = g.rect[i];
         key = ((unsigned long long)__float_as_uint(g.rec[(size_t)i * REC + 18]) << 32) | (unsigned)i;
     }
+    __shared__ int s_nbig;
+    __shared__ uint32_t s_bigx[256], s_bigy[256];
+    __shared__ unsigned long long s_bigkey[256];
+    if (threadIdx.x == 0) s_nbig = 0;
     __syncthreads();
+    const bool big = (unsigned)(rc.x1 - rc.x0) * (unsigned)(rc.y1 - rc.y0) > (unsigned)BIG_RECT;      // see k_preprocess
+    if (big) {
+        const int k = atomicAdd(&s_nbig, 1);
+        s_bigx[k] = (uint32_t)rc.x0 | ((uint32_t)rc.x1 << 16);
+        s_bigy[k] = (uint32_t)rc.y0 | ((uint32_t)rc.y1 << 16);
+        s_bigkey[k] = key;
+        rc = {0, 0, 0, 0};                  // its own lane walks nothing
+    }
     for (int y = rc.y0; y < rc.y1; y++)
         for (int x = rc.x0; x < rc.x1; x++) {
             const int slot = th_find_or_insert(th_key, (uint32_t)y * gx + x);
             if (slot >= 0) atomicAdd(&th_cnt[slot], 1u);
         }
     __syncthreads();
+    for (int b = 0; b < s_nbig; b++) {      // the workgroup's large rectangles: a tile per thread, positions straight from the cursors
+        const int bx0 = (int)(s_bigx[b] & 0xffffu), bx1 = (int)(s_bigx[b] >> 16), by0 = (int)(s_bigy[b] & 0xffffu), by1 = (int)(s_bigy[b] >> 16);
+        const int w = bx1 - bx0, area = w * (by1 - by0);
+        const unsigned long long bkey = s_bigkey[b];
+        for (int e = threadIdx.x; e < area; e += 256) {
+            const uint32_t tile = (uint32_t)(by0 + e / w) * gx + (uint32_t)(bx0 + e % w);
+            const size_t ee = (size_t)tile * CNT_SUB + sub;
+            const uint32_t pos = atomicAdd(tile_cursor + ee * CNT_STRIDE, 1u);
+            const int64_t at = (int64_t)sub_offset[ee] + pos;
+            if (at < capacity) keys[at] = bkey;
+        }
+    }
     for (int e = threadIdx.x; e < TH_SIZE; e += 256)
         if (th_key[e] != TH_EMPTY) {
             th_base[e] = atomicAdd(tile_cursor + ((size_t)th_key[e] * CNT_SUB + sub) * CNT_STRIDE, th_cnt[e]);

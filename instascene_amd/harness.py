@@ -660,6 +660,16 @@ class RgbTrainer:
         return loss + self.ln * normal_error.mean()
 
     def step(self, it: int):
+        from .rasterizer import BinningOverflow
+        try:
+            return self._step_once(it)
+        except BinningOverflow:
+            # the view outgrew its async binning estimate (the geometry trains): the estimate is corrected, nothing has
+            # reached the parameters (the check precedes the backward kernels) - run the iteration again
+            self.opt.zero_grad(set_to_none=True)
+            return self._step_once(it)
+
+    def _step_once(self, it: int):
         vi = view_for(it, self.rank, self.world, len(self.cams))
         if self.fused_update:
             self.model._leaves = self.opt.begin()

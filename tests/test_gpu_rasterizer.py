@@ -743,3 +743,36 @@ def test_culling_survives_grazing_and_near_camera_splats():
     got = hip_backward(args, out, dC, dO, dE, GRAD_EXTRA | GRAD_GEOMETRY, MODE_EXACT)
     for name, t in zip(GRAD_NAMES, got):
         assert_close(t.cpu().numpy().reshape(want[name].shape), want[name], 2e-3, "grazing:" + name)
+
+
+@pytest.mark.parametrize("F,W,H,mode", [(0, 256, 192, "fast"), (0, 512, 384, "exact"), (8, 512, 384, "fast")])
+def test_splats_larger_than_the_view(F, W, H, mode):
+    """A few surfels grown over the whole image (a train.py run produces them: backgrounds) touch every tile - 192 / 768
+    rectangles here.  The geometry pass counts them, the key scatter places them and the per-Gaussian backward sums their
+    hundreds of partial rows by the WORKGROUP (a tile / a row per thread), not in the lane that owns the splat: binning
+    bit-identical to the oracle, forward exact / within the FAST tolerance, every gradient within 1e-3."""
+    m = MODE_EXACT if mode == "exact" else MODE_FAST
+    sc, cams, inp = small_scene(P=1500, F=F, W=W, H=H, seed=77, mu_s=math.log(0.04))
+    cam = cams[1]
+    st0 = oracle_forward(inp, cam)
+    vis = np.nonzero(st0["radii"] > 0)[0]
+    back = vis[np.argsort(-st0["depths"][vis])[:4]]   # the four farthest visible ones become backdrops
+    scales = inp["scales"].clone()
+    scales[torch.tensor(back.copy())] = torch.tensor([1.0, 2.0, 1.0, 2.0])[:, None]
+    inp = dict(inp, scales=scales)
+    st = oracle_forward(inp, cam)
+    assert st["tiles_touched"].max() == ((W + 15) // 16) * ((H + 15) // 16) and (st["tiles_touched"] > 128).sum() >= 3
+    args, out = hip_forward(inp, cam, mode=m)
+    check_binning_exact(st, out)
+    if mode == "exact":
+        check_forward_exact(st, args, out)
+    else:
+        _images_within_fast_tolerance(out, st)
+    dC, dO, dE = _rand_grads(st, 5)
+    want = oracle.backward(st, dC, dO, dE)
+    mask = GRAD_GEOMETRY | (GRAD_EXTRA if F else 0)
+    got = hip_backward(args, out, dC, dO, dE, mask, m)
+    for name, t in zip(GRAD_NAMES, got):
+        if t is None or (name == "dL_dextra" and F == 0):
+            continue
+        assert_close(t.cpu().numpy().reshape(want[name].shape), want[name], 1e-3, f"{mode}:{name}")
