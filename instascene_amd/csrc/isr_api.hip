@@ -202,8 +202,8 @@ int isr_forward_prepare(int P, int D, int M, int width, int height, const float*
         ISR_LAUNCH_CHECK("k_preprocess");
         const int nb = (P + 1023) / 1024;
         ProfScope ps2_("k_scan_gaussians", s);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, P, g.tiles_touched, g.point_offsets, g.scan_tmp);
-        hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, g.scan_tmp);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, P, g.tiles_touched, g.point_offsets, g.scan_tmp, g.scan_tmp + nb + 1);
+        hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, g.scan_tmp, g.scan_tmp + nb + 1, g.header);
         hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, P, g.point_offsets, g.scan_tmp);
         ISR_LAUNCH_CHECK("k_scan");
     }
@@ -445,8 +445,8 @@ int iso_dist2_3nn(int P, const float* points, float* mean_dist2, void* scratch, 
     ISR_HIP(hipMemsetAsync(v.cursor, 0, sizeof(uint32_t) * ccap, s));
     hipLaunchKernelGGL(iso::kk_count, dim3(pb), dim3(256), 0, s, P, points, v.grid, v.count);
     const int nb = (ccap + 1023) / 1024;      // scan the whole capacity: unused cells hold zero
-    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, ccap, v.count, v.offset, v.sums);
-    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, v.sums);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, ccap, v.count, v.offset, v.sums, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, v.sums, (const uint32_t*)nullptr, (int64_t*)nullptr);
     hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, ccap, v.offset, v.sums);
     hipLaunchKernelGGL(iso::kk_scatter, dim3(pb), dim3(256), 0, s, P, points, v.grid, v.offset, v.cursor, v.sorted);
     // ISO_KNN_LDS=1: the LDS-bucketed query (built as north_star names it, measured 0.8-8x SLOWER than the ring walk from

@@ -1325,13 +1325,22 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     // A splat spread over very many tiles (a background surfel grown over the whole view: 6 468 candidate rows at 779x519) has
     // its rows summed by the WORKGROUP - a row per thread, a fixed reduction tree - not by its own lane while 255 others wait.
     constexpr uint32_t K10_BIG_ROWS = 512;
-    __shared__ int s_nbig;
-    __shared__ int s_big_owner[256];
-    __shared__ float s_bigsum[4][18];
+    // (its LDS lives in the four padding floats of the staged SH rows - three workgroups of 52 KB must still fit a CU - or, in
+    // the build without staging, in a small block of its own)
+    __shared__ float s_coop[STAGE_SH ? 1 : 3 * 256];
+    float* const coop = STAGE_SH ? s_sh + 48 : s_coop;             // slot (k, j), j < 3: coop[k * CS + j]
+    constexpr int CS = STAGE_SH ? SH_STRIDE : 3;
+    int& s_nbig = *reinterpret_cast<int*>(coop);                                       // slot (0, 0)
+    auto owner_at = [&](int k) -> int& { return *reinterpret_cast<int*>(coop + k * CS + 1); };       // slots (k, 1)
+    auto sum_at = [&](int w, int q) -> float& { return coop[(w * 18 + q) * CS + 2]; };               // slots (18 w + q, 2)
     const bool big_rows = nt > K10_BIG_ROWS;
-    if (threadIdx.x == 0) s_nbig = 0;
-    __syncthreads();
-    if (big_rows) s_big_owner[atomicAdd(&s_nbig, 1)] = (int)threadIdx.x;
+    // (view-uniform, from k_scan_tops: no barrier at all unless the view holds such a splat)
+    const bool any_big = g.header[1] * (int64_t)rpi > (int64_t)K10_BIG_ROWS;
+    if (any_big) {
+        if (threadIdx.x == 0) s_nbig = 0;
+        __syncthreads();
+        if (big_rows) owner_at(atomicAdd(&s_nbig, 1)) = (int)threadIdx.x;
+    }
     if (nt > 0 && !big_rows && rpi == 4) {
         // four rows per tile instance (k_render_bwd_geo): the instance's four flags are one aligned word, and the flagged rows
         // of an instance are requested together - a quarter of the dependent memory round trips of the row-by-row walk
@@ -1376,40 +1385,41 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
             gs[15] += d.w; gs[16] += e.x; gs[17] += e.y;
         }
     }
-    __syncthreads();
-    for (int bb = 0; bb < s_nbig; bb++) {
-        // (owners in the order of their thread index would be deterministic too; the sums do not depend on the order of the list)
-        const int owner = s_big_owner[bb];
-        const int oi = (int)(blockIdx.x * blockDim.x) + owner;
-        const uint32_t ont = g.tiles_touched[oi] * (uint32_t)rpi;
-        const float* src = partial + (size_t)g.point_offsets[oi] * rpi * row_stride + geom_off;
-        const uint8_t* fl = row_flags + (size_t)g.point_offsets[oi] * rpi;
-        float ps[18];
-#pragma unroll
-        for (int q = 0; q < 18; q++) ps[q] = 0.0f;
-        for (uint32_t r = threadIdx.x; r < ont; r += 256) {
-            if (!fl[r]) continue;
-            const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)r * row_stride);
-            const float4 a = s4[0], b = s4[1], c = s4[2], d = s4[3], e = s4[4];
-            ps[0] += a.x; ps[1] += a.y; ps[2] += a.z; ps[3] += a.w; ps[4] += b.x; ps[5] += b.y; ps[6] += b.z; ps[7] += b.w;
-            ps[8] += c.x; ps[9] += c.y; ps[10] += c.z; ps[11] += c.w; ps[12] += d.x; ps[13] += d.y; ps[14] += d.z;
-            ps[15] += d.w; ps[16] += e.x; ps[17] += e.y;
-        }
-#pragma unroll
-        for (int q = 0; q < 18; q++) {
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) ps[q] += __shfl_xor(ps[q], o);
-        }
-        if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-            for (int q = 0; q < 18; q++) s_bigsum[threadIdx.x >> 6][q] = ps[q];
-        }
+    if (any_big) {
         __syncthreads();
-        if ((int)threadIdx.x == owner) {
-#pragma unroll
-            for (int q = 0; q < 18; q++) gs[q] = (s_bigsum[0][q] + s_bigsum[1][q]) + (s_bigsum[2][q] + s_bigsum[3][q]);
+        for (int bb = 0; bb < s_nbig; bb++) {
+            const int owner = owner_at(bb);
+            const int oi = (int)(blockIdx.x * blockDim.x) + owner;
+            const uint32_t ont = g.tiles_touched[oi] * (uint32_t)rpi;
+            const float* src = partial + (size_t)g.point_offsets[oi] * rpi * row_stride + geom_off;
+            const uint8_t* fl = row_flags + (size_t)g.point_offsets[oi] * rpi;
+            float ps[18];
+    #pragma unroll
+            for (int q = 0; q < 18; q++) ps[q] = 0.0f;
+            for (uint32_t r = threadIdx.x; r < ont; r += 256) {
+                if (!fl[r]) continue;
+                const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)r * row_stride);
+                const float4 a = s4[0], b = s4[1], c = s4[2], d = s4[3], e = s4[4];
+                ps[0] += a.x; ps[1] += a.y; ps[2] += a.z; ps[3] += a.w; ps[4] += b.x; ps[5] += b.y; ps[6] += b.z; ps[7] += b.w;
+                ps[8] += c.x; ps[9] += c.y; ps[10] += c.z; ps[11] += c.w; ps[12] += d.x; ps[13] += d.y; ps[14] += d.z;
+                ps[15] += d.w; ps[16] += e.x; ps[17] += e.y;
+            }
+    #pragma unroll
+            for (int q = 0; q < 18; q++) {
+    #pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) ps[q] += __shfl_xor(ps[q], o);
+            }
+            if ((threadIdx.x & 63) == 0) {
+    #pragma unroll
+                for (int q = 0; q < 18; q++) sum_at(threadIdx.x >> 6, q) = ps[q];
+            }
+            __syncthreads();
+            if ((int)threadIdx.x == owner) {
+    #pragma unroll
+                for (int q = 0; q < 18; q++) gs[q] = (sum_at(0, q) + sum_at(1, q)) + (sum_at(2, q) + sum_at(3, q));
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (i < P) {
     F3 g0 = {gs[0], gs[1], gs[2]}, g1 = {gs[3], gs[4], gs[5]}, g2 = {gs[6], gs[7], gs[8]};

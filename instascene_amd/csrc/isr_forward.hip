@@ -107,8 +107,9 @@ __global__ __launch_bounds__(256) void k_preprocess(
     // cache lines per load instruction, and with ~250 KB of rows in flight per CU the 32 KB vector cache keeps none of
     // them between the twelve loads of a row: 0.65 GB of fetches for 0.47 GB of input.)
     constexpr int SH_STRIDE = 52;           // floats per staged row: 48 + 4 (16-byte aligned, spreads the LDS banks)
-    constexpr int LDS_WORDS = STAGE_SH ? 256 * SH_STRIDE : 2 * TH_SIZE;     // the tile hash reuses the SH staging area
-    static_assert(LDS_WORDS >= 2 * TH_SIZE, "tile hash does not fit");
+    constexpr int BIG_WORDS = 2 * 256 + 4;  // list of the workgroup's large rectangles (see the tile counting below)
+    constexpr int LDS_WORDS = STAGE_SH ? 256 * SH_STRIDE : 2 * TH_SIZE + BIG_WORDS;     // the tile hash + that list reuse the SH staging area
+    static_assert(LDS_WORDS >= 2 * TH_SIZE + BIG_WORDS, "tile hash does not fit");
     __shared__ __attribute__((aligned(16))) float s_sh[LDS_WORDS];
     uint32_t* th_key = reinterpret_cast<uint32_t*>(s_sh);
     uint32_t* th_cnt = th_key + TH_SIZE;
@@ -248,11 +249,13 @@ __global__ __launch_bounds__(256) void k_preprocess(
         g.rect[i] = rc;
     }
     // ---- tile counts: merged per workgroup in LDS, one global atomic per distinct tile ----
-    __shared__ int s_nbig;
-    __shared__ uint32_t s_bigx[256], s_bigy[256];
-    if (threadIdx.x == 0) s_nbig = 0;
     __syncthreads();                        // every lane is done with its staged SH row: the area becomes the hash table
+    uint32_t* s_bigx = th_cnt + TH_SIZE;    // (behind the hash table, inside the same LDS block: no occupancy lost)
+    uint32_t* s_bigy = s_bigx + 256;
+    int& s_nbig = *reinterpret_cast<int*>(s_bigy + 256);
+    if (threadIdx.x == 0) s_nbig = 0;
     for (int e = threadIdx.x; e < TH_SIZE; e += 256) { th_key[e] = TH_EMPTY; th_cnt[e] = 0u; }
+    __syncthreads();
     // A splat that reaches more than BIG_RECT tiles (a background surfel grown over the whole view: 1 617 tiles at 779x519)
     // is not walked by its own lane - one lane looping while its workgroup waits at the barrier; a few such splats made this
     // kernel 5x and k_scatter 30x slower late in a train.py run - but by the whole workgroup, a tile per thread.
@@ -434,18 +437,42 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int T, uint32_t* __restrict_
     }
 }
 
+// block_max (optional): the largest input of each block; k_scan_tops reduces them into header[1] = the largest number of
+// tiles any splat of this view touches - k_scatter and k_preprocess_bwd skip their workgroup-cooperative paths (and the
+// barrier those need) when no splat is large.
 __global__ __launch_bounds__(1024) void k_scan_blocks(int n, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                      uint32_t* __restrict__ block_sums) {
+                                                      uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_max) {
     __shared__ uint32_t s_warp[32];
+    __shared__ uint32_t s_mx[16];
     const int i = blockIdx.x * 1024 + threadIdx.x;
     const uint32_t v = i < n ? in[i] : 0u;
     uint32_t total;
     const uint32_t ex = block_exclusive_scan_1024(v, s_warp, total);
     if (i < n) out[i] = ex;
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    if (block_max != nullptr) {
+        uint32_t m = v;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t mm = 0;
+            for (int w = 0; w < 16; w++) mm = max(mm, s_mx[w]);
+            block_max[blockIdx.x] = mm;
+        }
+    }
 }
-__global__ __launch_bounds__(1024) void k_scan_tops(int nb, uint32_t* __restrict__ block_sums) {
+__global__ __launch_bounds__(1024) void k_scan_tops(int nb, uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ block_max,
+                                                    int64_t* __restrict__ header) {
     __shared__ uint32_t s_warp[32];
+    if (block_max != nullptr && threadIdx.x < 64) {
+        uint32_t m = 0;
+        for (int b = threadIdx.x; b < nb; b += 64) m = max(m, block_max[b]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        if (threadIdx.x == 0) header[1] = (int64_t)m;
+    }
     uint32_t carry = 0;
     for (int base = 0; base < nb; base += 1024) {
         const int i = base + threadIdx.x;
@@ -479,18 +506,22 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, GeomView g, cons
         rc = g.rect[i];
         key = ((unsigned long long)__float_as_uint(g.rec[(size_t)i * REC + 18]) << 32) | (unsigned)i;
     }
+    constexpr int BIG_MAX = 64;             // (1 KB of LDS: six workgroups per CU as before; a 65th large splat of a workgroup walks alone)
     __shared__ int s_nbig;
-    __shared__ uint32_t s_bigx[256], s_bigy[256];
-    __shared__ unsigned long long s_bigkey[256];
+    __shared__ uint32_t s_bigx[BIG_MAX], s_bigy[BIG_MAX];
+    __shared__ unsigned long long s_bigkey[BIG_MAX];
+    const bool any_big = g.header[1] > (int64_t)BIG_RECT;       // (view-uniform: k_scan_tops)
     if (threadIdx.x == 0) s_nbig = 0;
     __syncthreads();
-    const bool big = (unsigned)(rc.x1 - rc.x0) * (unsigned)(rc.y1 - rc.y0) > (unsigned)BIG_RECT;      // see k_preprocess
+    const bool big = any_big && (unsigned)(rc.x1 - rc.x0) * (unsigned)(rc.y1 - rc.y0) > (unsigned)BIG_RECT;      // see k_preprocess
     if (big) {
         const int k = atomicAdd(&s_nbig, 1);
-        s_bigx[k] = (uint32_t)rc.x0 | ((uint32_t)rc.x1 << 16);
-        s_bigy[k] = (uint32_t)rc.y0 | ((uint32_t)rc.y1 << 16);
-        s_bigkey[k] = key;
-        rc = {0, 0, 0, 0};                  // its own lane walks nothing
+        if (k < BIG_MAX) {
+            s_bigx[k] = (uint32_t)rc.x0 | ((uint32_t)rc.x1 << 16);
+            s_bigy[k] = (uint32_t)rc.y0 | ((uint32_t)rc.y1 << 16);
+            s_bigkey[k] = key;
+            rc = {0, 0, 0, 0};              // its own lane walks nothing
+        }
     }
     for (int y = rc.y0; y < rc.y1; y++)
         for (int x = rc.x0; x < rc.x1; x++) {
@@ -498,7 +529,7 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, GeomView g, cons
             if (slot >= 0) atomicAdd(&th_cnt[slot], 1u);
         }
     __syncthreads();
-    for (int b = 0; b < s_nbig; b++) {      // the workgroup's large rectangles: a tile per thread, positions straight from the cursors
+    for (int b = 0; b < min(s_nbig, BIG_MAX); b++) {      // the workgroup's large rectangles: a tile per thread, positions straight from the cursors
         const int bx0 = (int)(s_bigx[b] & 0xffffu), bx1 = (int)(s_bigx[b] >> 16), by0 = (int)(s_bigy[b] & 0xffffu), by1 = (int)(s_bigy[b] >> 16);
         const int w = bx1 - bx0, area = w * (by1 - by0);
         const unsigned long long bkey = s_bigkey[b];
