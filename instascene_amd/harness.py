@@ -33,6 +33,15 @@ from .render import prefetch, render
 from .streams import main_stream, side_stream  # noqa: E402,F401  (one side / one high-priority stream per device)
 
 
+def _unit_grad(owner, loss):
+    """dL/dL = 1 from a tensor cached on the trainer (autograd otherwise fills a fresh one every step: one more launch in the
+    step's chain)."""
+    one = getattr(owner, "_one", None)
+    if one is None or one.shape != loss.shape or one.device != loss.device or one.dtype != loss.dtype:
+        one = owner._one = torch.ones_like(loss)
+    return one
+
+
 class PipelineParams:
     compute_cov3D_python = False
     convert_SHs_python = False
@@ -339,11 +348,7 @@ class SegTrainer:
         return _Scope()
 
     def _unit_grad(self, loss):
-        """dL/dL = 1 from a cached tensor (autograd otherwise fills a fresh one every step: one more launch in the chain)."""
-        one = getattr(self, "_one", None)
-        if one is None or one.shape != loss.shape or one.device != loss.device or one.dtype != loss.dtype:
-            one = self._one = torch.ones_like(loss)
-        return one
+        return _unit_grad(self, loss)
 
     def _step_guarded(self, it: int):
         from .rasterizer import BinningOverflow
@@ -676,7 +681,7 @@ class RgbTrainer:
             try:
                 pkg = render(self.cams[vi], self.model, self.pipe, self.bg)
                 loss = self._loss(pkg, vi)
-                loss.backward(SegTrainer._unit_grad(self, loss))
+                loss.backward(_unit_grad(self, loss))
             finally:
                 self.model._leaves = None
             # one flat collective for all six groups' gradients (they are final only after the per-Gaussian backward pass)
