@@ -144,3 +144,16 @@ def test_render_package_evaluates_derived_maps_on_first_access(golden_dir, monke
     pkg2._pending = (cam, allmap, 0.0, False)
     assert all(v is not None for v in dict(pkg2).values()) and not pkg2["surf_normal"].requires_grad
     assert all(v is not None for _, v in pkg2.items())
+
+
+def test_async_capacity_rounding_is_monotone_and_tight():
+    """rasterizer._round_capacity: never below the request, at most 1/32 above it, monotone, and few distinct values over the
+    spread of a scene's views (what keeps the allocator's pools from growing view by view)."""
+    from instascene_amd.rasterizer import _round_capacity
+    prev = 0
+    for r in list(range(0, 5000, 7)) + [10 ** 5 + k * 977 for k in range(200)] + [19_400_000 + k * 3001 for k in range(200)]:
+        c = _round_capacity(r)
+        assert c >= r and (r == 0 or c <= r + max(1, r // 32) + 1), (r, c)
+    vals = [_round_capacity(r) for r in range(19_300_000, 19_500_000, 1000)]
+    assert vals == sorted(vals) and len(set(vals)) <= 2
+    assert _round_capacity(0) == 0 and _round_capacity(-5) == -5
