@@ -1131,6 +1131,16 @@ __global__ __launch_bounds__(256) void k_reduce_rows(int P, int ncol, const uint
 // that own a row (one float4 each) do all of it with the row in registers: in  x, m, v, gy (+ the flagged partial rows),
 // out  x, m, v, y, z.  ADAM = false stops after (2) and writes dL/dx (the multi-GPU trainer all-reduces it first).
 // Same expressions as the three kernels it replaces (bit-identical results).
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+    const nt_f4 q = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    return make_float4(q.x, q.y, q.z, q.w);
+}
+__device__ __forceinline__ void nt_store4(float* p, const float4& v) {
+    const nt_f4 q = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(q, reinterpret_cast<nt_f4*>(p));
+}
+
 template <bool ADAM>
 __global__ __launch_bounds__(256) void k_feature_rows_step(
     int row0, int P, int F, const uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ tiles_touched,
@@ -1159,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_feature_rows_step(
     if (ok && gy != nullptr) a = *reinterpret_cast<const float4*>(gy + off);
     const int gslot = (ok && gy_slot != nullptr) ? gy_slot[row] : -1;       // dL/dy as (row -> merged entry), iso_rows_compact
     float4 m4 = z4, v4 = z4;
-    if (ADAM && ok) { m4 = *reinterpret_cast<const float4*>(m + off); v4 = *reinterpret_cast<const float4*>(v + off); }
+    if (ADAM && ok) { m4 = nt_load4(m + off); v4 = nt_load4(v + off); }      // (moments: read once per step)
     // (1) dL/dz row: flagged per-tile partial rows in row order (+ a dense contribution, if any)
     float4 bd = z4;
     if (ok && gz_dense != nullptr) bd = *reinterpret_cast<const float4*>(gz_dense + off);
@@ -1235,9 +1245,9 @@ __global__ __launch_bounds__(256) void k_feature_rows_step(
             np4.e = xv.e - lr_over_bc1 * (m4.e / (__builtin_sqrtf(v4.e) * inv_sqrt_bc2 + eps));
             ISR_ADAM1(x) ISR_ADAM1(y) ISR_ADAM1(z) ISR_ADAM1(w)
 #undef ISR_ADAM1
-            *reinterpret_cast<float4*>(m + off) = m4;
-            *reinterpret_cast<float4*>(v + off) = v4;
-            *reinterpret_cast<float4*>(x + off) = np4;
+            nt_store4(m + off, m4);           // streamed once per step: do not displace the forward's records in L2
+            nt_store4(v + off, v4);
+            nt_store4(x + off, np4);
         }
         // (4) the next forward's normalisations of the updated row
         float s1 = np4.x * np4.x + np4.y * np4.y + np4.z * np4.z + np4.w * np4.w;
@@ -1249,7 +1259,7 @@ __global__ __launch_bounds__(256) void k_feature_rows_step(
         const float q2 = 1.0f / (__builtin_sqrtf(s2) + eps2);
         if (ok) {
             if (y != nullptr) *reinterpret_cast<float4*>(y + off) = y4;      // optional: iso_gather_rownorm recomputes rows
-            *reinterpret_cast<float4*>(z + off) = make_float4(y4.x * q2, y4.y * q2, y4.z * q2, y4.w * q2);
+            nt_store4(z + off, make_float4(y4.x * q2, y4.y * q2, y4.z * q2, y4.w * q2));
         }
     }
 }
