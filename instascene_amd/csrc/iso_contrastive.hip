@@ -669,6 +669,16 @@ __global__ __launch_bounds__(256) void rn2_kernel(long long N, int F, float eps1
 // next forward's y = p/(|p|+eps1), z = y/(|y|+eps2) cost two more streams out instead of a separate 1-in 2-out pass.
 // Arithmetic of torch.optim.Adam (no weight decay, no amsgrad):
 //   m = m + (1-b1)(g - m);  v = b2 v + (1-b2) g^2;  p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// (streamed once per step - as in k_feature_rows_step, the moments are loaded and x / m / v / z stored non-temporally)
+typedef float iso_nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 iso_nt_load4(const float* p) {
+    const iso_nt_f4 q = __builtin_nontemporal_load(reinterpret_cast<const iso_nt_f4*>(p));
+    return make_float4(q.x, q.y, q.z, q.w);
+}
+__device__ __forceinline__ void iso_nt_store4(float* p, const float4& v) {
+    const iso_nt_f4 q = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(q, reinterpret_cast<iso_nt_f4*>(p));
+}
 __global__ __launch_bounds__(256) void adam_rn2_kernel(long long N, int F, float lr_over_bc1, float om1, float beta2, float om2,
                                                        float inv_sqrt_bc2, float eps, float eps1, float eps2,
                                                        float* __restrict__ p, const float* __restrict__ g,
@@ -684,16 +694,16 @@ __global__ __launch_bounds__(256) void adam_rn2_kernel(long long N, int F, float
     float4 np4 = make_float4(0, 0, 0, 0);
     if (ok) {
         const float4 p4 = *reinterpret_cast<const float4*>(p + off), g4 = *reinterpret_cast<const float4*>(g + off);
-        float4 m4 = *reinterpret_cast<const float4*>(m + off), v4 = *reinterpret_cast<const float4*>(v + off);
+        float4 m4 = iso_nt_load4(m + off), v4 = iso_nt_load4(v + off);
 #define ISO_ADAM1(c)                                                                   \
         m4.c = m4.c + om1 * (g4.c - m4.c);                                             \
         v4.c = beta2 * v4.c + om2 * (g4.c * g4.c);                                     \
         np4.c = p4.c - lr_over_bc1 * (m4.c / (__builtin_sqrtf(v4.c) * inv_sqrt_bc2 + eps));
         ISO_ADAM1(x) ISO_ADAM1(y) ISO_ADAM1(z) ISO_ADAM1(w)
 #undef ISO_ADAM1
-        *reinterpret_cast<float4*>(m + off) = m4;
-        *reinterpret_cast<float4*>(v + off) = v4;
-        *reinterpret_cast<float4*>(p + off) = np4;
+        iso_nt_store4(m + off, m4);
+        iso_nt_store4(v + off, v4);
+        iso_nt_store4(p + off, np4);
     }
     float ss = np4.x * np4.x + np4.y * np4.y + np4.z * np4.z + np4.w * np4.w;
     for (int o = lpr >> 1; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
@@ -704,7 +714,7 @@ __global__ __launch_bounds__(256) void adam_rn2_kernel(long long N, int F, float
     const float r2 = 1.0f / (__builtin_sqrtf(s2) + eps2);
     if (ok) {
         if (y != nullptr) *reinterpret_cast<float4*>(y + off) = y4;
-        *reinterpret_cast<float4*>(z + off) = make_float4(y4.x * r2, y4.y * r2, y4.z * r2, y4.w * r2);
+        iso_nt_store4(z + off, make_float4(y4.x * r2, y4.y * r2, y4.z * r2, y4.w * r2));
     }
 }
 
