@@ -460,7 +460,10 @@ def main():
                               ["activations of the frozen parameters (exp / sigmoid / normalize, SH concat): evaluated once",
                                "per-view pools of labelled pixels and of visible labelled Gaussians, the cameras' ray tables, each "
                                "view's verified tile-instance count (SegTrainer.warm_view_caches: one untrained render per view)",
-                               "two priming steps whose effect on parameters / optimiser / RNG is undone (SegTrainer.prime)"]
+                               "two priming steps whose effect on parameters / optimiser / RNG is undone (SegTrainer.prime)",
+                               "render()'s `visibility_filter` (radii > 0, one elementwise kernel) and the tracer list's slice are "
+                               "evaluated on first access of the dict entry; a warmed-up step reads neither",
+                               "the next step's index draw (a function of seed, iteration and view) is issued behind this step's forward"]
                               if args.step == "seg" else
                               ["targets = initial renders + noise", "the cameras' ray tables, each view's verified tile-instance count"])},
                "roofline": roof}
