@@ -88,7 +88,7 @@ SIGNATURES = {
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    args = ["make", "-C", src_dir, "-s"]
+    args = ["make", "-C", src_dir, "-s", "-j", str(min(5, os.cpu_count() or 1))]
     if force:
         args.append("-B")
     subprocess.check_call(args)

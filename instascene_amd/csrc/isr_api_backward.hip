@@ -1,0 +1,108 @@
+// C-ABI entry points of libinstascene_hip.so, backward half: K9-K11 (declared in include/instascene_rasterizer.h).
+// Host-side only: argument checking, workspace carving and kernel launches on the
+// caller's stream.  No torch types, no allocation, no hidden synchronisation except
+// where the header says so.
+#include "isr_host.hpp"
+#include "isr_backward.hip"
+
+using namespace isr;
+
+extern "C" {
+
+size_t isr_backward_scratch_bytes(int64_t num_rendered, int ED, unsigned grad_mask) {
+    return backward_scratch_bytes(num_rendered, ED, grad_mask);
+}
+
+int isr_backward(int P, int D, int M, int64_t num_rendered, int ED, int width, int height, int mode, unsigned grad_mask,
+                 const float* background, const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+                 const float* extra_attrs, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                 float tan_fovx, float tan_fovy, const int* radii, const void* geom_buffer, const void* binning_buffer,
+                 const void* image_buffer, const float* dL_dout_color, const float* dL_dout_others,
+                 const float* dL_dout_extra, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
+                 float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                 float* dL_dextra, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!geom_buffer || !binning_buffer || !image_buffer) return fail(ISR_EINVAL, "null state buffer");
+    if (mode != ISR_MODE_EXACT && mode != ISR_MODE_FAST) return fail(ISR_EINVAL, "unknown mode %d", mode);
+    if ((grad_mask & ~(ISR_GRAD_EXTRA | ISR_GRAD_GEOMETRY)) || grad_mask == 0) return fail(ISR_EINVAL, "bad grad_mask");
+    if ((grad_mask & ISR_GRAD_EXTRA) && ED > 0 && !dL_dextra) return fail(ISR_EINVAL, "dL_dextra is NULL");
+    if ((grad_mask & ISR_GRAD_GEOMETRY) &&
+        (!dL_dmean2D || !dL_dnormal || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dtransMat || !dL_dscale ||
+         !dL_drot || (shs && !dL_dsh)))
+        return fail(ISR_EINVAL, "a geometry gradient output is NULL");
+    if (scratch_bytes < backward_scratch_bytes(num_rendered, ED, grad_mask) || (!scratch && scratch_bytes))
+        return fail(ISR_EINVAL, "backward scratch too small");
+    const int rc = launch_backward(P, D, M, num_rendered, ED, width, height, mode, grad_mask, background, means3D, shs,
+                           colors_precomp, scales, scale_modifier, rotations, transMat_precomp, extra_attrs, viewmatrix,
+                           projmatrix, cam_pos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer,
+                           dL_dout_color, dL_dout_others, dL_dout_extra, dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor,
+                           dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot, dL_dextra, scratch, scratch_bytes,
+                           (hipStream_t)stream);
+    if (rc != 0) return fail(ISR_EHIP, "backward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return ISR_OK;
+}
+
+size_t isr_backward_sampled_scratch_bytes(int64_t num_rendered, int ED, int n_samples, int width, int height) {
+    return backward_sampled_scratch_bytes(num_rendered, ED, n_samples, width, height);
+}
+
+int isr_sample_extra(int ED, int width, int height, int n_samples, const float* out_extra, const long long* pixels,
+                     float* sampled, void* stream) {
+    if (ED < 0 || width <= 0 || height <= 0 || n_samples < 0) return fail(ISR_EINVAL, "bad sample_extra sizes");
+    if (n_samples > 0 && ED > 0 && (!out_extra || !pixels || !sampled)) return fail(ISR_EINVAL, "sample_extra: null pointer");
+    if (launch_sample_gather(n_samples, ED, (long long)width * height, out_extra, pixels, sampled, (hipStream_t)stream) != 0)
+        return fail(ISR_EHIP, "sample_extra launch failed");
+    return ISR_OK;
+}
+
+int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int height, int mode, int n_samples,
+                         const long long* pixels, const float* dL_dsampled, const float* transMat_precomp,
+                         const void* geom_buffer, const void* binning_buffer, const void* image_buffer, float* dL_dextra,
+                         int accumulate, void* scratch, size_t scratch_bytes, void* stream) {
+    if (P < 0 || ED <= 0 || width <= 0 || height <= 0 || n_samples < 0) return fail(ISR_EINVAL, "bad backward_sampled sizes");
+    if (mode != ISR_MODE_EXACT && mode != ISR_MODE_FAST) return fail(ISR_EINVAL, "unknown mode %d", mode);
+    if (!geom_buffer || !binning_buffer || !image_buffer || !scratch) return fail(ISR_EINVAL, "null buffer");
+    if (n_samples > 0 && (!pixels || !dL_dsampled)) return fail(ISR_EINVAL, "backward_sampled: pixels / dL_dsampled required");
+    if (scratch_bytes < backward_sampled_scratch_bytes(num_rendered, ED, n_samples, width, height))
+        return fail(ISR_EINVAL, "backward_sampled scratch too small");
+    const int rc = launch_backward_sampled(P, num_rendered, ED, width, height, mode, n_samples, pixels, dL_dsampled,
+                                           transMat_precomp, geom_buffer, binning_buffer, image_buffer, dL_dextra, accumulate,
+                                           scratch, (hipStream_t)stream);
+    if (rc != 0) return fail(ISR_EHIP, "backward_sampled launch failed (%d)", rc);
+    return ISR_OK;
+}
+
+int isr_feature_rows_step(int P, int row_begin, int row_count, int64_t num_rendered, int ED, const void* geom_buffer,
+                          const void* rows_scratch,
+                          const float* gz_dense, const float* gy, const int* gy_slot, const float* gy_merged, float eps1,
+                          float eps2, float* x, float* grad_out, double lr, double beta1, double beta2, double eps,
+                          long long step, float* exp_avg, float* exp_avg_sq, float* y, float* z, void* stream) {
+    if (P < 0 || ED <= 0 || (ED & 3) != 0 || ED > 256) return fail(ISR_EINVAL, "feature_rows_step needs ED % 4 == 0 and ED <= 256");
+    if (row_begin < 0 || row_count < 0 || row_begin + row_count > P) return fail(ISR_EINVAL, "feature_rows_step: bad row range");
+    if (P == 0 || row_count == 0) return ISR_OK;
+    if (!x || (rows_scratch && !geom_buffer) || ((gy_slot != nullptr) != (gy_merged != nullptr)))
+        return fail(ISR_EINVAL, "feature_rows_step: null pointer");
+    float lr_over_bc1 = 0.f, inv_sqrt_bc2 = 0.f;
+    if (grad_out == nullptr) {
+        if (!exp_avg || !exp_avg_sq || !z) return fail(ISR_EINVAL, "feature_rows_step: Adam state / outputs required");
+        if (step < 1) return fail(ISR_EINVAL, "feature_rows_step: step counts from 1");
+        const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+        lr_over_bc1 = (float)(lr / bc1);
+        inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    }
+    const int rc = launch_feature_rows_step(P, row_begin, row_count, num_rendered, ED, geom_buffer, rows_scratch, gz_dense, gy, gy_slot, gy_merged, eps1,
+                                            eps2, x, grad_out, lr_over_bc1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                                            inv_sqrt_bc2, (float)eps, exp_avg, exp_avg_sq, y, z, (hipStream_t)stream);
+    if (rc != 0) return fail(ISR_EHIP, "feature_rows_step launch failed (%d)", rc);
+    return ISR_OK;
+}
+
+int isr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float*, uint8_t* present, void* stream) {
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return fail(ISR_EINVAL, "null argument");
+    if (P == 0) return ISR_OK;
+    hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, means3D, viewmatrix, present);
+    ISR_LAUNCH_CHECK_S("k_mark_visible", (hipStream_t)stream);
+    return ISR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+// libinstascene_hip.so, binning (K2-K7): scans, scatter, per-tile sort.  Host side: isr_host.hpp.
+#include "isr_host.hpp"
+#include "isr_binning.hip"
+
+namespace isr {
+
+int launch_scan_u32(int n, const uint32_t* in, uint32_t* out, uint32_t* sums, hipStream_t s) {
+    const int nb = (n + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, n, in, out, sums, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, sums, (const uint32_t*)nullptr, (int64_t*)nullptr);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, n, out, sums);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+
+// the two scans of isr_forward_prepare: Gaussians (tiles touched -> row offsets, and the largest rectangle into header[1])
+// and tiles (sub-counter totals -> bucket offsets, launch order)
+int launch_prepare_scans(int P, int T, const GeomView& g, const ImageView& iv, hipStream_t s) {
+    if (P > 0) {
+        const int nb = (P + 1023) / 1024;
+        ProfScope ps2_("k_scan_gaussians", s);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, P, g.tiles_touched, g.point_offsets, g.scan_tmp, g.scan_tmp + nb + 1);
+        hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, g.scan_tmp, g.scan_tmp + nb + 1, g.header);
+        hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, P, g.point_offsets, g.scan_tmp);
+    }
+    static const int order_classes = [] { const char* e = getenv("ISR_ORDER_CLASSES"); return e ? atoi(e) : 16; }();
+    { ProfScope ps3_("k_tile_scan", s);
+    hipLaunchKernelGGL(k_gather_counts, dim3((T * CNT_SUB + 255) / 256), dim3(256), 0, s, T * CNT_SUB, iv.tile_count, iv.sub_offset, iv.tile_cursor);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, iv.sub_offset, iv.tile_offset, g.header, iv.tile_order, order_classes); }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace isr
+
+using namespace isr;
+
+extern "C" {
+
+int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binning_buffer, int64_t binning_capacity,
+                    void* image_buffer, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!geom_buffer || !binning_buffer || !image_buffer) return fail(ISR_EINVAL, "null buffer");
+    const int gx = tiles_x(width), gy = tiles_y(height), T = gx * gy;
+    GeomView g = geom_view(geom_buffer, P < 1 ? 1 : P);
+    ImageView iv = image_view(image_buffer, width, height);
+    BinView bv = bin_view(binning_buffer, binning_capacity);
+    if (P > 0 && binning_capacity > 0) {
+        { ProfScope ps_("k_scatter", s);
+        hipLaunchKernelGGL(k_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, g, iv.sub_offset, iv.tile_cursor,
+                           bv.keys, binning_capacity); }
+        ISR_LAUNCH_CHECK("k_scatter");
+        { ProfScope ps_("k_tile_sort", s);
+        // dense scenes (more than ~1 500 instances per tile on average): buckets beyond the 4 096-key LDS budget get their
+        // own launch with 128 KB of LDS instead of the global-memory network
+        const int big = (binning_capacity / (T > 0 ? T : 1)) > 1500 ? 1 : 0;
+        static const bool wave_sort = [] { const char* e = getenv("ISR_WAVE_SORT"); return !(e && e[0] == '0'); }();
+        // buckets of up to 2 048 keys: one wave each, in registers; the LDS network takes the rest
+        static const int wave_max = [] { const char* e = getenv("ISR_WAVE_SORT_MAX"); return e ? atoi(e) : 128; }();
+        const int wk = !wave_sort ? 0 : (!big ? 32 : wave_max);           // keys per lane of the widest variant launched
+        const int wflags = wk == 0 ? 0 : wk == 32 ? 2 : wk == 64 ? 6 : 14;
+        if (wk == 128)
+            hipLaunchKernelGGL(k_tile_sort_wave<128>, dim3(T), dim3(64), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity);
+        else if (wk == 64)
+            hipLaunchKernelGGL(k_tile_sort_wave<64>, dim3(T), dim3(64), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity);
+        else if (wk == 32)
+            hipLaunchKernelGGL(k_tile_sort_wave<32>, dim3(T), dim3(64), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity);
+        hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity,
+                           big | wflags);
+        if (big) {
+            static const bool attr_ok = [] {
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           SORT_BIG_KEYS * (int)sizeof(unsigned long long)) == hipSuccess;
+            }();
+            if (!attr_ok) return fail(ISR_EHIP, "k_tile_sort_big: cannot reserve %d bytes of LDS", SORT_BIG_KEYS * 8);
+            hipLaunchKernelGGL(k_tile_sort_big, dim3(T), dim3(1024), SORT_BIG_KEYS * sizeof(unsigned long long), s, iv.tile_offset,
+                               bv.keys, bv.point_list, binning_capacity, wk > 64 ? wk * 64 : SORT_LDS_KEYS);
+        } }
+        ISR_LAUNCH_CHECK("k_tile_sort");
+    }
+    return ISR_OK;
+}
+
+}  // extern "C"

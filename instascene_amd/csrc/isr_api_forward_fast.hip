@@ -1,0 +1,42 @@
+// libinstascene_hip.so, the FAST forward blend (K8, k_render_fwd_fast).  Host side: isr_host.hpp.
+#include "isr_host.hpp"
+#include "isr_forward_fast.hip"
+
+namespace isr {
+
+thread_local unsigned long long* g_fwd_counters = nullptr;    // isr_forward_set_counters: consumed by the next FAST forward
+
+// FAST arithmetic: k_render_fwd_fast (isr_forward_fast.hip), 32 feature channels per pass
+int launch_render_fwd_fast(int tiles, hipStream_t s, int W, int H, int ED, int gx, const ImageView& iv,
+                                  const BinView& bv, const float* rec, const float* cull, const float* col_pre, const float* tm_pre,
+                                  const float* extras, const float* bg, float* out_color, float* out_others, float* out_extra,
+                                  int32_t* tracer, long long tcap, int32_t* tcount, int64_t capacity, bool aux) {
+    unsigned long long* counters = g_fwd_counters;
+    g_fwd_counters = nullptr;
+    static const int order_below = [] { const char* e = getenv("ISR_FWD_ORDER_BELOW"); return e ? atoi(e) : 4096; }();
+    const uint32_t* order = tiles < order_below ? iv.tile_order : nullptr;
+    int ch = 0, first = 1;
+    do {
+        ProfScope ps_("k_render_fwd", s);
+#define ISR_GO2(FEAT, STATS, AUX_, ORD)                                                                                   \
+    hipLaunchKernelGGL((k_render_fwd_fast<FEAT, STATS, AUX_, ORD>), dim3(tiles), dim3(256), 0, s, W, H, ED, ch, first, gx, \
+                       iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,    \
+                       out_color, out_others, out_extra, tracer, tcap, tcount, bv.box4, capacity, counters, order)
+#define ISR_GO(FEAT, STATS)                                                                                           \
+    do { if (aux) { if (order) ISR_GO2(FEAT, STATS, true, true); else ISR_GO2(FEAT, STATS, true, false); }            \
+         else { if (order) ISR_GO2(FEAT, STATS, false, true); else ISR_GO2(FEAT, STATS, false, false); } } while (0)
+        if (ED - ch <= 0) { if (counters) ISR_GO(false, true); else ISR_GO(false, false); }
+        else { if (counters) ISR_GO(true, true); else ISR_GO(true, false); }
+#undef ISR_GO2
+#undef ISR_GO
+        ISR_LAUNCH_CHECK("k_render_fwd_fast");
+        ch += MAX_FCHUNK;
+        first = 0;
+    } while (ch < ED);
+    return ISR_OK;
+}
+
+
+}  // namespace isr
+
+extern "C" void isr_forward_set_counters(unsigned long long* device_counters) { isr::g_fwd_counters = device_counters; }

@@ -1,432 +1,16 @@
-// C-ABI entry points of libinstascene_hip.so (declared in include/instascene_rasterizer.h).
+// C-ABI entry points of libinstascene_hip.so, the operators around the rasterizer (declared in include/instascene_ops.h).
 // Host-side only: argument checking, workspace carving and kernel launches on the
 // caller's stream.  No torch types, no allocation, no hidden synchronisation except
 // where the header says so.
-#include "isr_common.hpp"
-#include "isr_forward.hip"    // unity build: kernels are defined before the entry points
-#include "isr_forward_fast.hip"
-#include "isr_backward.hip"
+#include "isr_host.hpp"
 #include "iso_knn.hip"
 #include "iso_contrastive.hip"
 #include "iso_post.hip"
 #include "iso_ssim.hip"
 #include "iso_optim.hip"
-#include "../../include/instascene_rasterizer.h"
-#include "../../include/instascene_ops.h"
-
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-
-namespace isr {
-
-thread_local char g_err[512] = "";
-
-static int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define ISR_HIP(expr)                                                                                       \
-    do {                                                                                                    \
-        hipError_t e_ = (expr);                                                                             \
-        if (e_ != hipSuccess) return fail(ISR_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));       \
-    } while (0)
-// ISR_DEBUG_SYNC=1: synchronise after named stages and report which one faulted (debugging aid)
-static bool debug_sync() {
-    static const bool on = [] { const char* e = getenv("ISR_DEBUG_SYNC"); return e && e[0] == '1'; }();
-    return on;
-}
-#define ISR_STAGE(name, stream)                                                                             \
-    do {                                                                                                    \
-        if (debug_sync()) {                                                                                 \
-            fprintf(stderr, "[isr] stage %s\n", name);                                                      \
-            hipError_t e_ = hipStreamSynchronize(stream);                                                   \
-            if (e_ != hipSuccess) return fail(ISR_EHIP, "stage %s failed: %s", name, hipGetErrorString(e_)); \
-        }                                                                                                   \
-    } while (0)
-#define ISR_LAUNCH_CHECK(name)                                                                              \
-    do {                                                                                                    \
-        hipError_t e_ = hipGetLastError();                                                                  \
-        if (e_ != hipSuccess) return fail(ISR_EHIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
-    } while (0)
-
-thread_local unsigned long long* g_fwd_counters = nullptr;    // isr_forward_set_counters: consumed by the next FAST forward
-
-// FAST arithmetic: k_render_fwd_fast (isr_forward_fast.hip), 32 feature channels per pass
-static int launch_render_fwd_fast(int tiles, hipStream_t s, int W, int H, int ED, int gx, const ImageView& iv,
-                                  const BinView& bv, const float* rec, const float* cull, const float* col_pre, const float* tm_pre,
-                                  const float* extras, const float* bg, float* out_color, float* out_others, float* out_extra,
-                                  int32_t* tracer, long long tcap, int32_t* tcount, int64_t capacity, bool aux) {
-    unsigned long long* counters = g_fwd_counters;
-    g_fwd_counters = nullptr;
-    static const int order_below = [] { const char* e = getenv("ISR_FWD_ORDER_BELOW"); return e ? atoi(e) : 4096; }();
-    const uint32_t* order = tiles < order_below ? iv.tile_order : nullptr;
-    int ch = 0, first = 1;
-    do {
-        ProfScope ps_("k_render_fwd", s);
-#define ISR_GO2(FEAT, STATS, AUX_, ORD)                                                                                   \
-    hipLaunchKernelGGL((k_render_fwd_fast<FEAT, STATS, AUX_, ORD>), dim3(tiles), dim3(256), 0, s, W, H, ED, ch, first, gx, \
-                       iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,    \
-                       out_color, out_others, out_extra, tracer, tcap, tcount, bv.box4, capacity, counters, order)
-#define ISR_GO(FEAT, STATS)                                                                                           \
-    do { if (aux) { if (order) ISR_GO2(FEAT, STATS, true, true); else ISR_GO2(FEAT, STATS, true, false); }            \
-         else { if (order) ISR_GO2(FEAT, STATS, false, true); else ISR_GO2(FEAT, STATS, false, false); } } while (0)
-        if (ED - ch <= 0) { if (counters) ISR_GO(false, true); else ISR_GO(false, false); }
-        else { if (counters) ISR_GO(true, true); else ISR_GO(true, false); }
-#undef ISR_GO2
-#undef ISR_GO
-        ISR_LAUNCH_CHECK("k_render_fwd_fast");
-        ch += MAX_FCHUNK;
-        first = 0;
-    } while (ch < ED);
-    return ISR_OK;
-}
-
-template <class Math>
-static int launch_render_fwd(int tiles, hipStream_t s, int W, int H, int ED, int gx, const ImageView& iv,
-                             const BinView& bv, const float* rec, const float* cull, const float* col_pre, const float* tm_pre,
-                             const float* extras, const float* bg, float* out_color, float* out_others, float* out_extra,
-                             int32_t* tracer, long long tcap, int32_t* tcount, int64_t capacity) {
-    // first pass: geometry/colour/aux + the first feature chunk; further passes add 32 channels each
-    int ch = 0, first = 1;
-    do {
-        ProfScope ps_("k_render_fwd", s);
-        const int rem = ED - ch;
-#define ISR_GO(F, B)                                                                                                 \
-    hipLaunchKernelGGL((k_render_fwd<Math, F, B>), dim3(tiles), dim3(256), 0, s, W, H, ED, ch, first, gx,             \
-                       iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,    \
-                       out_color, out_others, out_extra, tracer, tcap, tcount, bv.box4, capacity)
-        if (rem <= 0) ISR_GO(0, 256);
-        else if (rem <= 8) ISR_GO(8, 256);
-        else if (rem <= 16) ISR_GO(16, 256);
-        else ISR_GO(32, 128);
-#undef ISR_GO
-        ISR_LAUNCH_CHECK("k_render_fwd");
-        ch += MAX_FCHUNK;
-        first = 0;
-    } while (ch < ED);
-    return ISR_OK;
-}
-
-}  // namespace isr
 
 using namespace isr;
 
-extern "C" {
-
-const char* isr_last_error(void) { return g_err; }
-int isr_version(void) { return 1; }
-
-void isr_forward_set_counters(unsigned long long* device_counters) { g_fwd_counters = device_counters; }
-
-void isr_profile_enable(int on) {
-    Prof& p = prof();
-    for (auto& r : p.recs) { p.pool.push_back(r.a); p.pool.push_back(r.b); }
-    p.recs.clear();
-    p.on = on != 0;
-    p.dominant_only = on == 2;
-}
-
-/* Writes "name count total_ms" lines for everything recorded since isr_profile_enable(1); synchronises
- * on the recorded events.  Returns the number of bytes written (0 if nothing / buffer too small). */
-size_t isr_profile_summary(char* buf, size_t len) {
-    Prof& p = prof();
-    std::vector<std::string> names;
-    std::vector<double> tot;
-    std::vector<int> cnt;
-    for (auto& r : p.recs) {
-        if (hipEventSynchronize(r.b) != hipSuccess) continue;
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
-        size_t k = 0;
-        for (; k < names.size(); k++) if (names[k] == r.name) break;
-        if (k == names.size()) { names.push_back(r.name); tot.push_back(0); cnt.push_back(0); }
-        tot[k] += ms; cnt[k] += 1;
-    }
-    std::string out;
-    for (size_t k = 0; k < names.size(); k++) {
-        char line[256];
-        snprintf(line, sizeof(line), "%s %d %.6f\n", names[k].c_str(), cnt[k], tot[k]);
-        out += line;
-    }
-    if (out.size() + 1 > len) return 0;
-    memcpy(buf, out.c_str(), out.size() + 1);
-    return out.size();
-}
-
-size_t isr_geom_bytes(int P) { return geom_bytes(P < 1 ? 1 : P); }
-size_t isr_image_bytes(int width, int height) { return image_bytes(width, height); }
-size_t isr_binning_bytes(int64_t num_rendered, int, int) { return bin_bytes(num_rendered); }
-size_t isr_backward_scratch_bytes(int64_t num_rendered, int ED, unsigned grad_mask) {
-    return backward_scratch_bytes(num_rendered, ED, grad_mask);
-}
-
-int isr_forward_prepare(int P, int D, int M, int width, int height, const float* means3D, const float* shs,
-                        const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
-                        const float* rotations, const float* transMat_precomp, const float* viewmatrix,
-                        const float* projmatrix, const float* cam_pos, float, float, int prefiltered, int* radii,
-                        void* geom_buffer, void* image_buffer, int64_t* num_rendered_host, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    if (P < 0 || width <= 0 || height <= 0) return fail(ISR_EINVAL, "bad sizes P=%d W=%d H=%d", P, width, height);
-    if (!geom_buffer || !image_buffer || (P > 0 && !radii)) return fail(ISR_EINVAL, "null workspace/radii");
-    if (P > 0 && (!means3D || !opacities || !viewmatrix || !projmatrix))
-        return fail(ISR_EINVAL, "means3D/opacities/viewmatrix/projmatrix must be given");
-    if ((shs == nullptr) == (colors_precomp == nullptr) && P > 0)
-        return fail(ISR_EINVAL, "provide exactly one of shs / colors_precomp");
-    if (P > 0 && (((scales == nullptr) || (rotations == nullptr)) == (transMat_precomp == nullptr)))
-        return fail(ISR_EINVAL, "provide exactly one of (scales, rotations) / transMat_precomp");
-    if (shs && !cam_pos) return fail(ISR_EINVAL, "cam_pos required with shs");
-    if (shs && (M < 1 || (D > 0 && M < 4) || (D > 1 && M < 9) || (D > 2 && M < 16) || D > 3))
-        return fail(ISR_EINVAL, "sh degree %d needs more coefficients than M=%d (max degree 3)", D, M);
-    const int gx = tiles_x(width), gy = tiles_y(height), T = gx * gy;
-    if (gx > 65535 || gy > 65535) return fail(ISR_EINVAL, "image too large for 16-bit tile coordinates");
-    GeomView g = geom_view(geom_buffer, P < 1 ? 1 : P);
-    ImageView iv = image_view(image_buffer, width, height);
-    ISR_HIP(hipMemsetAsync(iv.tile_count, 0, sizeof(uint32_t) * (size_t)T * CNT_SUB * CNT_STRIDE, s));
-    if (P > 0) {
-        { ProfScope ps_("k_preprocess", s);
-        const int tight = (prefiltered & ISR_PREPARE_TIGHT_RECTS) ? 1 : 0;
-        if (M == 16 && colors_precomp == nullptr && shs != nullptr)      // SH rows staged through LDS (coalesced reads)
-            hipLaunchKernelGGL(k_preprocess<true>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales,
-                               scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, viewmatrix,
-                               projmatrix, cam_pos, width, height, gx, gy, radii, g, iv.tile_count, tight);
-        else
-            hipLaunchKernelGGL(k_preprocess<false>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales,
-                               scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, viewmatrix,
-                               projmatrix, cam_pos, width, height, gx, gy, radii, g, iv.tile_count, tight); }
-        ISR_LAUNCH_CHECK("k_preprocess");
-        const int nb = (P + 1023) / 1024;
-        ProfScope ps2_("k_scan_gaussians", s);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, P, g.tiles_touched, g.point_offsets, g.scan_tmp, g.scan_tmp + nb + 1);
-        hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, g.scan_tmp, g.scan_tmp + nb + 1, g.header);
-        hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, P, g.point_offsets, g.scan_tmp);
-        ISR_LAUNCH_CHECK("k_scan");
-    }
-    static const int order_classes = [] { const char* e = getenv("ISR_ORDER_CLASSES"); return e ? atoi(e) : 16; }();
-    { ProfScope ps3_("k_tile_scan", s);
-    hipLaunchKernelGGL(k_gather_counts, dim3((T * CNT_SUB + 255) / 256), dim3(256), 0, s, T * CNT_SUB, iv.tile_count, iv.sub_offset, iv.tile_cursor);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, iv.sub_offset, iv.tile_offset, g.header, iv.tile_order, order_classes); }
-    ISR_LAUNCH_CHECK("k_tile_scan");
-    if (num_rendered_host) return isr_read_num_rendered(geom_buffer, num_rendered_host, stream);
-    return ISR_OK;
-}
-
-int isr_read_num_rendered(const void* geom_buffer, int64_t* num_rendered_host, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    if (!geom_buffer || !num_rendered_host) return fail(ISR_EINVAL, "null argument");
-    ISR_HIP(hipMemcpyAsync(num_rendered_host, geom_buffer, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    ISR_HIP(hipStreamSynchronize(s));
-    return ISR_OK;
-}
-
-int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binning_buffer, int64_t binning_capacity,
-                    void* image_buffer, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    if (!geom_buffer || !binning_buffer || !image_buffer) return fail(ISR_EINVAL, "null buffer");
-    const int gx = tiles_x(width), gy = tiles_y(height), T = gx * gy;
-    GeomView g = geom_view(geom_buffer, P < 1 ? 1 : P);
-    ImageView iv = image_view(image_buffer, width, height);
-    BinView bv = bin_view(binning_buffer, binning_capacity);
-    if (P > 0 && binning_capacity > 0) {
-        { ProfScope ps_("k_scatter", s);
-        hipLaunchKernelGGL(k_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, g, iv.sub_offset, iv.tile_cursor,
-                           bv.keys, binning_capacity); }
-        ISR_LAUNCH_CHECK("k_scatter");
-        { ProfScope ps_("k_tile_sort", s);
-        // dense scenes (more than ~1 500 instances per tile on average): buckets beyond the 4 096-key LDS budget get their
-        // own launch with 128 KB of LDS instead of the global-memory network
-        const int big = (binning_capacity / (T > 0 ? T : 1)) > 1500 ? 1 : 0;
-        static const bool wave_sort = [] { const char* e = getenv("ISR_WAVE_SORT"); return !(e && e[0] == '0'); }();
-        // buckets of up to 2 048 keys: one wave each, in registers; the LDS network takes the rest
-        static const int wave_max = [] { const char* e = getenv("ISR_WAVE_SORT_MAX"); return e ? atoi(e) : 128; }();
-        const int wk = !wave_sort ? 0 : (!big ? 32 : wave_max);           // keys per lane of the widest variant launched
-        const int wflags = wk == 0 ? 0 : wk == 32 ? 2 : wk == 64 ? 6 : 14;
-        if (wk == 128)
-            hipLaunchKernelGGL(k_tile_sort_wave<128>, dim3(T), dim3(64), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity);
-        else if (wk == 64)
-            hipLaunchKernelGGL(k_tile_sort_wave<64>, dim3(T), dim3(64), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity);
-        else if (wk == 32)
-            hipLaunchKernelGGL(k_tile_sort_wave<32>, dim3(T), dim3(64), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity);
-        hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity,
-                           big | wflags);
-        if (big) {
-            static const bool attr_ok = [] {
-                return hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           SORT_BIG_KEYS * (int)sizeof(unsigned long long)) == hipSuccess;
-            }();
-            if (!attr_ok) return fail(ISR_EHIP, "k_tile_sort_big: cannot reserve %d bytes of LDS", SORT_BIG_KEYS * 8);
-            hipLaunchKernelGGL(k_tile_sort_big, dim3(T), dim3(1024), SORT_BIG_KEYS * sizeof(unsigned long long), s, iv.tile_offset,
-                               bv.keys, bv.point_list, binning_capacity, wk > 64 ? wk * 64 : SORT_LDS_KEYS);
-        } }
-        ISR_LAUNCH_CHECK("k_tile_sort");
-    }
-    return ISR_OK;
-}
-
-int isr_forward_render(int P, int ED, int width, int height, int mode, const float* background,
-                       const float* colors_precomp, const float* transMat_precomp, const float* extra_attrs,
-                       void* geom_buffer, void* binning_buffer, int64_t binning_capacity, void* image_buffer,
-                       float* out_color, float* out_others, float* out_extra, int32_t* tracer_pairs,
-                       int64_t tracer_capacity, int32_t* tracer_count, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    const bool prebinned = (mode & ISR_MODE_PREBINNED) != 0;
-    const bool feature_only = (mode & ISR_MODE_FEATURE_ONLY) != 0;
-    mode &= ~(ISR_MODE_PREBINNED | ISR_MODE_FEATURE_ONLY);
-    if (feature_only && (mode != ISR_MODE_FAST || ED <= 0)) return fail(ISR_EINVAL, "ISR_MODE_FEATURE_ONLY needs ISR_MODE_FAST and ED > 0");
-    if (!geom_buffer || !binning_buffer || !image_buffer || !background || (!feature_only && (!out_color || !out_others)))
-        return fail(ISR_EINVAL, "null buffer");
-    if (ED < 0 || (ED > 0 && (!extra_attrs || !out_extra))) return fail(ISR_EINVAL, "extra_attrs/out_extra required when ED>0");
-    if (mode != ISR_MODE_EXACT && mode != ISR_MODE_FAST) return fail(ISR_EINVAL, "unknown mode %d", mode);
-    if (tracer_pairs && !tracer_count) return fail(ISR_EINVAL, "tracer_count required with tracer_pairs");
-    const int gx = tiles_x(width), gy = tiles_y(height), T = gx * gy;
-    GeomView g = geom_view(geom_buffer, P < 1 ? 1 : P);
-    ImageView iv = image_view(image_buffer, width, height);
-    BinView bv = bin_view(binning_buffer, binning_capacity);
-    if (tracer_pairs) ISR_HIP(hipMemsetAsync(tracer_count, 0xFF, sizeof(int32_t), s));     // -1: the counter ends at (pairs - 1)
-    if (!prebinned) {
-        const int rc = isr_forward_bin(P, width, height, geom_buffer, binning_buffer, binning_capacity, image_buffer, stream);
-        if (rc != ISR_OK) return rc;
-    }
-    if (mode == ISR_MODE_EXACT)
-        return launch_render_fwd<ExactMath>(T, s, width, height, ED, gx, iv, bv, g.rec, g.cull, colors_precomp, transMat_precomp,
-                                            extra_attrs, background, out_color, out_others, out_extra, tracer_pairs,
-                                            (long long)tracer_capacity, tracer_count, binning_capacity);
-    return launch_render_fwd_fast(T, s, width, height, ED, gx, iv, bv, g.rec, g.cull, colors_precomp, transMat_precomp,
-                                  extra_attrs, background, out_color, out_others, out_extra, feature_only ? nullptr : tracer_pairs,
-                                  (long long)tracer_capacity, tracer_count, binning_capacity, !feature_only);
-}
-
-int isr_backward(int P, int D, int M, int64_t num_rendered, int ED, int width, int height, int mode, unsigned grad_mask,
-                 const float* background, const float* means3D, const float* shs, const float* colors_precomp,
-                 const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
-                 const float* extra_attrs, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-                 float tan_fovx, float tan_fovy, const int* radii, const void* geom_buffer, const void* binning_buffer,
-                 const void* image_buffer, const float* dL_dout_color, const float* dL_dout_others,
-                 const float* dL_dout_extra, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
-                 float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                 float* dL_dextra, void* scratch, size_t scratch_bytes, void* stream) {
-    if (!geom_buffer || !binning_buffer || !image_buffer) return fail(ISR_EINVAL, "null state buffer");
-    if (mode != ISR_MODE_EXACT && mode != ISR_MODE_FAST) return fail(ISR_EINVAL, "unknown mode %d", mode);
-    if ((grad_mask & ~(ISR_GRAD_EXTRA | ISR_GRAD_GEOMETRY)) || grad_mask == 0) return fail(ISR_EINVAL, "bad grad_mask");
-    if ((grad_mask & ISR_GRAD_EXTRA) && ED > 0 && !dL_dextra) return fail(ISR_EINVAL, "dL_dextra is NULL");
-    if ((grad_mask & ISR_GRAD_GEOMETRY) &&
-        (!dL_dmean2D || !dL_dnormal || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dtransMat || !dL_dscale ||
-         !dL_drot || (shs && !dL_dsh)))
-        return fail(ISR_EINVAL, "a geometry gradient output is NULL");
-    if (scratch_bytes < backward_scratch_bytes(num_rendered, ED, grad_mask) || (!scratch && scratch_bytes))
-        return fail(ISR_EINVAL, "backward scratch too small");
-    const int rc = launch_backward(P, D, M, num_rendered, ED, width, height, mode, grad_mask, background, means3D, shs,
-                           colors_precomp, scales, scale_modifier, rotations, transMat_precomp, extra_attrs, viewmatrix,
-                           projmatrix, cam_pos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer,
-                           dL_dout_color, dL_dout_others, dL_dout_extra, dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor,
-                           dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot, dL_dextra, scratch, scratch_bytes,
-                           (hipStream_t)stream);
-    if (rc != 0) return fail(ISR_EHIP, "backward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
-    return ISR_OK;
-}
-
-size_t isr_backward_sampled_scratch_bytes(int64_t num_rendered, int ED, int n_samples, int width, int height) {
-    return backward_sampled_scratch_bytes(num_rendered, ED, n_samples, width, height);
-}
-
-int isr_sample_extra(int ED, int width, int height, int n_samples, const float* out_extra, const long long* pixels,
-                     float* sampled, void* stream) {
-    if (ED < 0 || width <= 0 || height <= 0 || n_samples < 0) return fail(ISR_EINVAL, "bad sample_extra sizes");
-    if (n_samples > 0 && ED > 0 && (!out_extra || !pixels || !sampled)) return fail(ISR_EINVAL, "sample_extra: null pointer");
-    if (launch_sample_gather(n_samples, ED, (long long)width * height, out_extra, pixels, sampled, (hipStream_t)stream) != 0)
-        return fail(ISR_EHIP, "sample_extra launch failed");
-    return ISR_OK;
-}
-
-int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int height, int mode, int n_samples,
-                         const long long* pixels, const float* dL_dsampled, const float* transMat_precomp,
-                         const void* geom_buffer, const void* binning_buffer, const void* image_buffer, float* dL_dextra,
-                         int accumulate, void* scratch, size_t scratch_bytes, void* stream) {
-    if (P < 0 || ED <= 0 || width <= 0 || height <= 0 || n_samples < 0) return fail(ISR_EINVAL, "bad backward_sampled sizes");
-    if (mode != ISR_MODE_EXACT && mode != ISR_MODE_FAST) return fail(ISR_EINVAL, "unknown mode %d", mode);
-    if (!geom_buffer || !binning_buffer || !image_buffer || !scratch) return fail(ISR_EINVAL, "null buffer");
-    if (n_samples > 0 && (!pixels || !dL_dsampled)) return fail(ISR_EINVAL, "backward_sampled: pixels / dL_dsampled required");
-    if (scratch_bytes < backward_sampled_scratch_bytes(num_rendered, ED, n_samples, width, height))
-        return fail(ISR_EINVAL, "backward_sampled scratch too small");
-    const int rc = launch_backward_sampled(P, num_rendered, ED, width, height, mode, n_samples, pixels, dL_dsampled,
-                                           transMat_precomp, geom_buffer, binning_buffer, image_buffer, dL_dextra, accumulate,
-                                           scratch, (hipStream_t)stream);
-    if (rc != 0) return fail(ISR_EHIP, "backward_sampled launch failed (%d)", rc);
-    return ISR_OK;
-}
-
-int isr_feature_rows_step(int P, int row_begin, int row_count, int64_t num_rendered, int ED, const void* geom_buffer,
-                          const void* rows_scratch,
-                          const float* gz_dense, const float* gy, const int* gy_slot, const float* gy_merged, float eps1,
-                          float eps2, float* x, float* grad_out, double lr, double beta1, double beta2, double eps,
-                          long long step, float* exp_avg, float* exp_avg_sq, float* y, float* z, void* stream) {
-    if (P < 0 || ED <= 0 || (ED & 3) != 0 || ED > 256) return fail(ISR_EINVAL, "feature_rows_step needs ED % 4 == 0 and ED <= 256");
-    if (row_begin < 0 || row_count < 0 || row_begin + row_count > P) return fail(ISR_EINVAL, "feature_rows_step: bad row range");
-    if (P == 0 || row_count == 0) return ISR_OK;
-    if (!x || (rows_scratch && !geom_buffer) || ((gy_slot != nullptr) != (gy_merged != nullptr)))
-        return fail(ISR_EINVAL, "feature_rows_step: null pointer");
-    float lr_over_bc1 = 0.f, inv_sqrt_bc2 = 0.f;
-    if (grad_out == nullptr) {
-        if (!exp_avg || !exp_avg_sq || !z) return fail(ISR_EINVAL, "feature_rows_step: Adam state / outputs required");
-        if (step < 1) return fail(ISR_EINVAL, "feature_rows_step: step counts from 1");
-        const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-        lr_over_bc1 = (float)(lr / bc1);
-        inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    }
-    const int rc = launch_feature_rows_step(P, row_begin, row_count, num_rendered, ED, geom_buffer, rows_scratch, gz_dense, gy, gy_slot, gy_merged, eps1,
-                                            eps2, x, grad_out, lr_over_bc1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                                            inv_sqrt_bc2, (float)eps, exp_avg, exp_avg_sq, y, z, (hipStream_t)stream);
-    if (rc != 0) return fail(ISR_EHIP, "feature_rows_step launch failed (%d)", rc);
-    return ISR_OK;
-}
-
-int isr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float*, uint8_t* present, void* stream) {
-    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return fail(ISR_EINVAL, "null argument");
-    if (P == 0) return ISR_OK;
-    hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, means3D, viewmatrix, present);
-    ISR_LAUNCH_CHECK("k_mark_visible");
-    return ISR_OK;
-}
-
-int isr_debug_state(int P, int width, int height, int64_t num_rendered, const void* geom_buffer,
-                    const void* binning_buffer, const void* image_buffer, uint32_t* tiles_touched, uint32_t* point_list,
-                    uint32_t* ranges, uint32_t* n_contrib, float* final_T, float* splat_records, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    GeomView g = geom_view(const_cast<void*>(geom_buffer), P < 1 ? 1 : P);
-    ImageView iv = image_view(const_cast<void*>(image_buffer), width, height);
-    const size_t N = (size_t)width * height, T = (size_t)tiles_x(width) * tiles_y(height);
-    if (tiles_touched && P) ISR_HIP(hipMemcpyAsync(tiles_touched, g.tiles_touched, 4 * (size_t)P, hipMemcpyDeviceToHost, s));
-    if (splat_records && P) ISR_HIP(hipMemcpyAsync(splat_records, g.rec, 4 * (size_t)P * REC, hipMemcpyDeviceToHost, s));
-    if (point_list && num_rendered > 0 && binning_buffer) {
-        BinView bv = bin_view(const_cast<void*>(binning_buffer), num_rendered);
-        ISR_HIP(hipMemcpyAsync(point_list, bv.point_list, 4 * (size_t)num_rendered, hipMemcpyDeviceToHost, s));
-    }
-    if (n_contrib) ISR_HIP(hipMemcpyAsync(n_contrib, iv.n_contrib, 8 * N, hipMemcpyDeviceToHost, s));
-    if (final_T) ISR_HIP(hipMemcpyAsync(final_T, iv.final_T, 12 * N, hipMemcpyDeviceToHost, s));
-    ISR_HIP(hipStreamSynchronize(s));
-    if (ranges) {
-        uint32_t* off = new uint32_t[T + 1];
-        hipError_t e = hipMemcpy(off, iv.tile_offset, 4 * (T + 1), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { delete[] off; return fail(ISR_EHIP, "copy of tile offsets failed"); }
-        for (size_t t = 0; t < T; t++) {
-            const bool empty = off[t] == off[t + 1];
-            ranges[2 * t] = empty ? 0u : off[t];        // the reference leaves empty tiles at (0,0)
-            ranges[2 * t + 1] = empty ? 0u : off[t + 1];
-        }
-        delete[] off;
-    }
-    return ISR_OK;
-}
-
-}  // extern "C"
-
-// ---------------------------------------------------------------------------
-// include/instascene_ops.h
 extern "C" {
 
 size_t iso_knn_scratch_bytes(int P) { return iso::knn_bytes(P); }
@@ -444,10 +28,8 @@ int iso_dist2_3nn(int P, const float* points, float* mean_dist2, void* scratch, 
     ISR_HIP(hipMemsetAsync(v.count, 0, sizeof(uint32_t) * ccap, s));
     ISR_HIP(hipMemsetAsync(v.cursor, 0, sizeof(uint32_t) * ccap, s));
     hipLaunchKernelGGL(iso::kk_count, dim3(pb), dim3(256), 0, s, P, points, v.grid, v.count);
-    const int nb = (ccap + 1023) / 1024;      // scan the whole capacity: unused cells hold zero
-    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, ccap, v.count, v.offset, v.sums, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, v.sums, (const uint32_t*)nullptr, (int64_t*)nullptr);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, ccap, v.offset, v.sums);
+    if (launch_scan_u32(ccap, v.count, v.offset, v.sums, s) != 0)      // the whole capacity: unused cells hold zero
+        return fail(ISR_EHIP, "iso_dist2_3nn: scan launch failed");
     hipLaunchKernelGGL(iso::kk_scatter, dim3(pb), dim3(256), 0, s, P, points, v.grid, v.offset, v.cursor, v.sorted);
     // ISO_KNN_LDS=1: the LDS-bucketed query (built as north_star names it, measured 0.8-8x SLOWER than the ring walk from
     // global memory - profiles/r02_knn_timing.json - because the cell-sorted points are L2-resident anyway and a clustered
@@ -797,7 +379,7 @@ int iso_gaussian_adam_step(int P, int M, float* const params[6], float* const ex
     a.P = P; a.M = M;
     const long long threads = (long long)P * (3 + 3LL * M + 1 + 2 + 1);
     hipLaunchKernelGGL(iso::gaussian_adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-    ISR_LAUNCH_CHECK("iso_gaussian_adam_step");
+    ISR_LAUNCH_CHECK_S("iso_gaussian_adam_step", (hipStream_t)stream);
     return ISR_OK;
 }
 
@@ -809,7 +391,7 @@ int iso_gather_rownorm(int n, int F, long long P, float eps, const float* x, con
     while (lpr < q) lpr <<= 1;
     hipLaunchKernelGGL(iso::gather_rownorm_kernel, dim3((unsigned)(((long long)n * lpr + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, n, F, P, eps, x, idx, out);
-    ISR_LAUNCH_CHECK("iso_gather_rownorm");
+    ISR_LAUNCH_CHECK_S("iso_gather_rownorm", (hipStream_t)stream);
     return ISR_OK;
 }
 
@@ -823,7 +405,7 @@ int iso_sample_step(unsigned long long seed, unsigned long long step, int B, lon
     if (n_pool3d > 0 && (!pool3d || !labels3d || !pick3d || !lab3d)) return fail(ISR_EINVAL, "sample_step: null 3-D argument");
     hipLaunchKernelGGL(iso::sample_step_kernel, dim3((3 * B + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed, step, B,
                        n_pool2d, pool2d, segmap_a, segmap_b, n_pool3d, pool3d, labels3d, pix, lab_a, lab_b, pick3d, lab3d);
-    ISR_LAUNCH_CHECK("iso_sample_step");
+    ISR_LAUNCH_CHECK_S("iso_sample_step", (hipStream_t)stream);
     return ISR_OK;
 }
 

@@ -245,6 +245,67 @@ __device__ __forceinline__ uint32_t pack_box4(float4 box, float tile_x0, float t
     return (uint32_t)(xl & 255) | ((uint32_t)(xh & 255) << 8) | ((uint32_t)(yl & 255) << 16) | ((uint32_t)(yh & 255) << 24);
 }
 
+// ----------------------------------------------------------------------------
+// Workgroup-level aggregation of per-tile counters.  Global atomics cost one memory transaction per distinct cache line
+// per wave instruction (~26 G/s on MI355X whatever the scope, tools/micro/atomics.hip), and K1 + the key scatter issue
+// 2R of them.  When neighbouring Gaussians in memory are neighbours on screen (scenes.spatially_sorted) the 256 Gaussians
+// of a workgroup touch a few dozen tiles: their increments are first merged in a small LDS hash table (open addressing,
+// integer LDS atomics) and each distinct tile costs ONE global atomic.  A tile that finds no slot within TH_PROBES steps
+// falls back to the direct global atomic, consistently in every phase (slots never become free again).
+constexpr int TH_SIZE = 2048, TH_BITS = 11, TH_PROBES = 32;
+constexpr int BIG_RECT = 128;            // tiles: rectangles beyond this are walked by the workgroup, not by the splat's own lane
+constexpr uint32_t TH_EMPTY = 0xffffffffu;
+__device__ __forceinline__ int th_find_or_insert(uint32_t* keys, uint32_t tile) {
+    uint32_t h = (tile * 2654435761u) >> (32 - TH_BITS);
+    for (int p = 0; p < TH_PROBES; p++) {
+        const uint32_t old = atomicCAS(&keys[h], TH_EMPTY, tile);
+        if (old == TH_EMPTY || old == tile) return (int)h;
+        h = (h + 1) & (TH_SIZE - 1);
+    }
+    return -1;
+}
+__device__ __forceinline__ int th_find(const uint32_t* keys, uint32_t tile) {
+    uint32_t h = (tile * 2654435761u) >> (32 - TH_BITS);
+    for (int p = 0; p < TH_PROBES; p++) {
+        const uint32_t k = keys[h];
+        if (k == tile) return (int)h;
+        if (k == TH_EMPTY) return -1;
+        h = (h + 1) & (TH_SIZE - 1);
+    }
+    return -1;
+}
+// every Gaussian of a workgroup uses the same sub-counter of a tile; concurrently running workgroups use different ones
+__device__ __forceinline__ int counter_sub(int block) { return block & (CNT_SUB - 1); }
+
+
+// Exclusive u32 scan over a workgroup of 1024 threads (s_warp: 32 words of LDS).
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* s_warp, uint32_t& total) {
+    // blockDim.x == 1024: 16 waves
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) s_warp[wid] = x;
+    __syncthreads();
+    if (wid == 0) {
+        uint32_t w = lane < 16 ? s_warp[lane] : 0;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            uint32_t y = __shfl_up(w, o);
+            if (lane >= o) w += y;
+        }
+        if (lane < 16) s_warp[16 + lane] = w;   // inclusive
+    }
+    __syncthreads();
+    const uint32_t base = wid == 0 ? 0u : s_warp[16 + wid - 1];
+    total = s_warp[16 + 15];
+    __syncthreads();
+    return base + x - v;
+}
+
 // Arithmetic policies for the per-pixel loops.
 struct ExactMath {
     static constexpr bool fast = false;

@@ -62,38 +62,6 @@ __device__ __forceinline__ F3 sh_to_rgb(int deg, F3 pos, F3 cam, const float* sh
     return {res.x < 0.0f ? 0.0f : res.x, res.y < 0.0f ? 0.0f : res.y, res.z < 0.0f ? 0.0f : res.z};
 }
 
-// ----------------------------------------------------------------------------
-// Workgroup-level aggregation of per-tile counters.  Global atomics cost one memory transaction per distinct cache line
-// per wave instruction (~26 G/s on MI355X whatever the scope, tools/micro/atomics.hip), and K1 + the key scatter issue
-// 2R of them.  When neighbouring Gaussians in memory are neighbours on screen (scenes.spatially_sorted) the 256 Gaussians
-// of a workgroup touch a few dozen tiles: their increments are first merged in a small LDS hash table (open addressing,
-// integer LDS atomics) and each distinct tile costs ONE global atomic.  A tile that finds no slot within TH_PROBES steps
-// falls back to the direct global atomic, consistently in every phase (slots never become free again).
-constexpr int TH_SIZE = 2048, TH_BITS = 11, TH_PROBES = 32;
-constexpr int BIG_RECT = 128;            // tiles: rectangles beyond this are walked by the workgroup, not by the splat's own lane
-constexpr uint32_t TH_EMPTY = 0xffffffffu;
-__device__ __forceinline__ int th_find_or_insert(uint32_t* keys, uint32_t tile) {
-    uint32_t h = (tile * 2654435761u) >> (32 - TH_BITS);
-    for (int p = 0; p < TH_PROBES; p++) {
-        const uint32_t old = atomicCAS(&keys[h], TH_EMPTY, tile);
-        if (old == TH_EMPTY || old == tile) return (int)h;
-        h = (h + 1) & (TH_SIZE - 1);
-    }
-    return -1;
-}
-__device__ __forceinline__ int th_find(const uint32_t* keys, uint32_t tile) {
-    uint32_t h = (tile * 2654435761u) >> (32 - TH_BITS);
-    for (int p = 0; p < TH_PROBES; p++) {
-        const uint32_t k = keys[h];
-        if (k == tile) return (int)h;
-        if (k == TH_EMPTY) return -1;
-        h = (h + 1) & (TH_SIZE - 1);
-    }
-    return -1;
-}
-// every Gaussian of a workgroup uses the same sub-counter of a tile; concurrently running workgroups use different ones
-__device__ __forceinline__ int counter_sub(int block) { return block & (CNT_SUB - 1); }
-
 template <bool STAGE_SH>
 __global__ __launch_bounds__(256) void k_preprocess(
     int P, int D, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
@@ -286,555 +254,6 @@ __global__ __launch_bounds__(256) void k_preprocess(
     __syncthreads();
     for (int e = threadIdx.x; e < TH_SIZE; e += 256)
         if (th_key[e] != TH_EMPTY) atomicAdd(tile_count + ((size_t)th_key[e] * CNT_SUB + sub) * CNT_STRIDE, th_cnt[e]);
-}
-
-// ----------------------------------------------------------------------------
-// Scans (exact u32).  Small single-block scan over tiles; three-pass scan over Gaussians.
-__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* s_warp, uint32_t& total) {
-    // blockDim.x == 1024: 16 waves
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint32_t x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t y = __shfl_up(x, o);
-        if (lane >= o) x += y;
-    }
-    if (lane == 63) s_warp[wid] = x;
-    __syncthreads();
-    if (wid == 0) {
-        uint32_t w = lane < 16 ? s_warp[lane] : 0;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            uint32_t y = __shfl_up(w, o);
-            if (lane >= o) w += y;
-        }
-        if (lane < 16) s_warp[16 + lane] = w;   // inclusive
-    }
-    __syncthreads();
-    const uint32_t base = wid == 0 ? 0u : s_warp[16 + wid - 1];
-    total = s_warp[16 + 15];
-    __syncthreads();
-    return base + x - v;
-}
-
-// dense copy of the padded sub-counters (and reset of the scatter cursors), then a single-workgroup scan
-__global__ __launch_bounds__(256) void k_gather_counts(int E, const uint32_t* __restrict__ count, uint32_t* __restrict__ dense,
-                                                       uint32_t* __restrict__ cursor) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= E) return;
-    dense[i] = count[(size_t)i * CNT_STRIDE];
-    cursor[(size_t)i * CNT_STRIDE] = 0u;
-}
-
-__global__ __launch_bounds__(1024) void k_tile_scan(int T, uint32_t* __restrict__ sub_offset /* in: counts, out: offsets */,
-                                                    uint32_t* __restrict__ offset, int64_t* header,
-                                                    uint32_t* __restrict__ tile_order, int order_classes) {
-    // one workgroup; every thread owns a contiguous run of elements (serial prefix in registers, 16-byte accesses) and
-    // the 1024 run totals are scanned once — instead of E / 1024 dependent workgroup scans
-    __shared__ uint32_t s_warp[32];
-    const int E = T * CNT_SUB;              // scan over (tile, sub-counter) in tile-major order
-    constexpr int RUN = 8;                  // elements per thread and round
-    uint32_t carry = 0;
-    for (int base = 0; base < E; base += 1024 * RUN) {
-        const int i0 = base + threadIdx.x * RUN;
-        uint32_t v[RUN];
-        if (i0 + RUN <= E) {
-            const uint4 a = *reinterpret_cast<const uint4*>(sub_offset + i0), b = *reinterpret_cast<const uint4*>(sub_offset + i0 + 4);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        } else {
-#pragma unroll
-            for (int u = 0; u < RUN; u++) v[u] = i0 + u < E ? sub_offset[i0 + u] : 0u;
-        }
-        uint32_t run = 0;
-#pragma unroll
-        for (int u = 0; u < RUN; u++) { const uint32_t c = v[u]; v[u] = run; run += c; }
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan_1024(run, s_warp, total);
-#pragma unroll
-        for (int u = 0; u < RUN; u++) {
-            const int i = i0 + u;
-            if (i < E) {
-                const uint32_t o = carry + ex + v[u];
-                sub_offset[i] = o;
-                if ((i & (CNT_SUB - 1)) == 0) offset[i / CNT_SUB] = o;
-            }
-        }
-        carry += total;
-    }
-    if (threadIdx.x == 0) {
-        offset[T] = carry;
-        header[0] = (int64_t)carry;
-    }
-    // Launch order for kernels whose grid is only a few waves per SIMD (k_render_bwd_geo at 779x519: 1.6): heaviest tiles
-    // first, so that the long lists start at once and the short ones fill in behind them.  A STABLE counting sort into
-    // `ncls` classes of the tile sizes relative to the largest one (tiles of a class keep their row-major order, i.e.
-    // neighbours - which share splats - still run close in time): thread i owns tiles [8 i, 8 i + 8).
-    __shared__ uint32_t s_cls[16 * 1024];                 // [class][thread] counts, then offsets
-    if (T < 4096) {
-        // small views (where this kernel sits in the step's chain): 256 classes of 16 instances, LDS atomics - which tile of a
-        // class comes first is left to the atomics (it changes no result)
-        if (threadIdx.x < 256) s_cls[threadIdx.x] = 0;
-        __syncthreads();
-        for (int t = threadIdx.x; t < T; t += 1024) {
-            const uint32_t n = offset[t + 1] - offset[t];
-            atomicAdd(&s_cls[255u - min(255u, n >> 4)], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) {                  // exclusive scan of the 256 class sizes: four per lane + a wave scan
-            uint32_t c[4], run = 0;
-#pragma unroll
-            for (int u = 0; u < 4; u++) { c[u] = s_cls[threadIdx.x * 4 + u]; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t x = c[u]; c[u] = run; run += x; }
-            uint32_t inc = run;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(inc, d, 64);
-                if ((int)threadIdx.x >= d) inc += o;
-            }
-            const uint32_t ex = inc - run;
-#pragma unroll
-            for (int u = 0; u < 4; u++) s_cls[threadIdx.x * 4 + u] = ex + c[u];
-        }
-        __syncthreads();
-        for (int t = threadIdx.x; t < T; t += 1024) {
-            const uint32_t n = offset[t + 1] - offset[t];
-            tile_order[atomicAdd(&s_cls[255u - min(255u, n >> 4)], 1u)] = (uint32_t)t;
-        }
-    } else {
-        __shared__ uint32_t s_max[1];
-        const int ncls = order_classes < 1 ? 1 : (order_classes > 16 ? 16 : order_classes);
-        if (threadIdx.x == 0) s_max[0] = 1;
-        for (int e = threadIdx.x; e < ncls * 1024; e += 1024) s_cls[e] = 0;
-        __syncthreads();
-        const int per = (T + 1023) / 1024;
-        const int t0 = threadIdx.x * per, t1 = min(T, t0 + per);
-        uint32_t mx = 0;
-        for (int t = t0; t < t1; t++) mx = max(mx, offset[t + 1] - offset[t]);
-        atomicMax(&s_max[0], mx);
-        __syncthreads();
-        const uint32_t top = s_max[0];
-        auto cls_of = [&](uint32_t n) { return (int)min((uint32_t)(ncls - 1), (uint32_t)(((unsigned long long)(top - n) * ncls) / (top + 1u))); };
-        for (int t = t0; t < t1; t++) s_cls[cls_of(offset[t + 1] - offset[t]) * 1024 + threadIdx.x]++;
-        __syncthreads();
-        // exclusive scan over (class, thread): ncls * 1024 counters, ncls per thread + one block scan
-        uint32_t mine[16], run = 0;
-        for (int k = 0; k < ncls; k++) { const int e = threadIdx.x * ncls + k; mine[k] = s_cls[e]; }
-        for (int k = 0; k < ncls; k++) { const uint32_t x = mine[k]; mine[k] = run; run += x; }
-        uint32_t total;
-        __syncthreads();
-        const uint32_t ex = block_exclusive_scan_1024(run, s_warp, total);
-        for (int k = 0; k < ncls; k++) s_cls[threadIdx.x * ncls + k] = ex + mine[k];
-        __syncthreads();
-        uint32_t cur[16];
-        for (int k = 0; k < ncls; k++) cur[k] = s_cls[k * 1024 + threadIdx.x];
-        for (int t = t0; t < t1; t++) {
-            const int c = cls_of(offset[t + 1] - offset[t]);
-            uint32_t at = 0;
-            for (int k = 0; k < ncls; k++) if (k == c) at = cur[k]++;
-            tile_order[at] = (uint32_t)t;
-        }
-    }
-}
-
-// block_max (optional): the largest input of each block; k_scan_tops reduces them into header[1] = the largest number of
-// tiles any splat of this view touches - k_scatter and k_preprocess_bwd skip their workgroup-cooperative paths (and the
-// barrier those need) when no splat is large.
-__global__ __launch_bounds__(1024) void k_scan_blocks(int n, const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                      uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_max) {
-    __shared__ uint32_t s_warp[32];
-    __shared__ uint32_t s_mx[16];
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    const uint32_t v = i < n ? in[i] : 0u;
-    uint32_t total;
-    const uint32_t ex = block_exclusive_scan_1024(v, s_warp, total);
-    if (i < n) out[i] = ex;
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-    if (block_max != nullptr) {
-        uint32_t m = v;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-        if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = m;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t mm = 0;
-            for (int w = 0; w < 16; w++) mm = max(mm, s_mx[w]);
-            block_max[blockIdx.x] = mm;
-        }
-    }
-}
-__global__ __launch_bounds__(1024) void k_scan_tops(int nb, uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ block_max,
-                                                    int64_t* __restrict__ header) {
-    __shared__ uint32_t s_warp[32];
-    if (block_max != nullptr && threadIdx.x < 64) {
-        uint32_t m = 0;
-        for (int b = threadIdx.x; b < nb; b += 64) m = max(m, block_max[b]);
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-        if (threadIdx.x == 0) header[1] = (int64_t)m;
-    }
-    uint32_t carry = 0;
-    for (int base = 0; base < nb; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < nb ? block_sums[i] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan_1024(v, s_warp, total);
-        if (i < nb) block_sums[i] = carry + ex;
-        carry += total;
-    }
-}
-__global__ __launch_bounds__(1024) void k_scan_add(int n, uint32_t* __restrict__ out, const uint32_t* __restrict__ block_sums) {
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    if (i < n) out[i] += block_sums[blockIdx.x];
-}
-
-// ----------------------------------------------------------------------------
-// Scatter: one (depth_bits, gaussian) key per touched tile into that tile's bucket.  The workgroup first counts its keys
-// per tile in the LDS hash, reserves one contiguous range per distinct tile with ONE returning global atomic, and then
-// hands out the positions inside the ranges with LDS atomics — so the keys of a workgroup that go to the same bucket are
-// neighbours in memory.  (The order inside a bucket is irrelevant: the per-tile sort orders the keys completely.)
-__global__ __launch_bounds__(256) void k_scatter(int P, int gx, GeomView g, const uint32_t* __restrict__ sub_offset,
-                                                 uint32_t* __restrict__ tile_cursor, unsigned long long* __restrict__ keys,
-                                                 int64_t capacity) {
-    __shared__ uint32_t th_key[TH_SIZE], th_cnt[TH_SIZE], th_base[TH_SIZE];
-    for (int e = threadIdx.x; e < TH_SIZE; e += 256) { th_key[e] = TH_EMPTY; th_cnt[e] = 0u; }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int sub = counter_sub(blockIdx.x);
-    Rect16 rc = {0, 0, 0, 0};
-    unsigned long long key = 0ull;
-    if (i < P && g.tiles_touched[i] != 0) {
-        rc = g.rect[i];
-        key = ((unsigned long long)__float_as_uint(g.rec[(size_t)i * REC + 18]) << 32) | (unsigned)i;
-    }
-    constexpr int BIG_MAX = 64;             // (1 KB of LDS: six workgroups per CU as before; a 65th large splat of a workgroup walks alone)
-    __shared__ int s_nbig;
-    __shared__ uint32_t s_bigx[BIG_MAX], s_bigy[BIG_MAX];
-    __shared__ unsigned long long s_bigkey[BIG_MAX];
-    const bool any_big = g.header[1] > (int64_t)BIG_RECT;       // (view-uniform: k_scan_tops)
-    if (threadIdx.x == 0) s_nbig = 0;
-    __syncthreads();
-    const bool big = any_big && (unsigned)(rc.x1 - rc.x0) * (unsigned)(rc.y1 - rc.y0) > (unsigned)BIG_RECT;      // see k_preprocess
-    if (big) {
-        const int k = atomicAdd(&s_nbig, 1);
-        if (k < BIG_MAX) {
-            s_bigx[k] = (uint32_t)rc.x0 | ((uint32_t)rc.x1 << 16);
-            s_bigy[k] = (uint32_t)rc.y0 | ((uint32_t)rc.y1 << 16);
-            s_bigkey[k] = key;
-            rc = {0, 0, 0, 0};              // its own lane walks nothing
-        }
-    }
-    for (int y = rc.y0; y < rc.y1; y++)
-        for (int x = rc.x0; x < rc.x1; x++) {
-            const int slot = th_find_or_insert(th_key, (uint32_t)y * gx + x);
-            if (slot >= 0) atomicAdd(&th_cnt[slot], 1u);
-        }
-    __syncthreads();
-    for (int b = 0; b < min(s_nbig, BIG_MAX); b++) {      // the workgroup's large rectangles: a tile per thread, positions straight from the cursors
-        const int bx0 = (int)(s_bigx[b] & 0xffffu), bx1 = (int)(s_bigx[b] >> 16), by0 = (int)(s_bigy[b] & 0xffffu), by1 = (int)(s_bigy[b] >> 16);
-        const int w = bx1 - bx0, area = w * (by1 - by0);
-        const unsigned long long bkey = s_bigkey[b];
-        for (int e = threadIdx.x; e < area; e += 256) {
-            const uint32_t tile = (uint32_t)(by0 + e / w) * gx + (uint32_t)(bx0 + e % w);
-            const size_t ee = (size_t)tile * CNT_SUB + sub;
-            const uint32_t pos = atomicAdd(tile_cursor + ee * CNT_STRIDE, 1u);
-            const int64_t at = (int64_t)sub_offset[ee] + pos;
-            if (at < capacity) keys[at] = bkey;
-        }
-    }
-    for (int e = threadIdx.x; e < TH_SIZE; e += 256)
-        if (th_key[e] != TH_EMPTY) {
-            th_base[e] = atomicAdd(tile_cursor + ((size_t)th_key[e] * CNT_SUB + sub) * CNT_STRIDE, th_cnt[e]);
-            th_cnt[e] = 0u;                 // becomes the fill counter of the reserved range
-        }
-    __syncthreads();
-    for (int y = rc.y0; y < rc.y1; y++)
-        for (int x = rc.x0; x < rc.x1; x++) {
-            const uint32_t tile = (uint32_t)y * gx + x;
-            const size_t e = (size_t)tile * CNT_SUB + sub;
-            const int slot = th_find(th_key, tile);
-            uint32_t pos;
-            if (slot >= 0) pos = th_base[slot] + atomicAdd(&th_cnt[slot], 1u);
-            else pos = atomicAdd(tile_cursor + e * CNT_STRIDE, 1u);
-            const int64_t at = (int64_t)sub_offset[e] + pos;
-            if (at < capacity) keys[at] = key;
-        }
-}
-
-// ----------------------------------------------------------------------------
-// Per-tile bucket sort.  All comparators are ascending (min to the lower index), so
-// indices >= n behave as +inf without being stored.
-constexpr int SORT_LDS_KEYS = 4096;
-
-// Two network stages per pass: every thread loads the 4 keys of a group that is closed under both stages, does the
-// four compare-exchanges in registers and stores them back — half the LDS traffic and half the barriers of a
-// stage-per-pass bitonic sort (30 passes instead of 55 for 1024 keys).
-//   flip(k) + step(k/4): {b+o, b+o+k/4, b+k-1-o-k/4, b+k-1-o}, o < k/4
-//   step(j) + step(j/2): {p, p+j/2, p+j, p+3j/2}
-#define ISR_CMPX(x, y) { if ((y) < (x)) { const unsigned long long t_ = (x); (x) = (y); (y) = t_; } }
-template <typename KeyPtr>
-__device__ __forceinline__ void sort_group4(KeyPtr a, int n, int i0, int i1, int i2, int i3, bool flip_first) {
-    if (i0 >= n) return;                 // i0 is the smallest index: nothing real in the group
-    const unsigned long long INF = ~0ull;
-    unsigned long long v0 = a[i0], v1 = i1 < n ? a[i1] : INF, v2 = i2 < n ? a[i2] : INF, v3 = i3 < n ? a[i3] : INF;
-    if (flip_first) { ISR_CMPX(v0, v3); ISR_CMPX(v1, v2); ISR_CMPX(v0, v1); ISR_CMPX(v2, v3); }
-    else { ISR_CMPX(v0, v2); ISR_CMPX(v1, v3); ISR_CMPX(v0, v1); ISR_CMPX(v2, v3); }
-    a[i0] = v0;                          // +inf never moves below a real key, so slots >= n stay virtual
-    if (i1 < n) a[i1] = v1;
-    if (i2 < n) a[i2] = v2;
-    if (i3 < n) a[i3] = v3;
-}
-
-template <typename KeyPtr>
-__device__ __forceinline__ void bitonic_flip_sort(KeyPtr a, int n) {
-    int npad = 1;
-    while (npad < n) npad <<= 1;
-    const int half = npad >> 1, quarter = npad >> 2;
-    for (int k = 2; k <= npad; k <<= 1) {
-        int j;
-        if (k == 2) {
-            for (int i = threadIdx.x; i < half; i += blockDim.x) {
-                const int lo = 2 * i, hi = lo + 1;
-                if (hi < n) {
-                    const unsigned long long x = a[lo], y = a[hi];
-                    if (y < x) { a[lo] = y; a[hi] = x; }
-                }
-            }
-            __syncthreads();
-            continue;
-        }
-        {   // flip(k) + step(k/4)
-            const int q = k >> 2;
-            for (int i = threadIdx.x; i < quarter; i += blockDim.x) {
-                const int blk = i / q, o = i - blk * q, base = blk * k;
-                sort_group4(a, n, base + o, base + o + q, base + k - 1 - o - q, base + k - 1 - o, true);
-            }
-            __syncthreads();
-            j = k >> 3;
-        }
-        for (; j >= 2; j >>= 2) {   // step(j) + step(j/2)
-            const int h = j >> 1;
-            for (int i = threadIdx.x; i < quarter; i += blockDim.x) {
-                const int p = (i / h) * 2 * j + (i % h);
-                sort_group4(a, n, p, p + h, p + j, p + j + h, false);
-            }
-            __syncthreads();
-        }
-        if (j == 1) {               // a single step(1) is left over
-            for (int i = threadIdx.x; i < half; i += blockDim.x) {
-                const int lo = 2 * i, hi = lo + 1;
-                if (hi < n) {
-                    const unsigned long long x = a[lo], y = a[hi];
-                    if (y < x) { a[lo] = y; a[hi] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-// The same network for a bucket that lives in LDS - the common case, and instruction-bound: 30 passes of ~90 vector
-// instructions over 8160 tiles x 4 waves were 0.13 ms at 1080p.  Here the slots [n, npad) really hold +inf (the array has
-// room up to the next power of two), so no access is bounds-checked, and every index is shifts and masks of powers of two
-// instead of divisions by run-time values.
-__device__ __forceinline__ void sort_group4_lds(unsigned long long* a, int i0, int i1, int i2, int i3, bool flip_first) {
-    unsigned long long v0 = a[i0], v1 = a[i1], v2 = a[i2], v3 = a[i3];
-    if (flip_first) { ISR_CMPX(v0, v3); ISR_CMPX(v1, v2); ISR_CMPX(v0, v1); ISR_CMPX(v2, v3); }
-    else { ISR_CMPX(v0, v2); ISR_CMPX(v1, v3); ISR_CMPX(v0, v1); ISR_CMPX(v2, v3); }
-    a[i0] = v0; a[i1] = v1; a[i2] = v2; a[i3] = v3;
-}
-__device__ __forceinline__ void sort_pairs_lds(unsigned long long* a, int half) {
-    for (int i = threadIdx.x; i < half; i += blockDim.x) {
-        const unsigned long long x = a[2 * i], y = a[2 * i + 1];
-        if (y < x) { a[2 * i] = y; a[2 * i + 1] = x; }
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ void bitonic_flip_sort_lds(unsigned long long* a, int n) {
-    int lg = 0;
-    while ((1 << lg) < n) lg++;
-    const int npad = 1 << lg, half = npad >> 1, quarter = npad >> 2;
-    for (int i = n + threadIdx.x; i < npad; i += blockDim.x) a[i] = ~0ull;
-    __syncthreads();
-    for (int lk = 1; lk <= lg; lk++) {          // k = 1 << lk
-        if (lk == 1) { sort_pairs_lds(a, half); continue; }
-        {   // flip(k) + step(k/4)
-            const int lq = lk - 2, q = 1 << lq, k1 = (1 << lk) - 1;
-            for (int i = threadIdx.x; i < quarter; i += blockDim.x) {
-                const int o = i & (q - 1), base = (i >> lq) << lk;
-                sort_group4_lds(a, base + o, base + o + q, base + k1 - o - q, base + k1 - o, true);
-            }
-            __syncthreads();
-        }
-        int lj = lk - 3;                        // j = k / 8 = 1 << lj
-        for (; lj >= 1; lj -= 2) {              // step(j) + step(j/2)
-            const int j = 1 << lj, h = j >> 1, lh = lj - 1;
-            for (int i = threadIdx.x; i < quarter; i += blockDim.x) {
-                const int p = ((i >> lh) << (lj + 1)) + (i & (h - 1));
-                sort_group4_lds(a, p, p + h, p + j, p + j + h, false);
-            }
-            __syncthreads();
-        }
-        if (lj == 0) sort_pairs_lds(a, half);   // a single step(1) is left over
-    }
-}
-#undef ISR_CMPX
-
-// Buckets of SORT_LDS_KEYS < n <= SORT_BIG_KEYS keys (dense scenes: C5 averages 3 100 instances per tile) are sorted by
-// k_tile_sort_big - 1024 threads, 128 KB of dynamic LDS, one workgroup per CU - instead of the in-place network in global
-// memory (a barrier and a round trip to L2 per pass: 2.1 ms of C5's side stream).  big_follows: this launch leaves them alone.
-constexpr int SORT_BIG_KEYS = 16384;
-__global__ __launch_bounds__(1024) void k_tile_sort_big(const uint32_t* __restrict__ tile_offset, unsigned long long* keys,
-                                                        uint32_t* __restrict__ point_list, int64_t capacity, int min_n) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long s_big[];
-    const uint32_t t = blockIdx.x;
-    const int64_t r0 = tile_offset[t];
-    int64_t r1 = tile_offset[t + 1];
-    if (r1 > capacity) r1 = capacity;
-    const int n = (int)(r1 - r0);
-    if (n <= min_n || n > SORT_BIG_KEYS) return;
-    unsigned long long* seg = keys + r0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) s_big[i] = seg[i];
-    bitonic_flip_sort_lds(s_big, n);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) point_list[r0 + i] = (uint32_t)s_big[i];
-}
-
-// Buckets of up to SORT_WAVE_KEYS keys (all but the densest tiles of a 1080p view) are sorted by ONE WAVE in registers:
-// lane l holds K consecutive elements of the (virtual) array, so the network's strides below K are compare-exchanges between
-// a lane's own registers and the strides of K and more are exchanges with lane l ^ (stride / K) (two ds_bpermute per key) -
-// no LDS allocation, no barrier, a third of the LDS network's instructions, 6-8 waves per SIMD.  The input order is
-// irrelevant to a sort, so the bucket is read striped (coalesced) and only the sorted ids are written lane-contiguous.
-constexpr int SORT_WAVE_KEYS = 2048;
-struct __attribute__((packed, aligned(4))) Ids4 { uint32_t x, y, z, w; };
-
-template <int K>
-__device__ __forceinline__ void wave_cmpx(unsigned long long& a, unsigned long long& b, bool desc) {
-    const bool sw = (a > b) != desc;
-    const unsigned long long lo = sw ? b : a, hi = sw ? a : b;
-    a = lo; b = hi;
-}
-
-// in-register half-cleaner cascade: strides J, J/2, .. 1 over the K registers of every lane, one direction per lane
-template <int K, int J>
-__device__ __forceinline__ void wave_merge_regs(unsigned long long (&v)[K], bool desc) {
-    if constexpr (J >= 1) {
-#pragma unroll
-        for (int r = 0; r < K; r++)
-            if ((r & J) == 0) wave_cmpx<K>(v[r], v[r | J], desc);
-        wave_merge_regs<K, J / 2>(v, desc);
-    }
-}
-
-// phases k = 2 .. K of the network (strides inside a lane): direction of element i = l K + r is bit k of i
-template <int K, int KK>
-__device__ __forceinline__ void wave_sort_regs(unsigned long long (&v)[K], int lane) {
-    if constexpr (KK <= K) {
-        if constexpr (KK > 2) wave_sort_regs<K, KK / 2>(v, lane);
-        // stride KK/2 .. 1 with per-register directions (bit KK of r; for KK == K: bit 0 of the lane)
-#pragma unroll
-        for (int j = KK / 2; j >= 1; j >>= 1) {
-#pragma unroll
-            for (int r = 0; r < K; r++)
-                if ((r & j) == 0) {
-                    const bool desc = KK < K ? (r & KK) != 0 : (lane & 1) != 0;
-                    wave_cmpx<K>(v[r], v[r | j], desc);
-                }
-        }
-    }
-}
-
-template <int K>
-__device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&v)[K], int lane) {
-    if constexpr (K > 1) wave_sort_regs<K, K>(v, lane);
-    // phases k = 2 K .. 64 K: lane-level bitonic merge (m = stride / K) followed by the in-register cascade
-    for (int kk = 2; kk <= 64; kk <<= 1) {
-        const bool desc = (lane & kk) != 0;                  // kk == 64: ascending everywhere
-        for (int m = kk >> 1; m >= 1; m >>= 1) {
-            const bool keep_min = ((lane & m) == 0) != desc;
-            const int src = (lane ^ m) << 2;
-#pragma unroll
-            for (int r = 0; r < K; r++) {
-                const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)v[r]);
-                const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(v[r] >> 32));
-                const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-                v[r] = ((o < v[r]) == keep_min) ? o : v[r];
-            }
-        }
-        if constexpr (K > 1) wave_merge_regs<K, K / 2>(v, desc);
-    }
-}
-
-template <int K>
-__device__ __forceinline__ void wave_sort_bucket(const unsigned long long* __restrict__ seg, uint32_t* __restrict__ out, int n,
-                                                 int lane) {
-    unsigned long long v[K];
-#pragma unroll
-    for (int r = 0; r < K; r++) {
-        const int i = r * 64 + lane;
-        v[r] = i < n ? seg[i] : ~0ull;
-    }
-    wave_bitonic_sort<K>(v, lane);
-    const int base = lane * K;
-    if constexpr (K >= 4) {
-        if (base + K <= n) {        // (dword-aligned 16-byte stores: the bucket's start is any multiple of 4 bytes)
-#pragma unroll
-            for (int r = 0; r < K; r += 4) {
-                Ids4 q = {(uint32_t)v[r], (uint32_t)v[r + 1], (uint32_t)v[r + 2], (uint32_t)v[r + 3]};
-                *reinterpret_cast<Ids4*>(out + base + r) = q;
-            }
-            return;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < K; r++)
-        if (base + r < n) out[base + r] = (uint32_t)v[r];
-}
-
-template <int MAXK>      // 32: buckets of up to 2 048 keys; 64 (dense scenes): up to 4 096, at half the waves per SIMD
-__global__ __launch_bounds__(64) void k_tile_sort_wave(const uint32_t* __restrict__ tile_offset,
-                                                       const unsigned long long* __restrict__ keys,
-                                                       uint32_t* __restrict__ point_list, int64_t capacity) {
-    const uint32_t t = blockIdx.x;
-    const int64_t r0 = tile_offset[t];
-    int64_t r1 = tile_offset[t + 1];
-    if (r1 > capacity) r1 = capacity;
-    const int n = (int)(r1 - r0);
-    if (n <= 0 || n > 64 * MAXK) return;
-    const unsigned long long* seg = keys + r0;
-    uint32_t* out = point_list + r0;
-    const int lane = threadIdx.x;
-    if (n <= 64) wave_sort_bucket<1>(seg, out, n, lane);
-    else if (n <= 128) wave_sort_bucket<2>(seg, out, n, lane);
-    else if (n <= 256) wave_sort_bucket<4>(seg, out, n, lane);
-    else if (n <= 512) wave_sort_bucket<8>(seg, out, n, lane);
-    else if (n <= 1024) wave_sort_bucket<16>(seg, out, n, lane);
-    else if (MAXK == 32 || n <= 2048) wave_sort_bucket<32>(seg, out, n, lane);
-    else if (MAXK == 64 || n <= 4096) wave_sort_bucket<64>(seg, out, n, lane);
-    else wave_sort_bucket<128>(seg, out, n, lane);
-}
-
-__global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ tile_offset, unsigned long long* keys,
-                                                   uint32_t* __restrict__ point_list, int64_t capacity, int big_follows) {
-    __shared__ unsigned long long s_keys[SORT_LDS_KEYS];
-    const uint32_t t = blockIdx.x;
-    const int64_t r0 = tile_offset[t];
-    int64_t r1 = tile_offset[t + 1];
-    if (r1 > capacity) r1 = capacity;
-    const int n = (int)(r1 - r0);
-    if (n <= 0) return;
-    if ((big_follows & 1) && n > SORT_LDS_KEYS && n <= SORT_BIG_KEYS) return;
-    if ((big_follows & 2) && n <= SORT_WAVE_KEYS) return;         // k_tile_sort_wave's
-    if ((big_follows & 4) && n <= 2 * SORT_WAVE_KEYS) return;     // k_tile_sort_wave<64>'s
-    if ((big_follows & 8) && n <= 4 * SORT_WAVE_KEYS) return;     // k_tile_sort_wave<128>'s
-    unsigned long long* seg = keys + r0;
-    if (n <= SORT_LDS_KEYS) {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) s_keys[i] = seg[i];
-        bitonic_flip_sort_lds(s_keys, n);         // (its first barrier also covers the loads above)
-        for (int i = threadIdx.x; i < n; i += blockDim.x) point_list[r0 + i] = (uint32_t)s_keys[i];
-    } else {
-        // rare: bucket larger than the LDS budget — same network, in place in global memory
-        // (one workgroup; __syncthreads() orders the workgroup's own global accesses).
-        bitonic_flip_sort(seg, n);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) point_list[r0 + i] = (uint32_t)seg[i];
-    }
 }
 
 // ----------------------------------------------------------------------------
