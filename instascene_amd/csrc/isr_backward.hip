@@ -19,9 +19,9 @@
 //   * The per-channel feature recurrences of the reference (2F registers) collapse to
 //     one scalar recurrence on q = <feature_g, dL/dfeature(pix)> (same algebra).
 #include "isr_common.hpp"
+#include "isr_fast_pair.hpp"
 
 namespace isr {
-
 
 constexpr int GEOM_ROW = 20;   // [0..8] dL_dT  [9,10] dL_dcentre  [11..13] dL_dnormal  [14] dL_dopacity  [15..17] dL_dcolor
 constexpr int BB = 32;         // instances per backward batch
@@ -41,6 +41,7 @@ inline size_t rows_bytes(int64_t R, int ED, unsigned mask) {
 // rows[R][stride] followed by one validity byte per (pass, row): a row is written (and flagged) only when some
 // wave actually evaluated that (tile, splat) instance — everything else is skipped by the reductions.
 size_t backward_scratch_bytes(int64_t R, int ED, unsigned mask) {
+    if (ED <= 0) mask &= ~1u;        // no feature channel: the launch lays the scratch out without the EXTRA bit (launch_backward_t)
     return rows_bytes(R, ED, mask) + align_up((size_t)(R > 0 ? R : 1) * rows_per_instance(ED, mask) * n_passes(ED, mask), 256) + 256;
 }
 
@@ -122,7 +123,9 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
     const uint32_t* __restrict__ point_offsets,
     const Rect16* __restrict__ rects, float* __restrict__ partial, uint8_t* __restrict__ row_flags,
     const uint8_t* __restrict__ tile_mode, int row_stride, int geom_off, int feat_off, int64_t capacity) {
-    constexpr int RS = 16;
+    // staged record: Tu Tv Tw | centre normal | opacity skip; FAST adds the affine form of the intersection
+    // (A.xyz, cx - X0 | B.xyz, cy - Y0 | C.xyz, det: isr_fast_pair.hpp) - the pair is evaluated exactly as k_render_fwd_fast did
+    constexpr int RS = Math::fast ? 28 : 16;
     constexpr int SB = 128;                 // (id, cull box) pairs staged per barrier round: two 64-bit hit masks per wave
     constexpr int PART = (GEOM ? GEOM_ROW : 0) + (FEAT ? 32 : 0);   // floats per instance per wave in LDS
     __shared__ __attribute__((aligned(16))) float s_rec[BB * RS];      // records of the current sub-batch (hit instances only)
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
     const size_t N = (size_t)W * H;
     const size_t pix = (size_t)W * py + px;
     const float pxf = (float)px, pyf = (float)py;
+    const float lxf = (float)((wv & 1) * 8 + (lane & 7)), lyf = (float)((wv >> 1) * 8 + (lane >> 3));     // tile-relative
 
     const int64_t r0 = tile_offset[tile];
     int64_t r1 = tile_offset[tile + 1];
@@ -346,13 +350,15 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
                     d.w = col_pre[3 * (size_t)id]; e.x = col_pre[3 * (size_t)id + 1]; e.y = col_pre[3 * (size_t)id + 2];
                 }
                 const float opa = d.z;
-                float skip = __builtin_inff();
-                if (opa <= 1.0f) {
-                    const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
-                    skip = 2.0f * l * 1.01f + 0.05f;
-                }
+                const float skip = fast_skip(opa);
                 float4* s4 = reinterpret_cast<float4*>(s_rec + t * RS);
                 s4[0] = a; s4[1] = b; s4[2] = c; s4[3] = make_float4(d.x, d.y, opa, skip);
+                if constexpr (Math::fast) {
+                    const FastSplat fs = fast_splat({a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, (float)(tx * TILE), (float)(ty * TILE));
+                    s4[4] = make_float4(fs.A.x, fs.A.y, fs.A.z, c.y - (float)(tx * TILE));
+                    s4[5] = make_float4(fs.B.x, fs.B.y, fs.B.z, c.z - (float)(ty * TILE));
+                    s4[6] = make_float4(fs.C.x, fs.C.y, fs.C.z, fs.det);
+                }
                 reinterpret_cast<float4*>(s_rgb)[t] = make_float4(d.w, e.x, e.y, 0.0f);
                 const Rect16 rc = rects[id];
                 s_slot[t] = point_offsets[id] + (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
@@ -384,6 +390,23 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
                     const float4 c = reinterpret_cast<const float4*>(s_rec + j * RS)[2];
                     const float4 d = reinterpret_cast<const float4*>(s_rec + j * RS)[3];
                     const F3 Tw = {b.z, b.w, c.x};
+                    if constexpr (Math::fast) {
+                        // the forward's own evaluation of the pair (isr_fast_pair.hpp): same decisions, bit for bit
+                        const float4 qa = reinterpret_cast<const float4*>(s_rec + j * RS)[4];
+                        const float4 qb = reinterpret_cast<const float4*>(s_rec + j * RS)[5];
+                        const float4 qc = reinterpret_cast<const float4*>(s_rec + j * RS)[6];
+                        const FastRay fr = fast_ray(lxf, lyf, qa.x, qa.y, qa.z, qb.x, qb.y, qb.z, qc.x, qc.y, qc.z, qa.w, qb.w);
+                        const FastHit fh = fast_hit(fr, qc.w, Tw.z, d.z);
+                        act = act && fast_near(fr, d.w) && fast_pass(fh);
+                        p = {fr.p_x, fr.p_y, fr.p_z};
+                        dx = fr.dx; dy = fr.dy; rho2d = fr.rho2d; rho3d = fr.rho3d; sx = fr.sx; sy = fr.sy;
+                        c_d = fh.depth; G = fh.G; alpha = fh.alpha;
+                        if constexpr (GEOM) {       // the adjoint of the intersection is written on k, l (values only)
+                            const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y};
+                            kk = {Math::msub(pxf, Tw.x, Tu.x), Math::msub(pxf, Tw.y, Tu.y), Math::msub(pxf, Tw.z, Tu.z)};
+                            ll = {Math::msub(pyf, Tw.x, Tv.x), Math::msub(pyf, Tw.y, Tv.y), Math::msub(pyf, Tw.z, Tv.z)};
+                        }
+                    } else {
                     if (act) {
                         const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y};
                         kk = {Math::msub(pxf, Tw.x, Tu.x), Math::msub(pxf, Tw.y, Tu.y), Math::msub(pxf, Tw.z, Tu.z)};
@@ -408,6 +431,7 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
                             alpha = fminf(0.99f, d.z * G);
                             if (alpha < 1.0f / 255.0f) act = false;
                         }
+                    }
                     }
                     if (act) {
                         if (GEOM) { T = Math::div(T, 1.f - alpha); w = alpha * T; }
@@ -648,6 +672,14 @@ __device__ __forceinline__ float splat_alpha(const F3 Tu, const F3 Tv, const F3 
     if (c_d < NEAR_N || power > 0.0f) return 0.0f;
     const float alpha = fminf(0.99f, opa * Math::ex(power));
     return alpha < 1.0f / 255.0f ? 0.0f : alpha;
+}
+
+// the same in FAST arithmetic: the forward's own evaluation of the pair (isr_fast_pair.hpp), tile-relative pixel
+__device__ __forceinline__ float splat_alpha_fast(const FastSplat& fs, float Twz, float cxr, float cyr, float opa, float skip,
+                                                  float lx, float ly) {
+    const FastRay fr = fast_ray(lx, ly, fs.A.x, fs.A.y, fs.A.z, fs.B.x, fs.B.y, fs.B.z, fs.C.x, fs.C.y, fs.C.z, cxr, cyr);
+    const FastHit fh = fast_hit(fr, fs.det, Twz, opa);
+    return (fast_near(fr, skip) && fast_pass(fh)) ? fh.alpha : 0.0f;
 }
 
 // Step 1 — which pixels carry an upstream gradient?  A streaming pass over dL/dE: one workgroup per strip of four
@@ -933,12 +965,11 @@ __global__ __launch_bounds__(64, 3) void k_render_bwd_sparse(
                 slot = po + ordinal;
                 Tu = {a.x, a.y, a.z}; Tv = {a.w, b.x, b.y}; Tw = {b.z, b.w, c.x};
                 cx = c.y; cy = c.z; opa = d.z;
-                skip = __builtin_inff();
-                if (opa <= 1.0f) {
-                    const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
-                    skip = 2.0f * l * 1.01f + 0.05f;
-                }
+                skip = fast_skip(opa);
             }
+            FastSplat fs = {{0, 0, 0}, {0, 0, 0}, {0, 0, 1}, 0.0f};
+            if constexpr (Math::fast) fs = fast_splat(Tu, Tv, Tw, tile_x0, tile_y0);
+            const float cxr = cx - tile_x0, cyr = cy - tile_y0;
             float acc[32];
 #pragma unroll
             for (int c2 = 0; c2 < 32; c2++) acc[c2] = 0.0f;
@@ -947,8 +978,12 @@ __global__ __launch_bounds__(64, 3) void k_render_bwd_sparse(
                 if (__ballot((hk >> k) & 1u) == 0ull) continue;
                 const int xy = s_lxy[k];
                 float alpha = 0.0f;
-                if ((hk >> k) & 1u)
-                    alpha = splat_alpha<Math>(Tu, Tv, Tw, cx, cy, opa, skip, tile_x0 + (float)(xy & 255), tile_y0 + (float)(xy >> 8));
+                if ((hk >> k) & 1u) {
+                    if constexpr (Math::fast)
+                        alpha = splat_alpha_fast(fs, Tw.z, cxr, cyr, opa, skip, (float)(xy & 255), (float)(xy >> 8));
+                    else
+                        alpha = splat_alpha<Math>(Tu, Tv, Tw, cx, cy, opa, skip, tile_x0 + (float)(xy & 255), tile_y0 + (float)(xy >> 8));
+                }
                 if (__ballot(alpha != 0.0f) == 0ull) continue;
                 const float incl = wave_scan_mul(1.0f - alpha);
                 const float excl = dpp_fetch<0x138, 0xF>(incl, 1.0f);        // wave_shr:1

@@ -16,6 +16,7 @@
 // were evaluated are flagged - 1.17 rows per tile instance on the C3 scene), and k_preprocess_bwd sums a Gaussian's rows
 // in slot order as before: still no atomics, bit-reproducible.
 #include "isr_common.hpp"
+#include "isr_fast_pair.hpp"
 
 namespace isr {
 
@@ -143,11 +144,7 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
                 }
                 Tu = {a.x, a.y, a.z}; Tv = {a.w, b.x, b.y}; Tw = {b.z, b.w, c.x};
                 cx = c.y; cy = c.z; nrm = {c.w, d.x, d.y}; opa = d.z; col = {d.w, e.x, e.y};
-                skip = __builtin_inff();
-                if (opa <= 1.0f) {
-                    const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
-                    skip = 2.0f * l * 1.01f + 0.05f;
-                }
+                skip = fast_skip(opa);
                 const Rect16 rc = rects[id];
                 slot = point_offsets[id] + (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
             }
@@ -155,14 +152,8 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
             // pixel coordinates, and so is its adjoint: dL/dA = sum lx dL/dp, dL/dB = sum ly dL/dp, dL/dC = sum dL/dp.  The pixel
             // loop accumulates those nine sums (instead of two cross products and nine FMAs per pair for dL/dTu, dL/dTv, dL/dTw);
             // they are turned into the gradient of the three rows once per (block, splat), after the loop.
-            const F3 A = {__builtin_fmaf(Tv.y, Tw.z, -(Tv.z * Tw.y)), __builtin_fmaf(Tv.z, Tw.x, -(Tv.x * Tw.z)),
-                          __builtin_fmaf(Tv.x, Tw.y, -(Tv.y * Tw.x))};
-            const F3 B = {__builtin_fmaf(Tw.y, Tu.z, -(Tw.z * Tu.y)), __builtin_fmaf(Tw.z, Tu.x, -(Tw.x * Tu.z)),
-                          __builtin_fmaf(Tw.x, Tu.y, -(Tw.y * Tu.x))};
-            const F3 k0 = {__builtin_fmaf(tile_x0, Tw.x, -Tu.x), __builtin_fmaf(tile_x0, Tw.y, -Tu.y), __builtin_fmaf(tile_x0, Tw.z, -Tu.z)};
-            const F3 l0 = {__builtin_fmaf(tile_y0, Tw.x, -Tv.x), __builtin_fmaf(tile_y0, Tw.y, -Tv.y), __builtin_fmaf(tile_y0, Tw.z, -Tv.z)};
-            const F3 C = {__builtin_fmaf(k0.y, l0.z, -(k0.z * l0.y)), __builtin_fmaf(k0.z, l0.x, -(k0.x * l0.z)),
-                          __builtin_fmaf(k0.x, l0.y, -(k0.y * l0.x))};
+            const FastSplat fs = fast_splat(Tu, Tv, Tw, tile_x0, tile_y0);
+            const F3 A = fs.A, B = fs.B, C = fs.C;
             const float cxr = cx - tile_x0, cyr = cy - tile_y0;
             float aP0 = 0, aP1 = 0, aP2 = 0, aX0 = 0, aX1 = 0, aX2 = 0, aY0 = 0, aY1 = 0, aY2 = 0;     // sum dL/dp, sum lx dL/dp, sum ly dL/dp
             float aZ0 = 0, aZ1 = 0, aZ2 = 0;            // sum dL/dz (sx, sy, 1)
@@ -177,20 +168,13 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
                 const bool cand = li >= 0 && (unsigned)li < last_p && bxl <= lxi && bxh >= lxi && byl <= lyi && byh >= lyi;
                 if (__ballot(cand) != 0ull) {       // (one latch for the loop: `continue`s here made the compiler rotate the accumulators)
                     const float lx = (float)lxi, ly = (float)lyi;
-                    const float p_x = __builtin_fmaf(lx, A.x, __builtin_fmaf(ly, B.x, C.x));
-                    const float p_y = __builtin_fmaf(lx, A.y, __builtin_fmaf(ly, B.y, C.y));
-                    const float p_z = __builtin_fmaf(lx, A.z, __builtin_fmaf(ly, B.z, C.z));
-                    const float dx = cxr - lx, dy = cyr - ly;
-                    const float rho2d = FILTER_INV_SQ * __builtin_fmaf(dy, dy, dx * dx);
-                    const float rz = __builtin_amdgcn_rcpf(p_z);
-                    const float sx = p_x * rz, sy = p_y * rz;
-                    const float rho3d = __builtin_fmaf(sy, sy, sx * sx);
-                    const float rho = fminf(rho3d, rho2d);
-                    const bool use3d = rho3d <= rho2d;
-                    const float c_d = use3d ? __builtin_fmaf(sy, Tw.y, sx * Tw.x) + Tw.z : Tw.z;
-                    const float G = __builtin_amdgcn_exp2f(rho * -0.72134752f);
-                    const float alpha = fminf(0.99f, opa * G);
-                    const bool act = cand && (rho <= skip) && (p_z != 0.0f) && !(c_d < NEAR_N) && !(alpha < 1.0f / 255.0f);
+                    // the forward's own evaluation of the pair (isr_fast_pair.hpp): same decisions, bit for bit
+                    const FastRay fr = fast_ray(lx, ly, A.x, A.y, A.z, B.x, B.y, B.z, C.x, C.y, C.z, cxr, cyr);
+                    const FastHit fh = fast_hit(fr, fs.det, Tw.z, opa);
+                    const float dx = fr.dx, dy = fr.dy, rz = fr.rz, sx = fr.sx, sy = fr.sy;
+                    const bool use3d = fh.use3d;
+                    const float c_d = fh.depth, G = fh.G, alpha = fh.alpha;
+                    const bool act = cand && fast_near(fr, skip) && fast_pass(fh);
                     if (__ballot(act) != 0ull) {
                         const float4 q0 = pq[0], q1 = pq[1], q2 = pq[2];
                         // q0 = dC.rgb, d_depth   q1 = d_accum, dN.xyz   q2 = d_median, d_reg, T_final, final_D   q3 = final_D2, last, median, bg_dot

@@ -18,6 +18,7 @@
 //   * The feature channels accumulate on the matrix cores exactly as before (two splats per pair of
 //     v_mfma_f32_32x32x2_f32); chunks narrower than 32 channels are zero-padded in LDS instead of taking a vector path.
 #include "isr_common.hpp"
+#include "isr_fast_pair.hpp"
 
 namespace isr {
 
@@ -128,21 +129,11 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
             }
             const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y}, Tw = {b.z, b.w, c.x};
             const float opa = d.z;
-            float skip = __builtin_inff();      // opa * exp(-rho/2) < 1/255 for every rho > skip (1 % + 0.05 margin)
-            if (opa <= 1.0f) {
-                const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
-                skip = 2.0f * l * 1.01f + 0.05f;
-            }
-            // p(px, py) = (px - X0) A + (py - Y0) B + C,  C = (X0 Tw - Tu) x (Y0 Tw - Tv)
-            const F3 A = {__builtin_fmaf(Tv.y, Tw.z, -(Tv.z * Tw.y)), __builtin_fmaf(Tv.z, Tw.x, -(Tv.x * Tw.z)),
-                          __builtin_fmaf(Tv.x, Tw.y, -(Tv.y * Tw.x))};
-            const F3 B = {__builtin_fmaf(Tw.y, Tu.z, -(Tw.z * Tu.y)), __builtin_fmaf(Tw.z, Tu.x, -(Tw.x * Tu.z)),
-                          __builtin_fmaf(Tw.x, Tu.y, -(Tw.y * Tu.x))};
-            const F3 k0 = {__builtin_fmaf(X0, Tw.x, -Tu.x), __builtin_fmaf(X0, Tw.y, -Tu.y), __builtin_fmaf(X0, Tw.z, -Tu.z)};
-            const F3 l0 = {__builtin_fmaf(Y0, Tw.x, -Tv.x), __builtin_fmaf(Y0, Tw.y, -Tv.y), __builtin_fmaf(Y0, Tw.z, -Tv.z)};
-            const F3 C = {__builtin_fmaf(k0.y, l0.z, -(k0.z * l0.y)), __builtin_fmaf(k0.z, l0.x, -(k0.x * l0.z)),
-                          __builtin_fmaf(k0.x, l0.y, -(k0.y * l0.x))};
-            const float det = __builtin_fmaf(C.x, Tw.x, __builtin_fmaf(C.y, Tw.y, C.z * Tw.z));
+            const float skip = fast_skip(opa);
+            // p(px, py) = (px - X0) A + (py - Y0) B + C,  C = (X0 Tw - Tu) x (Y0 Tw - Tv)     (isr_fast_pair.hpp)
+            const FastSplat fs = fast_splat(Tu, Tv, Tw, X0, Y0);
+            const F3 A = fs.A, B = fs.B, C = fs.C;
+            const float det = fs.det;
             float4* s4 = reinterpret_cast<float4*>(s_rec + t * RS);
             s4[0] = make_float4(A.x, A.y, A.z, c.y - X0);
             s4[1] = make_float4(B.x, B.y, B.z, c.z - Y0);
@@ -209,23 +200,17 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                 }
                 const float4* q = reinterpret_cast<const float4*>(s_rec + j * RS);
                 const float4 q0 = q[0], q1 = q[1], q2 = q[2];
-                const float p_x = __builtin_fmaf(lx, q0.x, __builtin_fmaf(ly, q1.x, q2.x));
-                const float p_y = __builtin_fmaf(lx, q0.y, __builtin_fmaf(ly, q1.y, q2.y));
-                const float p_z = __builtin_fmaf(lx, q0.z, __builtin_fmaf(ly, q1.z, q2.z));
-                const float dx = q0.w - lx, dy = q1.w - ly;
-                const float hh = __builtin_fmaf(dy, dy, dx * dx);
-                const float rho2d = hh + hh;                                  // FilterInvSquare = 2
-                const float rz = __builtin_amdgcn_rcpf(p_z);
-                const float sx = p_x * rz, sy = p_y * rz;
-                const float rho3d = __builtin_fmaf(sy, sy, sx * sx);
-                const float rho = fminf(rho3d, rho2d);
+                // the pair's arithmetic is isr_fast_pair.hpp's, shared with the FAST backward kernels: both passes take the
+                // same decisions on the same pair, bit for bit
+                const FastRay fr = fast_ray(lx, ly, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, q0.w, q1.w);
+                const float p_z = fr.p_z;
                 // beyond `skip` alpha < 1/255 is certain: when that holds for the whole wave nothing else is needed
-                const unsigned long long m_near = __ballot(rho <= q2.w) & __ballot(p_z != 0.0f) & ~m_done;
+                const unsigned long long m_near = __ballot(fr.rho <= q2.w) & __ballot(p_z != 0.0f) & ~m_done;
                 if (m_near == 0ull) continue;
                 const float4 q3 = q[3];
-                const bool use3d = rho3d <= rho2d;
-                const float depth = use3d ? q3.x * rz : q3.y;
-                const float alpha = fminf(0.99f, q3.z * __builtin_amdgcn_exp2f(rho * -0.72134752f));
+                const FastHit fh = fast_hit(fr, q3.x, q3.y, q3.z);
+                const bool use3d = fh.use3d;
+                const float depth = fh.depth, alpha = fh.alpha;
                 const float test_T = __builtin_fmaf(-T, alpha, T);
                 const unsigned long long m_pass = m_near & __ballot(!(depth < NEAR_N)) & __ballot(!(alpha < 1.0f / 255.0f));
                 const unsigned long long m_stop = m_pass & __ballot(test_T < 0.0001f);

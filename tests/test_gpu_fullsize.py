@@ -5,7 +5,8 @@ the CPU oracle takes ~5 s per C3 view and is used at small sizes elsewhere:
 * the feature map is LINEAR in the features and the backward is its ADJOINT:  <render(E), G> == <E, backward(G)>  for a
   dense G (MFMA kernel) and for a G that lives on 16 384 sampled pixels (pixel-major kernel, sampled entry point);
 * storing the Gaussians in Z-order changes no pixel whose splats have distinct depths (exact depth ties are broken by index);
-* FAST tile lists are order-preserving subsequences of the EXACT ones, FAST images agree to 1e-4 on > 99.9 % of pixels;
+* FAST binning is identical to EXACT binning (R, point_list, ranges), FAST images agree to 1e-4 on all but 1e-4 of the pixels;
+* C3 and C1 at full size against the CPU oracle (forward bit-identical in EXACT; sampled feature backward / all gradients);
 * 3-NN mean squared distance == brute force on a random subset of points;
 * the batched contrastive losses: directional derivative by central differences.
 """
@@ -140,26 +141,101 @@ def test_c3_z_order_changes_no_pixel():
 
 
 def test_c3_fast_mode_against_exact_mode():
+    """FAST differs from EXACT only in the arithmetic of the per-pixel loops: the geometry pass and the binning are the same
+    kernels, so radii, the instance count, point_list and ranges are identical at full size, and the images agree to 1e-4
+    of the maximum on all but 1e-4 of the pixels."""
     scene, cams, cfg, inp = _c3()
     P, W, H = cfg["P"], cfg["W"], cfg["H"]
     cam = cams[20]
     _, ex = _forward(inp, cam, cfg, MODE_EXACT)
     _, fa = _forward(inp, cam, cfg, MODE_FAST)
-    assert torch.equal(ex[3], fa[3])                                         # radii: identical
-    assert fa[0] <= ex[0]                                                    # tight tile rectangles: fewer instances
+    assert torch.equal(ex[3], fa[3])                                         # radii
+    assert fa[0] == ex[0]                                                    # R_fast == R_exact
+    de = rz.debug_state(P, W, H, ex[0], ex[5], ex[6], ex[7])
+    df = rz.debug_state(P, W, H, fa[0], fa[5], fa[6], fa[7])
+    np.testing.assert_array_equal(df["tiles_touched"], de["tiles_touched"])
+    np.testing.assert_array_equal(df["point_list"], de["point_list"])
+    np.testing.assert_array_equal(df["ranges"], de["ranges"])
     for k in (1, 4):
         ref = ex[k]
         bad = ((fa[k] - ref).abs() > 1e-4 * float(ref.abs().max())).any(dim=0)
-        assert float(bad.float().mean()) < 1e-3, k
-    de = rz.debug_state(P, W, H, ex[0], ex[5], ex[6], ex[7])
-    df = rz.debug_state(P, W, H, fa[0], fa[5], fa[6], fa[7])
-    rng = np.random.RandomState(0)
-    for t in rng.choice(de["ranges"].shape[0], 200, replace=False):          # FAST lists: subsequences of the EXACT ones
-        le = de["point_list"][de["ranges"][t, 0]:de["ranges"][t, 1]]
-        lf = df["point_list"][df["ranges"][t, 0]:df["ranges"][t, 1]]
-        pos = {int(g): i for i, g in enumerate(le)}
-        idx = [pos[int(g)] for g in lf]
-        assert idx == sorted(idx) and len(set(idx)) == len(idx)
+        assert float(bad.float().mean()) <= 1e-4, (k, float(bad.float().mean()))
+
+
+def test_c3_full_size_against_the_oracle():
+    """BASELINE config 3 at FULL size against the CPU oracle (about 5 s per view on the test box's cores): the EXACT forward
+    is bit-identical on every output and on all integer state; the sampled feature backward (the kernel the headline step
+    lives on) is within 1e-3 of the tensor's maximum on every row in EXACT mode, with the 99.9th percentile of the per-row
+    relative error within 1e-2; in FAST mode at most 1e-4 of the rows sit outside 1e-3 (decisions on a threshold that flip
+    against the two-rounding oracle, tests/test_gpu_fuzz.py), none by more than 5 % of the maximum."""
+    import oracle
+    from helpers import oracle_forward, assert_rows_close
+    scene, cams, cfg, inp = _c3()
+    P, W, H, F = cfg["P"], cfg["W"], cfg["H"], cfg["F"]
+    cam = cams[9]
+    cpu = {k: (None if v is None else v.cpu()) for k, v in inp.items()}
+    st = oracle_forward(cpu, cam)
+    a, o = _forward(inp, cam, cfg, MODE_EXACT)
+    assert o[0] == st["R"]
+    np.testing.assert_array_equal(o[3].cpu().numpy(), st["radii"])
+    dbg = rz.debug_state(P, W, H, o[0], o[5], o[6], o[7])
+    for k in ("tiles_touched", "point_list", "ranges", "n_contrib", "final_T"):
+        np.testing.assert_array_equal(dbg[k], st[k], err_msg=k)
+    np.testing.assert_array_equal(o[1].cpu().numpy(), st["color"])
+    np.testing.assert_array_equal(o[2].cpu().numpy(), st["others"])
+    np.testing.assert_array_equal(o[4].cpu().numpy(), st["extra"])
+    g = torch.Generator(device="cuda").manual_seed(31)
+    pix = torch.randint(0, W * H, (16384,), device="cuda", generator=g)
+    rows = torch.randn(16384, F, device="cuda", generator=g)
+    Gs = torch.zeros(F, H * W, device="cuda")
+    Gs.index_add_(1, pix, rows.t().contiguous())
+    want = oracle.backward(st, np.zeros((3, H, W), np.float32), np.zeros((7, H, W), np.float32),
+                           Gs.reshape(F, H, W).cpu().numpy())["dL_dextra"]
+    scale = np.abs(want).max()
+    for md in (MODE_EXACT, MODE_FAST):
+        if md == MODE_FAST:
+            a, o = _forward(inp, cam, cfg, MODE_FAST)
+        got = rz.rasterize_gaussians_backward_sampled(P, F, W, H, o[0], pix, rows, None, o[5], o[6], o[7], mode=md).cpu().numpy()
+        dev = np.abs(got - want).max(axis=1) / scale
+        if md == MODE_EXACT:
+            assert dev.max() <= 1e-3, float(dev.max())
+            assert_rows_close(got, want, "C3 exact dL_dextra")
+        else:
+            assert (dev > 1e-3).sum() <= 1e-4 * P and dev.max() <= 0.05, (int((dev > 1e-3).sum()), float(dev.max()))
+
+
+def test_c1_plumbing_config_against_the_oracle():
+    """BASELINE config 1 at its stated size (50 k Gaussians, 256 x 256, RGB only): EXACT forward bit-identical, all
+    gradients within 1e-3; FAST within the fuzz sweep's gates."""
+    import oracle
+    import test_gpu_rasterizer as TR
+    from helpers import oracle_forward, assert_rows_close
+    scene, cams, cfg = scenes.config_scene("C1")
+    assert (cfg["P"], cfg["W"], cfg["H"], cfg["F"]) == (50_000, 256, 256, 0)
+    inp = scenes.activated_inputs(scene)
+    cam = cams[2]
+    st = oracle_forward(inp, cam, bg=(0.3, 0.2, 0.1), tracer=True)
+    args, out = TR.hip_forward(inp, cam, bg=(0.3, 0.2, 0.1), mode=MODE_EXACT, tracer=True)
+    TR.check_forward_exact(st, args, out, tracer=True)
+    rng = np.random.RandomState(1)
+    dC = rng.randn(3, 256, 256).astype(np.float32)
+    dO = rng.randn(7, 256, 256).astype(np.float32)
+    dE = np.zeros((0, 256, 256), np.float32)
+    want = oracle.backward(st, dC, dO, None)
+    for md in (MODE_EXACT, MODE_FAST):
+        args, out = TR.hip_forward(inp, cam, bg=(0.3, 0.2, 0.1), mode=md)
+        got = TR.hip_backward(args, out, dC, dO, dE, TR.GRAD_GEOMETRY, md)
+        for name, t in zip(TR.GRAD_NAMES, got):
+            if t is None or name not in want or want[name].size == 0:
+                continue
+            w = want[name].reshape(cfg["P"], -1)
+            gg = t.cpu().numpy().reshape(w.shape)
+            dev = np.abs(gg - w).max(axis=1) / (np.abs(w).max() + 1e-30)
+            if md == MODE_EXACT:
+                assert dev.max() <= 1e-3, (name, float(dev.max()))
+                assert_rows_close(gg, w, f"C1 exact {name}")
+            else:
+                assert (dev > 1e-3).sum() <= max(4, 1e-4 * cfg["P"]) and dev.max() <= 0.05, (name, int((dev > 1e-3).sum()), float(dev.max()))
 
 
 def test_c3_three_nearest_neighbours_against_brute_force():
@@ -347,5 +423,7 @@ def test_c2_geometry_backward_adjoint_and_oracle_parity_at_full_size(mode):
         dev = np.abs(t.cpu().numpy().reshape(w.shape) - w).max(axis=1) / (np.abs(w).max() + 1e-30)
         if mode == "exact":
             assert dev.max() <= 1e-3, (name, float(dev.max()))
+            from helpers import assert_rows_close
+            assert_rows_close(t.cpu().numpy().reshape(w.shape), w, f"C2 exact {name}")
         else:
-            assert (dev > 1e-3).sum() <= 1e-4 * P and dev.max() <= 0.25, (name, int((dev > 1e-3).sum()), float(dev.max()))
+            assert (dev > 1e-3).sum() <= 1e-4 * P and dev.max() <= 0.05, (name, int((dev > 1e-3).sum()), float(dev.max()))

@@ -1,36 +1,44 @@
 """Randomised parity sweep on the GPU: 40 seeded scenes with extreme anisotropy (60:1 and 1:100), splat sizes from 0.3
 to 30 pixels and every fifth opacity sitting ON the alpha = 1/255 threshold (0.0039 / 0.004).
 
-* EXACT mode: forward bit-identical to the CPU oracle, every gradient within 1e-3 of the tensor's max.
-* FAST mode (bench.py's headline mode): binning bit-identical, and every gradient within 1e-3 of the tensor's max on all
-  rows (Gaussians) but a bounded handful per scene.  Two mechanisms put a row outside, both intrinsic to evaluating the same
-  formulas with fused multiply-adds and hardware rcp / exp (the reference's nvcc build contracts to FMA too, i.e. it differs
-  from the two-rounding oracle in the same places):
-    - a DECISION of the per-pixel loop flips for one (pixel, splat) pair that sits on a threshold - alpha = 1/255 (the
-      sweep plants opacities there), T = 1e-4, depth = 0.2, rho3d = rho2d - which changes that Gaussian's gradient by one
-      pixel's contribution (in these 300..3000-Gaussian scenes that is up to a few percent of the tensor's maximum);
-    - near edge-on surfels, where the ray-splat intersection cancels catastrophically.
-  (In FAST mode the forward evaluates the intersection in its affine form and the backward in the reference's form, so such a
-  decision can also differ between the two passes of one pixel; on regular scenes this is invisible - the full-size adjoint
-  identities of test_gpu_fullsize.py hold to 1e-5 - here it is part of the bounded handful.)
-  The gate: at most MAX_ROWS rows per tensor outside 1e-3, none off by more than MAX_DEV of the tensor's max.  The same
-  forward is also held to the image tolerance (1e-4 of the max on all but max(4, 3e-3 N) of these small images' pixels: a fifth of the splats sit on the
-  alpha threshold by construction; the regular scenes of test_gpu_rasterizer.py hold 1e-4 on all but 1e-4 of the pixels).
+* EXACT mode: forward bit-identical to the CPU oracle, every gradient within 1e-3 of the tensor's max, and the 99.9th
+  percentile of the PER-ROW relative error (helpers.row_rel_errors) within 1e-2.
+* FAST mode (bench.py's headline mode, the drop-in's default):
+    - binning bit-identical to the oracle;
+    - forward and backward are SELF-CONSISTENT: every FAST kernel evaluates a (pixel, splat) pair with the one instruction
+      sequence of csrc/isr_fast_pair.hpp, so the backward replays the forward's decisions bit for bit.  Checked without the
+      oracle through the adjoint identities  <render(E), G> == <E, backward(G)>  (features: dense kernel and sampled
+      kernel) and  <colour(c), G> == <c, dL/dcolour(G)>  on all 40 scenes, to 1e-5;
+    - against the oracle every gradient is within 1e-3 of the tensor's max on all rows (Gaussians) but a bounded handful
+      per scene: a DECISION of the per-pixel loop flips AGAINST THE ORACLE for a (pixel, splat) pair that sits on a
+      threshold - alpha = 1/255 (the sweep plants opacities there), T = 1e-4, depth = 0.2, rho3d = rho2d - because FAST
+      evaluates the same formulas with fused multiply-adds and hardware rcp / exp (the reference's nvcc build contracts
+      to FMA too, i.e. it differs from the two-rounding oracle in the same places).  A flip changes that Gaussian's
+      gradient by one pixel's contribution.  The gate: at most MAX_ROWS rows per tensor outside 1e-3, none off by more
+      than MAX_DEV of the tensor's max; every such row is listed (ISR_FUZZ_REPORT=<file> appends JSON lines: scene, tensor,
+      Gaussian, deviation, and whether the Gaussian's tile rectangle holds a pixel whose FAST image differs from the
+      oracle's, i.e. a visible flip) - profiles/r03_fuzz_outliers.jsonl is that list from the round's run.
+  The same forward is also held to the image tolerance (1e-4 of the max on all but max(4, 3e-3 N) of these small images'
+  pixels: a fifth of the splats sit on the alpha threshold by construction; the regular scenes of test_gpu_rasterizer.py
+  hold 1e-4 on all but 1e-4 of the pixels).
 """
+import json
 import math
+import os
 
 import numpy as np
 import pytest
 import torch
 
 import oracle
-from helpers import small_scene, oracle_forward, assert_close
+from helpers import small_scene, oracle_forward, assert_close, assert_rows_close
 import test_gpu_rasterizer as T
 
 pytestmark = pytest.mark.gpu
 
 MAX_ROWS = 4            # rows (Gaussians) of one gradient tensor allowed outside 1e-3 in FAST mode, per scene
-MAX_DEV = 0.25          # ... and their largest deviation, as a fraction of the tensor's max
+MAX_DEV = 0.05          # ... and their largest deviation, as a fraction of the tensor's max
+ADJ_TOL = 1e-5          # adjoint identities, relative to sum |a| |b|
 
 
 def _scene(case, seed0=1000):
@@ -52,13 +60,38 @@ def _scene(case, seed0=1000):
     return inp, cams[rng.randint(len(cams))], F
 
 
+def _dot(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b), float(np.abs(a) @ np.abs(b))
+
+
+def _flip_tiles(out, st):
+    """Tiles holding a pixel whose FAST colour / alpha / feature differs from the oracle's by more than 1e-4 of the max."""
+    H, W = st["H"], st["W"]
+    bad = np.zeros((H, W), bool)
+    for got, want in ((out[1], st["color"]), (out[2][1:2], st["others"][1:2]), (out[4], st["extra"])):
+        if want.size == 0:
+            continue
+        g = got.cpu().numpy().reshape(-1, H, W)
+        bad |= (np.abs(g - want.reshape(g.shape)) > 1e-4 * np.abs(want).max()).any(axis=0)
+    ys, xs = np.nonzero(bad)
+    return {(int(y) // 16, int(x) // 16) for y, x in zip(ys, xs)}
+
+
+def _rect_tiles(st, g):
+    """Tiles of Gaussian g's rectangle (reference auxiliary.h:68-78)."""
+    gx, gy = (st["W"] + 15) // 16, (st["H"] + 15) // 16
+    x0, y0, x1, y1 = oracle.test_tile_rect(float(st["means2D"][g, 0]), float(st["means2D"][g, 1]), int(st["radii"][g]), gx, gy)
+    return {(y, x) for y in range(y0, y1) for x in range(x0, x1)}
+
+
 @pytest.mark.parametrize("case", range(40))
 def test_fuzz_parity(case):
     inp, cam, F = _scene(case)
     st = oracle_forward(inp, cam)
     st.setdefault("means3D", inp["means3D"].numpy())
     mask = (T.GRAD_EXTRA | T.GRAD_GEOMETRY) if F else T.GRAD_GEOMETRY
-    # EXACT
+    # ---- EXACT
     args, out = T.hip_forward(inp, cam, mode=T.MODE_EXACT)
     T.check_forward_exact(st, args, out)
     dC, dO, dE = T._rand_grads(st, case)
@@ -67,13 +100,38 @@ def test_fuzz_parity(case):
     for name, t in zip(T.GRAD_NAMES, got):
         if t is None or name not in want or want[name].size == 0:
             continue
-        assert_close(t.cpu().numpy().reshape(want[name].shape), want[name], 1e-3, f"exact {name}")
-    # FAST (reference tile rectangles)
+        g = t.cpu().numpy().reshape(want[name].shape)
+        assert_close(g, want[name], 1e-3, f"exact {name}")
+        assert_rows_close(g, want[name], f"exact {name}")
+    # ---- FAST (reference tile rectangles)
     args, out = T.hip_forward(inp, cam, mode=T.MODE_FAST)
-    T.check_binning_exact(st, out)
+    dbg = T.check_binning_exact(st, out)
     T._images_within_fast_tolerance(out, st, frac=3e-3, floor=4)
     got = T.hip_backward(args, out, dC, dO, dE, mask, T.MODE_FAST)
+    # (a) self-consistency, no oracle involved: the backward is the adjoint of the (linear) colour and feature renders
+    rgb_used = np.where((st["radii"] > 0)[:, None], dbg["records"][:, 15:18], 0.0)   # what K1 handed to the blend (bg = 0 here;
+                                                                                     # culled Gaussians have no record)
+    lhs, mag = _dot(out[1].cpu().numpy(), dC)
+    rhs, _ = _dot(rgb_used, got[1].cpu().numpy())
+    assert abs(lhs - rhs) <= ADJ_TOL * mag, f"fast colour adjoint: {lhs} vs {rhs} (sum |.| {mag})"
+    if F:
+        E = inp["extra"].numpy()
+        lhs, mag = _dot(out[4].cpu().numpy(), dE)
+        rhs, _ = _dot(E, got[8].cpu().numpy())
+        assert abs(lhs - rhs) <= ADJ_TOL * mag, f"fast feature adjoint (dense kernel): {lhs} vs {rhs} (sum |.| {mag})"
+        rng = torch.Generator().manual_seed(case)
+        n = 96
+        pix = torch.randint(0, st["W"] * st["H"], (n,), generator=rng).cuda()
+        rows = torch.randn(n, F, generator=rng).cuda()
+        R, geom, binning, img = out[0], out[5], out[6], out[7]
+        dE_s = T.rz.rasterize_gaussians_backward_sampled(st["P"], F, st["W"], st["H"], R, pix, rows, None, geom, binning, img,
+                                                         mode=T.MODE_FAST)
+        lhs, mag = _dot(T.rz.sample_extra(out[4], pix).cpu().numpy(), rows.cpu().numpy())
+        rhs, _ = _dot(E, dE_s.cpu().numpy())
+        assert abs(lhs - rhs) <= ADJ_TOL * mag, f"fast feature adjoint (sampled kernel): {lhs} vs {rhs} (sum |.| {mag})"
+    # (b) against the oracle
     report = []
+    flips = None
     for name, t in zip(T.GRAD_NAMES, got):
         if t is None or name not in want or want[name].size == 0:
             continue
@@ -81,10 +139,18 @@ def test_fuzz_parity(case):
         g = t.cpu().numpy().reshape(w.shape)
         scale = np.abs(w).max() + 1e-30
         dev = np.abs(g - w).max(axis=1) / scale
-        rows = int((dev > 1e-3).sum())
-        if rows:
-            report.append((name, rows, float(dev.max())))
-        assert rows <= MAX_ROWS, f"fast {name}: {rows} rows outside 1e-3"
+        out_rows = np.nonzero(dev > 1e-3)[0]
+        for r in out_rows:
+            if flips is None:
+                flips = _flip_tiles(out, st)
+            report.append(dict(case=case, tensor=name, gaussian=int(r), dev_of_max=float(dev[r]),
+                               opacity=float(inp["opacities"][r]), flipped_pixel_in_its_tiles=bool(_rect_tiles(st, int(r)) & flips)))
+        assert len(out_rows) <= MAX_ROWS, f"fast {name}: {len(out_rows)} rows outside 1e-3"
         assert dev.max() <= MAX_DEV, f"fast {name}: a row is off by {dev.max():.3g} of the tensor's max"
     if report:
-        print(f"case {case}: rows outside 1e-3 (tensor, rows, worst/max):", report)
+        print(f"case {case}: rows outside 1e-3:", [(r["tensor"], r["gaussian"], round(r["dev_of_max"], 4)) for r in report])
+        path = os.environ.get("ISR_FUZZ_REPORT")
+        if path:
+            with open(path, "a") as f:
+                for r in report:
+                    f.write(json.dumps(r) + "\n")
