@@ -11,7 +11,8 @@ import subprocess
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libinstascene_hip.so")
+# ISR_LIB_PATH: an A/B build of the library (tools/build_variant.sh); default = the in-tree build
+LIB_PATH = os.environ.get("ISR_LIB_PATH") or os.path.join(_HERE, "libinstascene_hip.so")
 _lib = None
 
 MODE_EXACT, MODE_FAST = 0, 1

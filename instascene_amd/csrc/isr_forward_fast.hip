@@ -20,6 +20,10 @@
 #include "isr_common.hpp"
 #include "isr_fast_pair.hpp"
 
+#ifndef ISR_EXP
+#define ISR_EXP 0
+#endif
+
 namespace isr {
 
 constexpr int FF_BATCH = 128;       // instances staged per round
@@ -180,10 +184,33 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
             }
             unsigned long long m = __ballot(hit);
             if (STATS) st_cull += (unsigned)min(64, nb - c0);
+#if ISR_EXP & 1
+            // software pipeline: the next hit splat's three ray vectors are fetched from LDS while this one is evaluated
+            int jn = 0;
+            float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+            if (m != 0ull) {
+                jn = c0 + __builtin_ctzll(m);
+                const float4* qn = reinterpret_cast<const float4*>(s_rec + jn * RS);
+                n0 = qn[0]; n1 = qn[1]; n2 = qn[2];
+            }
+#endif
             while (m != 0ull) {
+#if !(ISR_EXP & 2)
                 if (m_done == ~0ull) break;
+#endif
+#if ISR_EXP & 1
+                const int j = jn;
+                const float4 q0 = n0, q1 = n1, q2 = n2;
+                m &= m - 1ull;
+                if (m != 0ull) {
+                    jn = c0 + __builtin_ctzll(m);
+                    const float4* qn = reinterpret_cast<const float4*>(s_rec + jn * RS);
+                    n0 = qn[0]; n1 = qn[1]; n2 = qn[2];
+                }
+#else
                 const int j = c0 + __builtin_ctzll(m);
                 m &= m - 1ull;
+#endif
                 if (STATS) {
                     st_eval++;
                     // how often could this splat and the next one of the wave's list share ONE evaluation (their alpha >= 1/255
@@ -199,7 +226,9 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                     }
                 }
                 const float4* q = reinterpret_cast<const float4*>(s_rec + j * RS);
+#if !(ISR_EXP & 1)
                 const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+#endif
                 // the pair's arithmetic is isr_fast_pair.hpp's, shared with the FAST backward kernels: both passes take the
                 // same decisions on the same pair, bit for bit
                 const FastRay fr = fast_ray(lx, ly, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, q0.w, q1.w);
@@ -215,6 +244,9 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                 const unsigned long long m_pass = m_near & __ballot(!(depth < NEAR_N)) & __ballot(!(alpha < 1.0f / 255.0f));
                 const unsigned long long m_stop = m_pass & __ballot(test_T < 0.0001f);
                 m_done |= m_stop;
+#if ISR_EXP & 2
+                if (m_stop != 0ull && m_done == ~0ull) m = 0ull;      // every pixel of the block has stopped: this splat is the last
+#endif
                 const unsigned long long m_ok = m_pass & ~m_stop;
                 if (m_ok == 0ull) continue;
                 if (STATS) { st_blend++; st_lanes += (unsigned)__popcll(m_ok); }

