@@ -53,6 +53,13 @@ extern "C" {
 const char* isr_last_error(void);
 int isr_version(void);
 
+/* Debug mode of the calling host thread - the reference's `debug` argument (rasterizer.h:60,90; CHECK_CUDA,
+ * auxiliary.h:297-304): while on, every entry point of this library synchronises the stream after each kernel it
+ * launches and fails with ISR_EHIP naming the kernel that faulted, instead of the error surfacing at some later call.
+ * ISR_DEBUG_SYNC=1 in the environment turns it on for the whole process.  Returns the previous setting.
+ * `fault_after` (testing aid): with debug on, the n-th checked launch from now (n >= 1) reports an injected fault; 0 = none. */
+int isr_set_debug(int on, int fault_after);
+
 /* ---- optional per-kernel timing (HIP events on the launch stream), used by bench.py.
  * isr_profile_enable(1) clears and starts recording every kernel, (2) only the forward blend kernel (two events per
  * step instead of ~25: the timed region of bench.py), (0) stops; isr_profile_summary() synchronises and writes one

@@ -25,6 +25,7 @@ _P = c_void_p
 SIGNATURES = {
     "isr_last_error": (c_char_p, []),
     "isr_version": (c_int, []),
+    "isr_set_debug": (c_int, [c_int, c_int]),
     "isr_profile_enable": (None, [c_int]),
     "isr_forward_set_counters": (None, [_P]),
     "isr_profile_summary": (c_size_t, [_P, c_size_t]),

@@ -38,7 +38,7 @@ int isr_backward(int P, int D, int M, int64_t num_rendered, int ED, int width, i
                            dL_dout_color, dL_dout_others, dL_dout_extra, dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor,
                            dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot, dL_dextra, scratch, scratch_bytes,
                            (hipStream_t)stream);
-    if (rc != 0) return fail(ISR_EHIP, "backward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (rc != 0) return ISR_EHIP;       // message set by the launcher
     return ISR_OK;
 }
 
@@ -51,7 +51,7 @@ int isr_sample_extra(int ED, int width, int height, int n_samples, const float* 
     if (ED < 0 || width <= 0 || height <= 0 || n_samples < 0) return fail(ISR_EINVAL, "bad sample_extra sizes");
     if (n_samples > 0 && ED > 0 && (!out_extra || !pixels || !sampled)) return fail(ISR_EINVAL, "sample_extra: null pointer");
     if (launch_sample_gather(n_samples, ED, (long long)width * height, out_extra, pixels, sampled, (hipStream_t)stream) != 0)
-        return fail(ISR_EHIP, "sample_extra launch failed");
+        return ISR_EHIP;
     return ISR_OK;
 }
 
@@ -68,7 +68,7 @@ int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int hei
     const int rc = launch_backward_sampled(P, num_rendered, ED, width, height, mode, n_samples, pixels, dL_dsampled,
                                            transMat_precomp, geom_buffer, binning_buffer, image_buffer, dL_dextra, accumulate,
                                            scratch, (hipStream_t)stream);
-    if (rc != 0) return fail(ISR_EHIP, "backward_sampled launch failed (%d)", rc);
+    if (rc != 0) return ISR_EHIP;
     return ISR_OK;
 }
 
@@ -93,7 +93,7 @@ int isr_feature_rows_step(int P, int row_begin, int row_count, int64_t num_rende
     const int rc = launch_feature_rows_step(P, row_begin, row_count, num_rendered, ED, geom_buffer, rows_scratch, gz_dense, gy, gy_slot, gy_merged, eps1,
                                             eps2, x, grad_out, lr_over_bc1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
                                             inv_sqrt_bc2, (float)eps, exp_avg, exp_avg_sq, y, z, (hipStream_t)stream);
-    if (rc != 0) return fail(ISR_EHIP, "feature_rows_step launch failed (%d)", rc);
+    if (rc != 0) return ISR_EHIP;
     return ISR_OK;
 }
 

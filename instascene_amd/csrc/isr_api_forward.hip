@@ -9,6 +9,7 @@ namespace isr {
 
 thread_local char g_err[512] = "";
 thread_local int g_debug = 0;
+thread_local int g_fault_after = 0;
 
 template <class Math>
 static int launch_render_fwd(int tiles, hipStream_t s, int W, int H, int ED, int gx, const ImageView& iv,
@@ -44,6 +45,13 @@ extern "C" {
 
 const char* isr_last_error(void) { return g_err; }
 int isr_version(void) { return 1; }
+
+int isr_set_debug(int on, int fault_after) {
+    const int was = g_debug;
+    g_debug = on != 0;
+    g_fault_after = (on != 0 && fault_after > 0) ? fault_after : 0;
+    return was;
+}
 
 void isr_profile_enable(int on) {
     Prof& p = prof();

@@ -18,7 +18,7 @@
 //     where some pixel contributes.
 //   * The per-channel feature recurrences of the reference (2F registers) collapse to
 //     one scalar recurrence on q = <feature_g, dL/dfeature(pix)> (same algebra).
-#include "isr_common.hpp"
+#include "isr_host.hpp"
 #include "isr_fast_pair.hpp"
 
 namespace isr {
@@ -1647,10 +1647,13 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
 #include "isr_backward_geo.hip"
 namespace isr {
 
-#define ISR_CHECK_LAUNCH_B(name)                                                  \
-    do {                                                                          \
-        hipError_t e_ = hipGetLastError();                                        \
-        if (e_ != hipSuccess) return -2;                                          \
+// (the launchers below return -2 with the message already in isr_last_error())
+#define ISR_CHECK_LAUNCH_B(name)                                                                            \
+    do {                                                                                                    \
+        hipError_t e_ = hipGetLastError();                                                                  \
+        if (e_ != hipSuccess) { fail(ISR_EHIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); return -2; } \
+        const char* m_ = debug_check(s);                                                                    \
+        if (m_ != nullptr) { fail(ISR_EHIP, "[debug] kernel %s failed: %s", name, m_); return -2; }         \
     } while (0)
 
 // ISR_SPARSE_BWD=0 disables the pixel-major kernel (A/B measurements)
@@ -1695,14 +1698,14 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
     const bool geo_splat = Math::fast && geomg && !featg && ED == 0 && geo_splat_enabled();
     const int rpi = geo_splat ? rows_per_instance(ED, eff_mask) : 1;
     if (R > 0 && geo_splat) {
-        if (hipMemsetAsync(flags, 0, (size_t)R * rpi, s) != hipSuccess) return -2;
+        if (hipMemsetAsync(flags, 0, (size_t)R * rpi, s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }
         ProfScope ps_("k_render_bwd", s);
         hipLaunchKernelGGL(k_render_bwd_geo, dim3(T * 4), dim3(64), 0, s, W, H, gx, iv.tile_offset, bv.point_list, bv.box4, g.rec,
                            col_pre, tm_pre, bg, iv.final_T, iv.n_contrib, dC, dO, g.point_offsets, g.rect, partial, flags, stride,
                            geom_off, R, geo_heavy_first() ? iv.tile_order : (const uint32_t*)nullptr);
         ISR_CHECK_LAUNCH_B("k_render_bwd_geo");
     } else if (R > 0) {
-        if (hipMemsetAsync(flags, 0, (size_t)R * npass, s) != hipSuccess) return -2;
+        if (hipMemsetAsync(flags, 0, (size_t)R * npass, s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }
         int pass = 0;
         bool first = true;
         int ch = 0;
@@ -1790,14 +1793,17 @@ static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int
     if (P == 0) return 0;
     // rows only (the caller finishes them with launch_feature_rows_step): also keep a per-Gaussian mask of flagged instances
     unsigned long long* row_mask = dL_dextra == nullptr ? g.row_mask : nullptr;
-    if (row_mask != nullptr && hipMemsetAsync(row_mask, 0, sizeof(unsigned long long) * (size_t)P, s) != hipSuccess) return -2;
+    if (row_mask != nullptr && hipMemsetAsync(row_mask, 0, sizeof(unsigned long long) * (size_t)P, s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }
     if (R > 0 && n > 0) {
         // row flags and the per-tile sample counters are neighbours in the scratch: one fill for both
-        if (hipMemsetAsync(flags, 0, (size_t)((char*)(cnt + T) - (char*)flags), s) != hipSuccess) return -2;
+        if (hipMemsetAsync(flags, 0, (size_t)((char*)(cnt + T) - (char*)flags), s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }
         ProfScope ps_("k_render_bwd", s);
         hipLaunchKernelGGL(k_sample_count, dim3((n + 255) / 256), dim3(256), 0, s, n, W, H, gx, pix, cnt);
+        ISR_CHECK_LAUNCH_B("k_sample_count");
         hipLaunchKernelGGL(k_sample_scan, dim3(1), dim3(1024), 0, s, T, cnt, off, cursor);
+        ISR_CHECK_LAUNCH_B("k_sample_scan");
         hipLaunchKernelGGL(k_sample_fill, dim3((n + 255) / 256), dim3(256), 0, s, n, W, H, gx, pix, off, cursor, iv.n_contrib, seg_idx);
+        ISR_CHECK_LAUNCH_B("k_sample_fill");
         for (int pass = 0, ch = 0; ch < ED; pass++, ch += 32)
             hipLaunchKernelGGL((k_render_bwd_sparse<Math, true>), dim3(T), dim3(64), 0, s, W, H, ED, ch, gx, iv.tile_offset,
                                bv.point_list, bv.box4, g.rec, tm_pre, (const float*)nullptr, g.point_offsets, g.rect, partial,
@@ -1805,7 +1811,7 @@ static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int
                                iv.n_contrib, pix, rows_in, off, seg_idx, pass == 0 ? row_mask : (unsigned long long*)nullptr);
         ISR_CHECK_LAUNCH_B("k_render_bwd_sparse");
     } else if (R > 0) {
-        if (hipMemsetAsync(flags, 0, align_up((size_t)R * npass, 256), s) != hipSuccess) return -2;
+        if (hipMemsetAsync(flags, 0, align_up((size_t)R * npass, 256), s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }
     }
     if (dL_dextra == nullptr) return 0;
     const size_t total = (size_t)P * ((ED + 3) / 4);

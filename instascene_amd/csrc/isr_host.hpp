@@ -42,16 +42,22 @@ static inline int fail(int code, const char* fmt, ...) {
 // launch and throw with the name of the kernel that faulted): on for the calling thread while isr_set_debug(1) holds,
 // or for the process with ISR_DEBUG_SYNC=1.
 extern thread_local int g_debug;              // isr_api_forward.hip
+extern thread_local int g_fault_after;        // isr_set_debug's injected fault (tests)
 static inline bool debug_sync() {
     static const bool env = [] { const char* e = getenv("ISR_DEBUG_SYNC"); return e && e[0] == '1'; }();
     return env || g_debug != 0;
 }
+// debug mode: the kernel just launched must have RUN without a fault before the next one is enqueued
+static inline const char* debug_check(hipStream_t stream) {
+    if (!debug_sync()) return nullptr;
+    if (g_fault_after > 0 && --g_fault_after == 0) return "injected fault (isr_set_debug)";
+    const hipError_t e = hipStreamSynchronize(stream);
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
 #define ISR_STAGE(name, stream)                                                                             \
     do {                                                                                                    \
-        if (debug_sync()) {                                                                                 \
-            hipError_t e_ = hipStreamSynchronize(stream);                                                   \
-            if (e_ != hipSuccess) return fail(ISR_EHIP, "stage %s failed: %s", name, hipGetErrorString(e_)); \
-        }                                                                                                   \
+        const char* m_ = debug_check(stream);                                                               \
+        if (m_ != nullptr) return fail(ISR_EHIP, "[debug] kernel %s failed: %s", name, m_);                 \
     } while (0)
 // after a launch: the launch error, and in debug mode the execution error of the kernel itself
 #define ISR_LAUNCH_CHECK_S(name, stream)                                                                    \

@@ -665,6 +665,34 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+def _cpu_snapshot(args):
+    """``cpu_deep_copy_tuple`` of the reference wrapper (diff_surfel_rasterization/__init__.py:17-19): tensors copied to
+    the host BEFORE the call, so that a fault cannot corrupt what gets dumped."""
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+class _debug_call:
+    """``raster_settings.debug`` (reference __init__.py:93-101,150-158; CHECK_CUDA, auxiliary.h:297-304): while the call
+    runs the library synchronises after every kernel and reports which one faulted (``isr_set_debug``); if it raises, the
+    argument snapshot taken beforehand goes to ``snapshot_fw.dump`` / ``snapshot_bw.dump`` in the working directory
+    (``torch.save``, as the reference does) and the exception propagates."""
+
+    def __init__(self, args, which):
+        self.snapshot, self.which = _cpu_snapshot(args), which
+
+    def __enter__(self):
+        self.was = lib().isr_set_debug(1, int(os.environ.get("ISR_DEBUG_FAULT_AFTER", "0")))
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        lib().isr_set_debug(self.was, 0)
+        if exc_type is not None:
+            name = "snapshot_fw.dump" if self.which == "forward" else "snapshot_bw.dump"
+            torch.save(self.snapshot, name)
+            print(f"\nAn error occured in {self.which}. Please forward {name} for debugging.")
+        return False
+
+
 class _Token:
     """Dies with the autograd context that holds it (see weakref.finalize in _RasterizeGaussians.forward)."""
     __slots__ = ("__weakref__",)
@@ -679,13 +707,19 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise Exception("feature_only forward: only extra_attrs may require grad")
         attr_degree = extra_attrs.shape[1] if extra_attrs.shape[0] != 0 else 0
         kept_state = []
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                extra_attrs, attr_degree, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
+                rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        kw = dict(_state_out=kept_state,
+                  _verify_at_backward=any(ctx.needs_input_grad),     # (grad mode is off inside Function.forward: ask the context)
+                  feature_only=feature_only)
+        if rs.debug:
+            with _debug_call(args, "forward"):
+                res = rasterize_gaussians(*args, **kw)
+        else:
+            res = rasterize_gaussians(*args, **kw)
         (num_rendered, color, depth, radii, extra, geomBuffer, binningBuffer, imgBuffer, gau_related_pixels,
-         gau_pixel_indices) = rasterize_gaussians(
-            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
-            extra_attrs, attr_degree, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
-            rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, _state_out=kept_state,
-            _verify_at_backward=any(ctx.needs_input_grad),     # (grad mode is off inside Function.forward: ask the context)
-            feature_only=feature_only)
+         gau_pixel_indices) = res
         if kept_state and any(ctx.needs_input_grad):
             # the cached view state now backs a pending backward: not reusable until that has run (or the graph is freed)
             kept_state[0].busy += 1
@@ -745,12 +779,16 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                       ctx.num_rendered, ctx.sample_pixels, grad_sampled, cov3Ds_precomp,
                                                       geomBuffer, binningBuffer, imgBuffer, mode=ctx.mode)
             return (None,) * 8 + (ge, None, None, None, None)
+        bargs = (rs.bg, means3D, radii, colors_precomp, scales, rotations, extra_attrs, rs.scale_modifier, cov3Ds_precomp,
+                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_out_extra, sh,
+                 rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
+        if rs.debug:
+            with _debug_call(bargs, "backward"):
+                grads = rasterize_gaussians_backward(*bargs, grad_mask=mask, mode=ctx.mode)
+        else:
+            grads = rasterize_gaussians_backward(*bargs, grad_mask=mask, mode=ctx.mode)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations, grad_extra_attrs) = rasterize_gaussians_backward(
-            rs.bg, means3D, radii, colors_precomp, scales, rotations, extra_attrs, rs.scale_modifier, cov3Ds_precomp,
-            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_out_extra, sh,
-            rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug, grad_mask=mask,
-            mode=ctx.mode)
+         grad_rotations, grad_extra_attrs) = grads
         if grad_sampled is not None and grad_extra_attrs is not None and grad_extra_attrs.numel():
             grad_extra_attrs = rasterize_gaussians_backward_sampled(
                 means3D.shape[0], extra_attrs.shape[1], rs.image_width, rs.image_height, ctx.num_rendered, ctx.sample_pixels,

@@ -776,3 +776,43 @@ def test_splats_larger_than_the_view(F, W, H, mode):
         if t is None or (name == "dL_dextra" and F == 0):
             continue
         assert_close(t.cpu().numpy().reshape(want[name].shape), want[name], 1e-3, f"{mode}:{name}")
+
+
+def test_debug_mode_checks_every_launch_and_dumps_on_a_fault(tmp_path, monkeypatch):
+    """``debug=True`` through the module: same results as without; with a fault injected at the library's third checked
+    launch (``isr_set_debug``'s testing aid) the forward raises, names a kernel, and leaves snapshot_fw.dump; the backward
+    likewise leaves snapshot_bw.dump."""
+    sc, cams, inp = small_scene(P=500, F=8, W=64, H=48, seed=77)
+    cam = cams[0]
+    monkeypatch.chdir(tmp_path)
+
+    def run(debug):
+        st = rz.GaussianRasterizationSettings(image_height=48, image_width=64, tanfovx=math.tan(cam.FoVx / 2),
+                                              tanfovy=math.tan(cam.FoVy / 2), bg=torch.zeros(3, device="cuda"), scale_modifier=1.0,
+                                              viewmatrix=cam.world_view_transform.cuda(), projmatrix=cam.full_proj_transform.cuda(),
+                                              sh_degree=3, campos=cam.camera_center.cuda(), prefiltered=False, debug=debug)
+        leaves = {k: inp[k].cuda().requires_grad_(True) for k in ("means3D", "opacities", "scales", "rotations", "shs", "extra")}
+        m2d = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        out = rz.GaussianRasterizer(st)(means3D=leaves["means3D"], means2D=m2d, opacities=leaves["opacities"], shs=leaves["shs"],
+                                        scales=leaves["scales"], rotations=leaves["rotations"], extra_attrs=leaves["extra"])
+        return out, leaves
+
+    (c0, r0, a0, e0, _), l0 = run(False)
+    (c1, r1, a1, e1, _), l1 = run(True)
+    assert torch.equal(c0, c1) and torch.equal(a0, a1) and torch.equal(e0, e1)
+    (c0.sum() + e0.sum()).backward()
+    (c1.sum() + e1.sum()).backward()
+    for k in l0:
+        assert torch.equal(l0[k].grad, l1[k].grad), k
+    monkeypatch.setenv("ISR_DEBUG_FAULT_AFTER", "3")
+    with pytest.raises(RuntimeError, match=r"\[debug\] kernel \w+ failed: injected fault"):
+        run(True)
+    assert (tmp_path / "snapshot_fw.dump").exists()
+    snap = torch.load(tmp_path / "snapshot_fw.dump")
+    assert torch.equal(snap[1], inp["means3D"])
+    monkeypatch.delenv("ISR_DEBUG_FAULT_AFTER")
+    (c2, _, _, e2, _), l2 = run(True)
+    monkeypatch.setenv("ISR_DEBUG_FAULT_AFTER", "2")
+    with pytest.raises(RuntimeError, match=r"\[debug\] kernel \w+ failed: injected fault"):
+        (c2.sum() + e2.sum()).backward()
+    assert (tmp_path / "snapshot_bw.dump").exists()

@@ -157,3 +157,64 @@ def test_async_capacity_rounding_is_monotone_and_tight():
     vals = [_round_capacity(r) for r in range(19_300_000, 19_500_000, 1000)]
     assert vals == sorted(vals) and len(set(vals)) <= 2
     assert _round_capacity(0) == 0 and _round_capacity(-5) == -5
+
+
+def test_debug_flag_dumps_the_argument_snapshot_on_failure(tmp_path, monkeypatch):
+    """``raster_settings.debug=True`` (reference diff_surfel_rasterization/__init__.py:93-101,150-158): when the native call
+    raises, the wrapper writes the CPU copy of its arguments taken BEFORE the call to snapshot_fw.dump / snapshot_bw.dump
+    and re-raises.  No GPU needed: the native entry points are replaced by ones that fail."""
+    import torch
+    from instascene_amd import rasterizer as rz
+
+    class FakeLib:
+        calls = []
+
+        def isr_set_debug(self, on, fault_after):
+            FakeLib.calls.append((on, fault_after))
+            return 0
+
+    monkeypatch.setattr(rz, "lib", lambda: FakeLib())
+    monkeypatch.chdir(tmp_path)
+    P = 5
+    means3D = torch.randn(P, 3, requires_grad=True)
+    means2D = torch.zeros(P, 3, requires_grad=True)
+    e = torch.empty(0)
+    settings = rz.GaussianRasterizationSettings(image_height=8, image_width=8, tanfovx=1.0, tanfovy=1.0, bg=torch.zeros(3),
+                                                scale_modifier=1.0, viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=0,
+                                                campos=torch.zeros(3), prefiltered=False, debug=True)
+
+    def boom(*a, **k):
+        a[1].mul_(0)             # "corrupt" an input after the snapshot was taken
+        raise rz._lib.IsrError("isr_forward_render failed (code -2): [debug] kernel k_render_fwd failed: injected")
+
+    monkeypatch.setattr(rz, "rasterize_gaussians", boom)
+    with pytest.raises(rz._lib.IsrError, match="k_render_fwd"):
+        with torch.no_grad():
+            rz._RasterizeGaussians.apply(means3D.detach().clone(), means2D, e, torch.rand(P, 3), torch.rand(P, 1), torch.rand(P, 2),
+                                         torch.rand(P, 4), e, e, settings)
+    snap = torch.load(tmp_path / "snapshot_fw.dump")
+    assert len(snap) == 21 and snap[-1] is True and snap[14] == 8          # the _C.rasterize_gaussians argument tuple
+    assert float(snap[1].abs().sum()) > 0                                    # copied before the call could touch it
+    assert FakeLib.calls == [(1, 0), (0, 0)]                                 # debug mode on around the call, restored after
+
+    # backward: a context as the forward would have left it
+    class Ctx:
+        raster_settings = settings
+        num_rendered = 3
+        mode = 0
+        sample_pixels = None
+        needs_input_grad = (True,) * 9 + (False,) * 4
+        saved_tensors = (e, means3D.detach(), torch.rand(P, 2), torch.rand(P, 4), e, torch.ones(P, dtype=torch.int32), e,
+                         torch.rand(P, 1, 3), torch.zeros(4, dtype=torch.uint8), torch.zeros(4, dtype=torch.uint8),
+                         torch.zeros(4, dtype=torch.uint8))
+
+    def boom_b(*a, **k):
+        raise rz._lib.IsrError("isr_backward failed (code -2): [debug] kernel k_render_bwd failed: injected")
+
+    monkeypatch.setattr(rz, "rasterize_gaussians_backward", boom_b)
+    FakeLib.calls.clear()
+    with pytest.raises(rz._lib.IsrError, match="k_render_bwd"):
+        rz._RasterizeGaussians.backward(Ctx, torch.ones(3, 8, 8), None, torch.ones(7, 8, 8), None, None)
+    snap = torch.load(tmp_path / "snapshot_bw.dump")
+    assert len(snap) == 24 and snap[20] == 3 and snap[-1] is True          # the _C.rasterize_gaussians_backward argument tuple
+    assert FakeLib.calls == [(1, 0), (0, 0)]
