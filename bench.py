@@ -173,9 +173,19 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
     scene, cams, cfg = scenes.config_scene(args.config)
     cfg["name"] = args.config
     n_views = 16
-    if args.step == "seg":
+    plain = args.step == "plain"
+    if plain:
+        # the reference's loop on the drop-in functions alone, library defaults (no async binning, tracer on): PlainSegTrainer
+        from instascene_amd.harness import PlainSegTrainer
+        rasterizer.set_async_binning(False)
+        rasterizer.set_tracer(True)
+        trainer = PlainSegTrainer(scene, cams[:n_views], device=dev, sample_batchsize=8192, use_class_feat=True,
+                                  empty_cache=bool(getattr(args, "empty_cache", False)))
+        view_index = lambda it: trainer.last_view
+    elif args.step == "seg":
         trainer = SegTrainer(scene, cams[:n_views], device=dev, sample_batchsize=8192, use_class_feat=True, rank=rank, world=world,
-                             spatial_sort=bool(args.spatial_sort), fused_sampling=bool(args.fused_sampling))
+                             spatial_sort=bool(args.spatial_sort), fused_sampling=bool(args.fused_sampling),
+                             multiview=bool(getattr(args, "multiview", False)))
         trainer.split_tail = bool(args.split_tail)
         if args.sharded_tail is not None:
             trainer.sharded_tail = bool(args.sharded_tail)
@@ -193,8 +203,7 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
             trainer.targets = [(render(c, trainer.model, trainer.pipe, trainer.bg)["render"]
                                 + 0.05 * torch.randn(3, cfg["H"], cfg["W"], device=dev, generator=g)).clamp(0, 1)
                                for c in trainer.cams]
-        from instascene_amd.dist_utils import view_for
-        view_index = lambda it: view_for(it, rank, world, n_views)
+        view_index = trainer.view_index
     L = lib()
 
     def sync():
@@ -233,10 +242,11 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    rec = {"value": round(world * args.steps / dt, 3), "ms_per_step": round(1e3 * dt / args.steps, 4),
+    rec = {"value": round(world * args.steps / dt, 3), "ms_per_step": round(1e3 * dt / args.steps, 4), "steps": args.steps,
            "arithmetic_mode": mode + ("+feature_only" if feature_only else ""),
            "sharded_tail": bool(getattr(trainer, "sharded_tail", False))}
-    extra_steps = min(5, args.steps)
+    # (steps with a multi-view leg every 10th iteration: the detail pass covers exactly one such iteration)
+    extra_steps = 10 if (plain or getattr(args, "multiview", False)) else min(5, args.steps)
     it0 = it_next
     if detail:
         # every kernel of the library, over a few extra (untimed) steps, HIP events on the launch stream (all ranks step:
@@ -256,34 +266,37 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
             if mode != "exact":
                 L.isr_forward_set_counters(ctypes.c_void_p(counters.data_ptr()))
             trainer.pipe.feature_only_forward = False
+            trainer.model._seg_cache = None
             pkg = render(trainer.cams[view_index(it0 - 1)], trainer.model, trainer.pipe, trainer.bg)
             V = int((pkg["radii"] > 0).sum().item())
             R = int(rasterizer.LAST_NUM_RENDERED)
             rasterizer.set_async_binning(was)
         cull_tests, pairs_eval, pairs_blend, lane_pairs, pairs_mergeable = (int(v) for v in counters.tolist()[:5])
-        P, N, F = cfg["P"], cfg["W"] * cfg["H"], (cfg["F"] if args.step == "seg" else 0)
+        P, N, F = cfg["P"], cfg["W"] * cfg["H"], (cfg["F"] if args.step in ("seg", "plain") else 0)
         tiles = ((cfg["W"] + 15) // 16) * ((cfg["H"] + 15) // 16)
         bm = byte_model(P, V, R, N, F, tiles)
         kern = {}
         for k, (cnt, tot) in sorted(prof_all.items()):
             ms = tot / cnt
-            key = "k_render_bwd_dense" if (k == "k_render_bwd" and args.step == "rgb") else k
+            key = "k_render_bwd_dense" if (k == "k_render_bwd" and args.step in ("rgb", "plain")) else k
             e = {"ms_per_launch": round(ms, 4), "launches_per_view": round(cnt / float(extra_steps), 2)}
             if key in bm:
-                per_launch = bm[key] / max(1.0, cnt / float(extra_steps)) if k != "k_render_fwd" else bm[key] / max(1.0, round(cnt / float(extra_steps)))
+                # a launch of a blend kernel covers one 32-channel chunk of one view; every other kernel one view
+                per_launch = bm[key] / (max(1, (F + 31) // 32) if key in ("k_render_fwd", "k_render_bwd_dense") else 1)
                 e["algorithmic_bytes"] = int(per_launch)
                 e["GB/s"] = round(per_launch / (ms * 1e-3) / 1e9, 1)
                 e["frac_hbm"] = round(per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             kern[k] = e
-        dom = "k_render_fwd" if args.step == "seg" else max(kern, key=lambda k: kern[k]["ms_per_launch"] * kern[k]["launches_per_view"])
+        dom = "k_render_fwd" if args.step == "seg" and not getattr(args, "multiview", False) else \
+            max(kern, key=lambda k: kern[k]["ms_per_launch"] * kern[k]["launches_per_view"])
         dom_ms = kern[dom]["ms_per_launch"]
         timing = "HIP events on the launch stream over %d extra untimed steps" % extra_steps
         if dom in prof_dom:              # the dominant forward kernel: measured over the timed region itself
             dom_ms = prof_dom[dom][1] / prof_dom[dom][0]
             kern[dom]["ms_per_launch"] = round(dom_ms, 4)
             timing = "HIP events on the launch stream: %s over the timed region, the other kernels over %d extra untimed steps" % (dom, extra_steps)
-        dom_key = "k_render_bwd_dense" if (dom == "k_render_bwd" and args.step == "rgb") else dom
-        launches = max(1, round(kern[dom]["launches_per_view"]))
+        dom_key = "k_render_bwd_dense" if (dom == "k_render_bwd" and args.step in ("rgb", "plain")) else dom
+        launches = max(1, (F + 31) // 32) if dom_key in ("k_render_fwd", "k_render_bwd_dense") else 1
         dom_bytes = bm.get(dom_key, 0) / launches
         gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic, tsrc = None, None
@@ -297,7 +310,9 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
                 traffic = None
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
+                "traffic_over_algorithmic_bytes": (round(traffic / dom_bytes, 3) if (traffic and dom_bytes) else None),
                 "avg_launch_ms": round(dom_ms, 4), "launches_per_view": launches,
+                "launches_per_step": kern[dom]["launches_per_view"],
                 "hbm": {"bytes": int(dom_bytes), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 5),
                         "frac_of_measured_copy_peak_6290": round(gbs / 6290.0, 5)},
                 "note": "the blend kernels are VALU / LDS issue-bound, not HBM-bound (SURVEY 8d): see `valu`",
@@ -331,14 +346,18 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--step", default=None, choices=[None, "seg", "rgb"],
-                    help="seg: train_semantic.py step (needs a feature channel: C3, C5); rgb: train.py step (C1, C2, C3)")
+    ap.add_argument("--step", default=None, choices=[None, "seg", "rgb", "plain"],
+                    help="seg: train_semantic.py step (needs a feature channel: C3, C5); rgb: train.py step (C1, C2, C3); "
+                         "plain (sub-records): the reference's train_semantic.py iteration on the drop-in functions alone")
     ap.add_argument("--mode", default=os.environ.get("ISR_MODE", "fast"), choices=["fast", "exact", "fast_tight"])
     ap.add_argument("--submodes", default="exact,fast_tight,fast+feature_only",
                     help="at one GPU: further modes timed the same way and reported as sub_records ('' = none)")
+    ap.add_argument("--more", type=int, default=1,
+                    help="1 (default, C3 seg at one GPU): also time the other BASELINE configs (C2 rgb, C5 seg), the step with the "
+                         "multi-view leg, a 500-step block and the plain drop-in loop, as sub_records")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tracer", type=int, default=1, help="produce gau_related_pixels each forward like the reference")
     ap.add_argument("--async-binning", type=int, default=1,
@@ -396,23 +415,67 @@ def main():
 
     head = run(args, args.mode, rank, world, dev, detail=True)
     subs = {}
+
+    def sub(name, mode=None, repeats=1, note=None, **over):
+        """One more measurement under the same clock, reported as sub_records[name]: same timing rules (warm-up, then a
+        block of steps between synchronisations), its own dominant kernel / roofline fraction / instance count."""
+        a = argparse.Namespace(**vars(args))
+        for k, v in over.items():
+            setattr(a, k, v)
+        try:
+            r = run(a, mode or a.mode, rank, world, dev, detail=True, repeats=repeats)
+        except Exception as e:       # the headline must still be printed
+            subs[name] = {"error": repr(e)}
+            import torch
+            torch.cuda.empty_cache()
+            return
+        roof = r.pop("roofline", None) or {}
+        cfg_ = r.pop("cfg", None) or {}
+        r["workload"] = "%s %s step: P=%s, %sx%s, F=%s" % (a.config, a.step, cfg_.get("P"), cfg_.get("W"), cfg_.get("H"),
+                                                           roof.get("workload", {}).get("F"))
+        r["dominant_kernel"] = roof.get("kernel")
+        r["dominant_kernel_ms"] = roof.get("avg_launch_ms")
+        r["dominant_kernel_launches_per_step"] = roof.get("launches_per_step")
+        r["dominant_kernel_frac_hbm"] = roof.get("frac")
+        if "valu" in roof:
+            r["dominant_kernel_frac_valu"] = roof["valu"].get("frac")
+        r["R"] = roof.get("workload", {}).get("R")
+        r["V"] = roof.get("workload", {}).get("V")
+        r["kernels_ms_x_launches_per_step"] = {k: [v["ms_per_launch"], v["launches_per_view"]] for k, v in roof.get("kernels", {}).items()}
+        if repeats > 1:
+            r["timing"] = "the faster of %d consecutive blocks of %d steps" % (repeats, a.steps)
+        if note:
+            r["note"] = note
+        subs[name] = r
+
     if world == 1:
+        parity = {"exact": "radii / tiles_touched / point_list / ranges / n_contrib / images bit-identical to the CPU oracle",
+                  "fast_tight": "tile lists are order-preserving subsequences of the reference's; images 1e-4",
+                  "fast": "binning bit-identical; images 1e-4",
+                  "fast+feature_only": "opt-in pipe.feature_only_forward (NOT the reference's behaviour: render() returns no colour / "
+                                       "depth / normal maps and no tracer list); feature map, binning and the step's parameters "
+                                       "bit-identical to `fast`"}
         for m in [m for m in args.submodes.split(",") if m and m != args.mode]:
             if m.endswith("+feature_only") and args.step != "seg":
                 continue
-            r = run(args, m, rank, world, dev, detail=True, repeats=2)
-            r["timing"] = "the faster of two consecutive blocks of %d steps (a process sees one ~40 ms runtime stall somewhere in its first few hundred steps)" % args.steps
-            roof = r.pop("roofline", None) or {}
-            r.pop("cfg", None)
-            r["dominant_kernel_ms"] = roof.get("avg_launch_ms")
-            r["R"] = roof.get("workload", {}).get("R")
-            r["parity"] = {"exact": "radii / tiles_touched / point_list / ranges / n_contrib / images bit-identical to the CPU oracle",
-                           "fast_tight": "tile lists are order-preserving subsequences of the reference's; images 1e-4",
-                           "fast": "binning bit-identical; images 1e-4",
-                           "fast+feature_only": "opt-in pipe.feature_only_forward (NOT the reference's behaviour: render() returns no colour / "
-                                                "depth / normal maps and no tracer list); feature map, binning and the step's parameters "
-                                                "bit-identical to `fast`"}[m]
-            subs[m] = r
+            sub(m, mode=m, repeats=2, note=parity.get(m))
+        if args.more and args.config == "C3" and args.step == "seg":
+            # the other BASELINE configurations and the other loops, in the same process under the same clock
+            sub("soak_500", steps=500, warmup=5, note="the headline configuration, one block of 500 steps")
+            sub("C3_multiview", steps=40, warmup=10, multiview=True,
+                note="the reference's default step: the multi-view leg (5 more views rendered with gradients through the dense "
+                     "[F,H,W] feature map, train_semantic.py:143-172, lambda_multiview_contras = 1e-6) every 10th iteration; "
+                     "40 steps = 4 such iterations, ms_per_step is their mean")
+            sub("C2_rgb", config="C2", step="rgb", steps=200, warmup=10, note="BASELINE config 2: the train.py step")
+            sub("C3_rgb", config="C3", step="rgb", steps=50, warmup=5, note="the train.py step at C3 size")
+            sub("C5_seg", config="C5", step="seg", steps=50, warmup=5, note="BASELINE config 5 in its 1-GPU form (F = 64: two feature passes)")
+            plain_note = ("harness.PlainSegTrainer: the reference's iteration as the reference writes it (train_semantic.py:95-208) on "
+                          "render() and contrastive_loss() alone, library defaults (blocking instance-count read, tracer on), "
+                          "multi-view leg every 10th iteration, torch.optim.Adam; 30 steps = 3 multi-view iterations")
+            sub("dropin_plain_fast", mode="fast", step="plain", steps=30, warmup=10, note=plain_note + "; the drop-in's default mode")
+            sub("dropin_plain_exact", mode="exact", step="plain", steps=30, warmup=10, note=plain_note + "; ISR_MODE=exact")
+            sub("dropin_plain_fast_empty_cache", mode="fast", step="plain", steps=30, warmup=10, empty_cache=True,
+                note=plain_note + "; plus torch.cuda.empty_cache() every iteration like the reference (:206)")
 
     if rank == 0:
         cfg = head.pop("cfg")
@@ -453,9 +516,10 @@ def main():
                                               "replicated: row-range pipelined all-reduce, Adam on every rank") if world > 1 else "n/a (one rank)",
                           "step_loop_stream": "the trainer's own high-priority HIP stream for the whole block of steps (SegTrainer.stream_scope); "
                                               "the next view's geometry pass + binning on one side stream",
-                          "view_order": "deterministic round-robin over 16 ring cameras (the reference pops a random view, "
-                                        "train_semantic.py:100): the next view is known, so its geometry pass + binning are issued "
-                                        "on a side stream during the current step",
+                          "view_order": "a seeded random permutation of the 16 ring cameras per epoch (dist_utils.view_order) = the "
+                                        "reference's random pop from a refilled stack (train_semantic.py:96-100) with the draws made up "
+                                        "front: the next view is known one step early, so its geometry pass + binning are issued on a "
+                                        "side stream during the current step",
                           "hoisted_out_of_the_timed_region": (
                               ["activations of the frozen parameters (exp / sigmoid / normalize, SH concat): evaluated once",
                                "per-view pools of labelled pixels and of visible labelled Gaussians, the cameras' ray tables, each "

@@ -15,8 +15,33 @@ import torch
 import torch.distributed as dist
 
 
-def view_for(step: int, rank: int, world: int, n_views: int) -> int:
-    return (step * world + rank) % n_views
+_EPOCHS = {}
+
+
+def view_order(n_views: int, epoch: int, seed: int = 0):
+    """The order in which epoch ``epoch`` visits the ``n_views`` training views: a seeded random permutation.  The reference
+    pops a random view from a stack that it refills when empty (train_semantic.py:96-100, train.py:66-69), i.e. every view
+    exactly once per epoch in random order; a permutation drawn per epoch is that process with the draws made up front, so
+    the NEXT view is known one step early (its geometry pass is prefetched) and every rank of a data-parallel job can
+    compute the whole schedule without communication."""
+    key = (n_views, epoch, seed)
+    order = _EPOCHS.get(key)
+    if order is None:
+        import numpy as np
+        if len(_EPOCHS) > 64:
+            _EPOCHS.clear()
+        order = _EPOCHS[key] = np.random.RandomState((seed * 1000003 + 7919 * epoch + 12345) & 0x7FFFFFFF).permutation(n_views).tolist()
+    return order
+
+
+def view_for(step: int, rank: int, world: int, n_views: int, seed: int = 0, shuffle: bool = True) -> int:
+    """View of rank ``rank`` at iteration ``step``: the ranks take consecutive entries of the epoch's random order
+    (:func:`view_order`), so one step of a W-rank job covers W distinct views and an epoch covers every view once.
+    ``shuffle=False``: plain round-robin."""
+    g = step * world + rank
+    if not shuffle:
+        return g % n_views
+    return view_order(n_views, g // n_views, seed)[g % n_views]
 
 
 def allreduce_grads(params: Iterable[torch.nn.Parameter], world: int) -> None:

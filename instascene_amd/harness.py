@@ -199,6 +199,7 @@ class SegTrainer:
             raise ValueError("fused_tail needs fused_update and sampled_path")
         if self.fused_tail:
             self.opt.store_y = False         # the step reads normalize(param) only through gather_rows (3-D loss)
+        self.view_seed = seed
         self.gen = torch.Generator(device=self.device).manual_seed(1000 + seed * 131 + rank)
         self.sample_seed = 1000 + seed * 131 + rank
         # all of a step's index sampling in one kernel (iso_sample_step; its own counter-based generator, so the samples
@@ -307,7 +308,8 @@ class SegTrainer:
         return contrastive_loss(feats, labels, predef_u_list=predef, num_labels=self.n_labels + 1) * (self.lsv * weight)
 
     def view_index(self, it):
-        return view_for(it, self.rank, self.world, len(self.cams))
+        # a random permutation of the views per epoch (the reference's random pop, train_semantic.py:96-100), known ahead
+        return view_for(it, self.rank, self.world, len(self.cams), seed=self.view_seed)
 
     def step(self, it: int):
         if self.high_priority_main and self.device.type == "cuda":
@@ -553,6 +555,106 @@ class SegTrainer:
         prefetch(self.cams[self.view_index(it + 1)], self.model, self.pipe, self.bg, stream=self._side)
 
 
+class PlainSegModel:
+    """``GaussianModel`` as ``train_semantic.py`` sees it, getter for getter (scene/gaussian_model.py:109-138): every
+    activation is re-evaluated on every call, nothing is cached."""
+
+    def __init__(self, scene: scenes.Scene, device, class_feat=None):
+        s = scene.to(device)
+        self._xyz, self._scaling, self._rotation, self._opacity = s.xyz, s.log_scale, s.rot, s.opacity_logit
+        self._features_dc, self._features_rest = s.features_dc, s.features_rest
+        self._seg_feature = nn.Parameter(s.seg_feature.clone().requires_grad_(True))
+        self.active_sh_degree = self.max_sh_degree = 3
+        self.class_feat = class_feat
+
+    get_xyz = property(lambda s: s._xyz)
+    get_scaling = property(lambda s: torch.exp(s._scaling))
+    get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation))
+    get_opacity = property(lambda s: torch.sigmoid(s._opacity))
+    get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
+    get_seg_feature = property(lambda s: s._seg_feature / (s._seg_feature.norm(dim=1, keepdim=True) + 1e-6))
+
+    def get_covariance(self, scaling_modifier=1):
+        return splat_to_world(self.get_xyz, self.get_scaling, scaling_modifier, self._rotation)
+
+
+class PlainSegTrainer:
+    """What a maintainer gets who installs the drop-in and runs ``train_semantic.py`` UNMODIFIED: the reference's iteration
+    (train_semantic.py:95-208) written the way the reference writes it, on top of nothing but the two drop-in functions -
+    ``render()`` and ``contrastive_loss()`` in their reference call forms.  No extension of :class:`SegTrainer` is used: a
+    random view popped from a stack; the model's getters re-evaluated per call; boolean-mask gathers of the dense feature
+    map (``seg_feature[:, mask][:, idx]``, the ``[F, Nv]`` temporary and its host sync); three separate losses; the dense
+    zero-filled ``[F,H,W]`` gradient through the blend backward; ``torch.optim.Adam`` on ``[P,F]``; the multi-view leg
+    every 10th iteration (``lambda_multiview_contras`` > 0 by default, arguments/__init__.py:114).  ``empty_cache``: also
+    call ``torch.cuda.empty_cache()`` every iteration like the reference (:206).  bench.py times it as ``dropin_plain``."""
+
+    def __init__(self, scene, cameras, device="cuda", sample_batchsize=8192, n_labels=64, lambda_sv=1e-6, lambda_mv=1e-6,
+                 lambda_3d=2.5e-6, sample_mv_frames=5, use_class_feat=True, seed=0, empty_cache=False):
+        import random
+        self.device = torch.device(device)
+        F = scene.seg_feature.shape[1]
+        class_feat = None
+        if use_class_feat:
+            g = torch.Generator().manual_seed(seed + 17)
+            class_feat = gram_schmidt(torch.rand(n_labels + 1, F, generator=g)).to(self.device)
+        self.model = PlainSegModel(scene, self.device, class_feat)
+        self.labels3d = scene.labels3d.to(self.device)
+        self.cams = [c.to(self.device) for c in cameras]
+        for i, c in enumerate(self.cams):
+            if c.segmap is None:
+                c.segmap = scenes.voronoi_labels(c.image_width, c.image_height, n_labels, 5000 + i, device=self.device)
+                c.sorted_segmap = c.segmap
+        self.pipe = PipelineParams()
+        self.bg = torch.zeros(3, dtype=torch.float32, device=self.device)
+        self.batch, self.lsv, self.lmv, self.l3d, self.mv_frames = sample_batchsize, lambda_sv, lambda_mv, lambda_3d, sample_mv_frames
+        self.opt = torch.optim.Adam([{"params": [self.model._seg_feature], "lr": 0.025, "name": "seg_feature"}], lr=0.0, eps=1e-15)
+        self.rng = random.Random(seed)
+        self.stack = None
+        self.empty_cache = bool(empty_cache)
+        self.last_view = None
+
+    def step(self, iteration: int):
+        m, dev = self.model, self.device
+        if not self.stack:
+            self.stack = list(range(len(self.cams)))
+        vi = self.stack.pop(self.rng.randint(0, len(self.stack) - 1))
+        self.last_view = vi
+        cam = self.cams[vi]
+        pkg = render(cam, m, self.pipe, self.bg)
+        seg_feature, visibility_filter = pkg["seg_feature"], pkg["visibility_filter"]
+        loss = 0
+        segmaps = [cam.segmap, cam.sorted_segmap] if m.class_feat is not None else [cam.segmap]
+        for k, gt in enumerate(segmaps):
+            valid = gt > 0
+            if valid.sum() > 0:
+                feats, labels = seg_feature[:, valid], gt[valid]
+                idx = torch.randint(0, len(labels), size=(self.batch,), device=dev)
+                loss = loss + contrastive_loss(feats[:, idx].T, labels[idx], predef_u_list=m.class_feat if k == 1 else None) \
+                    * self.lsv * (1 if k == 1 else 0.5)
+        if self.lmv > 0 and iteration % 10 == 0:
+            first = self.rng.randint(0, len(self.cams) - self.mv_frames - 1)
+            views = self.cams[first:first + self.mv_frames]
+            maps = torch.stack([render(v, m, self.pipe, self.bg)["seg_feature"] for v in views], dim=0)
+            labs = torch.stack([v.sorted_segmap for v in views], dim=0)
+            valid = labs > 0
+            feats, labels = maps.permute(1, 0, 2, 3)[:, valid], labs[valid]
+            idx = torch.randint(0, len(labels), size=(self.batch,), device=dev)
+            loss = loss + contrastive_loss(feats[:, idx].T, labels[idx], predef_u_list=m.class_feat) * self.lmv
+        vis_feat, vis_lab = m.get_seg_feature[visibility_filter], self.labels3d[visibility_filter]
+        if self.l3d > 0:
+            valid = vis_lab > 0
+            if valid.sum() > 0:
+                feats, labels = vis_feat[valid], vis_lab[valid]
+                idx = torch.randint(0, len(labels), size=(self.batch,), device=dev)
+                loss = loss + contrastive_loss(feats[idx], labels[idx], predef_u_list=m.class_feat) * self.l3d
+        loss.backward()
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        if self.empty_cache:
+            torch.cuda.empty_cache()
+        return loss.detach()
+
+
 class RgbGaussianModel:
     """Trainable 2DGS model for the ``train.py``-style step (scene/gaussian_model.py:109-138,206-253): six
     parameter groups with the reference's learning rates; densification is out of scope."""
@@ -664,6 +766,9 @@ class RgbTrainer:
         normal_error = (1 - (pkg["rend_normal"] * pkg["surf_normal"]).sum(dim=0))[None]
         return loss + self.ln * normal_error.mean()
 
+    def view_index(self, it):
+        return view_for(it, self.rank, self.world, len(self.cams))
+
     def step(self, it: int):
         from .rasterizer import BinningOverflow
         try:
@@ -675,7 +780,7 @@ class RgbTrainer:
             return self._step_once(it)
 
     def _step_once(self, it: int):
-        vi = view_for(it, self.rank, self.world, len(self.cams))
+        vi = self.view_index(it)
         if self.fused_update:
             self.model._leaves = self.opt.begin()
             try:

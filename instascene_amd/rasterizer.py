@@ -23,12 +23,14 @@ import torch.nn as nn
 from . import _lib
 from ._lib import GRAD_EXTRA, GRAD_GEOMETRY, MODE_EXACT, MODE_FAST, MODE_FEATURE_ONLY, MODE_PREBINNED, check, lib
 
-_ENV_MODE = os.environ.get("ISR_MODE", "exact").lower()
+_ENV_MODE = os.environ.get("ISR_MODE", "fast").lower()
 _CONFIG = {
-    # arithmetic mode of the per-pixel loops: "exact" (bit-identical to the CPU oracle) or "fast" (contracted FMAs,
-    # v_rcp / v_exp).  Both keep the reference's tile rectangles, so radii, tiles_touched, point_list and ranges are
-    # bit-identical to the reference's in either mode.
-    "mode": MODE_FAST if _ENV_MODE in ("fast", "fast_tight") else MODE_EXACT,
+    # arithmetic mode of the per-pixel loops: "fast" (the default: contracted FMAs, v_rcp / v_exp - what the reference's own
+    # nvcc build does with -use_fast_math-style contraction; images within 1e-4, gradients within 1e-3 of the two-rounding CPU
+    # oracle, forward and backward taking identical per-pixel decisions, csrc/isr_fast_pair.hpp) or "exact" (ISR_MODE=exact:
+    # op-for-op IEEE, bit-identical to the CPU oracle, 1.9x slower blend).  Both keep the reference's tile rectangles, so
+    # radii, tiles_touched, point_list and ranges are bit-identical to the reference's in either mode.
+    "mode": MODE_EXACT if _ENV_MODE == "exact" else MODE_FAST,
     # opt-in on top of "fast" (mode name "fast_tight", or ISR_TIGHT_RECTS=1): bin a splat only into the tiles its
     # alpha >= 1/255 bound reaches (ISR_PREPARE_TIGHT_RECTS).  Tile lists are then order-preserving SUBSEQUENCES of the
     # reference's - same images, but not the reference's point_list / ranges.

@@ -64,9 +64,12 @@ def test_two_rank_gradient_allreduce_equals_sum_of_view_gradients(tmp_path, over
     r0 = torch.load(tmp_path / "r0.pt")
     r1 = torch.load(tmp_path / "r1.pt")
     assert torch.equal(r0["p"], r1["p"])
-    # every step covers `world` distinct consecutive views
-    assert r0["seen"] == [(i * 2) % n_views for i in range(steps)]
-    assert r1["seen"] == [(i * 2 + 1) % n_views for i in range(steps)]
+    # the ranks take consecutive entries of each epoch's random order (dist_utils.view_order)
+    from instascene_amd.dist_utils import view_order
+    seq = [view_order(n_views, g // n_views)[g % n_views] for g in range(steps * world)]
+    assert r0["seen"] == seq[0::2] and r1["seen"] == seq[1::2]
+    assert sorted(view_order(n_views, 0)) == list(range(n_views)) and view_order(n_views, 0) != view_order(n_views, 1)
+    assert r0["seen"] != [(i * 2) % n_views for i in range(steps)]          # not the round-robin of earlier rounds
     # single-process reference: accumulate the same views' gradients, same optimiser
     p = torch.nn.Parameter(torch.linspace(-1, 1, 64 * 8).reshape(64, 8).clone())
     opt = torch.optim.Adam([p], lr=0.025, eps=1e-15)
