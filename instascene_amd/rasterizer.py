@@ -242,6 +242,28 @@ def _round_capacity(r: int) -> int:
     return (r + g - 1) // g * g
 
 
+_CLASSES = [4096]
+
+
+def _size_class(n: int) -> int:
+    """The smallest member >= n of a geometric sequence of sizes (x 1.25 per step).  Workspaces whose size follows a
+    quantity that DRIFTS - the tile-instance count of a view while the geometry trains, the number of Gaussians under
+    density control - are allocated in these classes (the library is told the true count, the buffer is merely larger):
+    the caching allocator then sees a new size only every +25 %, i.e. a handful of times per training run, instead of a new
+    size at every step of the drift (round 2's 3 000-iteration train.py soak: reserved memory 1.29 -> 2.91 GB, 24 -> 30
+    device allocations, because every 3 % step of R was a size the allocator had never served)."""
+    n = int(n)
+    while _CLASSES[-1] < n:
+        _CLASSES.append((int(_CLASSES[-1] * 1.25) + 255) // 256 * 256)
+    import bisect
+    return _CLASSES[bisect.bisect_left(_CLASSES, n)]
+
+
+def _workspace(nbytes_of, count, dev):
+    """A byte workspace for ``count`` units, sized for the count's class (``nbytes_of(count_class)`` bytes)."""
+    return torch.empty(nbytes_of(_size_class(max(1, int(count)))), dtype=torch.uint8, device=dev)
+
+
 def _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
              transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img, tight=None):
     """K1 + tile scan (``isr_forward_prepare``) into ``radii / geom / img``; returns ``(R, is_capacity)``: the instance
@@ -330,13 +352,13 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
                     t.record_stream(side)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
-            geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
+            geom = _workspace(L.isr_geom_bytes, P, dev)
             img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
             st = _stream()
             R, _ = _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier,
                             rotations, transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered,
                             radii, geom, img)
-            binning = torch.empty(L.isr_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
+            binning = _workspace(lambda c: L.isr_binning_bytes(c, W, H), R, dev)
             check(L.isr_forward_bin(P, W, H, _ptr(geom), _ptr(binning), R, _ptr(img), st), "isr_forward_bin")
             if side is not None:
                 done = torch.cuda.Event()
@@ -439,12 +461,12 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
             PREFETCH_HITS += 1
         else:
             radii = torch.empty((P,), dtype=torch.int32, device=dev)      # K1 writes every entry
-            geom = torch.empty(L.isr_geom_bytes(P), dtype=torch.uint8, device=dev)
+            geom = _workspace(L.isr_geom_bytes, P, dev)
             img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
             R, sized_by_estimate = _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales,
                                             scale_modifier, rotations, transMat_precomp, viewmatrix, projmatrix, campos,
                                             tan_fovx, tan_fovy, prefiltered, radii, geom, img, tight=tight)
-            binning = torch.empty(L.isr_binning_bytes(R, W, H), dtype=torch.uint8, device=dev)
+            binning = _workspace(lambda c: L.isr_binning_bytes(c, W, H), R, dev)
         if tracer:
             grp = torch.empty((H * W * 10, 2), dtype=torch.int32, device=dev)
             gcount = torch.empty((1,), dtype=torch.int32, device=dev)
@@ -525,8 +547,8 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, 
     if P == 0 or grad_mask == 0:
         return g2, gc, go, g3, gt, gsh, gs, gr, (ge if F else torch.empty(0, device=dev))
     _verify_pending(geomBuffer.data_ptr())
-    nbytes = L.isr_backward_scratch_bytes(int(R), F, grad_mask)
-    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    scratch = _workspace(lambda c: L.isr_backward_scratch_bytes(c, F, grad_mask), R, dev)
+    nbytes = scratch.numel()
     with torch.cuda.device(dev):
         check(L.isr_backward(P, int(degree), M, int(R), F, W, H, int(mode), grad_mask, _ptr(bg), _ptr(means3D), _ptr(sh),
                              _ptr(colors), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(transMat_precomp),
@@ -600,8 +622,8 @@ def rasterize_gaussians_backward_sampled(P, F, W, H, R, pixels, dL_dsampled, tra
         out = None
     else:
         out = accumulate_into if accumulate_into is not None else torch.empty((P, F), dtype=torch.float32, device=dev)
-    nbytes = L.isr_backward_sampled_scratch_bytes(int(R), F, n, W, H)
-    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    scratch = _workspace(lambda c: L.isr_backward_sampled_scratch_bytes(c, F, n, W, H), R, dev)
+    nbytes = scratch.numel()
     with torch.cuda.device(dev):
         check(L.isr_backward_sampled(P, int(R), F, W, H, int(mode), n, _ptr(pix), _ptr(g), _ptr(_f32c(transMat_precomp, "transMat_precomp")),
                                      _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(out),

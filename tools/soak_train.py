@@ -15,6 +15,7 @@ ap.add_argument("--step", default=None)
 ap.add_argument("--blocks", type=int, default=6)
 ap.add_argument("--block", type=int, default=500)
 ap.add_argument("--scale", type=float, default=1.0)
+ap.add_argument("--densify", type=int, default=0, help="rgb step: 1 = density control on (clone / split / prune every 100 iterations)")
 a = ap.parse_args()
 rasterizer.set_mode("fast"); rasterizer.set_tracer(True); rasterizer.set_async_binning(True)
 scene, cams, cfg = scenes.config_scene(a.config, a.scale)
@@ -23,7 +24,8 @@ dev = torch.device("cuda")
 if step == "rgb":
     scene.seg_feature = None
     H, W = cams[0].image_height, cams[0].image_width
-    tr = RgbTrainer(scene, cams[:16], [torch.zeros(3, H, W)] * 16, device="cuda")
+    dens = dict(from_iter=100, until_iter=10 ** 6, interval=100, opacity_reset_interval=3000, grad_threshold=0.00002) if a.densify else None
+    tr = RgbTrainer(scene, cams[:16], [torch.zeros(3, H, W)] * 16, device="cuda", densify=dens)
     g = torch.Generator(device=dev).manual_seed(5)
     with torch.no_grad():
         tr.targets = [(render(c, tr.model, tr.pipe, tr.bg)["render"].detach() + 0.05 * torch.randn(3, H, W, device=dev, generator=g)).clamp(0, 1)
@@ -44,8 +46,8 @@ for blk in range(a.blocks):
         loss = run(it); it += 1
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.block * 1e3
-    print("iterations %6d: %.3f ms/step  loss %.4f  tile instances (last view) %d  reserved %.2f GB  allocator growth %d" % (
-        it, dt, float(loss.detach()), rasterizer.LAST_NUM_RENDERED, torch.cuda.memory_reserved() / 2 ** 30,
+    print("iterations %6d: %.3f ms/step  loss %.4f  P %d  tile instances (last view) %d  reserved %.2f GB  allocator growth %d" % (
+        it, dt, float(loss.detach()), tr.model._xyz.shape[0], rasterizer.LAST_NUM_RENDERED, torch.cuda.memory_reserved() / 2 ** 30,
         torch.cuda.memory_stats().get("num_device_alloc", 0)), flush=True)
 if step == "rgb":
     with torch.no_grad():
