@@ -1098,47 +1098,6 @@ __global__ __launch_bounds__(256) void k_sample_fill(int n, int W, int H, int gx
     r[1] = (uint32_t)((qx % TILE) | ((qy % TILE) << 8));
     r[2] = n_contrib[q];
 }
-// The three kernels above as ONE launch when the per-tile counters fit the LDS of one workgroup (T <= SEG_FUSED_TILES: any
-// image up to 2048 x 2048): count with LDS atomics, scan the tiles in LDS, hand out positions with LDS cursors.  The work is
-// tiny (16 k samples, 8 k tiles) - three dependent launches of 5 + 33 + 6 us were launch latency and a single-wave-wide scan.
-constexpr int SEG_FUSED_TILES = 16384;
-__global__ __launch_bounds__(1024) void k_sample_segment(int n, int W, int H, int gx, int T, const long long* __restrict__ pix,
-                                                         const uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ off,
-                                                         uint32_t* __restrict__ seg_rec) {
-    extern __shared__ uint32_t s_seg[];          // [T] counters, then cursors; [T] offsets
-    __shared__ uint32_t s_warp[32];
-    uint32_t* s_cnt = s_seg;
-    uint32_t* s_off = s_seg + T;
-    const long long N = (long long)W * H;
-    for (int t = threadIdx.x; t < T; t += 1024) s_cnt[t] = 0u;
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const long long q = pix[i];
-        if (q >= 0 && q < N) atomicAdd(&s_cnt[((int)(q / W) / TILE) * gx + ((int)(q % W) / TILE)], 1u);
-    }
-    __syncthreads();
-    uint32_t carry = 0;
-    for (int base = 0; base < T; base += 1024) {
-        const int t = base + threadIdx.x;
-        const uint32_t v = t < T ? s_cnt[t] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan_1024(v, s_warp, total);
-        if (t < T) { s_off[t] = carry + ex; off[t] = carry + ex; s_cnt[t] = 0u; }
-        carry += total;
-    }
-    if (threadIdx.x == 0) off[T] = carry;
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const long long q = pix[i];
-        if (q < 0 || q >= N) continue;
-        const int qx = (int)(q % W), qy = (int)(q / W);
-        const int t = (qy / TILE) * gx + (qx / TILE);
-        uint32_t* r = seg_rec + 3 * (size_t)(s_off[t] + atomicAdd(&s_cnt[t], 1u));
-        r[0] = (uint32_t)i;
-        r[1] = (uint32_t)((qx % TILE) | ((qy % TILE) << 8));
-        r[2] = n_contrib[q];
-    }
-}
 // out[i, :] = map[:, pix[i]]  (the forward half of the sampled path)
 __global__ __launch_bounds__(256) void k_sample_gather(int n, int F, long long N, const float* __restrict__ map,
                                                        const long long* __restrict__ pix, float* __restrict__ out) {
@@ -1836,27 +1795,15 @@ static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int
     unsigned long long* row_mask = dL_dextra == nullptr ? g.row_mask : nullptr;
     if (row_mask != nullptr && hipMemsetAsync(row_mask, 0, sizeof(unsigned long long) * (size_t)P, s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }
     if (R > 0 && n > 0) {
-        static const bool fused_seg = [] { const char* e = getenv("ISR_FUSED_SEGMENT"); return !(e && e[0] == '0'); }();
-        const bool one_launch = fused_seg && T <= SEG_FUSED_TILES;
-        // row flags and (three-launch form) the per-tile sample counters are neighbours in the scratch: one fill for both
-        if (hipMemsetAsync(flags, 0, one_launch ? align_up((size_t)R * npass, 256) : (size_t)((char*)(cnt + T) - (char*)flags), s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }
+        // row flags and the per-tile sample counters are neighbours in the scratch: one fill for both
+        if (hipMemsetAsync(flags, 0, (size_t)((char*)(cnt + T) - (char*)flags), s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }
         ProfScope ps_("k_render_bwd", s);
-        if (one_launch) {
-            static const bool attr_ok = [] {
-                return hipFuncSetAttribute(reinterpret_cast<const void*>(k_sample_segment), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           2 * SEG_FUSED_TILES * (int)sizeof(uint32_t)) == hipSuccess;
-            }();
-            if (!attr_ok) { fail(ISR_EHIP, "k_sample_segment: cannot reserve its LDS"); return -2; }
-            hipLaunchKernelGGL(k_sample_segment, dim3(1), dim3(1024), 2 * (size_t)T * sizeof(uint32_t), s, n, W, H, gx, T, pix, iv.n_contrib, off, seg_idx);
-            ISR_CHECK_LAUNCH_B("k_sample_segment");
-        } else {
-            hipLaunchKernelGGL(k_sample_count, dim3((n + 255) / 256), dim3(256), 0, s, n, W, H, gx, pix, cnt);
-            ISR_CHECK_LAUNCH_B("k_sample_count");
-            hipLaunchKernelGGL(k_sample_scan, dim3(1), dim3(1024), 0, s, T, cnt, off, cursor);
-            ISR_CHECK_LAUNCH_B("k_sample_scan");
-            hipLaunchKernelGGL(k_sample_fill, dim3((n + 255) / 256), dim3(256), 0, s, n, W, H, gx, pix, off, cursor, iv.n_contrib, seg_idx);
-            ISR_CHECK_LAUNCH_B("k_sample_fill");
-        }
+        hipLaunchKernelGGL(k_sample_count, dim3((n + 255) / 256), dim3(256), 0, s, n, W, H, gx, pix, cnt);
+        ISR_CHECK_LAUNCH_B("k_sample_count");
+        hipLaunchKernelGGL(k_sample_scan, dim3(1), dim3(1024), 0, s, T, cnt, off, cursor);
+        ISR_CHECK_LAUNCH_B("k_sample_scan");
+        hipLaunchKernelGGL(k_sample_fill, dim3((n + 255) / 256), dim3(256), 0, s, n, W, H, gx, pix, off, cursor, iv.n_contrib, seg_idx);
+        ISR_CHECK_LAUNCH_B("k_sample_fill");
         for (int pass = 0, ch = 0; ch < ED; pass++, ch += 32)
             hipLaunchKernelGGL((k_render_bwd_sparse<Math, true>), dim3(T), dim3(64), 0, s, W, H, ED, ch, gx, iv.tile_offset,
                                bv.point_list, bv.box4, g.rec, tm_pre, (const float*)nullptr, g.point_offsets, g.rect, partial,

@@ -178,9 +178,6 @@ class SegTrainer:
         self.labels3d = scene.labels3d.to(self.device).to(torch.int64).contiguous()     # iso_sample_step reads int64
         self.cams = [c.to(self.device) for c in cameras]
         self.pipe = PipelineParams()
-        # render()'s seven derived maps are evaluated inside render() like the reference, on the side stream (this loop reads
-        # none of them): render.RenderPackage._join_side
-        self.pipe.post_on_side_stream = self.device.type == "cuda" and _os.environ.get("ISR_POST_SIDE", "1") == "1"
         self.bg = torch.zeros(3, dtype=torch.float32, device=self.device)
         self.batch = sample_batchsize
         self.lsv, self.lmv, self.l3d = lambda_sv, lambda_mv, lambda_3d

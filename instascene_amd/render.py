@@ -30,17 +30,6 @@ class RenderPackage(dict):
       (``train_semantic`` never reads them).  Default: inside ``render()`` like the reference."""
 
     _pending = None
-    _side_done = None        # (event, tensors): the derived maps were computed on the side stream (pipe.post_on_side_stream)
-
-    def _join_side(self):
-        job = self._side_done
-        if job is not None:
-            self._side_done = None
-            ev, tensors = job
-            cur = torch.cuda.current_stream(tensors[0].device)
-            cur.wait_event(ev)
-            for t in tensors:
-                t.record_stream(cur)
 
     def _materialize(self):
         job = self._pending
@@ -53,8 +42,6 @@ class RenderPackage(dict):
     def __getitem__(self, k):
         if self._pending is not None and k in _LAZY_KEYS:
             self._materialize()
-        if self._side_done is not None and k in _LAZY_KEYS:
-            self._join_side()
         v = dict.__getitem__(self, k)
         if v is None and k == "visibility_filter":
             # `radii > 0` (reference :110) on first access: the same values, one elementwise kernel over P Gaussians that a
@@ -71,7 +58,6 @@ class RenderPackage(dict):
 
     def __iter__(self):          # also routes dict(pkg) / {**pkg} through __getitem__
         self._materialize()
-        self._join_side()
         if dict.get(self, "visibility_filter", 0) is None:
             self["visibility_filter"]
         return dict.__iter__(self)
@@ -285,24 +271,6 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if getattr(pipe, "lazy_maps", False) or os.environ.get("ISR_LAZY_MAPS", "0") == "1":
         dict.update(rets, dict.fromkeys(_LAZY_KEYS))
         rets._pending = (viewpoint_camera, allmap, pipe.depth_ratio, torch.is_grad_enabled())
-    elif getattr(pipe, "post_on_side_stream", False) and allmap.is_cuda and not (torch.is_grad_enabled() and allmap.requires_grad):
-        # Opt-in (a trainer that does not read the derived maps right away, e.g. SegTrainer): the two post-processing kernels
-        # are computed NOW, as in the reference, but on the process's side stream behind this forward, so that they run beside
-        # the step's small loss kernels instead of in front of them; the first access of any of the seven entries makes the
-        # reader's stream wait for them (RenderPackage._join_side).  Same values, same moment of evaluation.
-        from .streams import side_stream
-        dev = allmap.device
-        cur, side = torch.cuda.current_stream(dev), side_stream(dev)
-        fwd_done = torch.cuda.Event()
-        fwd_done.record(cur)
-        side.wait_event(fwd_done)
-        allmap.record_stream(side)
-        with torch.cuda.stream(side):
-            maps = post_process(viewpoint_camera, allmap, pipe.depth_ratio)
-            done = torch.cuda.Event()
-            done.record(side)
-        dict.update(rets, maps)
-        rets._side_done = (done, tuple(maps.values()))
     else:
         rets.update(post_process(viewpoint_camera, allmap, pipe.depth_ratio))
     return rets

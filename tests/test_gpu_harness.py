@@ -417,40 +417,3 @@ def test_rgb_trainer_fused_loss_equals_the_composed_loss():
     assert (xa - xb).abs().max().item() <= 0.02 * 0.00016 * 6
     assert (sa - sb).abs().max().item() <= 0.02 * 0.005 * 6
     rz.set_tracer(True)
-
-
-def test_post_processing_on_the_side_stream_returns_the_same_maps():
-    """``pipe.post_on_side_stream`` (SegTrainer's default): render()'s seven derived maps are computed inside render() on the
-    side stream and joined on first access - bit-identical to the in-line evaluation, also when read immediately."""
-    sc, cams = _scene()
-    tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=1024, n_labels=12, seed=1)
-    assert tr.pipe.post_on_side_stream
-    plain = PipelineParams()
-    keys = ("rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal", "rend_depth", "rend_median_depth")
-    with torch.no_grad():
-        for cam in tr.cams[:3]:
-            a = render(cam, tr.model, tr.pipe, tr.bg)
-            b = render(cam, tr.model, plain, tr.bg)
-            assert a._side_done is not None and b._side_done is None
-            got = {k: a[k] for k in keys}                    # first access joins the side stream
-            assert a._side_done is None
-            for k in keys:
-                assert torch.equal(got[k], b[k]), k
-            c = render(cam, tr.model, tr.pipe, tr.bg)
-            assert set(dict(c)) == set(dict(b))              # dict(pkg) joins too
-    rz.set_mode("exact")
-
-
-def test_plain_loop_trainer_runs_the_reference_iteration():
-    """harness.PlainSegTrainer (bench.py's `dropin_plain`): the reference's iteration on render() + contrastive_loss() alone -
-    steps, trains, covers every view once per epoch in random order, multi-view leg at iteration 0 and 10."""
-    from instascene_amd.harness import PlainSegTrainer
-    sc, cams = _scene()
-    tr = PlainSegTrainer(sc, cams, device="cuda", sample_batchsize=1024, n_labels=12, sample_mv_frames=2, seed=2)
-    p0 = tr.model._seg_feature.detach().clone()
-    seen, losses = [], []
-    for it in range(12):
-        losses.append(float(tr.step(it)))
-        seen.append(tr.last_view)
-    assert all(np.isfinite(losses)) and not torch.equal(tr.model._seg_feature.detach(), p0)
-    assert sorted(seen[:6]) == list(range(6)) and sorted(seen[6:]) == list(range(6)) and seen[:6] != list(range(6))
