@@ -417,3 +417,18 @@ def test_rgb_trainer_fused_loss_equals_the_composed_loss():
     assert (xa - xb).abs().max().item() <= 0.02 * 0.00016 * 6
     assert (sa - sb).abs().max().item() <= 0.02 * 0.005 * 6
     rz.set_tracer(True)
+
+
+def test_plain_loop_trainer_runs_the_reference_iteration():
+    """harness.PlainSegTrainer (bench.py's `dropin_plain`): the reference's iteration on render() + contrastive_loss() alone -
+    steps, trains, covers every view once per epoch in random order, multi-view leg at iteration 0 and 10."""
+    from instascene_amd.harness import PlainSegTrainer
+    sc, cams = _scene()
+    tr = PlainSegTrainer(sc, cams, device="cuda", sample_batchsize=1024, n_labels=12, sample_mv_frames=2, seed=2)
+    p0 = tr.model._seg_feature.detach().clone()
+    seen, losses = [], []
+    for it in range(12):
+        losses.append(float(tr.step(it)))
+        seen.append(tr.last_view)
+    assert all(np.isfinite(losses)) and not torch.equal(tr.model._seg_feature.detach(), p0)
+    assert sorted(seen[:6]) == list(range(6)) and sorted(seen[6:]) == list(range(6)) and seen[:6] != list(range(6))
