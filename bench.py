@@ -338,6 +338,29 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
     if world > 1 and args.step == "seg":
         ms = time_allreduce(cfg["P"] * cfg["F"], dev, world)
         rec["allreduce_ms"] = None if ms is None else round(ms, 3)
+        if not getattr(trainer, "sharded_tail", False):
+            # per-phase device times of the multi-rank tail over a few extra (untimed) steps: how much of the collective the
+            # row-range pipeline hides
+            trainer.phase_timing = True
+            acc = []
+            for it in range(it0 + extra_steps, it0 + extra_steps + 5):
+                trainer.step(it)
+                if trainer.last_phases:
+                    acc.append(trainer.last_phases)
+            trainer.phase_timing = False
+            sync()
+            if acc:
+                mean = lambda k: round(sum(a[k] for a in acc) / len(acc), 4)
+                per = lambda k: [round(sum(a[k][i] for a in acc) / len(acc), 4) for i in range(len(acc[0][k]))]
+                exposed = mean("exposed_collective_ms")
+                rec["multi_rank_tail"] = {
+                    "tail_chunks": acc[0]["tail_chunks"], "tail_ms": mean("tail_ms"), "gradient_kernels_ms": mean("gradient_kernels_ms"),
+                    "exposed_collective_ms": exposed, "exposed_collective_ms_per_range": per("exposed_collective_ms_per_range"),
+                    "optimizer_kernels_ms_per_range": per("optimizer_kernels_ms_per_range"),
+                    "allreduce_alone_ms": rec["allreduce_ms"],
+                    "overlap_achieved": (None if not ms else round(max(0.0, 1.0 - exposed / ms), 4)),
+                    "note": "HIP events on the compute stream of rank 0, mean of 5 untimed steps; exposed = time the compute stream "
+                            "stood still waiting for a row range's all-reduce"}
     del trainer
     torch.cuda.empty_cache()
     return rec
@@ -509,6 +532,7 @@ def main():
                           "view_cache_gb": args.view_cache_gb,
                           "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
                           "allreduce_ms_per_step_alone": head.get("allreduce_ms"),
+                          "multi_rank_tail_phases": head.get("multi_rank_tail"),
                           "gaussian_order": "z-order of the centres, sorted once at load" if args.spatial_sort else "as generated (random)",
                           "derived_render_maps": "on first access (never read by the seg step)" if args.lazy_maps else "inside render(), like the reference",
                           "multi_rank_tail": ("sharded: reduce-scatter, owner-only Adam, all-gather of the parameter rows"

@@ -184,6 +184,14 @@ int iso_sample_step(unsigned long long seed, unsigned long long step, int B, lon
                     const long long* labels3d, long long* pix, long long* lab_a, long long* lab_b, long long* pick3d,
                     long long* lab3d, void* stream);
 
+/* dst[i] = sum_{w < W} sources[w][begin + i], i < count, added in the order w = 0 .. W-1: the reduce step of a direct
+ * reduce-scatter over peer-mapped buffers (every rank pulls its shard from all peers at once over the
+ * point-to-point xGMI links, instead of RCCL's ring).  `sources` is a HOST array of W <= 16 device pointers (the peers'
+ * buffers as mapped into this process, e.g. hipIpcOpenMemHandle; the rank's own buffer for w = rank), 16-byte aligned like
+ * `dst`.  Synchronisation between the ranks (buffers complete before they are read, reads complete before they are reused)
+ * is the caller's (instascene_amd/peer_exchange.py). */
+int iso_peer_sum(int W, const float* const* sources, long long begin, long long count, float* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,7 @@ SIGNATURES = {
     "iso_adam_rownorm2": (c_int, [ctypes.c_longlong, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                   ctypes.c_longlong, c_float,
                                   c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "iso_peer_sum": (c_int, [c_int, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P]),
     "iso_rownorm2": (c_int, [ctypes.c_longlong, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P]),
 }
 

@@ -118,4 +118,28 @@ __global__ __launch_bounds__(256) void gaussian_adam_kernel(GaussAdamArgs a) {
     }
 }
 
+
+// Direct exchange over mapped peer buffers (xGMI): dst[i] = sum over the W sources of src_w[begin + i], added in rank order
+// - the reduce half of a reduce-scatter in which every rank PULLS its own shard from all peers at once (all seven links of
+// an MI355X busy, where a ring keeps one busy per step).  The W pointers are device addresses of the peers' gradient
+// buffers (hipIpcOpenMemHandle); a float4 per thread and source, fully coalesced.
+struct PeerPtrs { const float* src[16]; };
+__global__ __launch_bounds__(256) void peer_sum_kernel(int W, PeerPtrs p, long long begin, long long count, float* __restrict__ dst) {
+    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= count) return;
+    if (i4 + 4 <= count && ((begin + i4) & 3) == 0) {
+        float4 acc = *reinterpret_cast<const float4*>(p.src[0] + begin + i4);
+        for (int w = 1; w < W; w++) {
+            const float4 v = *reinterpret_cast<const float4*>(p.src[w] + begin + i4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dst + i4) = acc;
+    } else {
+        for (long long i = i4; i < count && i < i4 + 4; i++) {
+            float acc = p.src[0][begin + i];
+            for (int w = 1; w < W; w++) acc += p.src[w][begin + i];
+            dst[i] = acc;
+        }
+    }
+}
 }  // namespace iso

@@ -438,4 +438,20 @@ int iso_rownorm2(long long N, int F, float eps1, float eps2, int backward, const
     return ISR_OK;
 }
 
+int iso_peer_sum(int W, const float* const* sources, long long begin, long long count, float* dst, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (W < 1 || W > 16 || begin < 0 || count < 0) return fail(ISR_EINVAL, "peer_sum: 1..16 sources, non-negative range");
+    if (count == 0) return ISR_OK;
+    if (!sources || !dst) return fail(ISR_EINVAL, "peer_sum: null pointer");
+    if (((uintptr_t)dst & 15) != 0) return fail(ISR_EINVAL, "peer_sum: dst must be 16-byte aligned");
+    iso::PeerPtrs p = {};
+    for (int w = 0; w < W; w++) {
+        if (!sources[w] || ((uintptr_t)sources[w] & 15) != 0) return fail(ISR_EINVAL, "peer_sum: source %d is null or not 16-byte aligned", w);
+        p.src[w] = sources[w];
+    }
+    hipLaunchKernelGGL(iso::peer_sum_kernel, dim3((unsigned)((count + 1023) / 1024)), dim3(256), 0, s, W, p, begin, count, dst);
+    ISR_LAUNCH_CHECK("iso_peer_sum");
+    return ISR_OK;
+}
+
 }  // extern "C"

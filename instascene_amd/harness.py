@@ -167,6 +167,8 @@ class SegTrainer:
         self.prefetch_early = _os.environ.get("ISR_PREFETCH_EARLY", "1") == "1"     # measured: 2.092 -> 2.066 ms per C3 step
         self.high_priority_main = _os.environ.get("ISR_MAIN_PRIORITY", "1") == "1"     # measured: 2.03 -> 1.995 ms per C3 step
         self.sharded_tail = _os.environ.get("ISR_SHARDED_TAIL", "0") == "1"    # opt-in (unmeasured on hardware): _tail_sharded
+        self.phase_timing = False    # multi-rank tail: record per-phase device times of each step into self.last_phases
+        self.last_phases = None
         self.split_tail = False      # tests: take the multi-rank form of the tail (dL/dx, all-reduce, Adam) with one rank
         self.tail_chunks = 4         # row ranges of that form (all-reduce of one overlaps the kernels of the others)
         F = scene.seg_feature.shape[1]
@@ -527,17 +529,41 @@ class SegTrainer:
             p.grad = torch.zeros_like(p.data)      # nothing reached this rank's leaves: it still takes part in the sums
         bounds = row_ranges(p.shape[0], self.tail_chunks)
         works = []
+        timed = self.phase_timing and self.device.type == "cuda"
+        ev = (lambda: torch.cuda.Event(enable_timing=True)) if timed else None
+        marks = []
+        if timed:
+            t_begin = ev(); t_begin.record()
         for r0, r1 in bounds:
             if tail is not None:
                 opt.tail_gradient(tail, r0, r1)
             works.append(allreduce_rows_async(p.grad, r0, r1, self.world))
+        if timed:
+            t_grads = ev(); t_grads.record()
         opt.begin_step()
         for (r0, r1), w in zip(bounds, works):
+            if timed:
+                a = ev(); a.record()
             if w is not None:
                 w.wait()                 # the compute stream waits for this range's collective; the host does not
+            if timed:
+                b = ev(); b.record()
             opt.step_range(r0, r1)
+            if timed:
+                c = ev(); c.record()
+                marks.append((a, b, c))
         opt.end_step()
         opt.zero_grad(set_to_none=True)
+        if timed:
+            t_end = ev(); t_end.record()
+            t_end.synchronize()
+            # per row range: how long the compute stream stood still for the range's collective (0 when the collective had
+            # finished under the kernels issued before it), and the range's optimiser kernel
+            stalls = [round(a.elapsed_time(b), 4) for a, b, _ in marks]
+            self.last_phases = {"tail_chunks": len(bounds), "gradient_kernels_ms": round(t_begin.elapsed_time(t_grads), 4),
+                                "exposed_collective_ms_per_range": stalls, "exposed_collective_ms": round(sum(stalls), 4),
+                                "optimizer_kernels_ms_per_range": [round(b.elapsed_time(c), 4) for _, b, c in marks],
+                                "tail_ms": round(t_begin.elapsed_time(t_end), 4)}
 
     def _prefetch_next(self, it):
         """Software pipelining across iterations: the NEXT view's geometry pass and binning (K1, scans, key scatter, tile

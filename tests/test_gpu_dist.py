@@ -247,6 +247,9 @@ def test_bench_launches_itself_for_several_ranks():
     assert rec["config"]["rccl_world_size"] == 2 and rec["config"]["allreduce_ms_per_step_alone"] is not None
     assert rec["roofline"]["kernel"] == "k_render_fwd" and rec["cpu_baseline"] is None
     assert rec["config"]["multi_rank_tail"].startswith("replicated")
+    ph = rec["config"]["multi_rank_tail_phases"]          # per-phase device times of the row-range pipelined tail
+    assert ph["tail_chunks"] == 4 and len(ph["exposed_collective_ms_per_range"]) == 4 and ph["tail_ms"] > 0
+    assert 0.0 <= ph["exposed_collective_ms"] <= ph["tail_ms"] and ph["allreduce_alone_ms"] == rec["config"]["allreduce_ms_per_step_alone"]
     # ... and the same flow with the opt-in sharded tail
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--no-cpu-baseline", "--submodes", "", "--sharded-tail", "1"], env=env, capture_output=True, text=True,
@@ -254,3 +257,39 @@ def test_bench_launches_itself_for_several_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["multi_rank_tail"].startswith("sharded")
+
+
+def _peer_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from instascene_amd.peer_exchange import PeerExchange
+    g = torch.Generator(device="cuda").manual_seed(100 + rank)
+    P, F = 6001, 20                                     # odd row count: ragged last shard, unaligned tail
+    buf = torch.empty(P, F, device="cuda")
+    ex = PeerExchange(buf)
+    results = []
+    for step in range(3):
+        buf.copy_(torch.randn(P, F, device="cuda", generator=g))
+        want = buf.clone()
+        dist.all_reduce(want)                           # the reference collective (gloo here, RCCL on a real node)
+        ex.all_reduce_()
+        results.append(bool(torch.equal(buf, want)))
+    torch.save({"ok": results, "sum": buf.cpu()}, os.path.join(out, f"p{rank}.pt"))
+    dist.barrier()
+    del ex
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_direct_peer_exchange_equals_the_collective(tmp_path):
+    """SURVEY section 5's direct reduce-scatter / all-gather over IPC-mapped peer buffers (peer_exchange.PeerExchange,
+    iso_peer_sum), two ranks sharing one GPU: the summed buffer is bit-identical to torch.distributed's all-reduce of the
+    same buffers, on both ranks, three steps in a row (buffers reused, as a training loop would)."""
+    world = 2
+    mp.spawn(_peer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "p0.pt"), torch.load(tmp_path / "p1.pt")
+    assert r0["ok"] == [True] * 3 and r1["ok"] == [True] * 3
+    assert torch.equal(r0["sum"], r1["sum"])
