@@ -83,13 +83,18 @@ def allreduce_bucket(tensors, world: int, like=None):
                 raise ValueError("allreduce_bucket: a missing gradient needs like[i] for its shape")
             t = torch.zeros_like(like[i], dtype=torch.float32)
         parts.append(t)
-    flat = torch.cat([t.reshape(-1).float() for t in parts])
+    # every segment starts on a 16-byte boundary of the flat buffer (kernels read the returned views with float4 loads:
+    # iso_gaussian_adam_step's rotation gradient): segments are padded to multiples of four floats
+    sizes = [t.numel() for t in parts]
+    starts, at = [], 0
+    for n in sizes:
+        starts.append(at)
+        at += (n + 3) // 4 * 4
+    flat = torch.zeros(at, dtype=torch.float32, device=parts[0].device)
+    for t, a, n in zip(parts, starts, sizes):
+        flat[a:a + n].copy_(t.reshape(-1))
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    out, at = [], 0
-    for t in parts:
-        out.append(flat[at:at + t.numel()].view(t.shape))
-        at += t.numel()
-    return out
+    return [flat[a:a + n].view(t.shape) for t, a, n in zip(parts, starts, sizes)]
 
 
 def row_ranges(n_rows: int, chunks: int):

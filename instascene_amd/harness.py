@@ -702,7 +702,9 @@ class RgbGaussianModel:
     get_seg_feature = property(lambda s: None)
 
     def get_covariance(self, scaling_modifier=1):
-        return splat_to_world(self.get_xyz, self.get_scaling, scaling_modifier, self._rotation)
+        # (with the fused optimiser's leaves active the gradient must reach leaves["rotation"] - the normalised quaternion,
+        # which rotation_matrices re-normalises harmlessly - not the raw parameter, whose .grad that optimiser never reads)
+        return splat_to_world(self.get_xyz, self.get_scaling, scaling_modifier, self._leaves["rotation"] if self._leaves else self._rotation)
 
     def param_groups(self):
         return [{"params": [self._xyz], "lr": 0.00016, "name": "xyz"},

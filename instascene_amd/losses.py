@@ -170,14 +170,17 @@ class _TrainLossHip(torch.autograd.Function):
         C, H, W = a.shape
         gg = g.reshape(1).contiguous().float()
         d_img = torch.empty_like(a)
-        d_rn = torch.empty_like(rn) if (rn is not None and ctx.needs_input_grad[3]) else None
-        d_sn = torch.empty_like(sn) if d_rn is not None else None
+        # the library produces both normal gradients or neither; each is handed back only where autograd asked for it
+        want_n = rn is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        d_rn = torch.empty_like(rn) if want_n else None
+        d_sn = torch.empty_like(sn) if want_n else None
         d_rd = torch.empty(dist_shape, dtype=torch.float32, device=a.device) if (use_d and ctx.needs_input_grad[6]) else None
         with torch.cuda.device(a.device):
             check(lib().iso_train_loss_backward(C, H, W, _ptr(a), _ptr(b), _ptr(dmaps), lam, _ptr(rn), _ptr(sn), ln, ldist,
                                                 _ptr(gg), _ptr(d_img), _ptr(d_rn), _ptr(d_sn), _ptr(d_rd), _stream()),
                   "iso_train_loss_backward")
-        return d_img, None, None, d_rn, d_sn, None, d_rd, None
+        return (d_img, None, None, d_rn if ctx.needs_input_grad[3] else None, d_sn if ctx.needs_input_grad[4] else None, None,
+                d_rd, None)
 
 
 def train_loss(image, gt, lambda_dssim, rend_normal=None, surf_normal=None, lambda_normal=0.0, rend_dist=None,

@@ -292,6 +292,9 @@ def _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, op
         _OVERFLOWED.pop(geom.data_ptr(), None)      # a recycled address
         LAST_NUM_RENDERED = _R_ESTIMATE[ekey]
     else:
+        # (this forward was sized exactly: whatever an earlier forward left under the same - recycled - buffer address is stale)
+        _PENDING.pop(geom.data_ptr(), None)
+        _OVERFLOWED.pop(geom.data_ptr(), None)
         R = int(num_rendered.value)
         _R_ESTIMATE[ekey] = R
         if len(_R_ESTIMATE) > 4096:
