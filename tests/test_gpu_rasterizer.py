@@ -816,3 +816,40 @@ def test_debug_mode_checks_every_launch_and_dumps_on_a_fault(tmp_path, monkeypat
     with pytest.raises(RuntimeError, match=r"\[debug\] kernel \w+ failed: injected fault"):
         (c2.sum() + e2.sum()).backward()
     assert (tmp_path / "snapshot_bw.dump").exists()
+
+
+@pytest.mark.parametrize("F", [0, 4, 40])
+def test_fast_mode_precomputed_paths_and_background(F):
+    """FAST arithmetic on the optional-input paths (precomputed colours + precomputed transMat, non-zero background): F = 0
+    takes the splat-major geometry backward, F = 4 / 40 the pixel-major one (one / two feature passes).  Binning identical
+    to the oracle's, images within the FAST tolerance, gradients within 1e-3 of the tensor's maximum on all rows but a
+    handful (threshold decisions, see tests/test_gpu_fuzz.py), and the colour adjoint identity with the background term."""
+    sc, cams, inp = small_scene(P=900, F=max(F, 1), W=80, H=64, seed=52)
+    if F == 0:
+        inp = dict(inp, extra=None)
+    cam = cams[2]
+    bg = (0.3, 0.1, 0.6)
+    st0 = oracle_forward(inp, cam, bg=bg)
+    colors = np.random.RandomState(1).rand(900, 3).astype(np.float32)
+    tm = st0["transMats"].copy()
+    st = oracle_forward(inp, cam, bg=bg, colors_precomp=colors, shs=None, transMat_precomp=tm, scales=None, rotations=None)
+    args, out = hip_forward(inp, cam, bg=bg, mode=MODE_FAST, colors_precomp=colors, transMat_precomp=tm)
+    check_binning_exact(st, out)
+    _images_within_fast_tolerance(out, st, frac=1e-3, floor=3)
+    dC, dO, dE = _rand_grads(st, 4)
+    want = oracle.backward(st, dC, dO, dE)
+    mask = GRAD_GEOMETRY | (GRAD_EXTRA if F else 0)
+    got = hip_backward(args, out, dC, dO, dE, mask, MODE_FAST)
+    for name in ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dtransMat"] + (["dL_dextra"] if F else []):
+        w = want[name].reshape(900, -1)
+        g = got[GRAD_NAMES.index(name)].cpu().numpy().reshape(w.shape)
+        dev = np.abs(g - w).max(axis=1) / (np.abs(w).max() + 1e-30)
+        assert (dev > 1e-3).sum() <= 4 and dev.max() <= 0.05, (name, int((dev > 1e-3).sum()), float(dev.max()))
+    # colour adjoint with a background: colour = sum w c + T bg, so <colour - T_final bg, dC> == <c, dL/dcolour>
+    dbg = rz.debug_state(900, 80, 64, out[0], out[5], out[6], out[7])
+    T_final = dbg["final_T"][0].reshape(64, 80)
+    lin = out[1].cpu().numpy() - T_final[None] * np.asarray(bg, np.float32)[:, None, None]
+    lhs = float((lin.astype(np.float64) * dC).sum())
+    rhs = float((colors.astype(np.float64) * got[1].cpu().numpy()).sum())
+    mag = float((np.abs(lin).astype(np.float64) * np.abs(dC)).sum())
+    assert abs(lhs - rhs) <= 2e-5 * mag, (lhs, rhs, mag)
