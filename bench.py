@@ -381,6 +381,10 @@ def main():
     ap.add_argument("--more", type=int, default=1,
                     help="1 (default, C3 seg at one GPU): also time the other BASELINE configs (C2 rgb, C5 seg), the step with the "
                          "multi-view leg, a 500-step block and the plain drop-in loop, as sub_records")
+    ap.add_argument("--multiview", type=int, default=0,
+                    help="seg step: 1 = with the reference's multi-view leg every 10th iteration (5 more views rendered with "
+                         "gradients, train_semantic.py:143-172); the headline is the single-view step, this is sub_records.C3_multiview")
+    ap.add_argument("--empty-cache", dest="empty_cache", type=int, default=0, help="plain step: torch.cuda.empty_cache() every iteration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tracer", type=int, default=1, help="produce gau_related_pixels each forward like the reference")
     ap.add_argument("--async-binning", type=int, default=1,
