@@ -55,7 +55,7 @@ int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binni
         const int big = (binning_capacity / (T > 0 ? T : 1)) > 1500 ? 1 : 0;
         static const bool wave_sort = [] { const char* e = getenv("ISR_WAVE_SORT"); return !(e && e[0] == '0'); }();
         // buckets of up to 2 048 keys: one wave each, in registers; the LDS network takes the rest
-        static const int wave_max = [] { const char* e = getenv("ISR_WAVE_SORT_MAX"); return e ? atoi(e) : 128; }();
+        static const int wave_max = [] { const char* e = getenv("ISR_WAVE_SORT_MAX"); return e ? atoi(e) : 64; }();
         const int wk = !wave_sort ? 0 : (!big ? 32 : wave_max);           // keys per lane of the widest variant launched
         const int wflags = wk == 0 ? 0 : wk == 32 ? 2 : wk == 64 ? 6 : 14;
         if (wk == 128)
