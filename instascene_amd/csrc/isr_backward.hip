@@ -1070,7 +1070,29 @@ __global__ __launch_bounds__(256) void k_sample_count(int n, int W, int H, int g
 }
 __global__ __launch_bounds__(1024) void k_sample_scan(int T, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off,
                                                       uint32_t* __restrict__ cursor) {
+    // a thread owns `per` CONSECUTIVE tiles (its counts read up front, all loads in flight together), one workgroup scan of
+    // the 1024 partial sums: one barrier-separated scan instead of one per 1024 tiles (8 of them at 1080p: 33 us -> 8 us)
     __shared__ uint32_t s_warp[32];
+    constexpr int MAXPER = 16;
+    const int per = (T + 1023) / 1024;
+    if (per <= MAXPER) {
+        const int t0 = (int)threadIdx.x * per;
+        uint32_t c[MAXPER];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < MAXPER; k++) {
+            c[k] = (k < per && t0 + k < T) ? cnt[t0 + k] : 0u;
+            mine += c[k];
+        }
+        uint32_t total;
+        uint32_t run = block_exclusive_scan_1024(mine, s_warp, total);
+#pragma unroll
+        for (int k = 0; k < MAXPER; k++) {
+            if (k < per && t0 + k < T) { off[t0 + k] = run; cursor[t0 + k] = 0u; run += c[k]; }
+        }
+        if (threadIdx.x == 0) off[T] = total;
+        return;
+    }
     uint32_t carry = 0;
     for (int base = 0; base < T; base += 1024) {
         const int i = base + threadIdx.x;
