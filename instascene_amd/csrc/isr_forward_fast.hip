@@ -20,10 +20,6 @@
 #include "isr_common.hpp"
 #include "isr_fast_pair.hpp"
 
-#ifndef ISR_EXP
-#define ISR_EXP 0
-#endif
-
 namespace isr {
 
 constexpr int FF_BATCH = 128;       // instances staged per round
@@ -184,115 +180,6 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
             }
             unsigned long long m = __ballot(hit);
             if (STATS) st_cull += (unsigned)min(64, nb - c0);
-#if ISR_EXP & 4
-            // TWO hit splats per iteration: the two (independent until the transmittance) evaluations interleave, one LDS round
-            // trip, one set of scalar branches and one pass of loop control serve both, and the pair goes straight into one
-            // pair of MFMAs.  A single leftover splat is paired with a phantom whose masks are empty.
-            while (m != 0ull) {
-                if (m_done == ~0ull) break;
-                const int j0 = c0 + __builtin_ctzll(m);
-                m &= m - 1ull;
-                const bool two = m != 0ull;
-                const int j1 = two ? c0 + __builtin_ctzll(m) : j0;
-                m &= m - 1ull;          // (0 & -1 = 0)
-                if (STATS) st_eval += two ? 2u : 1u;
-                const float4* qa = reinterpret_cast<const float4*>(s_rec + j0 * RS);
-                const float4* qb = reinterpret_cast<const float4*>(s_rec + j1 * RS);
-                const float4 a0 = qa[0], a1 = qa[1], a2 = qa[2];
-                const float4 b0 = qb[0], b1 = qb[1], b2 = qb[2];
-                const FastRay ra = fast_ray(lx, ly, a0.x, a0.y, a0.z, a1.x, a1.y, a1.z, a2.x, a2.y, a2.z, a0.w, a1.w);
-                const FastRay rb = fast_ray(lx, ly, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, b2.x, b2.y, b2.z, b0.w, b1.w);
-                const unsigned long long live = ~m_done;
-                const unsigned long long near_a = __ballot(ra.rho <= a2.w) & __ballot(ra.p_z != 0.0f) & live;
-                const unsigned long long near_b = two ? (__ballot(rb.rho <= b2.w) & __ballot(rb.p_z != 0.0f) & live) : 0ull;
-                if ((near_a | near_b) == 0ull) continue;
-                const float4 a3 = qa[3], b3 = qb[3];
-                const FastHit ha = fast_hit(ra, a3.x, a3.y, a3.z);
-                const FastHit hb = fast_hit(rb, b3.x, b3.y, b3.z);
-                const float Ta = T;
-                const float test_a = __builtin_fmaf(-Ta, ha.alpha, Ta);
-                const unsigned long long pass_a = near_a & __ballot(!(ha.depth < NEAR_N)) & __ballot(!(ha.alpha < 1.0f / 255.0f));
-                const unsigned long long stop_a = pass_a & __ballot(test_a < 0.0001f);
-                const unsigned long long ok_a = pass_a & ~stop_a;
-                const float Tb = __builtin_amdgcn_inverse_ballot_w64(ok_a) ? test_a : Ta;       // transmittance in front of the second splat
-                const float test_b = __builtin_fmaf(-Tb, hb.alpha, Tb);
-                const unsigned long long pass_b = near_b & ~stop_a & __ballot(!(hb.depth < NEAR_N)) & __ballot(!(hb.alpha < 1.0f / 255.0f));
-                const unsigned long long stop_b = pass_b & __ballot(test_b < 0.0001f);
-                const unsigned long long ok_b = pass_b & ~stop_b;
-                m_done |= stop_a | stop_b;
-                if ((ok_a | ok_b) == 0ull) continue;
-                if (STATS) { st_blend += (ok_a != 0ull ? 1u : 0u) + (ok_b != 0ull ? 1u : 0u); st_lanes += (unsigned)(__popcll(ok_a) + __popcll(ok_b)); }
-                float w_a = 0.0f, w_b = 0.0f;
-                if (__builtin_amdgcn_inverse_ballot_w64(ok_a)) {
-                    const float w = ha.alpha * Ta;
-                    w_a = w;
-                    const unsigned contributor = cbase + (unsigned)j0;
-                    if (AUX && first_pass) {
-                        const float4 q4 = qa[4], q5 = qa[5];
-                        const float inv_depth = ha.use3d ? ra.p_z * a3.w : q4.x;
-                        const float m_ = __builtin_fmaf(-(mscale * NEAR_N), inv_depth, mshift);      // m - m_ref
-                        const float mw = m_ * w;
-                        D = __builtin_fmaf(ha.depth, w, D);
-                        M1 += mw;
-                        M2 = __builtin_fmaf(m_, mw, M2);
-                        if (Ta > 0.5f) { median_depth = ha.depth; median_contributor = contributor; }
-                        N0 = __builtin_fmaf(q4.y, w, N0); N1 = __builtin_fmaf(q4.z, w, N1); N2 = __builtin_fmaf(q4.w, w, N2);
-                        C0 = __builtin_fmaf(q5.x, w, C0); C1 = __builtin_fmaf(q5.y, w, C1); C2 = __builtin_fmaf(q5.z, w, C2);
-                    }
-                    last_contributor = contributor;
-                }
-                T = Tb;
-                if (__builtin_amdgcn_inverse_ballot_w64(ok_b)) {
-                    const float w = hb.alpha * Tb;
-                    w_b = w;
-                    const unsigned contributor = cbase + (unsigned)j1;
-                    if (AUX && first_pass) {
-                        const float4 q4 = qb[4], q5 = qb[5];
-                        const float inv_depth = hb.use3d ? rb.p_z * b3.w : q4.x;
-                        const float m_ = __builtin_fmaf(-(mscale * NEAR_N), inv_depth, mshift);
-                        const float mw = m_ * w;
-                        D = __builtin_fmaf(hb.depth, w, D);
-                        M1 += mw;
-                        M2 = __builtin_fmaf(m_, mw, M2);
-                        if (Tb > 0.5f) { median_depth = hb.depth; median_contributor = contributor; }
-                        N0 = __builtin_fmaf(q4.y, w, N0); N1 = __builtin_fmaf(q4.z, w, N1); N2 = __builtin_fmaf(q4.w, w, N2);
-                        C0 = __builtin_fmaf(q5.x, w, C0); C1 = __builtin_fmaf(q5.y, w, C1); C2 = __builtin_fmaf(q5.z, w, C2);
-                    }
-                    T = test_b;
-                    last_contributor = contributor;
-                }
-                if (AUX && tracer != nullptr && first_pass) {
-                    const unsigned long long tr_a = __ballot(w_a >= 0.1f), tr_b = __ballot(w_b >= 0.1f);     // (double)w > 0.1  <=>  w >= 0.1f
-                    if ((tr_a | tr_b) != 0ull) {
-                        if (w_a >= 0.1f) {
-                            const int slot = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(tr_a >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tr_a, 0u));
-                            int* dst = s_trace + wv * 2 * WCAP + 2 * slot;
-                            dst[0] = s_id[j0];
-                            dst[1] = (int)pix;
-                        }
-                        wcnt += __popcll(tr_a);
-                        if (wcnt > WCAP - 64) flush_trace();
-                        if (w_b >= 0.1f) {
-                            const int slot = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(tr_b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tr_b, 0u));
-                            int* dst = s_trace + wv * 2 * WCAP + 2 * slot;
-                            dst[0] = s_id[j1];
-                            dst[1] = (int)pix;
-                        }
-                        wcnt += __popcll(tr_b);
-                        if (wcnt > WCAP - 64) flush_trace();
-                    }
-                }
-                if constexpr (FEAT) {
-                    // A[i = channel][k = splat]: lanes 0..31 carry the first splat's channels, 32..63 the second's;
-                    // B[k = splat][j = pixel]: v_permlane32_swap puts the two splats' weights of one half of the pixels
-                    // into the two halves of the wave.  (a phantom second splat has zero weights everywhere)
-                    const float a = s_feat[(lane < 32 ? j0 : j1) * FCH + (lane & 31)];
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(w_a), __float_as_uint(w_b), false, false);
-                    accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[0]), accA, 0, 0, 0);
-                    accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[1]), accB, 0, 0, 0);
-                }
-            }
-#else
             while (m != 0ull) {
                 if (m_done == ~0ull) break;
                 const int j = c0 + __builtin_ctzll(m);
@@ -380,7 +267,6 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                     }
                 }
             }
-#endif
         }
     }
     if constexpr (FEAT) {
