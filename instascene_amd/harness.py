@@ -210,6 +210,7 @@ class SegTrainer:
         # label maps are static per view: index the labelled pixels once (the reference re-derives the
         # boolean mask every iteration, train_semantic.py:118-125)
         self.n_labels = n_labels
+        self._mv_pools = {}
         self.vis_pool = {}        # view -> indices of visible, labelled Gaussians (geometry is frozen: static per view)
         self.valid_idx = {}
         for i, c in enumerate(self.cams):
@@ -457,18 +458,7 @@ class SegTrainer:
                     term = contrastive_loss(f, l, predef_u_list=u, num_labels=K) * w
                     loss = term if loss is None else loss + term
         if self.multiview and self.lmv > 0 and it % 10 == 0:
-            first = (vi + 1) % max(1, len(self.cams) - self.mv_frames)
-            feats, labs = [], []
-            for k in range(first, first + self.mv_frames):
-                p2 = render(self.cams[k], m, self.pipe, self.bg)
-                sf = p2["seg_feature"]
-                feats.append(sf.reshape(sf.shape[0], -1))
-                labs.append(self.cams[k].sorted_segmap.reshape(-1))
-            allf, alll = torch.cat(feats, dim=1), torch.cat(labs)
-            pool = torch.nonzero(alll > 0).reshape(-1)
-            pick = pool[torch.randint(0, pool.numel(), (self.batch,), device=self.device, generator=self.gen)]
-            loss = loss + contrastive_loss(allf[:, pick].T, alll[pick], predef_u_list=m.class_feat,
-                                           num_labels=self.n_labels + 1) * self.lmv
+            loss = loss + self._multiview_loss(it, vi)
         if self.fused_tail:
             with DeferredFeatureRows() as sink:
                 loss.backward(self._unit_grad(loss))
@@ -491,6 +481,53 @@ class SegTrainer:
         self.opt.zero_grad(set_to_none=True)
         m._seg_cache = None          # the graph of this step is gone
         return loss.detach()
+
+    def _multiview_loss(self, it, vi):
+        """The cross-view leg (train_semantic.py:143-172): ``mv_frames`` consecutive views rendered with gradients, one
+        batch sampled uniformly from their labelled pixels, one loss against the class prototypes.  The reference stacks the
+        five dense ``[F,H,W]`` maps and mask-gathers them (1.3 GB copied, 1.2 GB gathered, the same again zero-filled and
+        scattered in the backward); here the batch is drawn FIRST - how many of the B samples fall into each view is a host-
+        side multinomial draw with probabilities proportional to the views' labelled-pixel counts, the pixels themselves are
+        drawn on the device: the same distribution as uniform over the union - and every view hands back only its samples
+        (``render(sample_pixels=)``).  The next view's geometry pass is issued on the side stream while one renders."""
+        import numpy as np
+        m = self.model
+        n = len(self.cams)
+        first = (vi + 1) % max(1, n - self.mv_frames)
+        views = list(range(first, first + self.mv_frames))
+        pools = [self._sorted_pool(k) for k in views]
+        sizes = np.array([p.numel() for p in pools], dtype=np.float64)
+        if sizes.sum() == 0:
+            return 0.0
+        counts = np.random.RandomState((self.sample_seed * 7919 + it) & 0x7FFFFFFF).multinomial(self.batch, sizes / sizes.sum())
+        feats, labs = [], []
+        for j, (k, pool, nk) in enumerate(zip(views, pools, counts)):
+            if self.prefetch and self.device.type == "cuda" and j + 1 < len(views) and counts[j + 1] > 0:
+                if self._side is None:
+                    self._side = side_stream(self.device)
+                prefetch(self.cams[views[j + 1]], m, self.pipe, self.bg, stream=self._side)
+            if nk == 0:
+                continue
+            pix = pool[torch.randint(0, pool.numel(), (int(nk),), device=self.device, generator=self.gen)]
+            if self.sampled_path:
+                p2 = render(self.cams[k], m, self.pipe, self.bg, sample_pixels=pix, defer_rows=False)
+                feats.append(p2["sampled_seg_feature"])
+            else:
+                sf = render(self.cams[k], m, self.pipe, self.bg)["seg_feature"]
+                feats.append(sf.reshape(sf.shape[0], -1)[:, pix].T)
+            labs.append(self.cams[k].sorted_segmap.reshape(-1)[pix])
+        return contrastive_loss(torch.cat(feats, dim=0), torch.cat(labs), predef_u_list=m.class_feat,
+                                num_labels=self.n_labels + 1) * self.lmv
+
+    def _sorted_pool(self, k):
+        """Flat indices of the pixels of view ``k`` with a positive ``sorted_segmap`` label (static per view: cached)."""
+        cam = self.cams[k]
+        if cam.sorted_segmap is cam.segmap:
+            return self.valid_idx[k]
+        pool = self._mv_pools.get(k)
+        if pool is None:
+            pool = self._mv_pools[k] = torch.nonzero(cam.sorted_segmap.reshape(-1) > 0).reshape(-1)
+        return pool
 
     def _tail_sharded(self, sink):
         """Several ranks, opt-in (``sharded_tail``; P divisible by the world size): reduce-scatter of dL/dparam, Adam on THIS

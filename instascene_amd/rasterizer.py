@@ -368,7 +368,7 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
                 done.record()
     # the entry keeps the converted inputs alive until it is consumed or dropped
     _PREFETCHED[sig] = _Prefetched(sig, _refs(originals), radii, geom, img, R, binning, done, inputs)
-    while len(_PREFETCHED) > 2:                 # entries nobody came for
+    while len(_PREFETCHED) > 4:                 # entries nobody came for
         old = _PREFETCHED.pop(next(iter(_PREFETCHED)))
         _PENDING.pop(old.geom.data_ptr(), None)
     return True
@@ -728,8 +728,9 @@ class _Token:
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, extra_attrs,
-                raster_settings, sample_pixels=None, lazy_tracer=False, feature_only=False):
+                raster_settings, sample_pixels=None, lazy_tracer=False, feature_only=False, defer_rows=True):
         rs = raster_settings
+        ctx.defer_rows = bool(defer_rows)
         if feature_only and any(ctx.needs_input_grad[i] for i in (0, 1, 2, 3, 4, 5, 6, 7)):
             raise Exception("feature_only forward: only extra_attrs may require grad")
         attr_degree = extra_attrs.shape[1] if extra_attrs.shape[0] != 0 else 0
@@ -792,20 +793,21 @@ class _RasterizeGaussians(torch.autograd.Function):
             dense.index_add_(1, ctx.sample_pixels.to(torch.int64), grad_sampled.t().contiguous().float())
             grad_out_extra, grad_sampled = dense.reshape(Fm, Hm, Wm), None
         if mask == 0 or (grad_out_color is None and grad_depth is None and grad_out_extra is None and grad_sampled is None):
-            return (None,) * 13
+            return (None,) * 14
         if grad_sampled is not None and grad_out_color is None and grad_depth is None and grad_out_extra is None:
             # the common case of feature training: only sampled features carry gradient
             sink = _ROWS_SINK
-            if sink is not None and sink.rows is None and extra_attrs.shape[1] % 4 == 0 and extra_attrs.shape[1] <= 256:
+            if (sink is not None and sink.rows is None and ctx.defer_rows and extra_attrs.shape[1] % 4 == 0
+                    and extra_attrs.shape[1] <= 256):
                 sink.rows = rasterize_gaussians_backward_sampled(
                     means3D.shape[0], extra_attrs.shape[1], rs.image_width, rs.image_height, ctx.num_rendered,
                     ctx.sample_pixels, grad_sampled, cov3Ds_precomp, geomBuffer, binningBuffer, imgBuffer, mode=ctx.mode,
                     rows_only=True)
-                return (None,) * 13
+                return (None,) * 14
             ge = rasterize_gaussians_backward_sampled(means3D.shape[0], extra_attrs.shape[1], rs.image_width, rs.image_height,
                                                       ctx.num_rendered, ctx.sample_pixels, grad_sampled, cov3Ds_precomp,
                                                       geomBuffer, binningBuffer, imgBuffer, mode=ctx.mode)
-            return (None,) * 8 + (ge, None, None, None, None)
+            return (None,) * 8 + (ge, None, None, None, None, None)
         bargs = (rs.bg, means3D, radii, colors_precomp, scales, rotations, extra_attrs, rs.scale_modifier, cov3Ds_precomp,
                  rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_out_extra, sh,
                  rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
@@ -831,13 +833,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                 pick(3, grad_colors_precomp, colors_precomp), grad_opacities if need[4] else None,
                 pick(5, grad_scales, scales), pick(6, grad_rotations, rotations),
                 pick(7, grad_cov3Ds_precomp, cov3Ds_precomp),
-                grad_extra_attrs if (need[8] and extra_attrs.numel()) else None, None, None, None, None)
+                grad_extra_attrs if (need[8] and extra_attrs.numel()) else None, None, None, None, None, None)
 
 
 def rasterize_gaussians_autograd(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                 extra_attrs, raster_settings, sample_pixels=None, lazy_tracer=False, feature_only=False):
+                                 extra_attrs, raster_settings, sample_pixels=None, lazy_tracer=False, feature_only=False,
+                                 defer_rows=True):
     out = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                    cov3Ds_precomp, extra_attrs, raster_settings, sample_pixels, lazy_tracer, feature_only)
+                                    cov3Ds_precomp, extra_attrs, raster_settings, sample_pixels, lazy_tracer, feature_only,
+                                    defer_rows)
     return out if sample_pixels is not None else out[:5]
 
 
@@ -862,12 +866,15 @@ class GaussianRasterizer(nn.Module):
                                      rs.image_width, shs, rs.sh_degree, rs.campos, rs.prefiltered, stream=stream, after=after)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, extra_attrs=None, sample_pixels=None, lazy_tracer=False, feature_only=False):
+                cov3D_precomp=None, extra_attrs=None, sample_pixels=None, lazy_tracer=False, feature_only=False,
+                defer_rows=True):
         """Reference signature (:210-248).  Extensions: ``sample_pixels`` (int64 ``y*W + x``, may repeat) appends a sixth
         result, the feature map read at those pixels ``[n, F]``; its gradient is propagated without a dense map.
         ``lazy_tracer``: return the whole tracer buffer with its count attached (``slice_tracer``) instead of slicing it
         here, which needs the count on the host, i.e. a device sync (``render()`` slices on first access).
-        ``feature_only``: see :func:`rasterize_gaussians` (colour / allmap / tracer come back empty)."""
+        ``feature_only``: see :func:`rasterize_gaussians` (colour / allmap / tracer come back empty).  ``defer_rows=False``:
+        this render's sampled backward never hands its partial rows to a ``DeferredFeatureRows`` block (a trainer that renders
+        several views inside one block names the ONE render whose rows its fused tail consumes)."""
         rs = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -883,4 +890,4 @@ class GaussianRasterizer(nn.Module):
         cov3D_precomp = empty() if cov3D_precomp is None else cov3D_precomp
         extra_attrs = empty() if extra_attrs is None else extra_attrs
         return rasterize_gaussians_autograd(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                            cov3D_precomp, extra_attrs, rs, sample_pixels, lazy_tracer, feature_only)
+                                            cov3D_precomp, extra_attrs, rs, sample_pixels, lazy_tracer, feature_only, defer_rows)

@@ -218,7 +218,7 @@ def prefetch(viewpoint_camera, pc, pipe, bg_color=None, scaling_modifier=1.0, ov
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
-           norm_seg_feat=True, sample_pixels=None):
+           norm_seg_feat=True, sample_pixels=None, defer_rows=True):
     """Render the scene (reference gaussian_renderer/__init__.py:20).  ``pc`` needs the reference
     ``GaussianModel`` getters (get_xyz, get_opacity, get_scaling, get_rotation, get_features,
     get_seg_feature, active_sh_degree); background tensor must be on the GPU.  ``sample_pixels`` (extension, int64
@@ -253,7 +253,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
                     and _rz._CONFIG["mode"] == _lib.MODE_FAST and seg_feature.shape[1] > 0)
     # lazy_tracer: the tracer list is sliced to its valid length (a host sync) on first access of the dict entry
     res = rasterizer(means2D=means2D, extra_attrs=seg_feature, sample_pixels=sample_pixels if seg_feature is not None else None,
-                     lazy_tracer=True, feature_only=feature_only, **geo)
+                     lazy_tracer=True, feature_only=feature_only, defer_rows=defer_rows, **geo)
     rendered_image, radii, allmap, extra_attrs, gau_related_pixels = res[:5]
     if feature_only:
         rets = RenderPackage({"render": None, "viewspace_points": means2D, "visibility_filter": None, "radii": radii,
