@@ -218,3 +218,19 @@ def test_debug_flag_dumps_the_argument_snapshot_on_failure(tmp_path, monkeypatch
     snap = torch.load(tmp_path / "snapshot_bw.dump")
     assert len(snap) == 24 and snap[20] == 3 and snap[-1] is True          # the _C.rasterize_gaussians_backward argument tuple
     assert FakeLib.calls == [(1, 0), (0, 0)]
+
+
+def test_workspace_size_classes_are_geometric():
+    """rasterizer._size_class: the smallest member >= n of a x1.25 sequence - a drifting count changes the requested
+    workspace size only every +25 %."""
+    from instascene_amd.rasterizer import _size_class
+    seen = set()
+    prev = 0
+    for n in [1, 4096, 4097, 10_000, 611_750, 720_893, 5_870_199, 15_467_272, 3 * 10 ** 9]:
+        c = _size_class(n)
+        assert c >= n and c >= prev and (n <= 4096 or c < 1.26 * n + 256)
+        assert _size_class(c) == c
+        prev = c
+        seen.add(c)
+    drift = {_size_class(n) for n in range(611_750, 720_893, 997)}      # the C2 soak's 18 % drift of R
+    assert len(drift) <= 2
