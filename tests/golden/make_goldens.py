@@ -435,6 +435,95 @@ with CpuMode():
         traceback.print_exc()
         print("densification golden skipped:", repr(e))
 
+    # ------------------------------------------------------------------ PLY checkpoints (scene/gaussian_model.py:263-321,364-422)
+    # `plyfile` is not installed: its two entry points are replaced by RECORDING stand-ins for the duration of this block, so
+    # that the reference's own save_ply / load_ply run and what they hand to / ask from plyfile is captured - the structured
+    # array of the vertex element (property names in order, float32 values: everything a binary_little_endian PLY of float
+    # properties consists of besides its header syntax) and, on the way back, the parameter tensors load_ply builds from such a
+    # file.  The container syntax itself (header lines, little-endian packing) is the public PLY format, not the reference's.
+    try:
+        import scene.gaussian_model as _gmod
+
+        class _Rec:
+            elements = None
+
+        class _El:
+            def __init__(self, data, name):
+                self.data, self.name = data, name
+                self.properties = [types.SimpleNamespace(name=n) for n in data.dtype.names]
+
+            def __getitem__(self, key):
+                return self.data[key]
+
+        class _PlyElement:
+            @staticmethod
+            def describe(data, name):
+                return _El(np.array(data), name)
+
+        class _PlyData:
+            def __init__(self, elements):
+                self.elements = list(elements)
+
+            def write(self, path):
+                _Rec.elements = self.elements[0].data
+
+            @staticmethod
+            def read(path):
+                return _PlyData([_El(_Rec.elements, "vertex")])
+
+        class _O3D:         # the two colour previews the reference also writes with open3d are not part of the checkpoint
+            class geometry:
+                class PointCloud:
+                    points = colors = None
+
+            class utility:
+                Vector3dVector = staticmethod(lambda a: a)
+
+            class io:
+                write_point_cloud = staticmethod(lambda *a, **k: None)
+
+        saved = (_gmod.PlyData, _gmod.PlyElement, _gmod.o3d, _gmod.mkdir_p, _gmod.feature3d_to_rgb)
+        _gmod.PlyData, _gmod.PlyElement, _gmod.o3d, _gmod.mkdir_p = _PlyData, _PlyElement, _O3D, (lambda d: None)
+        _gmod.feature3d_to_rgb = lambda f: np.zeros((f.shape[0], 3))
+        try:
+            gen = torch.Generator().manual_seed(777)
+            out = {}
+            for tag, Fd in (("feat", 6), ("nofeat", 0)):
+                P = 23
+                gm = _gmod.GaussianModel(3)
+                init = dict(xyz=torch.randn(P, 3, generator=gen), f_dc=torch.randn(P, 1, 3, generator=gen),
+                            f_rest=torch.randn(P, 15, 3, generator=gen), opacity=torch.randn(P, 1, generator=gen),
+                            scaling=torch.randn(P, 2, generator=gen), rotation=torch.randn(P, 4, generator=gen))
+                gm._xyz, gm._features_dc, gm._features_rest = init["xyz"], init["f_dc"], init["f_rest"]
+                gm._opacity, gm._scaling, gm._rotation = init["opacity"], init["scaling"], init["rotation"]
+                gm._seg_feature = torch.randn(P, Fd, generator=gen) if Fd else None
+                if Fd:
+                    init["seg_feature"] = gm._seg_feature
+                crop = (torch.arange(P) % 4 != 1) if tag == "nofeat" else None
+                gm.save_ply("golden/point_cloud.ply", crop_mask=crop)
+                el = _Rec.elements
+                out.update({f"{tag}_in_{k}": v for k, v in init.items()})
+                if crop is not None:
+                    out[f"{tag}_crop"] = crop
+                out[f"{tag}_names"] = np.array(list(el.dtype.names))
+                out[f"{tag}_body"] = np.frombuffer(el.astype([(n, "<f4") for n in el.dtype.names]).tobytes(), dtype=np.uint8)
+                # and back through the reference's load_ply (it reads `use_seg_feature`, `load_seg_feat`, `seg_feat_dim`)
+                gl = _gmod.GaussianModel(3)
+                gl.use_seg_feature, gl.load_seg_feat, gl.seg_feat_dim = bool(Fd), bool(Fd), Fd
+                gl.load_ply("golden/point_cloud.ply")
+                for k, attr in (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"),
+                                ("scaling", "_scaling"), ("rotation", "_rotation")):
+                    out[f"{tag}_loaded_{k}"] = getattr(gl, attr).detach()
+                if Fd:
+                    out[f"{tag}_loaded_seg_feature"] = gl._seg_feature.detach()
+            save("ply.npz", **out)
+        finally:
+            _gmod.PlyData, _gmod.PlyElement, _gmod.o3d, _gmod.mkdir_p, _gmod.feature3d_to_rgb = saved
+    except Exception as e:  # pragma: no cover
+        import traceback
+        traceback.print_exc()
+        print("ply golden skipped:", repr(e))
+
     # ------------------------------------------------------------------ COLMAP sparse model
     try:
         import tempfile

@@ -1,6 +1,10 @@
 """PLY checkpoints in the reference's layout (scene/gaussian_model.py:263-321, 364-422).  `plyfile` is not installed in the
-build image, so the reference's writer cannot produce a golden here (parity unpinned by the reference); the tests pin the
-header text plyfile emits for this element, the channel-major SH order, and round trips incl. the 3DGS export."""
+build image; since round 3 the reference's own ``save_ply`` / ``load_ply`` pin the CONTENT anyway - they were run with
+recording stand-ins for plyfile's two entry points, and tests/golden/ply.npz holds the vertex element exactly as the reference
+builds it (property order, channel-major SH flattening, crop mask) and the tensors its loader builds back
+(``test_checkpoint_equals_what_the_reference_hands_to_plyfile``).  Only the container syntax - the header lines plyfile emits
+for float properties, little-endian packing: the public PLY format - is pinned by text here.  Plus round trips incl. the 3DGS
+export and an ASCII file."""
 import math
 import struct
 
@@ -76,3 +80,30 @@ def test_crop_mask_3dgs_export_and_ascii(tmp_path):
     assert sc2.features_rest.shape == (2, 15, 3) and float(sc2.features_rest[0, 1, 0]) == 7.0 and float(sc2.features_rest[0, 0, 1]) == 21.0
     with pytest.raises(ValueError):
         ply_io.load_ply(txt, max_sh_degree=2)
+
+
+@pytest.mark.parametrize("tag", ["feat", "nofeat"])
+def test_checkpoint_equals_what_the_reference_hands_to_plyfile(tmp_path, golden_dir, tag):
+    """tests/golden/ply.npz (make_goldens.py): the reference's own ``save_ply`` / ``load_ply`` run with recording stand-ins
+    for plyfile's two entry points - the vertex element's property names and float32 records exactly as the reference builds
+    them (scene/gaussian_model.py:285-313, incl. the crop mask), and the tensors its ``load_ply`` (:364-417) builds back.
+    Our writer's file = the PLY header for those names + those bytes, bit for bit; our reader returns the reference's
+    tensors."""
+    import os
+    z = np.load(os.path.join(golden_dir, "ply.npz"))
+    t = lambda k: torch.tensor(z[f"{tag}_in_{k}"])
+    seg = t("seg_feature") if f"{tag}_in_seg_feature" in z else None
+    crop = torch.tensor(z[f"{tag}_crop"]) if f"{tag}_crop" in z else None
+    path = str(tmp_path / "point_cloud.ply")
+    ply_io.save_ply(path, t("xyz"), t("f_dc"), t("f_rest"), t("opacity"), t("scaling"), t("rotation"), seg, crop_mask=crop)
+    names = [str(n) for n in z[f"{tag}_names"]]
+    body = z[f"{tag}_body"].tobytes()
+    n = len(body) // (4 * len(names))
+    header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % n + "".join(f"property float {p}\n" for p in names) + "end_header\n"
+    assert open(path, "rb").read() == header.encode() + body
+    back = ply_io.load_ply(path, seg_feat_dim=(seg.shape[1] if seg is not None else None))
+    for k, got in (("xyz", back.xyz), ("f_dc", back.features_dc), ("f_rest", back.features_rest), ("opacity", back.opacity_logit),
+                   ("scaling", back.log_scale), ("rotation", back.rot)):
+        np.testing.assert_array_equal(got.numpy(), z[f"{tag}_loaded_{k}"], err_msg=k)
+    if seg is not None:
+        np.testing.assert_array_equal(back.seg_feature.numpy(), z[f"{tag}_loaded_seg_feature"])
