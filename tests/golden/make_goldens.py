@@ -524,6 +524,34 @@ with CpuMode():
         traceback.print_exc()
         print("ply golden skipped:", repr(e))
 
+    # ------------------------------------------------------------------ tracer consumer (spatial_track/modules/init_tracker.py:16-47)
+    try:
+        import spatial_track.modules.init_tracker as _trk
+
+        gen = torch.Generator().manual_seed(99)
+        H, W, P, K = 40, 56, 3000, 20000
+        seg = torch.randint(0, 7, (H, W), generator=gen)
+        seg[seg == 6] = 5
+        seg[0, :3] = 6                                 # a mask with fewer than 50 distinct Gaussians: dropped (:40-41)
+        grp = torch.stack([torch.randint(0, P, (K,), generator=gen), torch.randint(0, H * W, (K,), generator=gen)], 1).int()
+        _saved_render = _trk.render
+        _trk.render = lambda view, gaussian, pipe, bg: {"gau_related_pixels": grp.long()}
+        try:
+            view = types.SimpleNamespace(segmap=seg)
+            gaussian = types.SimpleNamespace(pipelineparams=None)
+            info, frame_ids = _trk.get_segmap_gaussians(gaussian, view)
+        finally:
+            _trk.render = _saved_render
+        keys = sorted(int(k) for k in info)
+        out = {"segmap": seg, "gau_related_pixels": grp, "mask_ids": np.array(keys), "frame_ids": np.array(sorted(frame_ids))}
+        for k in keys:
+            out[f"mask_{k}"] = np.array(sorted(info[k]))
+        save("tracker.npz", **out)
+    except Exception as e:  # pragma: no cover
+        import traceback
+        traceback.print_exc()
+        print("tracker golden skipped:", repr(e))
+
     # ------------------------------------------------------------------ COLMAP sparse model
     try:
         import tempfile

@@ -51,3 +51,15 @@ def test_losses_match_reference_golden(golden_dir):
     assert abs(float(l1.detach()) - float(z["l1"])) < 1e-6
     assert abs(float(ss.detach()) - float(z["ssim"])) < 1e-5
     np.testing.assert_allclose(a.grad.numpy(), z["grad"], rtol=1e-3, atol=1e-8)
+
+
+def test_segmap_gaussians_matches_the_reference_function(golden_dir):
+    """tests/golden/tracker.npz: the reference's own ``get_segmap_gaussians`` (spatial_track/modules/init_tracker.py:16-47),
+    imported in the build container and run around a render() that returns a seeded tracer list - its mask -> Gaussian sets
+    (the < 50 threshold, mask 0 dropped) and the frame's Gaussian ids."""
+    z = np.load(os.path.join(golden_dir, "tracker.npz"))
+    info, frame = segmap_gaussians(torch.tensor(z["gau_related_pixels"]), torch.tensor(z["segmap"]), 50)
+    assert sorted(info.keys()) == z["mask_ids"].tolist()
+    for k in info:
+        assert info[k].tolist() == z[f"mask_{k}"].tolist()
+    assert frame.tolist() == z["frame_ids"].tolist()
