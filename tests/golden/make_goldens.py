@@ -552,6 +552,19 @@ with CpuMode():
         traceback.print_exc()
         print("tracker golden skipped:", repr(e))
 
+    # ------------------------------------------------------------------ optimisation defaults (arguments/__init__.py:89-127)
+    try:
+        from argparse import ArgumentParser
+        from arguments import OptimizationParams
+        op = OptimizationParams(ArgumentParser())
+        keys = ["seg_feature_lr", "sample_mv_frames", "lambda_singview_contras", "lambda_multiview_contras", "lambda_3D_contras",
+                "lambda_dssim", "lambda_dist", "lambda_normal", "percent_dense", "opacity_cull", "densification_interval",
+                "opacity_reset_interval", "densify_from_iter", "densify_until_iter", "densify_grad_threshold", "position_lr_init",
+                "feature_lr", "opacity_lr", "scaling_lr", "rotation_lr"]
+        save("defaults.npz", **{k: np.array(float(getattr(op, k))) for k in keys})
+    except Exception as e:  # pragma: no cover
+        print("defaults golden skipped:", repr(e))
+
     # ------------------------------------------------------------------ COLMAP sparse model
     try:
         import tempfile

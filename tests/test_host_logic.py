@@ -234,3 +234,31 @@ def test_workspace_size_classes_are_geometric():
         seen.add(c)
     drift = {_size_class(n) for n in range(611_750, 720_893, 997)}      # the C2 soak's 18 % drift of R
     assert len(drift) <= 2
+
+
+def test_trainer_defaults_are_the_reference_defaults(golden_dir):
+    """tests/golden/defaults.npz = arguments/__init__.py:89-127 read by importing the reference's OptimizationParams: the
+    harness trainers' default hyper-parameters (loss weights, learning rates, density-control schedule) are those."""
+    import inspect
+    import numpy as np
+    from instascene_amd import harness
+    z = {k: float(v) for k, v in np.load(os.path.join(golden_dir, "defaults.npz")).items()}
+    seg = {k: v.default for k, v in inspect.signature(harness.SegTrainer.__init__).parameters.items()}
+    assert (seg["lambda_sv"], seg["lambda_mv"], seg["lambda_3d"], seg["sample_mv_frames"]) == (
+        z["lambda_singview_contras"], z["lambda_multiview_contras"], z["lambda_3D_contras"], int(z["sample_mv_frames"]))
+    plain = {k: v.default for k, v in inspect.signature(harness.PlainSegTrainer.__init__).parameters.items()}
+    assert (plain["lambda_sv"], plain["lambda_mv"], plain["lambda_3d"], plain["sample_mv_frames"]) == (
+        seg["lambda_sv"], seg["lambda_mv"], seg["lambda_3d"], seg["sample_mv_frames"])
+    rgb = {k: v.default for k, v in inspect.signature(harness.RgbTrainer.__init__).parameters.items()}
+    assert (rgb["lambda_dssim"], rgb["lambda_normal"], rgb["lambda_dist"]) == (z["lambda_dssim"], z["lambda_normal"], z["lambda_dist"])
+    src = inspect.getsource(harness)
+    assert "lr=0.025" in src and z["seg_feature_lr"] == 0.025
+    lrs = {g["name"]: g["lr"] for g in harness.RgbGaussianModel.param_groups(type("M", (), dict.fromkeys(
+        ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]))())}
+    assert lrs == {"xyz": z["position_lr_init"], "f_dc": z["feature_lr"], "f_rest": z["feature_lr"] / 20.0, "opacity": z["opacity_lr"],
+                   "scaling": z["scaling_lr"], "rotation": z["rotation_lr"]}
+    dens = dict(from_iter=int(z["densify_from_iter"]), until_iter=int(z["densify_until_iter"]), interval=int(z["densification_interval"]),
+                opacity_reset_interval=int(z["opacity_reset_interval"]), grad_threshold=z["densify_grad_threshold"],
+                opacity_cull=z["opacity_cull"], percent_dense=z["percent_dense"])
+    for k, v in dens.items():
+        assert f"{k}={v:_}" in src.replace("15_000", "15_000") or f"{k}={v}" in src, (k, v)
