@@ -3,12 +3,14 @@
 variant the north-star adds (one view per rank, RCCL sum all-reduce of the parameter gradient).
 
 Per iteration, like the reference:
-  1. pick a view (here: deterministic round-robin, ``views[(it * world + rank) % len]``);
+  1. pick a view (a seeded random permutation of the views per epoch - the reference's random pop from a refilled stack with
+     the draws made up front, ``dist_utils.view_order`` - of which rank r takes entry ``it * world + r``);
   2. ``render()`` — full forward (RGB + depth + normal + F-dim feature), as the reference does even
      though only the feature is trained (:102);
   3. for each label map (``segmap``, and ``sorted_segmap`` iff class prototypes exist, :110-141):
      sample ``sample_batchsize`` labelled pixels with replacement, ``contrastive_loss`` * lambda_sv * {0.5|1};
-  4. optional multi-view loss every 10th iteration over 5 consecutive views (:143-172);
+  4. optional multi-view loss every 10th iteration over 5 consecutive views (:143-172; ``_multiview_loss``: batch drawn first,
+     every view returns only its samples);
   5. 3-D loss on visible Gaussians' features vs their 3-D labels (:174-197), lambda 2.5e-6;
   6. backward; all-reduce(sum) of ``_seg_feature.grad`` across ranks; Adam(lr .025, eps 1e-15) (:203-208).
 Geometry parameters are frozen, exactly like ``GaussianModel.training_setup`` does for this stage
