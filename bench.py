@@ -271,7 +271,7 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
             V = int((pkg["radii"] > 0).sum().item())
             R = int(rasterizer.LAST_NUM_RENDERED)
             rasterizer.set_async_binning(was)
-        cull_tests, pairs_eval, pairs_blend, lane_pairs, pairs_mergeable = (int(v) for v in counters.tolist()[:5])
+        cull_tests, pairs_eval, pairs_blend, lane_pairs, pairs_mergeable, sub_blocks = (int(v) for v in counters.tolist()[:6])
         P, N, F = cfg["P"], cfg["W"] * cfg["H"], (cfg["F"] if args.step in ("seg", "plain") else 0)
         tiles = ((cfg["W"] + 15) // 16) * ((cfg["H"] + 15) // 16)
         bm = byte_model(P, V, R, N, F, tiles)
@@ -329,6 +329,8 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
                 "consecutive_pairs_with_disjoint_pixel_bounds": pairs_mergeable, "pixel_splat_pairs_evaluated": 64 * pairs_eval,
                 "pixel_splat_pairs_contributing": lane_pairs,
                 "lane_utilisation_of_blending_pairs": round(lane_pairs / max(1, 64 * pairs_blend), 4),
+                "blending_4x4_sub_blocks_per_blending_pair": round(sub_blocks / max(1, pairs_blend), 4),
+                "lane_utilisation_at_4x4_granularity": round(lane_pairs / max(1, 16 * sub_blocks), 4),
                 "flop_model": "SURVEY 8(d): 40 flop per evaluated (pixel, splat) pair + 2*(3+7+F) per contributing pair",
                 "flops": int(flops_eval), "flops_upper_bound_256R": int(flops_model),
                 "TFLOP/s": round(tf, 2), "peak_TFLOP/s": VALU_PEAK_TFLOPS, "frac": round(tf / VALU_PEAK_TFLOPS, 4),

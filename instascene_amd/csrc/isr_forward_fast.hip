@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
     f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
     float w_pend = 0.0f, f_pend = 0.0f;
     bool pending = false;                    // wave-uniform
-    unsigned st_cull = 0, st_eval = 0, st_blend = 0, st_lanes = 0, st_merge = 0;      // STATS only
+    unsigned st_cull = 0, st_eval = 0, st_blend = 0, st_lanes = 0, st_merge = 0, st_sub = 0;      // STATS only
     bool st_skip_next = false;
     const float mscale = FAR_N / (FAR_N - NEAR_N);
     // The distortion map  sum_i w_i (m_i^2 A_i - 2 m_i M1_i + M2_i)  (A, M1, M2: the sums over the splats in front of i) is
@@ -217,7 +217,14 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                 m_done |= m_stop;
                 const unsigned long long m_ok = m_pass & ~m_stop;
                 if (m_ok == 0ull) continue;
-                if (STATS) { st_blend++; st_lanes += (unsigned)__popcll(m_ok); }
+                if (STATS) {
+                    st_blend++;
+                    st_lanes += (unsigned)__popcll(m_ok);
+                    // how many of the block's four 4x4 sub-blocks hold a blending pixel (what a finer decomposition would visit)
+                    const int sub = ((lyi >> 2) & 1) * 2 + ((lxi >> 2) & 1);
+                    const bool okl = (m_ok >> lane) & 1ull;
+                    for (int k = 0; k < 4; k++) st_sub += __ballot(okl && sub == k) != 0ull ? 1u : 0u;
+                }
                 float w_lane = 0.0f;
                 if (__builtin_amdgcn_inverse_ballot_w64(m_ok)) {
                     const float w = alpha * T;
@@ -285,6 +292,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
             atomicAdd(stats + 2, (unsigned long long)st_blend);
             atomicAdd(stats + 3, (unsigned long long)st_lanes);
             atomicAdd(stats + 4, (unsigned long long)st_merge);
+            atomicAdd(stats + 5, (unsigned long long)st_sub);
         }
     }
     if (!AUX && inside && first_pass) {
