@@ -123,9 +123,10 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
     const uint32_t* __restrict__ point_offsets,
     const Rect16* __restrict__ rects, float* __restrict__ partial, uint8_t* __restrict__ row_flags,
     const uint8_t* __restrict__ tile_mode, int row_stride, int geom_off, int feat_off, int64_t capacity) {
-    // staged record: Tu Tv Tw | centre normal | opacity skip; FAST adds the affine form of the intersection
-    // (A.xyz, cx - X0 | B.xyz, cy - Y0 | C.xyz, det: isr_fast_pair.hpp) - the pair is evaluated exactly as k_render_fwd_fast did
-    constexpr int RS = Math::fast ? 28 : 16;
+    // staged record, EXACT: Tu Tv Tw | centre normal | opacity skip.  FAST: the affine form of the intersection first
+    // (A.xyz, cx - X0 | B.xyz, cy - Y0 | C.xyz, det | Tw.z, opacity, skip: isr_fast_pair.hpp - the pair is evaluated exactly as
+    // k_render_fwd_fast did), and only for the geometry gradient also Tu Tv Tw | normal
+    constexpr int RS = (Math::fast && GEOM) ? 28 : 16;
     constexpr int SB = 128;                 // (id, cull box) pairs staged per barrier round: two 64-bit hit masks per wave
     constexpr int PART = (GEOM ? GEOM_ROW : 0) + (FEAT ? 32 : 0);   // floats per instance per wave in LDS
     __shared__ __attribute__((aligned(16))) float s_rec[BB * RS];      // records of the current sub-batch (hit instances only)
@@ -352,12 +353,15 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
                 const float opa = d.z;
                 const float skip = fast_skip(opa);
                 float4* s4 = reinterpret_cast<float4*>(s_rec + t * RS);
-                s4[0] = a; s4[1] = b; s4[2] = c; s4[3] = make_float4(d.x, d.y, opa, skip);
                 if constexpr (Math::fast) {
                     const FastSplat fs = fast_splat({a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, (float)(tx * TILE), (float)(ty * TILE));
-                    s4[4] = make_float4(fs.A.x, fs.A.y, fs.A.z, c.y - (float)(tx * TILE));
-                    s4[5] = make_float4(fs.B.x, fs.B.y, fs.B.z, c.z - (float)(ty * TILE));
-                    s4[6] = make_float4(fs.C.x, fs.C.y, fs.C.z, fs.det);
+                    s4[0] = make_float4(fs.A.x, fs.A.y, fs.A.z, c.y - (float)(tx * TILE));
+                    s4[1] = make_float4(fs.B.x, fs.B.y, fs.B.z, c.z - (float)(ty * TILE));
+                    s4[2] = make_float4(fs.C.x, fs.C.y, fs.C.z, fs.det);
+                    s4[3] = make_float4(c.x, opa, skip, 0.0f);
+                    if constexpr (GEOM) { s4[4] = a; s4[5] = b; s4[6] = make_float4(c.w, d.x, d.y, 0.0f); }
+                } else {
+                    s4[0] = a; s4[1] = b; s4[2] = c; s4[3] = make_float4(d.x, d.y, opa, skip);
                 }
                 reinterpret_cast<float4*>(s_rgb)[t] = make_float4(d.w, e.x, e.y, 0.0f);
                 const Rect16 rc = rects[id];
@@ -385,19 +389,24 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
                     bool act = lane_live && contributor < last_contributor;
                     float G = 0, alpha = 0, sx = 0, sy = 0, c_d = 0, rho3d = 0, rho2d = 0, dx = 0, dy = 0;
                     F3 kk = {0, 0, 0}, ll = {0, 0, 0}, p = {0, 0, 1};
-                    const float4 a = reinterpret_cast<const float4*>(s_rec + j * RS)[0];
-                    const float4 b = reinterpret_cast<const float4*>(s_rec + j * RS)[1];
-                    const float4 c = reinterpret_cast<const float4*>(s_rec + j * RS)[2];
-                    const float4 d = reinterpret_cast<const float4*>(s_rec + j * RS)[3];
-                    const F3 Tw = {b.z, b.w, c.x};
+                    const float4* sj = reinterpret_cast<const float4*>(s_rec + j * RS);
+                    float4 a = make_float4(0, 0, 0, 0), b = a, c = a, d = a;        // the EXACT record's four quads (d.z = opacity)
+                    F3 Tw = {0, 0, 1};
+                    float nx = 0, ny = 0, nz = 0;
                     if constexpr (Math::fast) {
                         // the forward's own evaluation of the pair (isr_fast_pair.hpp): same decisions, bit for bit
-                        const float4 qa = reinterpret_cast<const float4*>(s_rec + j * RS)[4];
-                        const float4 qb = reinterpret_cast<const float4*>(s_rec + j * RS)[5];
-                        const float4 qc = reinterpret_cast<const float4*>(s_rec + j * RS)[6];
+                        const float4 qa = sj[0], qb = sj[1], qc = sj[2], qd = sj[3];
+                        d.z = qd.y;
+                        Tw.z = qd.x;
+                        if constexpr (GEOM) {
+                            a = sj[4]; b = sj[5];
+                            const float4 qn = sj[6];
+                            Tw = {b.z, b.w, qd.x};
+                            nx = qn.x; ny = qn.y; nz = qn.z;
+                        }
                         const FastRay fr = fast_ray(lxf, lyf, qa.x, qa.y, qa.z, qb.x, qb.y, qb.z, qc.x, qc.y, qc.z, qa.w, qb.w);
-                        const FastHit fh = fast_hit(fr, qc.w, Tw.z, d.z);
-                        act = act && fast_near(fr, d.w) && fast_pass(fh);
+                        const FastHit fh = fast_hit(fr, qc.w, qd.x, qd.y);
+                        act = act && fast_near(fr, qd.z) && fast_pass(fh);
                         p = {fr.p_x, fr.p_y, fr.p_z};
                         dx = fr.dx; dy = fr.dy; rho2d = fr.rho2d; rho3d = fr.rho3d; sx = fr.sx; sy = fr.sy;
                         c_d = fh.depth; G = fh.G; alpha = fh.alpha;
@@ -407,6 +416,9 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
                             ll = {Math::msub(pyf, Tw.x, Tv.x), Math::msub(pyf, Tw.y, Tv.y), Math::msub(pyf, Tw.z, Tv.z)};
                         }
                     } else {
+                    a = sj[0]; b = sj[1]; c = sj[2]; d = sj[3];
+                    Tw = {b.z, b.w, c.x};
+                    nx = c.w; ny = d.x; nz = d.y;
                     if (act) {
                         const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y};
                         kk = {Math::msub(pxf, Tw.x, Tu.x), Math::msub(pxf, Tw.y, Tu.y), Math::msub(pxf, Tw.z, Tu.z)};
@@ -466,7 +478,6 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
                                 const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
                                 dL_dz += dL_dmd * dmd_dd;
                             }
-                            const float nx = c.w, ny = d.x, nz = d.y;
                             float q = 0.0f;
                             if constexpr (QF > 0) {
                                 const float* fj = s_feat + j * QF;
