@@ -76,6 +76,9 @@ int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binni
                                bv.keys, bv.point_list, binning_capacity, wk > 64 ? wk * 64 : SORT_LDS_KEYS);
         } }
         ISR_LAUNCH_CHECK("k_tile_sort");
+        { ProfScope ps_("k_pack_hits", s);
+        hipLaunchKernelGGL(k_pack_hits, dim3(T), dim3(256), 0, s, gx, binning_capacity, iv.tile_offset, bv.point_list, g.cull, bv.box4, bv.hit_mask); }
+        ISR_LAUNCH_CHECK("k_pack_hits");
     }
     return ISR_OK;
 }

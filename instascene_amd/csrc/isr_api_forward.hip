@@ -90,7 +90,7 @@ size_t isr_profile_summary(char* buf, size_t len) {
 
 size_t isr_geom_bytes(int P) { return geom_bytes(P < 1 ? 1 : P); }
 size_t isr_image_bytes(int width, int height) { return image_bytes(width, height); }
-size_t isr_binning_bytes(int64_t num_rendered, int, int) { return bin_bytes(num_rendered); }
+size_t isr_binning_bytes(int64_t num_rendered, int width, int height) { return bin_bytes(num_rendered, tiles_x(width) * tiles_y(height)); }
 
 int isr_forward_prepare(int P, int D, int M, int width, int height, const float* means3D, const float* shs,
                         const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,

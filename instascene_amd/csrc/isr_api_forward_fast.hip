@@ -15,7 +15,30 @@ int launch_render_fwd_fast(int tiles, hipStream_t s, int W, int H, int ED, int g
     g_fwd_counters = nullptr;
     static const int order_below = [] { const char* e = getenv("ISR_FWD_ORDER_BELOW"); return e ? atoi(e) : 4096; }();
     const uint32_t* order = tiles < order_below ? iv.tile_order : nullptr;
+    static const int per_block = [] { const char* e = getenv("ISR_FWD_WAVE"); return e ? atoi(e) : 1; }();
     int ch = 0, first = 1;
+    if (per_block) {
+        // k_render_fwd_fast_w: one wave per 8x8 block; the four blocks of a tile on one XCD (workgroup v -> XCD v % 8)
+        const int grid = (tiles + 7) / 8 * 32;
+        do {
+            ProfScope ps_("k_render_fwd", s);
+#define ISR_GW2(FEAT, STATS, AUX_, ORD)                                                                                       \
+    hipLaunchKernelGGL((k_render_fwd_fast_w<FEAT, STATS, AUX_, ORD>), dim3(grid), dim3(64), 0, s, W, H, ED, ch, first, gx, tiles, \
+                       iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,        \
+                       out_color, out_others, out_extra, tracer, tcap, tcount, bv.hit_mask, capacity, counters, order)
+#define ISR_GW(FEAT, STATS)                                                                                           \
+    do { if (aux) { if (order) ISR_GW2(FEAT, STATS, true, true); else ISR_GW2(FEAT, STATS, true, false); }            \
+         else { if (order) ISR_GW2(FEAT, STATS, false, true); else ISR_GW2(FEAT, STATS, false, false); } } while (0)
+            if (ED - ch <= 0) { if (counters) ISR_GW(false, true); else ISR_GW(false, false); }
+            else { if (counters) ISR_GW(true, true); else ISR_GW(true, false); }
+#undef ISR_GW2
+#undef ISR_GW
+            ISR_LAUNCH_CHECK("k_render_fwd_fast_w");
+            ch += MAX_FCHUNK;
+            first = 0;
+        } while (ch < ED);
+        return ISR_OK;
+    }
     do {
         ProfScope ps_("k_render_fwd", s);
 #define ISR_GO2(FEAT, STATS, AUX_, ORD)                                                                                   \

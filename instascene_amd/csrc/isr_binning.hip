@@ -528,4 +528,44 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
 }
 
 
+// After the sort: what the blend's four 8x8 blocks of a tile need to know about every list entry BEFORE touching its record.
+// Per 64-entry chunk of a tile's list and per block one 64-bit word - bit l: the entry's alpha >= 1/255 octagon (K1's cull
+// bounds) meets the block - so that a block's wave finds its hits with one scalar load per chunk instead of gathering 32
+// bytes per entry (four times per tile); and the tile-relative int8 box the backward kernels test (box4).
+// The float tests are the blend kernels' own (isr_forward_fast.hip), evaluated once here.
+__global__ __launch_bounds__(256) void k_pack_hits(int gx, int64_t capacity, const uint32_t* __restrict__ tile_offset,
+                                                   const uint32_t* __restrict__ point_list, const float* __restrict__ cull,
+                                                   uint32_t* __restrict__ box4, unsigned long long* __restrict__ hit_mask) {
+    const int tile = blockIdx.x;
+    const int64_t r0 = tile_offset[tile];
+    int64_t r1 = tile_offset[tile + 1];
+    if (r1 > capacity) r1 = capacity;
+    const int len = (int)(r1 - r0);
+    if (len <= 0) return;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float X0 = (float)((tile % gx) * TILE), Y0 = (float)((tile / gx) * TILE);
+    for (int c = wv; c * 64 < len; c += 4) {
+        const int i = c * 64 + lane;
+        bool h0 = false, h1 = false, h2 = false, h3 = false;
+        if (i < len) {
+            const int id = (int)point_list[r0 + i];
+            const float4 bb = reinterpret_cast<const float4*>(cull + (size_t)id * 8)[0];
+            const float4 dg = reinterpret_cast<const float4*>(cull + (size_t)id * 8)[1];
+            box4[r0 + i] = pack_box4(bb, X0, Y0);
+            const bool xa = !(bb.x > X0 + 7.0f) && !(bb.y < X0), xb = !(bb.x > X0 + 15.0f) && !(bb.y < X0 + 8.0f);
+            const bool ya = !(bb.z > Y0 + 7.0f) && !(bb.w < Y0), yb = !(bb.z > Y0 + 15.0f) && !(bb.w < Y0 + 8.0f);
+            auto diag = [&](float bx0, float by0) {
+                const float bx1 = bx0 + 7.0f, by1 = by0 + 7.0f;
+                return !(dg.x > bx1 + by1) && !(dg.y < bx0 + by0) && !(dg.z > bx1 - by0) && !(dg.w < bx0 - by1);
+            };
+            h0 = xa && ya && diag(X0, Y0);
+            h1 = xb && ya && diag(X0 + 8.0f, Y0);
+            h2 = xa && yb && diag(X0, Y0 + 8.0f);
+            h3 = xb && yb && diag(X0 + 8.0f, Y0 + 8.0f);
+        }
+        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+        if (lane < 4) hit_mask[hit_mask_word(r0, tile, c) + lane] = lane == 0 ? m0 : lane == 1 ? m1 : lane == 2 ? m2 : m3;
+    }
+}
+
 }  // namespace isr

@@ -57,8 +57,12 @@ struct ImageView {
 struct BinView {
     unsigned long long* keys;  // [R] (depth_bits << 32) | gaussian, bucketed by tile
     uint32_t* point_list;      // [R] sorted gaussian ids
-    uint32_t* box4;            // [R] per-instance cull box, tile-relative int8 (x_lo, x_hi, y_lo, y_hi), written by K8
+    uint32_t* box4;            // [R] per-instance cull box, tile-relative int8 (x_lo, x_hi, y_lo, y_hi), written by k_pack_hits
+    unsigned long long* hit_mask;   // [(R / 64 + tiles + 2), 4] per 64-instance chunk of a tile's list and 8x8 block of the tile:
+                                    // bit l = instance 64 c + l meets the block (k_pack_hits -> k_render_fwd_fast_w)
 };
+// chunk c of tile t (list start r0) owns the four words from here: distinct for every (t, c), monotone in t
+__host__ __device__ inline size_t hit_mask_word(int64_t r0, int tile, int chunk) { return ((size_t)(r0 >> 6) + (size_t)tile + (size_t)chunk) * 4; }
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -117,11 +121,12 @@ inline BinView bin_view(void* buf, int64_t R) {
     b.keys = carve<unsigned long long>(p, (size_t)(R > 0 ? R : 1));
     b.point_list = carve<uint32_t>(p, (size_t)(R > 0 ? R : 1));
     b.box4 = carve<uint32_t>(p, (size_t)(R > 0 ? R : 1));
+    b.hit_mask = carve<unsigned long long>(p, 0);           // to the end of the buffer (bin_bytes)
     return b;
 }
-inline size_t bin_bytes(int64_t R) {
+inline size_t bin_bytes(int64_t R, int tiles) {
     BinView b = bin_view((void*)0, R);
-    return (size_t)(b.box4 + (size_t)(R > 0 ? R : 1)) + 256;
+    return (size_t)(b.hit_mask + ((size_t)((R > 0 ? R : 1) >> 6) + (size_t)tiles + 2) * 4) + 256;
 }
 
 // ---------------------------------------------------------------------------

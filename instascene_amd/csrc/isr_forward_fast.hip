@@ -336,4 +336,310 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same blend with the four 8x8 blocks of a tile DECOUPLED: one wave = one workgroup = one 8x8 pixel block that culls,
+// stages and walks its own hit list.  In the tile-wide kernel above a wave spends 21 % of its life in workgroup barriers
+// (its block's hit count differs from its neighbours' in every 128-instance round) and 18 % in the staging phase between
+// them (cycle counters); here there is no barrier at all:
+//   scan:   64 tile instances per step, lane = instance: id, cull bounds (32 B gather), the block test; hits are appended
+//           (id, position in the tile's list) to a ring in LDS until 32 are pending or the list ends;
+//   stage:  lane = hit: record gather + the per-(tile, splat) precompute for HITS only (30 % of the instances);
+//   walk:   the staged hits in order - no hit-mask iteration, every visited splat meets the block.
+// A block stops scanning when its own 64 pixels are done, not when the tile's 256 are.  Workgroup v lands on XCD v % 8: the
+// four blocks of tile t are slots 4 (t / 8) .. + 3 of XCD t % 8, i.e. they share one L2 and are dispatched together.
+constexpr int FW_HITS = 32;         // hits staged per round
+constexpr int FW_RING = 128;        // pending (id, position) pairs
+
+template <bool FEAT, bool STATS, bool AUX, bool ORDER>
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(4, 4))) void k_render_fwd_fast_w(
+    int W, int H, int ED, int ch_base, int first_pass, int gx, int tiles, const uint32_t* __restrict__ tile_offset,
+    const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ cull,
+    const float* __restrict__ col_pre, const float* __restrict__ tm_pre, const float* __restrict__ extras,
+    const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+    float* __restrict__ out_others, float* __restrict__ out_extra, int32_t* __restrict__ tracer, long long tracer_cap,
+    int32_t* __restrict__ tracer_count, const unsigned long long* __restrict__ hit_mask, int64_t capacity,
+    unsigned long long* __restrict__ stats, const uint32_t* __restrict__ tile_order) {
+    constexpr int RS = FF_RS, FCH = 32, NH = FW_HITS;
+    __shared__ __attribute__((aligned(16))) float s_rec[NH * RS];
+    __shared__ __attribute__((aligned(16))) float s_feat[FEAT ? NH * FCH : 4];
+    __shared__ __attribute__((aligned(8))) int2 s_ring[FW_RING];
+    constexpr int WCAP = 128;
+    __shared__ int s_trace[2 * WCAP];
+    int wcnt = 0;
+
+    const int v = (int)blockIdx.x, kk = v >> 3;
+    const int slot = (kk >> 2) * 8 + (v & 7), sub = kk & 3;
+    if (slot >= tiles) return;
+    const int tile = ORDER ? (int)tile_order[slot] : slot;
+    const int tx = tile % gx, ty = tile / gx;
+    const int lane = threadIdx.x;
+    const int lxi = (sub & 1) * 8 + (lane & 7), lyi = (sub >> 1) * 8 + (lane >> 3);       // tile-relative pixel
+    const unsigned px = tx * TILE + lxi, py = ty * TILE + lyi;
+    const bool inside = px < (unsigned)W && py < (unsigned)H;
+    const size_t N = (size_t)W * H;
+    const size_t pix = (size_t)W * py + px;
+    const float lx = (float)lxi, ly = (float)lyi;
+    const float X0 = (float)(tx * TILE), Y0 = (float)(ty * TILE);
+
+    const int64_t r0 = tile_offset[tile];
+    int64_t r1 = tile_offset[tile + 1];
+    if (r1 > capacity) r1 = capacity;
+    const int len = (int)(r1 - r0);
+    const int nfeat = FEAT ? min(FCH, ED - ch_base) : 0;
+
+    unsigned long long m_done = __ballot(!inside);
+    float T = 1.0f;
+    unsigned last_contributor = 0, median_contributor = 0;
+    float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, D = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
+    f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
+    float w_pend = 0.0f, f_pend = 0.0f;
+    bool pending = false;
+    unsigned st_cull = 0, st_eval = 0, st_blend = 0, st_lanes = 0, st_sub = 0;
+    const float mscale = FAR_N / (FAR_N - NEAR_N);
+    // the distortion moments are kept relative to m_ref, the mapped depth of the TILE's nearest splat (as in the tile-wide kernel:
+    // every block of a tile uses the same shift, and the two kernels produce the same bits)
+    float m_ref = 0.9f, mshift = mscale - 0.9f;
+    if (AUX && len > 0) {
+        const int id0 = (int)point_list[r0];
+        const float z0 = tm_pre != nullptr ? tm_pre[9 * (size_t)id0 + 8] : rec[(size_t)id0 * REC + 8];
+        const float mr = fminf(1.0f, fmaxf(0.0f, mscale - mscale * NEAR_N * __builtin_amdgcn_rcpf(z0)));
+        m_ref = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mr)));
+        mshift = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mscale - mr)));
+    }
+    const size_t mask0 = hit_mask_word(r0, tile, 0) + (size_t)sub;
+
+    auto flush_trace = [&]() {
+        const int n = wcnt;
+        if (n > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int gb = 0;
+            if (lane == 0) gb = atomicAdd(tracer_count, n) + 1;        // counter starts at -1
+            gb = __builtin_amdgcn_readfirstlane(gb);
+            for (int e = lane; e < n; e += 64)
+                if (gb + e < tracer_cap)
+                    *reinterpret_cast<int2*>(tracer + 2 * (size_t)(gb + e)) = make_int2(s_trace[2 * e], s_trace[2 * e + 1]);
+            __builtin_amdgcn_wave_barrier();
+            wcnt = 0;
+        }
+    };
+
+    int scan = 0, head = 0, pend = 0;                 // wave-uniform
+    int nid = lane < len ? (int)point_list[r0 + lane] : 0;
+    while (true) {
+        // ---- scan: append this block's hits among the next instances of the tile's list (k_pack_hits' word per chunk and block)
+#pragma clang loop unroll(disable)
+        while (pend < NH && scan < len) {
+            const unsigned long long m = hit_mask[mask0 + (size_t)(scan >> 6) * 4];
+            const int i = scan + lane;
+            const int id = nid;
+            if (i + 64 < len) nid = (int)point_list[r0 + i + 64];
+            if ((m >> lane) & 1ull) {
+                const int at = pend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                s_ring[(head + at) & (FW_RING - 1)] = make_int2(id, i + 1);
+            }
+            pend += __popcll(m);
+            if (STATS) st_cull += (unsigned)min(64, len - scan);
+            scan += 64;
+        }
+        if (pend == 0) break;
+        const int nh = min(pend, NH);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- stage: lane = hit
+        if (lane < nh) {
+            const int2 hp = s_ring[(head + lane) & (FW_RING - 1)];
+            const int id = hp.x;
+            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
+            float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3], e = r4[4];
+            if (tm_pre != nullptr) {
+                const float* tp = tm_pre + 9 * (size_t)id;
+                a = make_float4(tp[0], tp[1], tp[2], tp[3]);
+                b = make_float4(tp[4], tp[5], tp[6], tp[7]);
+                c.x = tp[8];
+            }
+            if (col_pre != nullptr) {
+                d.w = col_pre[3 * (size_t)id]; e.x = col_pre[3 * (size_t)id + 1]; e.y = col_pre[3 * (size_t)id + 2];
+            }
+            const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y}, Tw = {b.z, b.w, c.x};
+            const float opa = d.z;
+            const float skip = fast_skip(opa);
+            const FastSplat fs = fast_splat(Tu, Tv, Tw, X0, Y0);
+            float4* s4 = reinterpret_cast<float4*>(s_rec + lane * RS);
+            s4[0] = make_float4(fs.A.x, fs.A.y, fs.A.z, c.y - X0);
+            s4[1] = make_float4(fs.B.x, fs.B.y, fs.B.z, c.z - Y0);
+            s4[2] = make_float4(fs.C.x, fs.C.y, fs.C.z, skip);
+            s4[3] = make_float4(fs.det, Tw.z, opa, __builtin_amdgcn_rcpf(fs.det));
+            s4[4] = make_float4(__builtin_amdgcn_rcpf(Tw.z), c.w, d.x, d.y);
+            s4[5] = make_float4(d.w, e.x, e.y, __int_as_float(hp.y));          // .w: position in the tile's list (1-based)
+        }
+        if (FEAT) {
+            if ((ED & 3) == 0 && nfeat == FCH) {
+                // NH * 8 float4 over 64 lanes: four requests in flight per lane, then the four LDS writes
+                float4 fv[NH * (FCH / 4) / 64];
+#pragma unroll
+                for (int k = 0; k < NH * (FCH / 4) / 64; k++) {
+                    const int e = lane + 64 * k;
+                    const int inst = e / (FCH / 4), part = e - inst * (FCH / 4);
+                    const int id = s_ring[(head + inst) & (FW_RING - 1)].x;           // (a stale ring entry beyond nh: a valid id, unused)
+                    fv[k] = e < nh * (FCH / 4) ? *reinterpret_cast<const float4*>(extras + (size_t)id * ED + ch_base + part * 4)
+                                               : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+#pragma unroll
+                for (int k = 0; k < NH * (FCH / 4) / 64; k++) {
+                    const int e = lane + 64 * k;
+                    if (e < nh * (FCH / 4)) reinterpret_cast<float4*>(s_feat)[e] = fv[k];
+                }
+            } else {                    // narrow or ragged chunk: zero-padded to 32 channels
+                for (int e = lane; e < nh * FCH; e += 64) {
+                    const int inst = e / FCH, c = e - inst * FCH;
+                    const int id = s_ring[(head + inst) & (FW_RING - 1)].x;
+                    s_feat[e] = c < nfeat ? extras[(size_t)id * ED + ch_base + c] : 0.0f;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- walk
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < nh && m_done != ~0ull; j++) {
+            if (STATS) st_eval++;
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const float4* q = reinterpret_cast<const float4*>(s_rec + j * RS);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+            v4f q3v = reinterpret_cast<const v4f*>(q)[3];
+            const FastRay fr = fast_ray(lx, ly, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, q0.w, q1.w);
+            const float p_z = fr.p_z;
+            float rho_pin = fr.rho;
+            asm volatile("" : "+v"(q3v), "+v"(rho_pin));          // q3 is requested with q0..q2, not after the first branch
+            const unsigned long long m_near = __ballot(rho_pin <= q2.w) & __ballot(p_z != 0.0f) & ~m_done;
+            if (m_near == 0ull) continue;
+            const float4 q3 = make_float4(q3v.x, q3v.y, q3v.z, q3v.w);
+            v4f q4e = reinterpret_cast<const v4f*>(q)[4], q5e = reinterpret_cast<const v4f*>(q)[5];
+            float f_early = FEAT ? s_feat[j * FCH + (lane & 31)] : 0.0f;
+            const FastHit fh = fast_hit(fr, q3.x, q3.y, q3.z);
+            const bool use3d = fh.use3d;
+            const float depth = fh.depth, alpha = fh.alpha;
+            float test_T = __builtin_fmaf(-T, alpha, T);
+            asm volatile("" : "+v"(q4e), "+v"(q5e), "+v"(f_early), "+v"(test_T));      // ... and the blend's operands before ITS branch
+            const unsigned long long m_pass = m_near & __ballot(!(depth < NEAR_N)) & __ballot(!(alpha < 1.0f / 255.0f));
+            const unsigned long long m_stop = m_pass & __ballot(test_T < 0.0001f);
+            m_done |= m_stop;
+            const unsigned long long m_ok = m_pass & ~m_stop;
+            if (m_ok == 0ull) continue;
+            if (STATS) {
+                st_blend++;
+                st_lanes += (unsigned)__popcll(m_ok);
+                const int sb = ((lyi >> 2) & 1) * 2 + ((lxi >> 2) & 1);
+                const bool okl = (m_ok >> lane) & 1ull;
+                for (int k = 0; k < 4; k++) st_sub += __ballot(okl && sb == k) != 0ull ? 1u : 0u;
+            }
+            float w_lane = 0.0f;
+            if (__builtin_amdgcn_inverse_ballot_w64(m_ok)) {
+                const float w = alpha * T;
+                w_lane = w;
+                const unsigned contributor = __float_as_uint(q5e.w);
+                if (AUX && first_pass) {
+                    const float inv_depth = use3d ? p_z * q3.w : q4e.x;
+                    const float m_ = __builtin_fmaf(-(mscale * NEAR_N), inv_depth, mshift);      // m - m_ref
+                    const float mw = m_ * w;
+                    D = __builtin_fmaf(depth, w, D);
+                    M1 += mw;
+                    M2 = __builtin_fmaf(m_, mw, M2);
+                    if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }
+                    N0 = __builtin_fmaf(q4e.y, w, N0); N1 = __builtin_fmaf(q4e.z, w, N1); N2 = __builtin_fmaf(q4e.w, w, N2);
+                    C0 = __builtin_fmaf(q5e.x, w, C0); C1 = __builtin_fmaf(q5e.y, w, C1); C2 = __builtin_fmaf(q5e.z, w, C2);
+                }
+                T = test_T;
+                last_contributor = contributor;
+            }
+            if (AUX && tracer != nullptr && first_pass) {
+                const unsigned long long m_tr = __ballot(w_lane >= 0.1f);     // (double)w > 0.1  <=>  w >= 0.1f
+                if (m_tr != 0ull) {
+                    if (w_lane >= 0.1f) {
+                        const int slot_ = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_tr >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((unsigned)m_tr, 0u));
+                        int* dst = s_trace + 2 * slot_;
+                        dst[0] = s_ring[(head + j) & (FW_RING - 1)].x;
+                        dst[1] = (int)pix;
+                    }
+                    wcnt += __popcll(m_tr);
+                    if (wcnt > WCAP - 64) flush_trace();
+                }
+            }
+            if constexpr (FEAT) {
+                const float f_lane = f_early;
+                if (!pending) { w_pend = w_lane; f_pend = f_lane; pending = true; }
+                else {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(w_pend), __float_as_uint(w_lane), false, false);
+                    const float a = lane < 32 ? f_pend : f_lane;
+                    accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[0]), accA, 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[1]), accB, 0, 0, 0);
+                    pending = false;
+                }
+            }
+        }
+        if (m_done == ~0ull) break;
+        head = (head + nh) & (FW_RING - 1);
+        pend -= nh;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (FEAT) {
+        if (pending) {          // odd number of contributing splats: pair the last one with a zero
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(w_pend), 0u, false, false);
+            const float a = lane < 32 ? f_pend : 0.0f;
+            accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[0]), accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[1]), accB, 0, 0, 0);
+        }
+    }
+    if (AUX && tracer != nullptr && first_pass) flush_trace();
+    if (STATS) {
+        if (lane == 0 && first_pass) {
+            atomicAdd(stats + 0, (unsigned long long)st_cull);
+            atomicAdd(stats + 1, (unsigned long long)st_eval);
+            atomicAdd(stats + 2, (unsigned long long)st_blend);
+            atomicAdd(stats + 3, (unsigned long long)st_lanes);
+            atomicAdd(stats + 5, (unsigned long long)st_sub);
+        }
+    }
+    if (!AUX && inside && first_pass) {
+        final_T[pix] = T;
+        n_contrib[pix] = last_contributor;
+    }
+    if (AUX && inside && first_pass) {
+        const float A_ = 1.0f - T;
+        distortion = __builtin_fmaf(A_, M2, -(M1 * M1));
+        final_T[pix] = T;
+        final_T[pix + N] = __builtin_fmaf(m_ref, A_, M1);
+        final_T[pix + 2 * N] = __builtin_fmaf(m_ref, __builtin_fmaf(m_ref, A_, M1 + M1), M2);
+        n_contrib[pix] = last_contributor;
+        n_contrib[pix + N] = median_contributor;
+        out_color[pix] = __builtin_fmaf(T, bg[0], C0);
+        out_color[N + pix] = __builtin_fmaf(T, bg[1], C1);
+        out_color[2 * N + pix] = __builtin_fmaf(T, bg[2], C2);
+        out_others[pix] = D;
+        out_others[N + pix] = 1 - T;
+        out_others[2 * N + pix] = N0;
+        out_others[3 * N + pix] = N1;
+        out_others[4 * N + pix] = N2;
+        out_others[5 * N + pix] = median_depth;
+        out_others[6 * N + pix] = distortion;
+    }
+    if constexpr (FEAT) {
+#pragma unroll
+        for (int grp = 0; grp < 2; grp++) {
+            const int p = grp * 32 + (lane & 31);                       // pixel (wave lane numbering) held by this lane
+            const unsigned qx = tx * TILE + (sub & 1) * 8 + (p & 7), qy = ty * TILE + (sub >> 1) * 8 + (p >> 3);
+            if (qx < (unsigned)W && qy < (unsigned)H) {
+                const size_t qp = (size_t)W * qy + qx;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int ch = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (ch < nfeat) out_extra[(size_t)(ch_base + ch) * N + qp] = grp == 0 ? accA[r] : accB[r];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace isr
