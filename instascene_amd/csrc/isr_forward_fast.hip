@@ -363,7 +363,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     __shared__ __attribute__((aligned(16))) float s_rec[NH * RS];
     __shared__ __attribute__((aligned(16))) float s_feat[FEAT ? NH * FCH : 4];
     __shared__ __attribute__((aligned(8))) int2 s_ring[FW_RING];
-    constexpr int WCAP = 128;
+#ifndef ISR_WCAP
+#define ISR_WCAP 256
+#endif
+    constexpr int WCAP = ISR_WCAP;          // tracer pairs buffered per wave: one atomic on the list's counter per flush
     __shared__ int s_trace[2 * WCAP];
     int wcnt = 0;
 
