@@ -166,7 +166,10 @@ class SegTrainer:
         # backward and the bandwidth-bound tail)
         import os as _os
         self.draw_ahead = _os.environ.get("ISR_DRAW_AHEAD", "1") == "1"
-        self.prefetch_early = _os.environ.get("ISR_PREFETCH_EARLY", "1") == "1"     # measured: 2.092 -> 2.066 ms per C3 step
+        # ISR_PREFETCH_EARLY=1 / 0 select "early" / "after" (the two orders of rounds 2-3)
+        self.prefetch_distance = max(1, int(_os.environ.get("ISR_PREFETCH_DISTANCE", "2")))
+        _pe = _os.environ.get("ISR_PREFETCH_EARLY")
+        self.prefetch_mode = _os.environ.get("ISR_PREFETCH_MODE", "behind" if _pe is None else ("early" if _pe == "1" else "after"))
         self.high_priority_main = _os.environ.get("ISR_MAIN_PRIORITY", "1") == "1"     # measured: 2.03 -> 1.995 ms per C3 step
         self.sharded_tail = _os.environ.get("ISR_SHARDED_TAIL", "0") == "1"    # opt-in (unmeasured on hardware): _tail_sharded
         self.phase_timing = False    # multi-rank tail: record per-phase device times of each step into self.last_phases
@@ -403,14 +406,22 @@ class SegTrainer:
             pool = self.valid_idx[vi]
             pick = torch.randint(0, pool.numel(), (2 * self.batch,), device=self.device, generator=self.gen)
             pix = pool[pick]
-        if self.prefetch_early:
+        # When does the side stream's chain (the NEXT view's geometry pass + binning) become runnable?
+        #   "early"  before this forward is enqueued: its first kernels take the chip's LDS ahead of the blend
+        #   "behind" (default) as soon as the blend has been ENQUEUED - an event recorded before it, the side launches after
+        #            it: the blend's workgroups are placed first and the chain fills in at its tail and under the loss
+        #            kernels
+        #   "after"  when the blend has completed
+        mode = self.prefetch_mode
+        if mode == "early":
             self._prefetch_next(it)
+        gate = None
+        if mode == "behind" and self.prefetch and self.device.type == "cuda":
+            gate = torch.cuda.Event()
+            gate.record()
         pkg = render(cam, m, self.pipe, self.bg, sample_pixels=pix if self.sampled_path else None)
-        # the next view's geometry pass + binning: enqueued now (the host runs only slightly ahead of the GPU), on a side
-        # stream that waits for the forward just issued.  (Started together with the forward it slows the forward by more
-        # than it hides: measured.)
-        if not self.prefetch_early:
-            self._prefetch_next(it)
+        if mode != "early":
+            self._prefetch_next(it, after=gate)
         if merged and self.fused_sampling and self.draw_ahead:
             vn = self.view_index(it + 1)
             if self.valid_idx[vn].numel() > 0 and (self.l3d <= 0 or self.vis_pool.get(vn) is not None):
@@ -604,7 +615,7 @@ class SegTrainer:
                                 "optimizer_kernels_ms_per_range": [round(b.elapsed_time(c), 4) for _, b, c in marks],
                                 "tail_ms": round(t_begin.elapsed_time(t_end), 4)}
 
-    def _prefetch_next(self, it):
+    def _prefetch_next(self, it, after=None):
         """Software pipelining across iterations: the NEXT view's geometry pass and binning (K1, scans, key scatter, tile
         sort — atomic- and latency-bound kernels that read only frozen geometry and SH) are issued on a side stream that
         waits for this step's forward only, so they run next to this step's loss kernels (microseconds each), its backward
@@ -617,7 +628,16 @@ class SegTrainer:
             return
         if self._side is None:
             self._side = side_stream(self.device)
-        prefetch(self.cams[self.view_index(it + 1)], self.model, self.pipe, self.bg, stream=self._side)
+        # `prefetch_distance` views ahead (default 2): the chain of view it + 2 runs during step it and the first part of step
+        # it + 1, so the blend of step it + 1 never waits for a chain that started only when the previous blend ended (with
+        # distance 1 that chain - ~0.6 ms of kernels alone, 0.9 ms next to the loss kernels - is longer than the window
+        # between two blends and the main stream idles ~0.13 ms per step at C3: profiles/r03_timeline_C3_seg.txt)
+        hi = it + self.prefetch_distance
+        upto = getattr(self, "_prefetched_upto", it)
+        lo = upto + 1 if it <= upto <= hi else it + 1
+        for t in range(lo, hi + 1):
+            prefetch(self.cams[self.view_index(t)], self.model, self.pipe, self.bg, stream=self._side, after=after)
+        self._prefetched_upto = hi
 
 
 class PlainSegModel:

@@ -368,7 +368,7 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
                 done.record()
     # the entry keeps the converted inputs alive until it is consumed or dropped
     _PREFETCHED[sig] = _Prefetched(sig, _refs(originals), radii, geom, img, R, binning, done, inputs)
-    while len(_PREFETCHED) > 4:                 # entries nobody came for
+    while len(_PREFETCHED) > 8:                 # entries nobody came for
         old = _PREFETCHED.pop(next(iter(_PREFETCHED)))
         _PENDING.pop(old.geom.data_ptr(), None)
     return True
