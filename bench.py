@@ -50,6 +50,7 @@ def byte_model(P, V, R, N, F, tiles):
         "k_preprocess": 12 * P + 220 * V + 92 * V + 20 * P + 32 * V,         # xyz; scale/rot/opacity/SH in; record, rect, counts, radii, cull out
         "k_scatter": 16 * V + 8 * R,
         "k_tile_sort": 12 * R,
+        "k_pack_hits": R * (4 + 32 + 4) + R // 2,                           # id + K1's bounds in; box4 + the per-chunk hit masks out
         "k_feature_rows_step": 8 * P + 7 * 4 * F * P,                        # mask/offsets + x, m, v in; x, m, v, z out (+ flagged rows)
         "k_preprocess_bwd": 340 * V + 252 * P,
         "pp_maps": (28 + 44) * N,
@@ -315,7 +316,9 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
                 "launches_per_step": kern[dom]["launches_per_view"],
                 "hbm": {"bytes": int(dom_bytes), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 5),
                         "frac_of_measured_copy_peak_6290": round(gbs / 6290.0, 5)},
-                "note": "the blend kernels are VALU / LDS issue-bound, not HBM-bound (SURVEY 8d): see `valu`",
+                "note": "the blend kernel is bound neither by HBM nor by vector throughput: one wave per 8x8 block walks its hit "
+                        "list serially (~1 000 cycles per splat at 4 waves per SIMD, ~880 alone) and spends ~30 % of its life "
+                        "waiting for the record / feature gathers of the next 32 hits (DESIGN 9.11); `valu` is the work model",
                 "timing": timing, "kernels": kern,
                 "workload": {"P": P, "V": V, "R": R, "N": N, "F": F, "tiles": tiles}}
         if dom == "k_render_fwd" and pairs_eval:
@@ -326,7 +329,7 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
             roof["valu"] = {
                 "wave_splat_cull_tests": cull_tests, "wave_splat_pairs_evaluated": pairs_eval,
                 "wave_splat_pairs_blending": pairs_blend,
-                "consecutive_pairs_with_disjoint_pixel_bounds": pairs_mergeable, "pixel_splat_pairs_evaluated": 64 * pairs_eval,
+                "pixel_splat_pairs_evaluated": 64 * pairs_eval,
                 "pixel_splat_pairs_contributing": lane_pairs,
                 "lane_utilisation_of_blending_pairs": round(lane_pairs / max(1, 64 * pairs_blend), 4),
                 "blending_4x4_sub_blocks_per_blending_pair": round(sub_blocks / max(1, pairs_blend), 4),
@@ -548,8 +551,9 @@ def main():
                                               "the next view's geometry pass + binning on one side stream",
                           "view_order": "a seeded random permutation of the 16 ring cameras per epoch (dist_utils.view_order) = the "
                                         "reference's random pop from a refilled stack (train_semantic.py:96-100) with the draws made up "
-                                        "front: the next view is known one step early, so its geometry pass + binning are issued on a "
-                                        "side stream during the current step",
+                                        "front: the coming views are known ahead, so the geometry pass + binning of the view TWO steps "
+                                        "ahead are issued on a side stream during the current step (SegTrainer.prefetch_distance; every "
+                                        "step still runs one full chain - the main stream just never waits for it)",
                           "hoisted_out_of_the_timed_region": (
                               ["activations of the frozen parameters (exp / sigmoid / normalize, SH concat): evaluated once",
                                "per-view pools of labelled pixels and of visible labelled Gaussians, the cameras' ray tables, each "
