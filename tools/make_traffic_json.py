@@ -9,7 +9,7 @@ tag = sys.argv[2] if len(sys.argv) > 2 else os.path.basename(d.rstrip("/"))
 out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `python bench.py --config C --step S --steps 3 "
                  f"--warmup 2 --submodes ''` (tools/refresh_profiles.sh {tag}); bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024; "
                  f"raw counters: profiles/{tag}_pmc_FETCH_SIZE_*.txt, profiles/{tag}_pmc_WRITE_SIZE_*.txt"}
-short = {"k_render_fwd_fast": "k_render_fwd", "k_render_fwd": "k_render_fwd", "k_render_bwd_geo": "k_render_bwd",
+short = {"k_render_fwd_fast_w": "k_render_fwd", "k_render_fwd_fast": "k_render_fwd", "k_render_fwd": "k_render_fwd", "k_pack_hits": "k_pack_hits", "k_render_bwd_geo": "k_render_bwd",
          "k_render_bwd_sparse": "k_render_bwd_sparse", "k_render_bwd": "k_render_bwd", "k_preprocess_bwd": "k_preprocess_bwd",
          "k_preprocess": "k_preprocess", "k_scatter": "k_scatter", "k_tile_sort": "k_tile_sort", "k_tile_sort_wave": "k_tile_sort_wave",
          "k_feature_rows_step": "k_feature_rows_step", "gaussian_adam_kernel": "gaussian_adam_kernel", "ssim_fwd": "ssim_fwd",
@@ -35,7 +35,7 @@ for cfg, step in (("C3", "seg"), ("C2", "rgb"), ("C5", "seg")):
             # several template instances share a key (the STATS-instrumented k_render_fwd_fast<.., true, ..> runs once per bench
             # for the work counters): the record is the instance that was launched most often, i.e. the production kernel
             n = int(m.group(2))
-            if re.match(r"k_render_fwd_fast<\w+, true", full):
+            if re.match(r"k_render_fwd_fast(_w)?<\w+, true", full):
                 continue
             if n >= seen.get((key, k), 0):
                 seen[(key, k)] = n

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collect the evidence kept under profiles/ (round 3): the default bench line (with all sub_records), rocprofv3 kernel
+# Collect the evidence kept under profiles/ (round 3; rerun after the forward blend was re-decomposed: TAG r03b): the default bench line (with all sub_records), rocprofv3 kernel
 # stats + per-step trace of the headline and of C2 rgb / C5 seg / the multi-view step, PMC traffic passes (FETCH_SIZE /
 # WRITE_SIZE, each alone; --pmc with --kernel-trace only), the blend kernels' issue counters, kernels timed alone.
 # Usage (on the GPU box, from the repo root):  bash tools/refresh_profiles.sh TAG  -> gpurun_out/prof_TAG/ ; then
