@@ -1735,7 +1735,7 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
         ProfScope ps_("k_render_bwd", s);
         hipLaunchKernelGGL(k_render_bwd_geo, dim3(T * 4), dim3(64), 0, s, W, H, gx, iv.tile_offset, bv.point_list, bv.box4, g.rec,
                            col_pre, tm_pre, bg, iv.final_T, iv.n_contrib, dC, dO, g.point_offsets, g.rect, partial, flags, stride,
-                           geom_off, R, geo_heavy_first() ? iv.tile_order : (const uint32_t*)nullptr);
+                           geom_off, R, geo_heavy_first() ? iv.tile_order : (const uint32_t*)nullptr, bv.hit_mask);
         ISR_CHECK_LAUNCH_B("k_render_bwd_geo");
     } else if (R > 0) {
         if (hipMemsetAsync(flags, 0, (size_t)R * npass, s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
     const float* __restrict__ tm_pre, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dC, const float* __restrict__ dO,
     const uint32_t* __restrict__ point_offsets, const Rect16* __restrict__ rects, float* __restrict__ partial,
-    uint8_t* __restrict__ row_flags, int row_stride, int geom_off, int64_t capacity, const uint32_t* __restrict__ tile_order) {
+    uint8_t* __restrict__ row_flags, int row_stride, int geom_off, int64_t capacity, const uint32_t* __restrict__ tile_order,
+    const unsigned long long* __restrict__ hit_mask) {
     __shared__ __attribute__((aligned(16))) float s_pix[64 * 16];
     __shared__ int s_q[GEO_QCAP];
 
@@ -104,10 +105,10 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
                 const int i = seg_hi - 1 - (64 * u + lane);
                 bool hit = false;
                 if (i >= seg_lo) {
-                    const unsigned bx = box4[r0 + i];
-                    const int xl = (int)(signed char)(bx & 255u), xh = (int)(signed char)((bx >> 8) & 255u);
-                    const int yl = (int)(signed char)((bx >> 16) & 255u), yh = (int)(signed char)(bx >> 24);
-                    hit = xl <= bxo + 7 && xh >= bxo && yl <= byo + 7 && yh >= byo;
+                    // k_pack_hits' word for the entry's 64-chunk and this block: the bounding OCTAGON of the alpha >= 1/255 region
+                    // against the block (the packed box alone keeps ~1/6 more entries; each costs a lane in a 64-pixel loop)
+                    const unsigned long long m = hit_mask[hit_mask_word(r0, tile, i >> 6) + blk];
+                    hit = (m >> (i & 63)) & 1ull;
                 }
                 const unsigned long long b = __ballot(hit);
                 if (hit) s_q[n_q + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))] = i;
