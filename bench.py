@@ -283,7 +283,8 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
             e = {"ms_per_launch": round(ms, 4), "launches_per_view": round(cnt / float(extra_steps), 2)}
             if key in bm:
                 # a launch of a blend kernel covers one 32-channel chunk of one view; every other kernel one view
-                per_launch = bm[key] / (max(1, (F + 31) // 32) if key in ("k_render_fwd", "k_render_bwd_dense") else 1)
+                # a view's bytes over the launches it took (blend kernels: one per 32-channel chunk, or per 64 in the wide pass)
+                per_launch = bm[key] / (max(1, int(round(cnt / float(extra_steps)))) if key in ("k_render_fwd", "k_render_bwd_dense") else 1)
                 e["algorithmic_bytes"] = int(per_launch)
                 e["GB/s"] = round(per_launch / (ms * 1e-3) / 1e9, 1)
                 e["frac_hbm"] = round(per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -297,7 +298,7 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
             kern[dom]["ms_per_launch"] = round(dom_ms, 4)
             timing = "HIP events on the launch stream: %s over the timed region, the other kernels over %d extra untimed steps" % (dom, extra_steps)
         dom_key = "k_render_bwd_dense" if (dom == "k_render_bwd" and args.step in ("rgb", "plain")) else dom
-        launches = max(1, (F + 31) // 32) if dom_key in ("k_render_fwd", "k_render_bwd_dense") else 1
+        launches = max(1, int(round(kern[dom]["launches_per_view"]))) if dom_key in ("k_render_fwd", "k_render_bwd_dense") else 1
         dom_bytes = bm.get(dom_key, 0) / launches
         gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic, tsrc = None, None

@@ -22,21 +22,25 @@ int launch_render_fwd_fast(int tiles, hipStream_t s, int W, int H, int ED, int g
     if (per_block) {
         // k_render_fwd_fast_w: one wave per 8x8 block; the four blocks of a tile on one XCD (workgroup v -> XCD v % 8)
         const int grid = (tiles + 7) / 8 * 32;
+        static const bool wide_ok = [] { const char* e = getenv("ISR_FWD_WIDE"); return !(e && e[0] == '0'); }();
         do {
             ProfScope ps_("k_render_fwd", s);
-#define ISR_GW2(FEAT, STATS, AUX_, ORD)                                                                                       \
-    hipLaunchKernelGGL((k_render_fwd_fast_w<FEAT, STATS, AUX_, ORD>), dim3(grid), dim3(64), 0, s, W, H, ED, ch, first, gx, tiles, \
+#define ISR_GW2(FEAT, STATS, AUX_, ORD, NC_)                                                                                       \
+    hipLaunchKernelGGL((k_render_fwd_fast_w<FEAT, STATS, AUX_, ORD, NC_>), dim3(grid), dim3(64), 0, s, W, H, ED, ch, first, gx, tiles, \
                        iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,        \
                        out_color, out_others, out_extra, tracer, tcap, tcount, bv.hit_mask, capacity, counters, order)
-#define ISR_GW(FEAT, STATS)                                                                                           \
-    do { if (aux) { if (order) ISR_GW2(FEAT, STATS, true, true); else ISR_GW2(FEAT, STATS, true, false); }            \
-         else { if (order) ISR_GW2(FEAT, STATS, false, true); else ISR_GW2(FEAT, STATS, false, false); } } while (0)
-            if (ED - ch <= 0) { if (counters) ISR_GW(false, true); else ISR_GW(false, false); }
-            else { if (counters) ISR_GW(true, true); else ISR_GW(true, false); }
+#define ISR_GW(FEAT, STATS, NC_)                                                                                           \
+    do { if (aux) { if (order) ISR_GW2(FEAT, STATS, true, true, NC_); else ISR_GW2(FEAT, STATS, true, false, NC_); }            \
+         else { if (order) ISR_GW2(FEAT, STATS, false, true, NC_); else ISR_GW2(FEAT, STATS, false, false, NC_); } } while (0)
+            // 64 channels per pass while at least 64 remain (and the rows are float4-aligned): section 9.11
+            const bool wide = wide_ok && ED - ch >= 64 && (ED & 3) == 0;
+            if (ED - ch <= 0) { if (counters) ISR_GW(false, true, 1); else ISR_GW(false, false, 1); }
+            else if (wide) { if (counters) ISR_GW(true, true, 2); else ISR_GW(true, false, 2); }
+            else { if (counters) ISR_GW(true, true, 1); else ISR_GW(true, false, 1); }
 #undef ISR_GW2
 #undef ISR_GW
             ISR_LAUNCH_CHECK("k_render_fwd_fast_w");
-            ch += MAX_FCHUNK;
+            ch += wide ? 2 * MAX_FCHUNK : MAX_FCHUNK;
             first = 0;
         } while (ch < ED);
         return ISR_OK;

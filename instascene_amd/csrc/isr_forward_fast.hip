@@ -350,8 +350,10 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
 constexpr int FW_HITS = 32;         // hits staged per round
 constexpr int FW_RING = 128;        // pending (id, position) pairs
 
-template <bool FEAT, bool STATS, bool AUX, bool ORDER>
-__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(4, 4))) void k_render_fwd_fast_w(
+// NC = 32-channel chunks of the feature blended per pass: 1 (four waves per SIMD), or 2 for F >= 64 - two more accumulator
+// tiles and 8 KB of feature rows per wave cost the fourth wave (+27 % per pass), one pass instead of two is still 0.7x.
+template <bool FEAT, bool STATS, bool AUX, bool ORDER, int NC>
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(NC == 1 ? 4 : 3, NC == 1 ? 4 : 3))) void k_render_fwd_fast_w(
     int W, int H, int ED, int ch_base, int first_pass, int gx, int tiles, const uint32_t* __restrict__ tile_offset,
     const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ cull,
     const float* __restrict__ col_pre, const float* __restrict__ tm_pre, const float* __restrict__ extras,
@@ -359,7 +361,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     float* __restrict__ out_others, float* __restrict__ out_extra, int32_t* __restrict__ tracer, long long tracer_cap,
     int32_t* __restrict__ tracer_count, const unsigned long long* __restrict__ hit_mask, int64_t capacity,
     unsigned long long* __restrict__ stats, const uint32_t* __restrict__ tile_order) {
-    constexpr int RS = FF_RS, FCH = 32, NH = FW_HITS;
+#ifndef ISR_FW_HITS2
+#define ISR_FW_HITS2 24
+#endif
+    constexpr int RS = FF_RS, FCH = 32 * NC, NH = NC == 1 ? FW_HITS : ISR_FW_HITS2;      // (64 channels: 24 hits per round = 11.25 KB of LDS per wave; 16 / 24 / 32: 1.10 / 1.05 / 1.21 ms at C5)
     __shared__ __attribute__((aligned(16))) float s_rec[NH * RS];
     __shared__ __attribute__((aligned(16))) float s_feat[FEAT ? NH * FCH : 4];
     __shared__ __attribute__((aligned(8))) int2 s_ring[FW_RING];
@@ -394,8 +399,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     float T = 1.0f;
     unsigned last_contributor = 0, median_contributor = 0;
     float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, D = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
-    f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
-    float w_pend = 0.0f, f_pend = 0.0f;
+    f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA, accC = accA, accD = accA;     // C, D: NC == 2
+    float w_pend = 0.0f, f_pend = 0.0f, f_pend2 = 0.0f;
     bool pending = false;
     unsigned st_cull = 0, st_eval = 0, st_blend = 0, st_lanes = 0, st_sub = 0;
     const float mscale = FAR_N / (FAR_N - NEAR_N);
@@ -520,10 +525,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             const float4 q3 = make_float4(q3v.x, q3v.y, q3v.z, q3v.w);
             v4f q4e = reinterpret_cast<const v4f*>(q)[4], q5e = reinterpret_cast<const v4f*>(q)[5];
             float f_early = FEAT ? s_feat[j * FCH + (lane & 31)] : 0.0f;
+            float f_early2 = (FEAT && NC == 2) ? s_feat[j * FCH + 32 + (lane & 31)] : 0.0f;
             const FastHit fh = fast_hit(fr, q3.x, q3.y, q3.z);
             const bool use3d = fh.use3d;
             const float depth = fh.depth, alpha = fh.alpha;
             float test_T = __builtin_fmaf(-T, alpha, T);
+            if (NC == 2) asm volatile("" : "+v"(f_early2));
             asm volatile("" : "+v"(q4e), "+v"(q5e), "+v"(f_early), "+v"(test_T));      // ... and the blend's operands before ITS branch
             const unsigned long long m_pass = m_near & __ballot(!(depth < NEAR_N)) & __ballot(!(alpha < 1.0f / 255.0f));
             const unsigned long long m_stop = m_pass & __ballot(test_T < 0.0001f);
@@ -572,12 +579,17 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             }
             if constexpr (FEAT) {
                 const float f_lane = f_early;
-                if (!pending) { w_pend = w_lane; f_pend = f_lane; pending = true; }
+                if (!pending) { w_pend = w_lane; f_pend = f_lane; f_pend2 = f_early2; pending = true; }
                 else {
                     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(w_pend), __float_as_uint(w_lane), false, false);
                     const float a = lane < 32 ? f_pend : f_lane;
                     accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[0]), accA, 0, 0, 0);
                     accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[1]), accB, 0, 0, 0);
+                    if (NC == 2) {
+                        const float a2 = lane < 32 ? f_pend2 : f_early2;
+                        accC = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, __uint_as_float(sw[0]), accC, 0, 0, 0);
+                        accD = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, __uint_as_float(sw[1]), accD, 0, 0, 0);
+                    }
                     pending = false;
                 }
             }
@@ -593,6 +605,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             const float a = lane < 32 ? f_pend : 0.0f;
             accA = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[0]), accA, 0, 0, 0);
             accB = __builtin_amdgcn_mfma_f32_32x32x2f32(a, __uint_as_float(sw[1]), accB, 0, 0, 0);
+            if (NC == 2) {
+                const float a2 = lane < 32 ? f_pend2 : 0.0f;
+                accC = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, __uint_as_float(sw[0]), accC, 0, 0, 0);
+                accD = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, __uint_as_float(sw[1]), accD, 0, 0, 0);
+            }
         }
     }
     if (AUX && tracer != nullptr && first_pass) flush_trace();
@@ -639,6 +656,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                 for (int r = 0; r < 16; r++) {
                     const int ch = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (ch < nfeat) out_extra[(size_t)(ch_base + ch) * N + qp] = grp == 0 ? accA[r] : accB[r];
+                    if (NC == 2 && ch + 32 < nfeat) out_extra[(size_t)(ch_base + 32 + ch) * N + qp] = grp == 0 ? accC[r] : accD[r];
                 }
             }
         }
