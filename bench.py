@@ -455,6 +455,15 @@ def main():
         a = argparse.Namespace(**vars(args))
         for k, v in over.items():
             setattr(a, k, v)
+        # every record starts from a compact allocator: what the previous record left cached or prefetched (C5-size states,
+        # two views ahead) is dropped - the plain loop's empty_cache() variant otherwise pays for returning it
+        import gc
+        import torch
+        from instascene_amd import rasterizer as _rz
+        torch.cuda.synchronize()
+        _rz._PREFETCHED.clear()
+        gc.collect()
+        torch.cuda.empty_cache()
         try:
             r = run(a, mode or a.mode, rank, world, dev, detail=True, repeats=repeats)
         except Exception as e:       # the headline must still be printed

@@ -458,8 +458,15 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
         if (lane < nh) {
             const int2 hp = s_ring[(head + lane) & (FW_RING - 1)];
             const int id = hp.x;
-            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
-            float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3], e = r4[4];
+            typedef float v4f_ __attribute__((ext_vector_type(4)));
+            const v4f_* r4 = reinterpret_cast<const v4f_*>(rec + (size_t)id * REC);
+            v4f_ ra = r4[0], rb = r4[1], rc_ = r4[2], rd = r4[3], re = r4[4];
+            // five whole 16-byte requests (left alone the compiler trims the unused words and issues six: +2 % - what a staging
+            // wave waits for is the vector-memory path, ~2 500 cycles per instruction under load.  Three requests per lane with
+            // the record split over lanes l and l + 32 and v_permlane32_swap measured +1.5 % again.)
+            asm volatile("" : "+v"(ra), "+v"(rb), "+v"(rc_), "+v"(rd), "+v"(re));
+            float4 a = make_float4(ra.x, ra.y, ra.z, ra.w), b = make_float4(rb.x, rb.y, rb.z, rb.w), c = make_float4(rc_.x, rc_.y, rc_.z, rc_.w);
+            float4 d = make_float4(rd.x, rd.y, rd.z, rd.w), e = make_float4(re.x, re.y, re.z, re.w);
             if (tm_pre != nullptr) {
                 const float* tp = tm_pre + 9 * (size_t)id;
                 a = make_float4(tp[0], tp[1], tp[2], tp[3]);
