@@ -293,7 +293,7 @@ def _images_within_fast_tolerance(out, st, frac=1e-4, floor=2):
 
 
 @pytest.mark.parametrize("P,F,W,H,seed", [(1500, 16, 100, 70, 41), (3000, 32, 160, 112, 42), (2000, 0, 128, 96, 43),
-                                          (2500, 40, 96, 80, 44)])
+                                          (2500, 40, 96, 80, 44), (1200, 72, 96, 64, 46), (1000, 128, 80, 64, 47)])
 def test_fast_mode_keeps_the_reference_binning_bit_for_bit(P, F, W, H, seed):
     """The headline mode of bench.py: FAST arithmetic in the per-pixel loops (contracted FMAs, v_rcp / v_exp), the
     reference's tile rectangles.  radii, tiles_touched, point_list and ranges are bit-identical to the oracle's;
