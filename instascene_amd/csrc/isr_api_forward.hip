@@ -2,6 +2,7 @@
 // Host-side only: argument checking, workspace carving and kernel launches on the
 // caller's stream.  No torch types, no allocation, no hidden synchronisation except
 // where the header says so.
+#include <type_traits>
 #include "isr_host.hpp"
 #include "isr_forward.hip"    // the unit's kernels are defined before the entry points that launch them
 
@@ -18,6 +19,28 @@ static int launch_render_fwd(int tiles, hipStream_t s, int W, int H, int ED, int
                              int32_t* tracer, long long tcap, int32_t* tcount, int64_t capacity) {
     // first pass: geometry/colour/aux + the first feature chunk; further passes add 32 channels each
     int ch = 0, first = 1;
+    static const int per_block = [] { const char* e = getenv("ISR_FWD_WAVE"); return e ? atoi(e) : 1; }();
+    if (per_block && std::is_same<Math, ExactMath>::value) {
+        // k_render_fwd_w: one wave per 8x8 block (isr_forward_fast.hip's decomposition), longest lists first
+        const int grid = (tiles + 7) / 8 * 32;
+        do {
+            ProfScope ps_("k_render_fwd", s);
+            const int rem = ED - ch;
+#define ISR_GOW(F)                                                                                                    \
+    hipLaunchKernelGGL((k_render_fwd_w<F>), dim3(grid), dim3(64), 0, s, W, H, ED, ch, first, gx, tiles, iv.tile_offset,  \
+                       bv.point_list, rec, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib, out_color, out_others, \
+                       out_extra, tracer, tcap, tcount, bv.hit_mask, capacity, iv.tile_order)
+            if (rem <= 0) ISR_GOW(0);
+            else if (rem <= 8) ISR_GOW(8);
+            else if (rem <= 16) ISR_GOW(16);
+            else ISR_GOW(32);
+#undef ISR_GOW
+            ISR_LAUNCH_CHECK("k_render_fwd_w");
+            ch += MAX_FCHUNK;
+            first = 0;
+        } while (ch < ED);
+        return ISR_OK;
+    }
     do {
         ProfScope ps_("k_render_fwd", s);
         const int rem = ED - ch;

@@ -564,6 +564,247 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// K8 in EXACT arithmetic with the per-block decomposition of isr_forward_fast.hip (k_render_fwd_fast_w): one wave = one
+// workgroup = one 8x8 pixel block that finds its hits in k_pack_hits' masks, stages them (lane = hit) and walks them.  The
+// per-pixel arithmetic is k_render_fwd<ExactMath>'s, operation for operation (the reference's order): every output stays
+// bit-identical to the CPU oracle.  What changes is what a wave does NOT do any more: no workgroup barrier (the tile-wide
+// kernel's waves wait for each other three times per 128 instances), no staging of instances that miss the block, no
+// hit-mask iteration.
+template <int FCH>
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(4, 4))) void k_render_fwd_w(
+    int W, int H, int ED, int ch_base, int first_pass, int gx, int tiles, const uint32_t* __restrict__ tile_offset,
+    const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ col_pre,
+    const float* __restrict__ tm_pre, const float* __restrict__ extras, const float* __restrict__ bg,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_others,
+    float* __restrict__ out_extra, int32_t* __restrict__ tracer, long long tracer_cap, int32_t* __restrict__ tracer_count,
+    const unsigned long long* __restrict__ hit_mask, int64_t capacity, const uint32_t* __restrict__ tile_order) {
+    typedef ExactMath Math;
+    constexpr int RS = 20, NH = 32, RING = 128;     // staged floats per hit: Tu Tv Tw cx cy n opa skip | rgb position
+    __shared__ __attribute__((aligned(16))) float s_rec[NH * RS];
+    __shared__ __attribute__((aligned(16))) float s_feat[FCH > 0 ? NH * FCH : 4];
+    __shared__ __attribute__((aligned(8))) int2 s_ring[RING];
+    constexpr int WCAP = 256;          // tracer pairs buffered per wave (the list's one counter: isr_forward_fast.hip)
+    __shared__ int s_trace[2 * WCAP];
+    int wcnt = 0;
+
+    const int v = (int)blockIdx.x, kk = v >> 3;
+    const int slot = (kk >> 2) * 8 + (v & 7), sub = kk & 3;
+    if (slot >= tiles) return;
+    const int tile = tile_order != nullptr ? (int)tile_order[slot] : slot;
+    const int tx = tile % gx, ty = tile / gx;
+    const int lane = threadIdx.x;
+    const unsigned px = tx * TILE + (sub & 1) * 8 + (lane & 7), py = ty * TILE + (sub >> 1) * 8 + (lane >> 3);
+    const bool inside = px < (unsigned)W && py < (unsigned)H;
+    const size_t N = (size_t)W * H;
+    const size_t pix = (size_t)W * py + px;
+    const float pxf = (float)px, pyf = (float)py;
+    const int64_t r0 = tile_offset[tile];
+    int64_t r1 = tile_offset[tile + 1];
+    if (r1 > capacity) r1 = capacity;
+    const int len = (int)(r1 - r0);
+    const int nfeat = FCH > 0 ? min(FCH, ED - ch_base) : 0;
+    const size_t mask0 = hit_mask_word(r0, tile, 0) + (size_t)sub;
+
+    unsigned long long m_done = __ballot(!inside);
+    float T = 1.0f;
+    unsigned last_contributor = 0, median_contributor = 0;
+    float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, D = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
+    float E[FCH > 0 ? FCH : 1];
+#pragma unroll
+    for (int c = 0; c < (FCH > 0 ? FCH : 1); c++) E[c] = 0.0f;
+    const float mscale = FAR_N / (FAR_N - NEAR_N);
+
+    auto flush_trace = [&]() {
+        const int n = wcnt;
+        if (n > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int gb = 0;
+            if (lane == 0) gb = atomicAdd(tracer_count, n) + 1;        // counter starts at -1
+            gb = __builtin_amdgcn_readfirstlane(gb);
+            for (int e = lane; e < n; e += 64)
+                if (gb + e < tracer_cap)
+                    *reinterpret_cast<int2*>(tracer + 2 * (size_t)(gb + e)) = make_int2(s_trace[2 * e], s_trace[2 * e + 1]);
+            __builtin_amdgcn_wave_barrier();
+            wcnt = 0;
+        }
+    };
+
+    constexpr int QF4 = FCH > 0 ? FCH / 4 : 1;
+    int scan = 0, head = 0, pend = 0;
+    int nid = lane < len ? (int)point_list[r0 + lane] : 0;
+    while (true) {
+#pragma clang loop unroll(disable)
+        while (pend < NH && scan < len) {
+            const unsigned long long m = hit_mask[mask0 + (size_t)(scan >> 6) * 4];
+            const int i = scan + lane;
+            const int id = nid;
+            if (i + 64 < len) nid = (int)point_list[r0 + i + 64];
+            if ((m >> lane) & 1ull) {
+                const int at = pend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                s_ring[(head + at) & (RING - 1)] = make_int2(id, i + 1);
+            }
+            pend += __popcll(m);
+            scan += 64;
+        }
+        if (pend == 0) break;
+        const int nh = min(pend, NH);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nh) {
+            const int2 hp = s_ring[(head + lane) & (RING - 1)];
+            const int id = hp.x;
+            const float4* r4 = reinterpret_cast<const float4*>(rec + (size_t)id * REC);
+            float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3], e = r4[4];
+            if (tm_pre != nullptr) {
+                const float* tp = tm_pre + 9 * (size_t)id;
+                a = make_float4(tp[0], tp[1], tp[2], tp[3]);
+                b = make_float4(tp[4], tp[5], tp[6], tp[7]);
+                c.x = tp[8];
+            }
+            if (col_pre != nullptr) {
+                d.w = col_pre[3 * (size_t)id]; e.x = col_pre[3 * (size_t)id + 1]; e.y = col_pre[3 * (size_t)id + 2];
+            }
+            const float opa = d.z;
+            float skip = __builtin_inff();          // opa * exp(-rho / 2) < 1/255 for every rho > skip (1 % + 0.05 margin)
+            if (opa <= 1.0f) {
+                const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
+                skip = 2.0f * l * 1.01f + 0.05f;
+            }
+            float4* s4 = reinterpret_cast<float4*>(s_rec + lane * RS);
+            s4[0] = a;                                      // Tu.xyz Tv.x
+            s4[1] = b;                                      // Tv.yz Tw.xy
+            s4[2] = c;                                      // Tw.z cx cy nx
+            s4[3] = make_float4(d.x, d.y, opa, skip);       // ny nz opa skip
+            s4[4] = make_float4(d.w, e.x, e.y, __int_as_float(hp.y));      // rgb, position in the tile's list (1-based)
+        }
+        if (FCH > 0) {
+            if ((ED & 3) == 0 && nfeat == FCH) {
+                for (int e = lane; e < nh * QF4; e += 64) {
+                    const int inst = e / QF4, part = e - inst * QF4;
+                    const int id = s_ring[(head + inst) & (RING - 1)].x;
+                    reinterpret_cast<float4*>(s_feat)[e] = *reinterpret_cast<const float4*>(extras + (size_t)id * ED + ch_base + part * 4);
+                }
+            } else {
+                for (int e = lane; e < nh * FCH; e += 64) {
+                    const int inst = e / FCH, c = e - inst * FCH;
+                    const int id = s_ring[(head + inst) & (RING - 1)].x;
+                    s_feat[e] = c < nfeat ? extras[(size_t)id * ED + ch_base + c] : 0.0f;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma clang loop unroll(disable)
+        for (int j = 0; j < nh && m_done != ~0ull; j++) {
+            // Flat, predicated evaluation: a lane for which a test fails computes garbage that is never used - identical results
+            // to the reference's chain of `continue`s (forward.cu:356-393).
+            const float4 a = reinterpret_cast<const float4*>(s_rec + j * RS)[0];
+            const float4 b = reinterpret_cast<const float4*>(s_rec + j * RS)[1];
+            const float4 c = reinterpret_cast<const float4*>(s_rec + j * RS)[2];
+            const float4 d = reinterpret_cast<const float4*>(s_rec + j * RS)[3];
+            const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y}, Tw = {b.z, b.w, c.x};
+            const F3 kq = {Math::msub(pxf, Tw.x, Tu.x), Math::msub(pxf, Tw.y, Tu.y), Math::msub(pxf, Tw.z, Tu.z)};
+            const F3 lq = {Math::msub(pyf, Tw.x, Tv.x), Math::msub(pyf, Tw.y, Tv.y), Math::msub(pyf, Tw.z, Tv.z)};
+            const F3 p = {Math::msub(kq.y, lq.z, kq.z * lq.y), Math::msub(kq.z, lq.x, kq.x * lq.z), Math::msub(kq.x, lq.y, kq.y * lq.x)};
+            const float dx = c.y - pxf, dy = c.z - pyf;
+            const float rho2d = FILTER_INV_SQ * Math::mad(dy, dy, dx * dx);
+            const float skip = d.w;
+            const bool far_a = rho2d > skip, far_b = Math::mad(p.y, p.y, p.x * p.x) > skip * (p.z * p.z) * 1.01f;
+            const bool nz = p.z != 0.0f;
+            const unsigned long long m_cand = ~m_done & ~(__ballot(far_a) & __ballot(far_b)) & __ballot(nz);
+            if (m_cand == 0ull) continue;
+            const float sx = Math::div(p.x, p.z), sy = Math::div(p.y, p.z);
+            const float rho3d = Math::mad(sy, sy, sx * sx);
+            const float rho = fminf(rho3d, rho2d);
+            const float depth = (rho3d <= rho2d) ? Math::mad(sy, Tw.y, sx * Tw.x) + Tw.z : Tw.z;
+            const float power = -0.5f * rho;
+            const float alpha = fminf(0.99f, d.z * Math::ex(power));
+            const float test_T = T * (1 - alpha);
+            const bool t_near = !(depth < NEAR_N), t_pow = !(power > 0.0f), t_alpha = !(alpha < 1.0f / 255.0f);
+            const bool t_stop = test_T < 0.0001f;
+            const unsigned long long m_pass = m_cand & __ballot(t_near) & __ballot(t_pow) & __ballot(t_alpha);
+            const unsigned long long m_stop = m_pass & __ballot(t_stop);
+            m_done |= m_stop;
+            const unsigned long long m_ok = m_pass & ~m_stop;
+            if (m_ok == 0ull) continue;
+            const float4 col = reinterpret_cast<const float4*>(s_rec + j * RS)[4];
+            float w_lane = 0.0f;
+            if (__builtin_amdgcn_inverse_ballot_w64(m_ok)) {
+                const float w = alpha * T;
+                w_lane = w;
+                const unsigned contributor = __float_as_uint(col.w);
+                if (first_pass) {
+                    const float A = 1 - T;
+                    const float m_ = mscale * (1 - Math::div(NEAR_N, depth));
+                    distortion += (Math::mad(m_ * m_, A, M2) - 2 * m_ * M1) * w;
+                    D = Math::mad(depth, w, D);
+                    M1 = Math::mad(m_, w, M1);
+                    M2 = Math::mad(m_ * m_, w, M2);
+                    if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }
+                    N0 = Math::mad(c.w, w, N0); N1 = Math::mad(d.x, w, N1); N2 = Math::mad(d.y, w, N2);
+                    C0 = Math::mad(col.x, w, C0); C1 = Math::mad(col.y, w, C1); C2 = Math::mad(col.z, w, C2);
+                }
+                if (FCH > 0) {
+                    const float4* fj = reinterpret_cast<const float4*>(s_feat + j * FCH);
+#pragma unroll
+                    for (int q4 = 0; q4 < QF4; q4++) {
+                        const float4 vv = fj[q4];            // reference forward.cu:415 order: (e * alpha) * T
+                        E[4 * q4 + 0] += vv.x * alpha * T;
+                        E[4 * q4 + 1] += vv.y * alpha * T;
+                        E[4 * q4 + 2] += vv.z * alpha * T;
+                        E[4 * q4 + 3] += vv.w * alpha * T;
+                    }
+                }
+                T = test_T;
+                last_contributor = contributor;
+            }
+            if (tracer != nullptr && first_pass) {
+                const unsigned long long m_tr = __ballot(w_lane >= 0.1f);     // (double)w > 0.1  <=>  w >= 0.1f
+                if (m_tr != 0ull) {
+                    if (w_lane >= 0.1f) {
+                        const int at = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_tr >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_tr, 0u));
+                        s_trace[2 * at] = s_ring[(head + j) & (RING - 1)].x;
+                        s_trace[2 * at + 1] = (int)pix;
+                    }
+                    wcnt += __popcll(m_tr);
+                    if (wcnt > WCAP - 64) flush_trace();
+                }
+            }
+        }
+        if (m_done == ~0ull) break;
+        head = (head + nh) & (RING - 1);
+        pend -= nh;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (tracer != nullptr && first_pass) flush_trace();
+    if (inside) {
+        if (first_pass) {
+            final_T[pix] = T;
+            final_T[pix + N] = M1;
+            final_T[pix + 2 * N] = M2;
+            n_contrib[pix] = last_contributor;
+            n_contrib[pix + N] = median_contributor;
+            out_color[pix] = C0 + T * bg[0];
+            out_color[N + pix] = C1 + T * bg[1];
+            out_color[2 * N + pix] = C2 + T * bg[2];
+            out_others[pix] = D;
+            out_others[N + pix] = 1 - T;
+            out_others[2 * N + pix] = N0;
+            out_others[3 * N + pix] = N1;
+            out_others[4 * N + pix] = N2;
+            out_others[5 * N + pix] = median_depth;
+            out_others[6 * N + pix] = distortion;
+        }
+        if (FCH > 0) {
+#pragma unroll
+            for (int q = 0; q < FCH; q++)
+                if (q < nfeat) out_extra[(size_t)(ch_base + q) * N + pix] = E[q];
+        }
+    }
+}
+
 // explicit instantiations used by the host API (isr_api.hip)
 #define ISR_INST_FWD(M, F, B)                                                                                          \
     template __global__ void k_render_fwd<M, F, B>(int, int, int, int, int, int, const uint32_t*, const uint32_t*,     \
