@@ -860,29 +860,30 @@ import hashlib, math, sys, torch
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
 from helpers import small_scene
 from instascene_amd import rasterizer as rz
-from instascene_amd._lib import MODE_FAST
-for P, F, W, H, seed in ((3000, 32, 160, 112, 42), (2000, 0, 128, 96, 43), (2500, 40, 97, 83, 44), (60000, 32, 320, 200, 45)):
-    sc, cams, inp = small_scene(P=P, F=F, W=W, H=H, seed=seed, mu_s=math.log(0.05 if P < 10000 else 0.02))
-    e = torch.empty(0, device="cuda")
-    for cam in cams[:2]:
-        out = rz.rasterize_gaussians(torch.tensor([0.1, 0.2, 0.3], device="cuda"), inp["means3D"].cuda(), e, inp["opacities"].cuda(),
-                                     inp["scales"].cuda(), inp["rotations"].cuda(), 1.0, e, inp["extra"].cuda() if F else e, F,
-                                     cam.world_view_transform.cuda(), cam.full_proj_transform.cuda(), math.tan(cam.FoVx / 2),
-                                     math.tan(cam.FoVy / 2), H, W, inp["shs"].cuda(), 3, cam.camera_center.cuda(), False, False,
-                                     mode=MODE_FAST, tracer=True)
-        h = hashlib.sha256()
-        for t in (out[1], out[2], out[3], out[4]):          # colour, allmap, radii, feature map
-            h.update(t.detach().cpu().numpy().tobytes())
-        tr = out[8][: int(out[9]) + 1].detach().cpu().numpy()      # the tracer list: a SET of (gaussian, pixel) pairs
-        h.update(tr[(tr[:, 0].astype("int64") * (W * H) + tr[:, 1]).argsort()].tobytes())
-        print(h.hexdigest())
+from instascene_amd._lib import MODE_FAST, MODE_EXACT
+for mode in (MODE_FAST, MODE_EXACT):
+  for P, F, W, H, seed in ((3000, 32, 160, 112, 42), (2000, 0, 128, 96, 43), (2500, 40, 97, 83, 44), (60000, 32, 320, 200, 45)):
+      sc, cams, inp = small_scene(P=P, F=F, W=W, H=H, seed=seed, mu_s=math.log(0.05 if P < 10000 else 0.02))
+      e = torch.empty(0, device="cuda")
+      for cam in cams[:2]:
+          out = rz.rasterize_gaussians(torch.tensor([0.1, 0.2, 0.3], device="cuda"), inp["means3D"].cuda(), e, inp["opacities"].cuda(),
+                                       inp["scales"].cuda(), inp["rotations"].cuda(), 1.0, e, inp["extra"].cuda() if F else e, F,
+                                       cam.world_view_transform.cuda(), cam.full_proj_transform.cuda(), math.tan(cam.FoVx / 2),
+                                       math.tan(cam.FoVy / 2), H, W, inp["shs"].cuda(), 3, cam.camera_center.cuda(), False, False,
+                                       mode=mode, tracer=True)
+          h = hashlib.sha256()
+          for t in (out[1], out[2], out[3], out[4]):          # colour, allmap, radii, feature map
+              h.update(t.detach().cpu().numpy().tobytes())
+          tr = out[8][: int(out[9]) + 1].detach().cpu().numpy()      # the tracer list: a SET of (gaussian, pixel) pairs
+          h.update(tr[(tr[:, 0].astype("int64") * (W * H) + tr[:, 1]).argsort()].tobytes())
+          print(h.hexdigest())
 """
 
 
-def test_per_block_and_tile_wide_fast_blend_kernels_produce_the_same_bits(tmp_path):
-    """``k_render_fwd_fast_w`` (one wave per 8x8 block with its own hit list, hit masks from ``k_pack_hits``; the default) and
-    ``k_render_fwd_fast`` (the tile-wide kernel of rounds 2-3, ``ISR_FWD_WAVE=0``) share the pair arithmetic of
-    ``isr_fast_pair.hpp``: every map is bit-identical and the tracer lists are equal as sets.  The switch is read once per
+def test_per_block_and_tile_wide_blend_kernels_produce_the_same_bits(tmp_path):
+    """``k_render_fwd_fast_w`` / ``k_render_fwd_w`` (one wave per 8x8 block with its own hit list, hit masks from ``k_pack_hits``;
+    the default) and ``k_render_fwd_fast`` / ``k_render_fwd<ExactMath>`` (the tile-wide kernels of rounds 1-3, ``ISR_FWD_WAVE=0``)
+    share their pair arithmetic: every map is bit-identical and the tracer lists are equal as sets, in both arithmetic modes.  The switch is read once per
     process, hence two child processes."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -894,4 +895,4 @@ def test_per_block_and_tile_wide_fast_blend_kernels_produce_the_same_bits(tmp_pa
         r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if len(l) == 64])
-    assert len(outs[0]) == 8 and outs[0] == outs[1]
+    assert len(outs[0]) == 16 and outs[0] == outs[1]
