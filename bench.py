@@ -318,8 +318,8 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
                 "hbm": {"bytes": int(dom_bytes), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 5),
                         "frac_of_measured_copy_peak_6290": round(gbs / 6290.0, 5)},
                 "note": "the blend kernel is bound neither by HBM nor by vector throughput: one wave per 8x8 block walks its hit "
-                        "list serially (~1 000 cycles per splat at 4 waves per SIMD, ~880 alone) and spends ~30 % of its life "
-                        "waiting for the record / feature gathers of the next 32 hits (DESIGN 9.11); `valu` is the work model",
+                        "list serially (~830 cycles per splat at 4 waves per SIMD: 79 % of a wave's life; staging the next 32 hits 14 %, "
+                        "finding them 4 % - DESIGN 9.11); `valu` is the work model",
                 "timing": timing, "kernels": kern,
                 "workload": {"P": P, "V": V, "R": R, "N": N, "F": F, "tiles": tiles}}
         if dom == "k_render_fwd" and pairs_eval:
