@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
 // The same blend with the four 8x8 blocks of a tile DECOUPLED: one wave = one workgroup = one 8x8 pixel block that culls,
 // stages and walks its own hit list.  In the tile-wide kernel above a wave spends 21 % of its life in workgroup barriers
 // (its block's hit count differs from its neighbours' in every 128-instance round) and 18 % in the staging phase between
-// them (cycle counters, DESIGN 9.4); here there is no barrier at all:
+// them (cycle counters, DESIGN 9.11); here there is no barrier at all:
 //   scan:   64 tile instances per step, lane = instance: id, cull bounds (32 B gather), the block test; hits are appended
 //           (id, position in the tile's list) to a ring in LDS until 32 are pending or the list ends;
 //   stage:  lane = hit: record gather + the per-(tile, splat) precompute for HITS only (30 % of the instances);
@@ -461,9 +461,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             typedef float v4f_ __attribute__((ext_vector_type(4)));
             const v4f_* r4 = reinterpret_cast<const v4f_*>(rec + (size_t)id * REC);
             v4f_ ra = r4[0], rb = r4[1], rc_ = r4[2], rd = r4[3], re = r4[4];
-            // five whole 16-byte requests (left alone the compiler trims the unused words and issues six: +2 % - what a staging
-            // wave waits for is the vector-memory path, ~2 500 cycles per instruction under load.  Three requests per lane with
-            // the record split over lanes l and l + 32 and v_permlane32_swap measured +1.5 % again.)
+            // five whole 16-byte requests (left alone the compiler trims the unused words and issues six: +2 %.  Three requests
+            // per lane with the record split over lanes l and l + 32 and v_permlane32_swap measured +1.5 % again.)
             asm volatile("" : "+v"(ra), "+v"(rb), "+v"(rc_), "+v"(rd), "+v"(re));
             float4 a = make_float4(ra.x, ra.y, ra.z, ra.w), b = make_float4(rb.x, rb.y, rb.z, rb.w), c = make_float4(rc_.x, rc_.y, rc_.z, rc_.w);
             float4 d = make_float4(rd.x, rd.y, rd.z, rd.w), e = make_float4(re.x, re.y, re.z, re.w);
