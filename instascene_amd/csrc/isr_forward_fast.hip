@@ -522,11 +522,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             const float4* q = reinterpret_cast<const float4*>(s_rec + j * RS);
             const float4 q0 = q[0], q1 = q[1], q2 = q[2];
             v4f q3v = reinterpret_cast<const v4f*>(q)[3];
-            const FastRay fr = fast_ray(lx, ly, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, q0.w, q1.w);
+            FastRay fr = fast_ray(lx, ly, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, q0.w, q1.w);
             const float p_z = fr.p_z;
-            float rho_pin = fr.rho;
-            asm volatile("" : "+v"(q3v), "+v"(rho_pin));          // q3 is requested with q0..q2, not after the first branch
-            const unsigned long long m_near = __ballot(rho_pin <= q2.w) & __ballot(p_z != 0.0f) & ~m_done;
+            asm volatile("" : "+v"(q3v), "+v"(fr.rho));          // q3 is requested with q0..q2, not after the first branch
+            const unsigned long long m_near = __ballot(fr.rho <= q2.w) & __ballot(p_z != 0.0f) & ~m_done;
             if (m_near == 0ull) continue;
             const float4 q3 = make_float4(q3v.x, q3v.y, q3v.z, q3v.w);
             v4f q4e = reinterpret_cast<const v4f*>(q)[4], q5e = reinterpret_cast<const v4f*>(q)[5];
