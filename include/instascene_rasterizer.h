@@ -77,6 +77,8 @@ size_t isr_profile_summary(char* buf, size_t len);
  *      (reference: GeometryState / ImageState / BinningState, rasterizer_impl.h:29-65). */
 size_t isr_geom_bytes(int P);
 size_t isr_image_bytes(int width, int height);
+/* width / height: the image's (the binning workspace also holds one 64-bit hit mask per 64 list entries, tile and 8x8 block:
+ * its size depends on the number of tiles); the same num_rendered must be passed to every call that takes this workspace */
 size_t isr_binning_bytes(int64_t num_rendered, int width, int height);
 /* scratch for the deterministic (atomic-free) gradient reduction in isr_backward */
 size_t isr_backward_scratch_bytes(int64_t num_rendered, int ED, unsigned grad_mask);
