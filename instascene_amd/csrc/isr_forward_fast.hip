@@ -338,11 +338,12 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The same blend with the four 8x8 blocks of a tile DECOUPLED: one wave = one workgroup = one 8x8 pixel block that culls,
-// stages and walks its own hit list.  In the tile-wide kernel above a wave spends 21 % of its life in workgroup barriers
-// (its block's hit count differs from its neighbours' in every 128-instance round) and 18 % in the staging phase between
-// them (cycle counters); here there is no barrier at all:
-//   scan:   64 tile instances per step, lane = instance: id, cull bounds (32 B gather), the block test; hits are appended
-//           (id, position in the tile's list) to a ring in LDS until 32 are pending or the list ends;
+// stages and walks its own hit list.  In the tile-wide kernel above a wave waits in workgroup barriers (its block's hit count
+// differs from its neighbours' in every 128-instance round) and in the staging phase between them for about as long as it walks
+// hits (cycle counters); here there is no barrier at all:
+//   scan:   64 entries of the tile's list per step: k_pack_hits' 64-bit word for (chunk, block) says which of them meet the
+//           block (one scalar load; ids by one coalesced load); hits are appended (id, position in the tile's list) to a ring
+//           in LDS until 32 are pending or the list ends;
 //   stage:  lane = hit: record gather + the per-(tile, splat) precompute for HITS only (30 % of the instances);
 //   walk:   the staged hits in order - no hit-mask iteration, every visited splat meets the block.
 // A block stops scanning when its own 64 pixels are done, not when the tile's 256 are.  Workgroup v lands on XCD v % 8: the
