@@ -192,7 +192,7 @@ int isr_forward_render(int P, int ED, int width, int height, int mode, const flo
         return launch_render_fwd<ExactMath>(T, s, width, height, ED, gx, iv, bv, g.rec, g.cull, colors_precomp, transMat_precomp,
                                             extra_attrs, background, out_color, out_others, out_extra, tracer_pairs,
                                             (long long)tracer_capacity, tracer_count, binning_capacity);
-    return launch_render_fwd_fast(T, s, width, height, ED, gx, iv, bv, g.rec, g.cull, colors_precomp, transMat_precomp,
+    return launch_render_fwd_fast(P, T, s, width, height, ED, gx, iv, bv, g.rec, g.cull, colors_precomp, transMat_precomp,
                                   extra_attrs, background, out_color, out_others, out_extra, feature_only ? nullptr : tracer_pairs,
                                   (long long)tracer_capacity, tracer_count, binning_capacity, !feature_only);
 }

@@ -7,7 +7,7 @@ namespace isr {
 thread_local unsigned long long* g_fwd_counters = nullptr;    // isr_forward_set_counters: consumed by the next FAST forward
 
 // FAST arithmetic: k_render_fwd_fast (isr_forward_fast.hip), 32 feature channels per pass
-int launch_render_fwd_fast(int tiles, hipStream_t s, int W, int H, int ED, int gx, const ImageView& iv,
+int launch_render_fwd_fast(int P, int tiles, hipStream_t s, int W, int H, int ED, int gx, const ImageView& iv,
                                   const BinView& bv, const float* rec, const float* cull, const float* col_pre, const float* tm_pre,
                                   const float* extras, const float* bg, float* out_color, float* out_others, float* out_extra,
                                   int32_t* tracer, long long tcap, int32_t* tcount, int64_t capacity, bool aux) {
@@ -19,7 +19,7 @@ int launch_render_fwd_fast(int tiles, hipStream_t s, int W, int H, int ED, int g
     static const int order_below = [] { const char* e = getenv("ISR_FWD_ORDER_BELOW"); return e ? atoi(e) : 0; }();
     const uint32_t* order = tiles < (order_below > 0 ? order_below : per_block ? (1 << 30) : 4096) ? iv.tile_order : nullptr;
     int ch = 0, first = 1;
-    if (per_block) {
+    if (per_block && P <= (1 << 26)) {           // (the per-block kernel packs a tracer pair into 32 bits: 26 for the Gaussian)
         // k_render_fwd_fast_w: one wave per 8x8 block; the four blocks of a tile on one XCD (workgroup v -> XCD v % 8)
         const int grid = (tiles + 7) / 8 * 32;
         static const bool wide_ok = [] { const char* e = getenv("ISR_FWD_WIDE"); return !(e && e[0] == '0'); }();

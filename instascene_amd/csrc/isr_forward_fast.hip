@@ -370,10 +370,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     __shared__ __attribute__((aligned(16))) float s_feat[FEAT ? NH * FCH : 4];
     __shared__ __attribute__((aligned(8))) int2 s_ring[FW_RING];
 #ifndef ISR_WCAP
-#define ISR_WCAP 256
+#define ISR_WCAP 512
 #endif
-    constexpr int WCAP = ISR_WCAP;          // tracer pairs buffered per wave: one atomic on the list's counter per flush
-    __shared__ int s_trace[2 * WCAP];
+    // tracer pairs buffered per wave, ONE atomic on the list's counter per flush (that counter bounded the kernel while a wave
+    // flushed every 64 pairs: DESIGN 9.11).  A pair is packed into 32 bits - pixel of the block << 26 | gaussian (the launcher
+    // sends scenes of more than 2^26 Gaussians to the tile-wide kernel) - so 2 KB hold 512: a block has ~214, its wave flushes
+    // once, at its end, and that flush's atomic is issued BEFORE the output maps are stored and consumed after them.
+    constexpr int WCAP = ISR_WCAP;
+    __shared__ unsigned s_trace[WCAP];
     int wcnt = 0;
 
     const int v = (int)blockIdx.x, kk = v >> 3;
@@ -417,6 +421,16 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     }
     const size_t mask0 = hit_mask_word(r0, tile, 0) + (size_t)sub;
 
+    const int blk_x0 = tx * TILE + (sub & 1) * 8, blk_y0 = ty * TILE + (sub >> 1) * 8;
+    auto store_trace = [&](int gb, int n) {
+        for (int e = lane; e < n; e += 64)
+            if (gb + e < tracer_cap) {
+                const unsigned pk = s_trace[e];
+                const int p6 = (int)(pk >> 26);
+                *reinterpret_cast<int2*>(tracer + 2 * (size_t)(gb + e)) =
+                    make_int2((int)(pk & 0x3ffffffu), W * (blk_y0 + (p6 >> 3)) + blk_x0 + (p6 & 7));
+            }
+    };
     auto flush_trace = [&]() {
         const int n = wcnt;
         if (n > 0) {
@@ -425,9 +439,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             int gb = 0;
             if (lane == 0) gb = atomicAdd(tracer_count, n) + 1;        // counter starts at -1
             gb = __builtin_amdgcn_readfirstlane(gb);
-            for (int e = lane; e < n; e += 64)
-                if (gb + e < tracer_cap)
-                    *reinterpret_cast<int2*>(tracer + 2 * (size_t)(gb + e)) = make_int2(s_trace[2 * e], s_trace[2 * e + 1]);
+            store_trace(gb, n);
             __builtin_amdgcn_wave_barrier();
             wcnt = 0;
         }
@@ -575,9 +587,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                     if (w_lane >= 0.1f) {
                         const int slot_ = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_tr >> 32),
                                                        __builtin_amdgcn_mbcnt_lo((unsigned)m_tr, 0u));
-                        int* dst = s_trace + 2 * slot_;
-                        dst[0] = s_ring[(head + j) & (FW_RING - 1)].x;
-                        dst[1] = (int)pix;
+                        s_trace[slot_] = ((unsigned)lane << 26) | (unsigned)s_ring[(head + j) & (FW_RING - 1)].x;
                     }
                     wcnt += __popcll(m_tr);
                     if (wcnt > WCAP - 64) flush_trace();
@@ -618,7 +628,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             }
         }
     }
-    if (AUX && tracer != nullptr && first_pass) flush_trace();
+    // the last flush: its atomic goes out here, the output maps are stored while it is under way, the pairs follow at the end
+    int gb_last = 0;
+    const int n_last = (AUX && tracer != nullptr && first_pass) ? wcnt : 0;
+    if (n_last > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (lane == 0) gb_last = atomicAdd(tracer_count, n_last) + 1;
+    }
     if (STATS) {
         if (lane == 0 && first_pass) {
             atomicAdd(stats + 0, (unsigned long long)st_cull);
@@ -667,6 +683,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             }
         }
     }
+    if (n_last > 0) store_trace(__builtin_amdgcn_readfirstlane(gb_last), n_last);
 }
 
 }  // namespace isr

@@ -75,7 +75,7 @@ int launch_prepare_scans(int P, int T, const GeomView& g, const ImageView& iv, h
 
 // ---- isr_api_forward_fast.hip
 extern thread_local unsigned long long* g_fwd_counters;     // isr_forward_set_counters: consumed by the next FAST forward
-int launch_render_fwd_fast(int tiles, hipStream_t s, int W, int H, int ED, int gx, const ImageView& iv, const BinView& bv,
+int launch_render_fwd_fast(int P, int tiles, hipStream_t s, int W, int H, int ED, int gx, const ImageView& iv, const BinView& bv,
                            const float* rec, const float* cull, const float* col_pre, const float* tm_pre, const float* extras,
                            const float* bg, float* out_color, float* out_others, float* out_extra, int32_t* tracer,
                            long long tcap, int32_t* tcount, int64_t capacity, bool aux);
