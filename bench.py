@@ -503,14 +503,9 @@ def main():
             sub(m, mode=m, repeats=2, note=parity.get(m))
         if args.more and args.config == "C3" and args.step == "seg":
             # the other BASELINE configurations and the other loops, in the same process under the same clock
-            sub("soak_500", steps=500, warmup=5, note="the headline configuration, one block of 500 steps")
-            sub("C3_multiview", steps=40, warmup=10, multiview=True,
-                note="the reference's default step: the multi-view leg (5 more views rendered with gradients through the dense "
-                     "[F,H,W] feature map, train_semantic.py:143-172, lambda_multiview_contras = 1e-6) every 10th iteration; "
-                     "40 steps = 4 such iterations, ms_per_step is their mean")
-            sub("C2_rgb", config="C2", step="rgb", steps=200, warmup=10, note="BASELINE config 2: the train.py step")
-            sub("C3_rgb", config="C3", step="rgb", steps=50, warmup=5, note="the train.py step at C3 size")
-            sub("C5_seg", config="C5", step="seg", steps=50, warmup=5, note="BASELINE config 5 in its 1-GPU form (F = 64: two feature passes)")
+            # (the plain loop first: its empty_cache() variant returns and re-requests device memory every iteration, and how
+            # long the driver takes for that depends on what the process has allocated before - 17 ms per iteration in a fresh
+            # process, up to 90 ms after the C5-size records)
             plain_note = ("harness.PlainSegTrainer: the reference's iteration as the reference writes it (train_semantic.py:95-208) on "
                           "render() and contrastive_loss() alone, library defaults (blocking instance-count read, tracer on), "
                           "multi-view leg every 10th iteration, torch.optim.Adam; 30 steps = 3 multi-view iterations")
@@ -518,6 +513,14 @@ def main():
             sub("dropin_plain_exact", mode="exact", step="plain", steps=30, warmup=10, note=plain_note + "; ISR_MODE=exact")
             sub("dropin_plain_fast_empty_cache", mode="fast", step="plain", steps=30, warmup=10, empty_cache=True,
                 note=plain_note + "; plus torch.cuda.empty_cache() every iteration like the reference (:206)")
+            sub("soak_500", steps=500, warmup=5, note="the headline configuration, one block of 500 steps")
+            sub("C3_multiview", steps=40, warmup=10, multiview=True,
+                note="the reference's default step: the multi-view leg (5 more views rendered with gradients through the dense "
+                     "[F,H,W] feature map, train_semantic.py:143-172, lambda_multiview_contras = 1e-6) every 10th iteration; "
+                     "40 steps = 4 such iterations, ms_per_step is their mean")
+            sub("C2_rgb", config="C2", step="rgb", steps=200, warmup=10, note="BASELINE config 2: the train.py step")
+            sub("C3_rgb", config="C3", step="rgb", steps=50, warmup=5, note="the train.py step at C3 size")
+            sub("C5_seg", config="C5", step="seg", steps=50, warmup=5, note="BASELINE config 5 in its 1-GPU form (F = 64: one 64-channel feature pass)")
 
     if rank == 0:
         cfg = head.pop("cfg")
