@@ -512,7 +512,9 @@ def main():
             sub("dropin_plain_fast", mode="fast", step="plain", steps=30, warmup=10, note=plain_note + "; the drop-in's default mode")
             sub("dropin_plain_exact", mode="exact", step="plain", steps=30, warmup=10, note=plain_note + "; ISR_MODE=exact")
             sub("dropin_plain_fast_empty_cache", mode="fast", step="plain", steps=30, warmup=10, empty_cache=True,
-                note=plain_note + "; plus torch.cuda.empty_cache() every iteration like the reference (:206)")
+                note=plain_note + "; plus torch.cuda.empty_cache() every iteration like the reference (:206).  This record measures "
+                     "the driver as much as the library: every iteration hands all cached device memory back and requests it again; "
+                     "17 ms per iteration on most boxes of the pool, 55-90 ms on some (same build, same process history)")
             sub("soak_500", steps=500, warmup=5, note="the headline configuration, one block of 500 steps")
             sub("C3_multiview", steps=40, warmup=10, multiview=True,
                 note="the reference's default step: the multi-view leg (5 more views rendered with gradients through the dense "
