@@ -317,8 +317,8 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
                 "launches_per_step": kern[dom]["launches_per_view"],
                 "hbm": {"bytes": int(dom_bytes), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 5),
                         "frac_of_measured_copy_peak_6290": round(gbs / 6290.0, 5)},
-                "note": "the blend kernel is bound neither by HBM nor by vector throughput: one wave per 8x8 block walks its hit "
-                        "list serially (~830 cycles per splat at 4 waves per SIMD: 79 % of a wave's life; staging the next 32 hits 14 %, "
+                "note": "the blend kernel is bound by vector-instruction issue (PMC: vector pipe 72-75 % busy, LDS array 38 %, matrix "
+                        "pipe 16 %), not by HBM: one wave per 8x8 block walks its hit list serially (~830 cycles per splat at 4 waves per SIMD: 79 % of a wave's life; staging the next 32 hits 14 %, "
                         "finding them 4 % - DESIGN 9.11); `valu` is the work model",
                 "timing": timing, "kernels": kern,
                 "workload": {"P": P, "V": V, "R": R, "N": N, "F": F, "tiles": tiles}}
