@@ -26,7 +26,11 @@ int launch_prepare_scans(int P, int T, const GeomView& g, const ImageView& iv, h
     static const int order_classes = [] { const char* e = getenv("ISR_ORDER_CLASSES"); return e ? atoi(e) : 16; }();
     { ProfScope ps3_("k_tile_scan", s);
     hipLaunchKernelGGL(k_gather_counts, dim3((T * CNT_SUB + 255) / 256), dim3(256), 0, s, T * CNT_SUB, iv.tile_count, iv.sub_offset, iv.tile_cursor);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, iv.sub_offset, iv.tile_offset, g.header, iv.tile_order, order_classes); }
+    static const bool regs_scan = [] { const char* e = getenv("ISR_TILE_SCAN_REGS"); return !(e && e[0] == '0'); }();
+    if (regs_scan && T >= 4096 && T <= 8192)
+        hipLaunchKernelGGL(k_tile_scan_regs, dim3(1), dim3(1024), 0, s, T, iv.sub_offset, iv.tile_offset, g.header, iv.tile_order, order_classes);
+    else
+        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, T, iv.sub_offset, iv.tile_offset, g.header, iv.tile_order, order_classes); }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -896,3 +896,46 @@ def test_per_block_and_tile_wide_blend_kernels_produce_the_same_bits(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if len(l) == 64])
     assert len(outs[0]) == 16 and outs[0] == outs[1]
+
+
+_TWO_TILE_SCANS = r"""
+import hashlib, math, sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from helpers import small_scene
+from instascene_amd import rasterizer as rz
+from instascene_amd._lib import MODE_FAST
+for P, F, W, H, seed in ((40000, 8, 1296, 968, 51), (50000, 0, 1920, 1080, 52), (30000, 8, 1030, 1020, 53)):
+    sc, cams, inp = small_scene(P=P, F=F, W=W, H=H, seed=seed, mu_s=math.log(0.03))
+    e = torch.empty(0, device="cuda")
+    cam = cams[1]
+    out = rz.rasterize_gaussians(torch.tensor([0.1, 0.2, 0.3], device="cuda"), inp["means3D"].cuda(), e, inp["opacities"].cuda(),
+                                 inp["scales"].cuda(), inp["rotations"].cuda(), 1.0, e, inp["extra"].cuda() if F else e, F,
+                                 cam.world_view_transform.cuda(), cam.full_proj_transform.cuda(), math.tan(cam.FoVx / 2),
+                                 math.tan(cam.FoVy / 2), H, W, inp["shs"].cuda(), 3, cam.camera_center.cuda(), False, False,
+                                 mode=MODE_FAST, tracer=False)
+    dbg = rz.debug_state(P, W, H, out[0], out[5], out[6], out[7])
+    h = hashlib.sha256()
+    for t in (out[1], out[2], out[3], out[4]):
+        h.update(t.detach().cpu().numpy().tobytes())
+    for k in ("tiles_touched", "point_list", "ranges", "n_contrib"):
+        h.update(dbg[k].tobytes())
+    print(h.hexdigest(), int(out[0]))
+"""
+
+
+def test_register_resident_tile_scan_equals_the_general_one(tmp_path):
+    """Views of 4 096 .. 8 192 tiles take ``k_tile_scan_regs`` (a thread's eight tiles in registers: one round of loads);
+    ``ISR_TILE_SCAN_REGS=0`` keeps the general kernel.  Same tile offsets, lists and images bit for bit at 81 x 61, 120 x 68 and
+    65 x 64 tiles.  The switch is read once per process, hence two child processes."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "two_tile_scans.py"
+    script.write_text(_TWO_TILE_SCANS)
+    outs = []
+    for regs in ("1", "0"):
+        env = dict(os.environ, ISR_TILE_SCAN_REGS=regs, ISR_MODE="fast")
+        r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if len(l.split()) == 2 and len(l.split()[0]) == 64])
+    assert len(outs[0]) == 3 and outs[0] == outs[1]
+    assert all(int(l.split()[1]) > 0 for l in outs[0])
