@@ -317,14 +317,14 @@ class FeatureAdam:
         torch.autograd.graph.increment_version(p)       # the kernel wrote through the raw pointer: tell autograd
         self.normalized = (p._version, y, z)
 
-    def step_rows(self, rows=None, grad_only: bool = False, row_grads=None):
+    def step_rows(self, rows=None, grad_only: bool = False, row_grads=None, dense=None):
         """Leaf mode: finish the step from the gradients that reached the leaves of ``normalized_chain()`` — ``y.grad``
         (3-D loss), ``z.grad`` (any dense rasterizer gradient) — and the partial rows ``rows`` a
         ``rasterizer.DeferredFeatureRows`` block collected: reduction, chain rule through both normalisations, Adam and
         the next normalisations in ONE kernel (``isr_feature_rows_step``).  ``grad_only``: stop at ``param.grad`` (for an
         all-reduce; ``step()`` then completes).  ``row_grads``: sparse gradient on ``y`` rows — ``(idx int64, [n,F])``, or
         the ``(slot int32 [P], merged [n,F])`` pair ``compact_row_grads`` makes of it (``gather_rows`` does so itself)."""
-        tail = self.begin_tail(rows, row_grads)
+        tail = self.begin_tail(rows, row_grads, dense)
         if tail is None:
             return
         P = self.param.shape[0]
@@ -334,9 +334,10 @@ class FeatureAdam:
             self.tail_update(tail)
 
     # -- the tail in pieces (a data-parallel trainer walks the table in row ranges: see SegTrainer) ------------------
-    def begin_tail(self, rows=None, row_grads=None):
+    def begin_tail(self, rows=None, row_grads=None, dense=None):
         """Collect what the leaves received; returns an opaque state for ``tail_gradient`` / ``tail_update`` (None when
-        nothing carries a gradient)."""
+        nothing carries a gradient).  ``dense``: a ``[P,F]`` gradient on ``z`` collected outside autograd
+        (``DeferredFeatureRows(collect_dense=True).dense``)."""
         p = self.param
         if self.leaves is None:
             raise RuntimeError("step_rows: normalized_chain() was not called in leaf mode")
@@ -346,6 +347,8 @@ class FeatureAdam:
                                "FeatureAdam.store_y = False only gather_rows may read it")
         gy = None if y_leaf.grad is None else y_leaf.grad.contiguous().float()
         gz = None if z_leaf.grad is None else z_leaf.grad.contiguous().float()
+        if dense is not None:
+            gz = dense if gz is None else gz + dense
         self.leaves = None
         if rows is None and gy is None and gz is None and row_grads is None:
             return None

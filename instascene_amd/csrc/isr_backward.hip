@@ -1158,12 +1158,13 @@ __global__ __launch_bounds__(256) void k_reduce_rows(int P, int ncol, const uint
     const size_t base = point_offsets[g];
     const uint8_t* fl = row_flags + (size_t)(c >> 5) * R + base;     // pass (c / 32) wrote feature chunk (c / 32)
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool any = false;
     // eight rows per round: flags, then the flagged rows, are independent loads in flight together (the common
     // Gaussian touches < 8 tiles, so the whole reduction is two memory round trips); summed in row order
     for (uint32_t r = 0; r < n; r += 8) {
         bool f[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) f[u] = (r + u < n) && fl[r + u] != 0;
+        for (int u = 0; u < 8; u++) { f[u] = (r + u < n) && fl[r + u] != 0; any |= f[u]; }
         float4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++)
@@ -1174,6 +1175,7 @@ __global__ __launch_bounds__(256) void k_reduce_rows(int P, int ncol, const uint
             if (f[u]) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
     }
     float* o = out + (size_t)g * out_stride + c;
+    if (accumulate && !any) return;         // nothing to add: the row is neither read nor written (a view's samples reach few rows)
     if (accumulate) {
         s.x += o[0];
         if (c + 1 < ncol) s.y += o[1];

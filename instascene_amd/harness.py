@@ -166,6 +166,7 @@ class SegTrainer:
         # backward and the bandwidth-bound tail)
         import os as _os
         self.draw_ahead = _os.environ.get("ISR_DRAW_AHEAD", "1") == "1"
+        self.collect_dense = _os.environ.get("ISR_COLLECT_DENSE", "1") == "1"
         # ISR_PREFETCH_EARLY=1 / 0 select "early" / "after" (the two orders of rounds 2-3)
         self.prefetch_distance = max(1, int(_os.environ.get("ISR_PREFETCH_DISTANCE", "2")))
         _pe = _os.environ.get("ISR_PREFETCH_EARLY")
@@ -473,10 +474,12 @@ class SegTrainer:
         if self.multiview and self.lmv > 0 and it % 10 == 0:
             loss = loss + self._multiview_loss(it, vi)
         if self.fused_tail:
-            with DeferredFeatureRows() as sink:
+            # (every render of the step differentiates the same z leaf: the cross-view leg's sampled backwards add into one
+            # [P,F] tensor, sink.dense, which the tail takes as the dense part of dL/dz)
+            with DeferredFeatureRows(collect_dense=self.collect_dense) as sink:
                 loss.backward(self._unit_grad(loss))
             if self.world == 1 and not self.split_tail:
-                self.opt.step_rows(sink.rows, row_grads=sink.row_grads)
+                self.opt.step_rows(sink.rows, row_grads=sink.row_grads, dense=sink.dense)
                 m._seg_cache = None
                 return loss.detach()
             if self.sharded_tail and m._seg_feature.shape[0] % self.world == 0:
@@ -551,7 +554,7 @@ class SegTrainer:
         from .dist_utils import all_gather_rows, reduce_scatter_rows, shard_rows
         opt, p = self.opt, self.model._seg_feature
         P = p.shape[0]
-        tail = opt.begin_tail(sink.rows, sink.row_grads)
+        tail = opt.begin_tail(sink.rows, sink.row_grads, sink.dense)
         if tail is None:
             p.grad = torch.zeros_like(p.data)
         else:
@@ -572,7 +575,7 @@ class SegTrainer:
         range runs while the gradient kernels of the next ranges and the Adam kernels of the previous ones execute —
         instead of kernel, 192 MB collective, kernel in sequence."""
         opt, p = self.opt, self.model._seg_feature
-        tail = opt.begin_tail(sink.rows, sink.row_grads)
+        tail = opt.begin_tail(sink.rows, sink.row_grads, sink.dense)
         if tail is None:
             if self.world == 1:
                 return

@@ -589,11 +589,16 @@ class DeferredFeatureRows:
     ``extra_attrs`` (the caller owns the rest of the chain); any further such backward inside the block takes the normal
     path and its dense ``[P,F]`` gradient reaches ``extra_attrs`` through autograd as usual.  Likewise the first backward
     of a ``contrastive.gather_rows`` leaves its sparse gradient in ``sink.row_grads`` instead of scattering it into a dense
-    ``[P,F]`` tensor."""
+    ``[P,F]`` tensor.  ``collect_dense=True`` (a trainer whose renders inside the block all differentiate the SAME
+    ``extra_attrs`` tensor, and which adds ``sink.dense`` to that tensor's gradient itself): the further sampled backwards add
+    their rows into ONE ``[P,F]`` tensor ``sink.dense`` - zero-filled once, each view touching only the rows its samples reach
+    - and report no gradient, instead of a dense ``[P,F]`` reduction per render plus autograd's sum of them."""
 
-    def __init__(self):
+    def __init__(self, collect_dense: bool = False):
         self.rows: Optional[FeatureRows] = None
         self.row_grads = None          # (indices, [n,F] gradient) of the first contrastive.gather_rows backward
+        self.collect_dense = bool(collect_dense)
+        self.dense = None              # [P,F] sum of the non-deferred sampled backwards (collect_dense)
 
     def __enter__(self):
         global _ROWS_SINK
@@ -803,6 +808,14 @@ class _RasterizeGaussians(torch.autograd.Function):
                     means3D.shape[0], extra_attrs.shape[1], rs.image_width, rs.image_height, ctx.num_rendered,
                     ctx.sample_pixels, grad_sampled, cov3Ds_precomp, geomBuffer, binningBuffer, imgBuffer, mode=ctx.mode,
                     rows_only=True)
+                return (None,) * 14
+            if sink is not None and sink.collect_dense:
+                if sink.dense is None:
+                    sink.dense = torch.zeros((means3D.shape[0], extra_attrs.shape[1]), dtype=torch.float32, device=means3D.device)
+                rasterize_gaussians_backward_sampled(means3D.shape[0], extra_attrs.shape[1], rs.image_width, rs.image_height,
+                                                     ctx.num_rendered, ctx.sample_pixels, grad_sampled, cov3Ds_precomp,
+                                                     geomBuffer, binningBuffer, imgBuffer, mode=ctx.mode,
+                                                     accumulate_into=sink.dense)
                 return (None,) * 14
             ge = rasterize_gaussians_backward_sampled(means3D.shape[0], extra_attrs.shape[1], rs.image_width, rs.image_height,
                                                       ctx.num_rendered, ctx.sample_pixels, grad_sampled, cov3Ds_precomp,

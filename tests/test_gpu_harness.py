@@ -71,6 +71,28 @@ def test_prefetched_geometry_pass_changes_nothing():
         rz.set_tracer(True)
 
 
+def test_cross_view_leg_gradients_collected_in_one_tensor_change_nothing():
+    """The five extra views of the cross-view leg add their sampled backwards into ONE [P,F] tensor, touching only the rows
+    their samples reach (``DeferredFeatureRows(collect_dense=True)``), instead of a dense reduction per view summed by
+    autograd: same losses and parameters bit for bit."""
+    rz.set_mode("fast")
+    rz.set_tracer(False)
+    try:
+        outs = []
+        for collect in (False, True):
+            sc, cams = _scene()
+            tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=2048, n_labels=12, use_class_feat=True, multiview=True,
+                            sample_mv_frames=3, seed=3)
+            tr.collect_dense = collect
+            losses = [float(tr.step(it)) for it in range(12)]          # the leg runs at it == 0 and 10
+            outs.append((losses, tr.model._seg_feature.detach().clone()))
+        assert outs[0][0] == outs[1][0]
+        assert torch.equal(outs[0][1], outs[1][1])
+    finally:
+        rz.set_mode("exact")
+        rz.set_tracer(True)
+
+
 def test_view_cache_reproduces_the_plain_loop():
     """Opt-in cache of the per-view geometry pass + binning (frozen geometry): same losses and parameters bit for bit,
     every revisit of a view is a hit, and a second forward of a view whose backward is still outstanding bypasses it."""
