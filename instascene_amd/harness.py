@@ -167,6 +167,7 @@ class SegTrainer:
         import os as _os
         self.draw_ahead = _os.environ.get("ISR_DRAW_AHEAD", "1") == "1"
         self.collect_dense = _os.environ.get("ISR_COLLECT_DENSE", "1") == "1"
+        self.mv_chain_streams = int(_os.environ.get("ISR_MV_CHAIN_STREAMS", "3"))
         # ISR_PREFETCH_EARLY=1 / 0 select "early" / "after" (the two orders of rounds 2-3)
         self.prefetch_distance = max(1, int(_os.environ.get("ISR_PREFETCH_DISTANCE", "2")))
         _pe = _os.environ.get("ISR_PREFETCH_EARLY")
@@ -509,16 +510,18 @@ class SegTrainer:
         import numpy as np
         m = self.model
         n = len(self.cams)
-        first = (vi + 1) % max(1, n - self.mv_frames)
-        views = list(range(first, first + self.mv_frames))
+        views = self._multiview_views(vi)
         pools = [self._sorted_pool(k) for k in views]
         sizes = np.array([p.numel() for p in pools], dtype=np.float64)
         if sizes.sum() == 0:
             return 0.0
         counts = np.random.RandomState((self.sample_seed * 7919 + it) & 0x7FFFFFFF).multinomial(self.batch, sizes / sizes.sum())
         feats, labs = [], []
+        lanes = self.mv_chain_streams
+        if lanes > 0:
+            self._issue_leg_chains(views, counts)
         for j, (k, pool, nk) in enumerate(zip(views, pools, counts)):
-            if self.prefetch and self.device.type == "cuda" and j + 1 < len(views) and counts[j + 1] > 0:
+            if lanes <= 0 and self.prefetch and self.device.type == "cuda" and j + 1 < len(views) and counts[j + 1] > 0:
                 if self._side is None:
                     self._side = side_stream(self.device)
                 prefetch(self.cams[views[j + 1]], m, self.pipe, self.bg, stream=self._side)
@@ -534,6 +537,26 @@ class SegTrainer:
             labs.append(self.cams[k].sorted_segmap.reshape(-1)[pix])
         return contrastive_loss(torch.cat(feats, dim=0), torch.cat(labs), predef_u_list=m.class_feat,
                                 num_labels=self.n_labels + 1) * self.lmv
+
+    def _multiview_views(self, vi):
+        n = len(self.cams)
+        first = (vi + 1) % max(1, n - self.mv_frames)
+        return list(range(first, first + self.mv_frames))
+
+    def _issue_leg_chains(self, views, counts=None):
+        """All of the cross-view leg's binning chains at once, spread over ``mv_chain_streams`` side streams: a chain cannot
+        run under a blend (the blend's waves hold every register), so one issued per view, inside the leg, is exposed in
+        full; two or three of them next to each other take hardly longer than one (latency- and atomic-bound kernels)."""
+        lanes = self.mv_chain_streams
+        if lanes <= 0 or not self.prefetch or self.device.type != "cuda":
+            return
+        from .streams import extra_side_stream
+        if self._side is None:
+            self._side = side_stream(self.device)
+        for j, k in enumerate(views):
+            if counts is None or counts[j] > 0:
+                st = self._side if j % lanes == 0 else extra_side_stream(self.device, j % lanes)
+                prefetch(self.cams[k], self.model, self.pipe, self.bg, stream=st)
 
     def _sorted_pool(self, k):
         """Flat indices of the pixels of view ``k`` with a positive ``sorted_segmap`` label (static per view: cached)."""

@@ -329,6 +329,9 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
     kept = _VIEW_CACHE.get(sig) if _CONFIG.get("view_cache_bytes", 0) > 0 else None
     if kept is not None and kept.busy == 0 and _same_objects(kept.refs, originals):
         return False                      # the view cache already holds this view's state
+    waiting = _PREFETCHED.get(sig)
+    if waiting is not None and _same_objects(waiting.refs, originals):
+        return True                       # already issued for exactly these inputs and not consumed yet
     # fp32 / contiguous forms (made on the caller's stream; a non-contiguous reference Camera matrix gets a temporary)
     means3D = _f32c(means3D, "means3D")
     colors, opacity = _f32c(colors, "colors"), _f32c(opacity, "opacity")
@@ -368,7 +371,7 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
                 done.record()
     # the entry keeps the converted inputs alive until it is consumed or dropped
     _PREFETCHED[sig] = _Prefetched(sig, _refs(originals), radii, geom, img, R, binning, done, inputs)
-    while len(_PREFETCHED) > 8:                 # entries nobody came for
+    while len(_PREFETCHED) > 12:                # entries nobody came for
         old = _PREFETCHED.pop(next(iter(_PREFETCHED)))
         _PENDING.pop(old.geom.data_ptr(), None)
     return True

@@ -19,6 +19,19 @@ def side_stream(device) -> "torch.cuda.Stream":
     return st
 
 
+_EXTRA_SIDE = {}
+
+
+def extra_side_stream(device, lane: int) -> "torch.cuda.Stream":
+    """Further side streams (lane 1, 2, ...) for work that several binning chains can do next to each other."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(lane))
+    st = _EXTRA_SIDE.get(key)
+    if st is None:
+        st = _EXTRA_SIDE[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 _MAIN_STREAMS = {}
 
 
