@@ -1191,6 +1191,71 @@ __global__ __launch_bounds__(256) void k_reduce_rows(int P, int ncol, const uint
     }
 }
 
+// k_reduce_rows behind a sampled backward, which also leaves a 64-bit word per Gaussian (bit i = its i-th tile instance holds a
+// row: k_render_bwd_sparse): one coalesced 8-byte read decides for the ~99 % of Gaussians a view's few thousand samples
+// never reach - they are left alone when the sums are added to an existing gradient (accumulate), zero-filled otherwise -
+// instead of the instance count, the offset and the byte flags of every instance (0.10 ms per view at P = 1.5 M however
+// few rows there are).  Flagged rows are summed in ascending instance order, like k_reduce_rows.
+__global__ __launch_bounds__(256) void k_reduce_rows_masked(int P, int ncol, const uint32_t* __restrict__ point_offsets,
+                                                            const uint32_t* __restrict__ tiles_touched,
+                                                            const unsigned long long* __restrict__ row_mask,
+                                                            const float* __restrict__ partial, const uint8_t* __restrict__ row_flags,
+                                                            int64_t R, int row_stride, float* __restrict__ out, int out_stride,
+                                                            int accumulate) {
+    const int q4 = (ncol + 3) >> 2;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)P * q4) return;
+    const int g = (int)(e / q4), q = (int)(e - (size_t)g * q4);
+    const int c = 4 * q;
+    const unsigned long long mk = row_mask[g];
+    if (mk == 0ull && accumulate) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mk != 0ull) {
+        const size_t base = point_offsets[g];
+        unsigned long long bits = mk & ~(1ull << 63);
+        while (bits != 0ull) {
+            int idx[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                idx[u] = bits != 0ull ? __builtin_ctzll(bits) : -1;
+                bits &= bits - 1ull;
+            }
+            float4 pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                pv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx[u] >= 0) pv[u] = *reinterpret_cast<const float4*>(partial + (base + idx[u]) * row_stride + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (idx[u] >= 0) { s.x += pv[u].x; s.y += pv[u].y; s.z += pv[u].z; s.w += pv[u].w; }
+        }
+        if (mk >> 63) {                                  // more than 63 tile instances: byte flags from there on
+            const uint32_t n = tiles_touched[g];
+            const uint8_t* fl = row_flags + (size_t)(c >> 5) * R + base;
+            for (uint32_t r = 63; r < n; r++)
+                if (fl[r] != 0) {
+                    const float4 pv = *reinterpret_cast<const float4*>(partial + (base + r) * row_stride + c);
+                    s.x += pv.x; s.y += pv.y; s.z += pv.z; s.w += pv.w;
+                }
+        }
+    }
+    float* o = out + (size_t)g * out_stride + c;
+    if (accumulate) {
+        s.x += o[0];
+        if (c + 1 < ncol) s.y += o[1];
+        if (c + 2 < ncol) s.z += o[2];
+        if (c + 3 < ncol) s.w += o[3];
+    }
+    if (c + 3 < ncol && (out_stride & 3) == 0) *reinterpret_cast<float4*>(o) = s;
+    else {
+        o[0] = s.x;
+        if (c + 1 < ncol) o[1] = s.y;
+        if (c + 2 < ncol) o[2] = s.z;
+        if (c + 3 < ncol) o[3] = s.w;
+    }
+}
+
 // ----------------------------------------------------------------------------
 // Feature training: the whole per-Gaussian tail of a step in ONE pass over the [P,F] rows.
 //
@@ -1826,8 +1891,10 @@ static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int
     uint32_t* cursor = off + T + 1;
     uint32_t* seg_idx = cursor + T;
     if (P == 0) return 0;
-    // rows only (the caller finishes them with launch_feature_rows_step): also keep a per-Gaussian mask of flagged instances
-    unsigned long long* row_mask = dL_dextra == nullptr ? g.row_mask : nullptr;
+    // a per-Gaussian mask of flagged instances: for the caller that finishes the rows itself (launch_feature_rows_step) and
+    // for the reduction below
+    static const bool masked_reduce = [] { const char* e = getenv("ISR_MASKED_REDUCE"); return !(e && e[0] == '0'); }();
+    unsigned long long* row_mask = (dL_dextra == nullptr || masked_reduce) ? g.row_mask : nullptr;
     if (row_mask != nullptr && hipMemsetAsync(row_mask, 0, sizeof(unsigned long long) * (size_t)P, s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }
     if (R > 0 && n > 0) {
         // row flags and the per-tile sample counters are neighbours in the scratch: one fill for both
@@ -1851,8 +1918,12 @@ static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int
     if (dL_dextra == nullptr) return 0;
     const size_t total = (size_t)P * ((ED + 3) / 4);
     ProfScope ps_("k_reduce_rows", s);
-    hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P, ED, g.point_offsets,
-                       g.tiles_touched, partial, flags, R, stride, 0, dL_dextra, ED, accumulate);
+    if (row_mask != nullptr && R > 0 && n > 0)
+        hipLaunchKernelGGL(k_reduce_rows_masked, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P, ED, g.point_offsets,
+                           g.tiles_touched, row_mask, partial, flags, R, stride, dL_dextra, ED, accumulate);
+    else
+        hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P, ED, g.point_offsets,
+                           g.tiles_touched, partial, flags, R, stride, 0, dL_dextra, ED, accumulate);
     ISR_CHECK_LAUNCH_B("k_reduce_rows");
     return 0;
 }
