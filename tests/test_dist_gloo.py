@@ -95,12 +95,14 @@ def _bucket_worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = torch.Generator().manual_seed(7 + rank)
-    shapes = [(50, 3), (50, 16, 3), (50, 1), (50, 2), (50, 4)]           # the five gradients of a train.py-style step
+    shapes = [(51, 3), (51, 16, 3), (51, 1), (51, 2), (51, 4)]           # the five gradients of a train.py-style step, ODD row count
     ts = [torch.randn(s, generator=g) for s in shapes]
     if rank == 1:
         ts[2] = None                                                     # a rank without a gradient for one tensor
     like = [torch.empty(s) for s in shapes]
     summed = allreduce_bucket(ts, world, like=like)
+    # every segment starts on a 16-byte boundary of the flat buffer (iso_gaussian_adam_step reads the views with float4 loads)
+    assert all(t.storage_offset() % 4 == 0 for t in summed), [t.storage_offset() for t in summed]
     torch.save({"sum": [t.clone() for t in summed], "mine": [None if t is None else t.clone() for t in ts]},
                os.path.join(out, f"b{rank}.pt"))
     dist.destroy_process_group()
