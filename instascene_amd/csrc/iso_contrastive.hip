@@ -806,6 +806,57 @@ __global__ __launch_bounds__(1024) void rows_compact_kernel(int n, int F, long l
     }
 }
 
+// The same result in three small launches without the index list in LDS (the default: rows_compact_kernel's 1 024-thread /
+// 64 KB workgroups wait for a compute unit with that much room whenever the next view's binning chain is running beside
+// the step - 59 us on average in the C3 step against 16 us alone, profiles/r03c_kernel_stats_C3_seg.csv):
+//   rows_first_kernel   slot[row] = min i over the occurrences of the row (unsigned atomicMin on the 0xFFFFFFFF-filled table:
+//                       -1 stays "no entry");
+//   rows_copy_kernel    merged = vals, and every later occurrence sets a flag bit in its row's slot;
+//   rows_merge_kernel   a wave per sample: the flagged heads add their later occurrences in ascending position - the order of
+//                       index_put_(accumulate=True) and of rows_compact_kernel, hence the same bits - and clear the flag.
+constexpr unsigned ROWS_DUP_BIT = 0x40000000u;
+__global__ __launch_bounds__(256) void rows_first_kernel(int n, long long P, const long long* __restrict__ idx, unsigned* __restrict__ slot) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long v = idx[i];
+    if (v >= 0 && v < P) atomicMin(slot + v, (unsigned)i);
+}
+__global__ __launch_bounds__(256) void rows_copy_kernel(int n, int F, long long P, const long long* __restrict__ idx,
+                                                        const float* __restrict__ vals, unsigned* __restrict__ slot,
+                                                        float* __restrict__ merged) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x, total = (long long)n * F;
+    if ((F & 3) == 0) {
+        if (4 * e < total) reinterpret_cast<float4*>(merged)[e] = reinterpret_cast<const float4*>(vals)[e];
+    } else {
+        for (long long k = 4 * e; k < total && k < 4 * e + 4; k++) merged[k] = vals[k];
+    }
+    if (e < n) {
+        const long long v = idx[e];
+        if (v >= 0 && v < P && (slot[v] & ~ROWS_DUP_BIT) != (unsigned)e) atomicOr(slot + v, ROWS_DUP_BIT);
+    }
+}
+__global__ __launch_bounds__(256) void rows_merge_kernel(int n, int F, long long P, const long long* __restrict__ idx,
+                                                         const float* __restrict__ vals, unsigned* __restrict__ slot,
+                                                         float* __restrict__ merged) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const long long v = idx[i];
+    if (v < 0 || v >= P) return;
+    const unsigned sv = slot[v];
+    if (sv != ((unsigned)i | ROWS_DUP_BIT)) return;             // not the head of a row that was drawn again
+    float* dst = merged + (size_t)i * F;
+    for (int j0 = i + 1; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        unsigned long long m = __ballot(j < n && idx[j] == v);
+        while (m != 0ull) {
+            const int jj = j0 + __builtin_ctzll(m);
+            m &= m - 1ull;
+            for (int c = lane; c < F; c += 64) dst[c] += vals[(size_t)jj * F + c];
+        }
+    }
+    if (lane == 0) slot[v] = (unsigned)i;
+}
+
 // out[i, :] = x[idx[i], :] / (|x[idx[i], :]| + eps): rows of the normalised table without the table (the same lanes-per-row
 // layout and summation order as rn2_kernel / adam_rn2_kernel, hence the same bits as their `y` rows).  Rows with an index
 // outside [0, P) are zero.

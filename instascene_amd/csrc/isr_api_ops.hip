@@ -2,6 +2,7 @@
 // Host-side only: argument checking, workspace carving and kernel launches on the
 // caller's stream.  No torch types, no allocation, no hidden synchronisation except
 // where the header says so.
+#include <algorithm>
 #include "isr_host.hpp"
 #include "iso_knn.hip"
 #include "iso_contrastive.hip"
@@ -418,8 +419,20 @@ int iso_rows_compact(int n, int F, long long P, const long long* idx, const floa
     if (P > 0 && hipMemsetAsync(slot, 0xFF, sizeof(int) * (size_t)P, s) != hipSuccess) return fail(ISR_EHIP, "rows_compact: memset failed");
     if (n == 0 || P == 0) return ISR_OK;
     if (n > iso::ROWS_COMPACT_MAX) return fail(ISR_EINVAL, "rows_compact: at most %d rows", iso::ROWS_COMPACT_MAX);
-    hipLaunchKernelGGL(iso::rows_compact_kernel, dim3((n + 63) / 64), dim3(1024), 0, s, n, F, P, idx, vals, slot, merged);
-    ISR_LAUNCH_CHECK("iso_rows_compact");
+    static const bool lds_form = [] { const char* e = getenv("ISR_ROWS_COMPACT"); return e && e[0] == 'l'; }();    // "lds": the one-launch form
+    if (lds_form) {
+        hipLaunchKernelGGL(iso::rows_compact_kernel, dim3((n + 63) / 64), dim3(1024), 0, s, n, F, P, idx, vals, slot, merged);
+        ISR_LAUNCH_CHECK("iso_rows_compact");
+        return ISR_OK;
+    }
+    unsigned* us = reinterpret_cast<unsigned*>(slot);
+    hipLaunchKernelGGL(iso::rows_first_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, P, idx, us);
+    ISR_LAUNCH_CHECK("rows_first_kernel");
+    const long long quads = ((long long)n * F + 3) / 4;
+    hipLaunchKernelGGL(iso::rows_copy_kernel, dim3((unsigned)((std::max<long long>(quads, n) + 255) / 256)), dim3(256), 0, s, n, F, P, idx, vals, us, merged);
+    ISR_LAUNCH_CHECK("rows_copy_kernel");
+    hipLaunchKernelGGL(iso::rows_merge_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, F, P, idx, vals, us, merged);
+    ISR_LAUNCH_CHECK("rows_merge_kernel");
     return ISR_OK;
 }
 
