@@ -811,10 +811,11 @@ __global__ __launch_bounds__(1024) void rows_compact_kernel(int n, int F, long l
 // the step - 59 us on average in the C3 step against 16 us alone, profiles/r03c_kernel_stats_C3_seg.csv):
 //   rows_first_kernel   slot[row] = min i over the occurrences of the row (unsigned atomicMin on the 0xFFFFFFFF-filled table:
 //                       -1 stays "no entry");
-//   rows_copy_kernel    merged = vals, and every later occurrence sets a flag bit in its row's slot;
-//   rows_merge_kernel   a wave per sample: the flagged heads add their later occurrences in ascending position - the order of
-//                       index_put_(accumulate=True) and of rows_compact_kernel, hence the same bits - and clear the flag.
-constexpr unsigned ROWS_DUP_BIT = 0x40000000u;
+//   rows_copy_kernel    merged = vals, and every later occurrence counts itself in bits 14.. of its row's slot;
+//   rows_merge_kernel   a wave per sample: a row drawn twice gets its second occurrence added by that occurrence's wave, a row
+//                       drawn three times or more by its head's wave in ascending position - the order of
+//                       index_put_(accumulate=True) and of rows_compact_kernel, hence the same bits; the count is cleared.
+constexpr unsigned ROWS_POS_MASK = 0x3fffu, ROWS_REPEAT_ONE = 0x4000u;       // slot while the three kernels run: repeats << 14 | first position (n <= 16 384)
 __global__ __launch_bounds__(256) void rows_first_kernel(int n, long long P, const long long* __restrict__ idx, unsigned* __restrict__ slot) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -832,7 +833,7 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(int n, int F, long long 
     }
     if (e < n) {
         const long long v = idx[e];
-        if (v >= 0 && v < P && (slot[v] & ~ROWS_DUP_BIT) != (unsigned)e) atomicOr(slot + v, ROWS_DUP_BIT);
+        if (v >= 0 && v < P && (slot[v] & ROWS_POS_MASK) != (unsigned)e) atomicAdd(slot + v, ROWS_REPEAT_ONE);
     }
 }
 __global__ __launch_bounds__(256) void rows_merge_kernel(int n, int F, long long P, const long long* __restrict__ idx,
@@ -843,15 +844,35 @@ __global__ __launch_bounds__(256) void rows_merge_kernel(int n, int F, long long
     const long long v = idx[i];
     if (v < 0 || v >= P) return;
     const unsigned sv = slot[v];
-    if (sv != ((unsigned)i | ROWS_DUP_BIT)) return;             // not the head of a row that was drawn again
+    const unsigned first = sv & ROWS_POS_MASK, repeats = sv >> 14;
+    if (repeats == 0u) return;                                   // the row was drawn once
+    if (repeats == 1u) {
+        // drawn twice (nearly every repeat): the SECOND occurrence adds itself to the head's row - four dependent memory round
+        // trips instead of the head's scan of the whole index list for it
+        if ((unsigned)i != first) {
+            for (int c = lane; c < F; c += 64) merged[(size_t)first * F + c] += vals[(size_t)i * F + c];
+            if (lane == 0) slot[v] = first;
+        }
+        return;
+    }
+    if ((unsigned)i != first) return;                            // three or more: the head adds them in ascending position
     float* dst = merged + (size_t)i * F;
-    for (int j0 = i + 1; j0 < n; j0 += 64) {
-        const int j = j0 + lane;
-        unsigned long long m = __ballot(j < n && idx[j] == v);
-        while (m != 0ull) {
-            const int jj = j0 + __builtin_ctzll(m);
-            m &= m - 1ull;
-            for (int c = lane; c < F; c += 64) dst[c] += vals[(size_t)jj * F + c];
+    constexpr int U = 16;                       // index loads in flight per lane (one dependent round trip per 1 024 entries)
+    for (int j0 = i + 1; j0 < n; j0 += 64 * U) {
+        long long w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int j = j0 + 64 * u + lane;
+            w[u] = j < n ? idx[j] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            unsigned long long m = __ballot(w[u] == v);
+            while (m != 0ull) {                 // ascending position
+                const int jj = j0 + 64 * u + __builtin_ctzll(m);
+                m &= m - 1ull;
+                for (int c = lane; c < F; c += 64) dst[c] += vals[(size_t)jj * F + c];
+            }
         }
     }
     if (lane == 0) slot[v] = (unsigned)i;
