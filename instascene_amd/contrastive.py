@@ -81,10 +81,14 @@ class _ProtoNCEBatch(torch.autograd.Function):
     shape, evaluated by ONE sequence of launches (``iso_contrastive_forward_batch``)."""
 
     @staticmethod
-    def forward(ctx, K, temp_lambda, consider_negative, min_pixnum, weights, labels, predefs, *features):
+    def forward(ctx, K, temp_lambda, consider_negative, min_pixnum, weights, labels, predefs, stacked, *features):
         L = lib()
-        nb = len(features)
-        feats = [f.contiguous().float() for f in features]
+        # ``stacked`` = k > 1: features[0] is [k N, F], the first k problems stacked (a trainer's sampled rows of one render);
+        # its gradient comes back as ONE tensor instead of k that autograd would have to concatenate
+        first = features[0].contiguous().float()
+        feats = ([first[j * (first.shape[0] // stacked):(j + 1) * (first.shape[0] // stacked)] for j in range(stacked)]
+                 if stacked > 1 else [first]) + [f.contiguous().float() for f in features[1:]]
+        nb = len(feats)
         N, F = feats[0].shape
         labs = [l.contiguous() if l.dtype == torch.int64 else l.to(torch.int64).contiguous() for l in labels]
         pres = [p.contiguous().float() if p is not None else None for p in predefs]
@@ -100,7 +104,7 @@ class _ProtoNCEBatch(torch.autograd.Function):
                                                   _p(loss), ctypes.c_void_p(loss.data_ptr() + 4 * nb), _p(state), one * nb,
                                                   _stream()), "iso_contrastive_forward_batch")
         ctx.save_for_backward(state)
-        ctx.dims = (nb, N, F, K, one * nb, [p is not None for p in pres], [float(x) for x in weights])
+        ctx.dims = (nb, N, F, K, one * nb, [p is not None for p in pres], [float(x) for x in weights], int(stacked))
         ctx.mark_non_differentiable(loss)
         ctx.set_materialize_grads(False)      # (no zero-filled gradient for the non-differentiable second output)
         return loss[nb], loss
@@ -109,39 +113,52 @@ class _ProtoNCEBatch(torch.autograd.Function):
     def backward(ctx, grad_total, _grad_parts):
         L = lib()
         (state,) = ctx.saved_tensors
-        nb, N, F, K, nbytes, has_pre, weights = ctx.dims
+        nb, N, F, K, nbytes, has_pre, weights, stacked = ctx.dims
+        n_in = nb - (stacked - 1 if stacked > 1 else 0)
         if grad_total is None:
-            return (None,) * (7 + nb)
+            return (None,) * (8 + n_in)
         g = grad_total.reshape(1).contiguous().float()
-        outs = [torch.empty((N, F), dtype=torch.float32, device=state.device) for _ in range(nb)]
+        if stacked > 1:
+            head = torch.empty((stacked * N, F), dtype=torch.float32, device=state.device)
+            parts = [head[j * N:(j + 1) * N] for j in range(stacked)]
+            rest = [torch.empty((N, F), dtype=torch.float32, device=state.device) for _ in range(nb - stacked)]
+            outs, ret = parts + rest, [head] + rest
+        else:
+            outs = [torch.empty((N, F), dtype=torch.float32, device=state.device) for _ in range(nb)]
+            ret = outs
         flags = (ctypes.c_int * nb)(*[int(h) for h in has_pre])
         w = (ctypes.c_float * nb)(*weights)
         optr = (ctypes.c_void_p * nb)(*[o.data_ptr() for o in outs])
         with torch.cuda.device(state.device):
             check(L.iso_contrastive_backward_batch(nb, N, F, K, flags, _p(g), w, optr, _p(state), nbytes, _stream()),
                   "iso_contrastive_backward_batch")
-        return (None,) * 7 + tuple(outs)
+        return (None,) * 8 + tuple(ret)
 
 
 def contrastive_loss_batch(features, masks, predef_u_lists, weights, num_labels, min_pixnum=0, temp_lambda=1000,
-                           consider_negative=False):
+                           consider_negative=False, stacked: int = 0):
     """``sum_b weights[b] * contrastive_loss(features[b], masks[b], predef_u_lists[b], num_labels=num_labels)`` (weighted
     losses added in order) for 1..4 problems whose ``[N,F]`` shapes agree and whose prototypes, where predefined, have
     ``num_labels`` rows; one sequence of launches instead of one per loss.  Returns ``(total, weighted_parts[nb+1])``."""
-    nb = len(features)
-    if not (1 <= nb <= 4) or len(masks) != nb or len(predef_u_lists) != nb or len(weights) != nb:
+    stacked = int(stacked) if stacked and int(stacked) > 1 else 0
+    nb = len(masks)
+    if not (1 <= nb <= 4) or len(features) != nb - max(0, stacked - 1) or len(predef_u_lists) != nb or len(weights) != nb:
         raise ValueError("contrastive_loss_batch: 1..4 problems, one mask / prototype entry / weight each")
-    shape = features[0].shape
+    if stacked and (features[0].dim() != 2 or features[0].shape[0] % stacked):
+        raise ValueError("contrastive_loss_batch: features[0] must stack `stacked` problems of equal size")
+    # (``stacked`` = k: features[0] is [k N, F] and holds the first k problems one after the other)
+    shape = (features[0].shape[0] // stacked, features[0].shape[1]) if stacked else tuple(features[0].shape)
     K = max(int(num_labels), 1)
-    for f, p in zip(features, predef_u_lists):
+    for j, f in enumerate(features):
         if not f.is_cuda:
             raise RuntimeError("contrastive_loss_batch: features must be CUDA tensors (the HIP library is the only backend)")
-        if f.shape != shape or shape[0] == 0:
+        if (tuple(f.shape) != shape and not (stacked and j == 0)) or shape[0] == 0:
             raise ValueError("contrastive_loss_batch: all problems need the same non-empty [N,F] shape")
+    for p in predef_u_lists:
         if p is not None and int(p.shape[0]) != K:
             raise ValueError("contrastive_loss_batch: predefined prototypes must have num_labels rows")
     return _ProtoNCEBatch.apply(K, float(temp_lambda), bool(consider_negative), int(min_pixnum), tuple(weights),
-                                tuple(masks), tuple(predef_u_lists), *features)
+                                tuple(masks), tuple(predef_u_lists), stacked, *features)
 
 
 class _RowNorm(torch.autograd.Function):

@@ -179,6 +179,7 @@ class SegTrainer:
         self.phase_timing = False    # multi-rank tail: record per-phase device times of each step into self.last_phases
         self.last_phases = None
         self.split_tail = False      # tests: take the multi-rank form of the tail (dL/dx, all-reduce, Adam) with one rank
+        self.stacked_losses = _os.environ.get("ISR_STACKED_LOSSES", "1") == "1"   # the two single-view losses read ONE [2B,F] input
         self.tail_chunks = 4         # row ranges of that form (all-reduce of one overlaps the kernels of the others)
         F = scene.seg_feature.shape[1]
         class_feat = None
@@ -436,6 +437,7 @@ class SegTrainer:
         if merged:
             feats = pkg["sampled_seg_feature"] if self.sampled_path else seg_feature.reshape(seg_feature.shape[0], -1)[:, pix].T
             fa, fb = feats.split(self.batch)          # one cat in the backward instead of two zero-fill + copy + add
+            stacked_feats = feats if (self.sampled_path and feats.shape[0] == 2 * self.batch) else None
             if drawn is not None:
                 la, lb = drawn[1], drawn[2]
             else:
@@ -467,8 +469,12 @@ class SegTrainer:
             if self.batched_losses and len(problems) > 1 and same:
                 # one sequence of launches for all of them (iso_contrastive_forward_batch): each loss is ~8 kernels of a
                 # few microseconds, i.e. launch-bound
-                part = contrastive_loss_batch([q[0] for q in problems], [q[1] for q in problems], [q[2] for q in problems],
-                                              [q[3] for q in problems], num_labels=K)[0]
+                fl = [q[0] for q in problems]
+                stk = 0
+                if merged and self.stacked_losses and stacked_feats is not None and fl[0] is fa and fl[1] is fb:
+                    fl, stk = [stacked_feats] + fl[2:], 2      # the render's sampled rows as ONE input: no cat in the backward
+                part = contrastive_loss_batch(fl, [q[1] for q in problems], [q[2] for q in problems],
+                                              [q[3] for q in problems], num_labels=K, stacked=stk)[0]
                 loss = part if loss is None else loss + part
             else:
                 for f, l, u, w in problems:
