@@ -783,7 +783,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 template <class Math, bool SAMPLED>
-__global__ __launch_bounds__(64, 3) void k_render_bwd_sparse(
+#ifndef ISR_SPARSE_WAVES
+#define ISR_SPARSE_WAVES 3
+#endif
+__global__ __launch_bounds__(64, ISR_SPARSE_WAVES) void k_render_bwd_sparse(
     int W, int H, int ED, int ch_base, int gx, const uint32_t* __restrict__ tile_offset,
     const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ box4, const float* __restrict__ rec,
     const float* __restrict__ tm_pre, const float* __restrict__ dE, const uint32_t* __restrict__ point_offsets,
