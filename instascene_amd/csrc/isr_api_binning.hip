@@ -7,8 +7,7 @@ namespace isr {
 int launch_scan_u32(int n, const uint32_t* in, uint32_t* out, uint32_t* sums, hipStream_t s) {
     const int nb = (n + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, n, in, out, sums, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, sums, (const uint32_t*)nullptr, (int64_t*)nullptr);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, n, out, sums);
+    hipLaunchKernelGGL(k_scan_add_tops, dim3(nb), dim3(1024), 0, s, n, nb, out, sums, (const uint32_t*)nullptr, (int64_t*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -20,8 +19,13 @@ int launch_prepare_scans(int P, int T, const GeomView& g, const ImageView& iv, h
         const int nb = (P + 1023) / 1024;
         ProfScope ps2_("k_scan_gaussians", s);
         hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, P, g.tiles_touched, g.point_offsets, g.scan_tmp, g.scan_tmp + nb + 1);
-        hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, g.scan_tmp, g.scan_tmp + nb + 1, g.header);
-        hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, P, g.point_offsets, g.scan_tmp);
+        static const bool two = [] { const char* e = getenv("ISR_SCAN_LAUNCHES"); return e && e[0] == '3'; }();     // "3": rounds 1-3's tops + add
+        if (two) {
+            hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, g.scan_tmp, g.scan_tmp + nb + 1, g.header);
+            hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, P, g.point_offsets, g.scan_tmp);
+        } else {
+            hipLaunchKernelGGL(k_scan_add_tops, dim3(nb), dim3(1024), 0, s, P, nb, g.point_offsets, g.scan_tmp, g.scan_tmp + nb + 1, g.header);
+        }
     }
     static const int order_classes = [] { const char* e = getenv("ISR_ORDER_CLASSES"); return e ? atoi(e) : 16; }();
     { ProfScope ps3_("k_tile_scan", s);

@@ -248,6 +248,35 @@ __global__ __launch_bounds__(1024) void k_scan_add(int n, uint32_t* __restrict__
     const int i = blockIdx.x * 1024 + threadIdx.x;
     if (i < n) out[i] += block_sums[blockIdx.x];
 }
+// k_scan_tops + k_scan_add in one launch: every workgroup sums the totals of the workgroups before it itself (at most a few
+// thousand coalesced loads: P / 1024 totals), workgroup 0 also reduces the block maxima into header[1].  One launch less on the
+// binning chain; same integers.
+__global__ __launch_bounds__(1024) void k_scan_add_tops(int n, int nb, uint32_t* __restrict__ out, const uint32_t* __restrict__ block_sums,
+                                                        const uint32_t* __restrict__ block_max, int64_t* __restrict__ header) {
+    __shared__ uint32_t s_part[16];
+    __shared__ uint32_t s_prefix;
+    uint32_t acc = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 1024) acc += block_sums[j];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += (uint32_t)__shfl_xor((int)acc, o);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 16; w++) t += s_part[w];
+        s_prefix = t;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < n) out[i] += s_prefix;
+    if (blockIdx.x == 0 && block_max != nullptr && header != nullptr && threadIdx.x < 64) {
+        uint32_t m = 0;
+        for (int b = threadIdx.x; b < nb; b += 64) m = max(m, block_max[b]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        if (threadIdx.x == 0) header[1] = (int64_t)m;
+    }
+}
 
 // ----------------------------------------------------------------------------
 // Scatter: one (depth_bits, gaussian) key per touched tile into that tile's bucket.  The workgroup first counts its keys
