@@ -18,13 +18,20 @@ int launch_prepare_scans(int P, int T, const GeomView& g, const ImageView& iv, h
     if (P > 0) {
         const int nb = (P + 1023) / 1024;
         ProfScope ps2_("k_scan_gaussians", s);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, P, g.tiles_touched, g.point_offsets, g.scan_tmp, g.scan_tmp + nb + 1);
-        static const bool two = [] { const char* e = getenv("ISR_SCAN_LAUNCHES"); return e && e[0] == '3'; }();     // "3": rounds 1-3's tops + add
-        if (two) {
-            hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, g.scan_tmp, g.scan_tmp + nb + 1, g.header);
-            hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, P, g.point_offsets, g.scan_tmp);
+        // ISR_SCAN_LAUNCHES: 1 (default) K1 has scanned inside its workgroups, one launch adds the totals; 2 / 3: the scan of
+        // rounds 1-3 in two / three launches of its own (they overwrite what K1 wrote)
+        static const int launches = [] { const char* e = getenv("ISR_SCAN_LAUNCHES"); return e ? atoi(e) : 1; }();
+        if (launches <= 1) {
+            const int nb256 = (P + 255) / 256;
+            hipLaunchKernelGGL(k_scan_add_tops256, dim3(nb), dim3(1024), 0, s, P, nb256, g.point_offsets, g.scan_tmp, g.scan_tmp + nb256 + 1, g.header);
         } else {
-            hipLaunchKernelGGL(k_scan_add_tops, dim3(nb), dim3(1024), 0, s, P, nb, g.point_offsets, g.scan_tmp, g.scan_tmp + nb + 1, g.header);
+            hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, P, g.tiles_touched, g.point_offsets, g.scan_tmp, g.scan_tmp + nb + 1);
+            if (launches >= 3) {
+                hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, nb, g.scan_tmp, g.scan_tmp + nb + 1, g.header);
+                hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, P, g.point_offsets, g.scan_tmp);
+            } else {
+                hipLaunchKernelGGL(k_scan_add_tops, dim3(nb), dim3(1024), 0, s, P, nb, g.point_offsets, g.scan_tmp, g.scan_tmp + nb + 1, g.header);
+            }
         }
     }
     static const int order_classes = [] { const char* e = getenv("ISR_ORDER_CLASSES"); return e ? atoi(e) : 16; }();

@@ -278,6 +278,39 @@ __global__ __launch_bounds__(1024) void k_scan_add_tops(int n, int nb, uint32_t*
     }
 }
 
+// Second (and last) level of the Gaussian offset scan when K1 has done the first per 256 Gaussians (k_preprocess): a workgroup
+// covers four of K1's, sums the totals before them itself and adds; workgroup 0 reduces the maxima into header[1].
+__global__ __launch_bounds__(1024) void k_scan_add_tops256(int n, int nb, uint32_t* __restrict__ out, const uint32_t* __restrict__ sums,
+                                                           const uint32_t* __restrict__ maxima, int64_t* __restrict__ header) {
+    __shared__ uint32_t s_part[16];
+    __shared__ uint32_t s_prefix;
+    const int b4 = (int)blockIdx.x * 4;
+    uint32_t acc = 0;
+    for (int j = threadIdx.x; j < b4 && j < nb; j += 1024) acc += sums[j];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += (uint32_t)__shfl_xor((int)acc, o);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 16; w++) t += s_part[w];
+        s_prefix = t;
+    }
+    __syncthreads();
+    const int q = threadIdx.x >> 8;
+    uint32_t extra = 0;
+    for (int k = 0; k < q; k++) extra += (b4 + k < nb) ? sums[b4 + k] : 0u;
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < n) out[i] += s_prefix + extra;
+    if (blockIdx.x == 0 && header != nullptr && threadIdx.x < 64) {
+        uint32_t m = 0;
+        for (int b = threadIdx.x; b < nb; b += 64) m = max(m, maxima[b]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        if (threadIdx.x == 0) header[1] = (int64_t)m;
+    }
+}
+
 // ----------------------------------------------------------------------------
 // Scatter: one (depth_bits, gaussian) key per touched tile into that tile's bucket.  The workgroup first counts its keys
 // per tile in the LDS hash, reserves one contiguous range per distinct tile with ONE returning global atomic, and then

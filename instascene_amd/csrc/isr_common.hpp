@@ -87,7 +87,7 @@ inline GeomView geom_view(void* buf, int P) {
     g.rect = carve<Rect16>(p, P);
     g.clamped = carve<uint8_t>(p, P);
     g.radii = carve<int>(p, P);
-    g.scan_tmp = carve<uint32_t>(p, (size_t)(P / 1024 + 2) * 2);
+    g.scan_tmp = carve<uint32_t>(p, (size_t)(P / 256 + 2) * 2);       // per 256 Gaussians (a K1 workgroup): total, then (from +nb+1) maximum
     g.row_mask = carve<unsigned long long>(p, P);
     g.cull = carve<float>(p, (size_t)P * 8);
     return g;

@@ -254,6 +254,30 @@ __global__ __launch_bounds__(256) void k_preprocess(
     __syncthreads();
     for (int e = threadIdx.x; e < TH_SIZE; e += 256)
         if (th_key[e] != TH_EMPTY) atomicAdd(tile_count + ((size_t)th_key[e] * CNT_SUB + sub) * CNT_STRIDE, th_cnt[e]);
+    // ---- first level of the Gaussian offset scan (tiles touched -> row offsets of the backward's partial rows): exclusive scan
+    // inside the workgroup, its total and its largest rectangle into scan_tmp; k_scan_add_tops256 adds the totals of the
+    // workgroups before it (one launch, k_scan_blocks, less on the binning chain)
+    {
+        __shared__ uint32_t s_wsum[4], s_wmax[4];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const uint32_t v = i < P ? touched : 0u;
+        uint32_t inc = v, mx = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, o);
+            if (lane >= o) inc += t;
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+        }
+        if (lane == 63) { s_wsum[wv] = inc; s_wmax[wv] = mx; }
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wv; w++) base += s_wsum[w];
+        if (i < P) g.point_offsets[i] = base + inc - v;
+        if (threadIdx.x == 0) {
+            g.scan_tmp[blockIdx.x] = (s_wsum[0] + s_wsum[1]) + (s_wsum[2] + s_wsum[3]);
+            g.scan_tmp[gridDim.x + 1 + blockIdx.x] = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------
