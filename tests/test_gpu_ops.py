@@ -207,6 +207,16 @@ def test_contrastive_batch_equals_separate_losses(N, F, K):
     assert float(parts[3]) == float(got.detach())
     for a, b in zip(batched, singles):
         assert torch.equal(a.grad, b.grad)
+    # the first two problems stacked in one [2N,F] input (what a trainer's sampled rows of one render are): same value, and the
+    # stacked input's gradient is the two gradients one after the other - without autograd concatenating anything
+    stacked = torch.cat([feats[0], feats[1]]).requires_grad_(True)
+    third = feats[2].clone().requires_grad_(True)
+    got2, parts2 = contrastive_loss_batch([stacked, third], labels, predefs, w, num_labels=K, stacked=2)
+    got2.backward()
+    assert float(got2.detach()) == float(want.detach()) and torch.equal(parts2, parts)
+    assert torch.equal(stacked.grad, torch.cat([singles[0].grad, singles[1].grad])) and torch.equal(third.grad, singles[2].grad)
+    with pytest.raises(ValueError):
+        contrastive_loss_batch([stacked[:-1], third], labels, predefs, w, num_labels=K, stacked=2)
     # a batch of one is the plain loss
     one = feats[1].clone().requires_grad_(True)
     l1, _ = contrastive_loss_batch([one], [labels[1]], [pre], [1.0], num_labels=K)
