@@ -159,14 +159,13 @@ class SegTrainer:
         self.sampled_path = bool(sampled_path)      # render(sample_pixels=...) instead of indexing the feature map
         self.batched_losses = (self.device.type == "cuda") if batched_losses is None else bool(batched_losses)
         # the next view's geometry pass + binning run on a side stream next to the rest of this step (_prefetch_next)
-        import os as _os0
+        import os as _os
         # (ISR_PREFETCH=0, diagnostic: every kernel of the step on ONE stream, i.e. its time without the side chain beside it)
-        self.prefetch = (_os0.environ.get("ISR_PREFETCH", "1") == "1") if prefetch_geometry is None else bool(prefetch_geometry)
+        self.prefetch = (_os.environ.get("ISR_PREFETCH", "1") == "1") if prefetch_geometry is None else bool(prefetch_geometry)
         self._side = None
         # True: issue the next view's geometry pass + binning BEFORE this step's forward (they then run beside the blend
         # kernel, which is issue-bound and leaves the memory system idle) instead of behind it (beside the loss kernels, the
         # backward and the bandwidth-bound tail)
-        import os as _os
         self.draw_ahead = _os.environ.get("ISR_DRAW_AHEAD", "1") == "1"
         self.collect_dense = _os.environ.get("ISR_COLLECT_DENSE", "1") == "1"
         self.mv_chain_streams = int(_os.environ.get("ISR_MV_CHAIN_STREAMS", "3"))
