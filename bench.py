@@ -272,7 +272,7 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
             V = int((pkg["radii"] > 0).sum().item())
             R = int(rasterizer.LAST_NUM_RENDERED)
             rasterizer.set_async_binning(was)
-        cull_tests, pairs_eval, pairs_blend, lane_pairs, pairs_mergeable, sub_blocks = (int(v) for v in counters.tolist()[:6])
+        cull_tests, pairs_eval, pairs_blend, lane_pairs, pairs_mergeable, sub_blocks, pairs_exact, band_violations = (int(v) for v in counters.tolist()[:8])
         P, N, F = cfg["P"], cfg["W"] * cfg["H"], (cfg["F"] if args.step in ("seg", "plain") else 0)
         tiles = ((cfg["W"] + 15) // 16) * ((cfg["H"] + 15) // 16)
         bm = byte_model(P, V, R, N, F, tiles)
@@ -330,6 +330,9 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
             roof["valu"] = {
                 "wave_splat_cull_tests": cull_tests, "wave_splat_pairs_evaluated": pairs_eval,
                 "wave_splat_pairs_blending": pairs_blend,
+                # guard bands (csrc/isr_fast_pair.hpp): evaluations that took EXACT's instruction sequence, and pairs OUTSIDE the bands
+                # whose decision differs from EXACT's (the band's bound, checked on the device: must be 0)
+                "wave_splat_pairs_on_the_exact_path": pairs_exact, "pairs_outside_the_guard_bands_deciding_unlike_exact": band_violations,
                 "pixel_splat_pairs_evaluated": 64 * pairs_eval,
                 "pixel_splat_pairs_contributing": lane_pairs,
                 "lane_utilisation_of_blending_pairs": round(lane_pairs / max(1, 64 * pairs_blend), 4),

@@ -351,14 +351,19 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
                     d.w = col_pre[3 * (size_t)id]; e.x = col_pre[3 * (size_t)id + 1]; e.y = col_pre[3 * (size_t)id + 2];
                 }
                 const float opa = d.z;
-                const float skip = fast_skip(opa);
+                float skip = __builtin_inff();          // EXACT's cull: opa * exp(-rho / 2) < 1/255 for every rho > skip (1 % + 0.05 margin)
+                if (opa <= 1.0f) {
+                    const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
+                    skip = 2.0f * l * 1.01f + 0.05f;
+                }
                 float4* s4 = reinterpret_cast<float4*>(s_rec + t * RS);
                 if constexpr (Math::fast) {
                     const FastSplat fs = fast_splat({a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, (float)(tx * TILE), (float)(ty * TILE));
+                    const FastBand fb = fast_band(opa, e.w);          // rec[19]: K1's guard band (isr_fast_pair.hpp)
                     s4[0] = make_float4(fs.A.x, fs.A.y, fs.A.z, c.y - (float)(tx * TILE));
                     s4[1] = make_float4(fs.B.x, fs.B.y, fs.B.z, c.z - (float)(ty * TILE));
                     s4[2] = make_float4(fs.C.x, fs.C.y, fs.C.z, fs.det);
-                    s4[3] = make_float4(c.x, opa, skip, 0.0f);
+                    s4[3] = make_float4(c.x, opa, fb.hi, fb.lo);
                     if constexpr (GEOM) { s4[4] = a; s4[5] = b; s4[6] = make_float4(c.w, d.x, d.y, 0.0f); }
                 } else {
                     s4[0] = a; s4[1] = b; s4[2] = c; s4[3] = make_float4(d.x, d.y, opa, skip);
@@ -404,9 +409,17 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
                             Tw = {b.z, b.w, qd.x};
                             nx = qn.x; ny = qn.y; nz = qn.z;
                         }
-                        const FastRay fr = fast_ray(lxf, lyf, qa.x, qa.y, qa.z, qb.x, qb.y, qb.z, qc.x, qc.y, qc.z, qa.w, qb.w);
-                        const FastHit fh = fast_hit(fr, qc.w, qd.x, qd.y);
-                        act = act && fast_near(fr, qd.z) && fast_pass(fh);
+                        FastRay fr = fast_ray(lxf, lyf, qa.x, qa.y, qa.z, qb.x, qb.y, qb.z, qc.x, qc.y, qc.z, qa.w, qb.w);
+                        FastHit fh = fast_hit(fr, qc.w, qd.x, qd.y);
+                        const bool near = act && fast_near(fr, qd.z);
+                        const bool inb = near && fast_in_band(fr, fast_band_of(qd.z, qd.w));
+                        act = near && fast_pass(fh);
+                        if (__ballot(inb) != 0ull) {          // rare: the pair is re-evaluated as EXACT does (the forward did the same)
+                            FastRay er; FastHit eh;
+                            const bool ep = exact_pair_rec(pxf, pyf, rec, __builtin_amdgcn_readfirstlane(s_id[sub_lo + j]), er, eh);
+                            fast_take(inb, er, eh, fr, fh);
+                            act = inb ? ep : act;
+                        }
                         p = {fr.p_x, fr.p_y, fr.p_z};
                         dx = fr.dx; dy = fr.dy; rho2d = fr.rho2d; rho3d = fr.rho3d; sx = fr.sx; sy = fr.sy;
                         c_d = fh.depth; G = fh.G; alpha = fh.alpha;
@@ -685,12 +698,13 @@ __device__ __forceinline__ float splat_alpha(const F3 Tu, const F3 Tv, const F3 
     return alpha < 1.0f / 255.0f ? 0.0f : alpha;
 }
 
-// the same in FAST arithmetic: the forward's own evaluation of the pair (isr_fast_pair.hpp), tile-relative pixel
-__device__ __forceinline__ float splat_alpha_fast(const FastSplat& fs, float Twz, float cxr, float cyr, float opa, float skip,
-                                                  float lx, float ly) {
-    const FastRay fr = fast_ray(lx, ly, fs.A.x, fs.A.y, fs.A.z, fs.B.x, fs.B.y, fs.B.z, fs.C.x, fs.C.y, fs.C.z, cxr, cyr);
-    const FastHit fh = fast_hit(fr, fs.det, Twz, opa);
-    return (fast_near(fr, skip) && fast_pass(fh)) ? fh.alpha : 0.0f;
+// the same in FAST arithmetic: the forward's own evaluation of the pair (isr_fast_pair.hpp: EXACT inside the guard bands),
+// tile-relative pixel (lx, ly) = absolute pixel (pxf, pyf)
+__device__ __forceinline__ float splat_alpha_fast(const FastSplat& fs, const F3 Tu, const F3 Tv, const F3 Tw, float cx, float cy,
+                                                  float cxr, float cyr, float opa, const FastBand& fb, float lx, float ly,
+                                                  float pxf, float pyf) {
+    FastRay fr; FastHit fh;
+    return fast_pair_lane(fs, Tu, Tv, Tw, cx, cy, opa, fb, cxr, cyr, lx, ly, pxf, pyf, fr, fh) ? fh.alpha : 0.0f;
 }
 
 // Step 1 — which pixels carry an upstream gradient?  A streaming pass over dL/dE: one workgroup per strip of four
@@ -931,6 +945,7 @@ __global__ __launch_bounds__(64, ISR_SPARSE_WAVES) void k_render_bwd_sparse(
 #pragma unroll
         for (int j = 0; j < 4; j++) piece_n[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         Rect16 rc_n = {0, 0, 0, 0};
+        float band_n = 0.0f;
         auto fetch = [&](int at) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -944,6 +959,7 @@ __global__ __launch_bounds__(64, ISR_SPARSE_WAVES) void k_render_bwd_sparse(
             if (hk_n != 0u) {
                 rc_n = rects[id_n];
                 po_n = point_offsets[id_n];
+                if constexpr (Math::fast) band_n = rec[(size_t)id_n * REC + 19];     // K1's guard band (isr_fast_pair.hpp)
             }
         };
         auto ready = [&](int at) { return n_c - at >= 64 || (drained && at < n_c); };
@@ -952,6 +968,7 @@ __global__ __launch_bounds__(64, ISR_SPARSE_WAVES) void k_render_bwd_sparse(
             const int id = id_n;
             const unsigned hk = hk_n, po = po_n;
             const Rect16 rc = rc_n;
+            const float band = band_n;
             wave_lds_sync();                                   // the staging area is free (rows of the previous chunk are out)
 #pragma unroll
             for (int j = 0; j < 4; j++)
@@ -979,10 +996,14 @@ __global__ __launch_bounds__(64, ISR_SPARSE_WAVES) void k_render_bwd_sparse(
                 slot = po + ordinal;
                 Tu = {a.x, a.y, a.z}; Tv = {a.w, b.x, b.y}; Tw = {b.z, b.w, c.x};
                 cx = c.y; cy = c.z; opa = d.z;
-                skip = fast_skip(opa);
+                if (opa <= 1.0f) {       // EXACT's cull: opa * exp(-rho / 2) < 1/255 for every rho > skip (1 % + 0.05 margin)
+                    const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
+                    skip = 2.0f * l * 1.01f + 0.05f;
+                } else skip = __builtin_inff();
             }
             FastSplat fs = {{0, 0, 0}, {0, 0, 0}, {0, 0, 1}, 0.0f};
-            if constexpr (Math::fast) fs = fast_splat(Tu, Tv, Tw, tile_x0, tile_y0);
+            FastBand fb = {0.0f, 0.0f, 0.0f};
+            if constexpr (Math::fast) { fs = fast_splat(Tu, Tv, Tw, tile_x0, tile_y0); fb = fast_band(opa, band); }
             const float cxr = cx - tile_x0, cyr = cy - tile_y0;
             float acc[32];
 #pragma unroll
@@ -994,7 +1015,8 @@ __global__ __launch_bounds__(64, ISR_SPARSE_WAVES) void k_render_bwd_sparse(
                 float alpha = 0.0f;
                 if ((hk >> k) & 1u) {
                     if constexpr (Math::fast)
-                        alpha = splat_alpha_fast(fs, Tw.z, cxr, cyr, opa, skip, (float)(xy & 255), (float)(xy >> 8));
+                        alpha = splat_alpha_fast(fs, Tu, Tv, Tw, cx, cy, cxr, cyr, opa, fb, (float)(xy & 255), (float)(xy >> 8),
+                                                 tile_x0 + (float)(xy & 255), tile_y0 + (float)(xy >> 8));
                     else
                         alpha = splat_alpha<Math>(Tu, Tv, Tw, cx, cy, opa, skip, tile_x0 + (float)(xy & 255), tile_y0 + (float)(xy >> 8));
                 }

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
             done += 64;
             // ---- the splat (one per lane; lane order = back to front)
             F3 Tu = {0, 0, 0}, Tv = {0, 0, 0}, Tw = {0, 0, 1}, nrm = {0, 0, 0}, col = {0, 0, 0};
-            float cx = 0, cy = 0, opa = 0, skip = 0;
+            float cx = 0, cy = 0, opa = 0, band = 0;
             int bxl = 127, bxh = -128, byl = 127, byh = -128;           // empty box: a lane without a splat touches no pixel
             unsigned slot = 0;
             if (li >= 0) {
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
                 }
                 Tu = {a.x, a.y, a.z}; Tv = {a.w, b.x, b.y}; Tw = {b.z, b.w, c.x};
                 cx = c.y; cy = c.z; nrm = {c.w, d.x, d.y}; opa = d.z; col = {d.w, e.x, e.y};
-                skip = fast_skip(opa);
+                band = e.w;                     // K1's guard band (isr_fast_pair.hpp)
                 const Rect16 rc = rects[id];
                 slot = point_offsets[id] + (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
             }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
             // loop accumulates those nine sums (instead of two cross products and nine FMAs per pair for dL/dTu, dL/dTv, dL/dTw);
             // they are turned into the gradient of the three rows once per (block, splat), after the loop.
             const FastSplat fs = fast_splat(Tu, Tv, Tw, tile_x0, tile_y0);
-            const F3 A = fs.A, B = fs.B, C = fs.C;
+            const FastBand fb = fast_band(opa, band);
             const float cxr = cx - tile_x0, cyr = cy - tile_y0;
             float aP0 = 0, aP1 = 0, aP2 = 0, aX0 = 0, aX1 = 0, aX2 = 0, aY0 = 0, aY1 = 0, aY2 = 0;     // sum dL/dp, sum lx dL/dp, sum ly dL/dp
             float aZ0 = 0, aZ1 = 0, aZ2 = 0;            // sum dL/dz (sx, sy, 1)
@@ -169,13 +169,13 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
                 const bool cand = li >= 0 && (unsigned)li < last_p && bxl <= lxi && bxh >= lxi && byl <= lyi && byh >= lyi;
                 if (__ballot(cand) != 0ull) {       // (one latch for the loop: `continue`s here made the compiler rotate the accumulators)
                     const float lx = (float)lxi, ly = (float)lyi;
-                    // the forward's own evaluation of the pair (isr_fast_pair.hpp): same decisions, bit for bit
-                    const FastRay fr = fast_ray(lx, ly, A.x, A.y, A.z, B.x, B.y, B.z, C.x, C.y, C.z, cxr, cyr);
-                    const FastHit fh = fast_hit(fr, fs.det, Tw.z, opa);
+                    // the forward's own evaluation of the pair (isr_fast_pair.hpp; EXACT inside the guard bands): same decisions, bit for bit
+                    FastRay fr; FastHit fh;
+                    const bool pass = fast_pair_lane(fs, Tu, Tv, Tw, cx, cy, opa, fb, cxr, cyr, lx, ly, tile_x0 + lx, tile_y0 + ly, fr, fh);
                     const float dx = fr.dx, dy = fr.dy, rz = fr.rz, sx = fr.sx, sy = fr.sy;
                     const bool use3d = fh.use3d;
                     const float c_d = fh.depth, G = fh.G, alpha = fh.alpha;
-                    const bool act = cand && fast_near(fr, skip) && fast_pass(fh);
+                    const bool act = cand && pass;
                     if (__ballot(act) != 0ull) {
                         const float4 q0 = pq[0], q1 = pq[1], q2 = pq[2];
                         // q0 = dC.rgb, d_depth   q1 = d_accum, dN.xyz   q2 = d_median, d_reg, T_final, final_D   q3 = final_D2, last, median, bg_dot

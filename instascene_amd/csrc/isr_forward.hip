@@ -16,6 +16,7 @@
 //   sort on (tile, depth_bits) produces: point_list and ranges are bit-identical.
 //   HBM traffic is ~20 B/instance instead of ~144 B/instance for six radix passes.
 #include "isr_common.hpp"
+#include "isr_fast_pair.hpp"
 
 namespace isr {
 
@@ -205,7 +206,8 @@ __global__ __launch_bounds__(256) void k_preprocess(
         r4[1] = make_float4(Tv.y, Tv.z, Tw.x, Tw.y);
         r4[2] = make_float4(Tw.z, cx, cy, normal.x);
         r4[3] = make_float4(normal.y, normal.z, opacities[i], rgb.x);
-        r4[4] = make_float4(rgb.y, rgb.z, pv.z, 0.0f);
+        // rec[19]: the noise bound of FAST's rho against EXACT's over this splat's footprint (isr_fast_pair.hpp: guard bands)
+        r4[4] = make_float4(rgb.y, rgb.z, pv.z, splat_band(Tu, Tv, Tw, cx, cy, opa, cb, W, H));
         radius_i = sat_i32(radius);
         touched = (unsigned)(y1 - y0) * (unsigned)(x1 - x0);
         rc = {(uint16_t)x0, (uint16_t)y0, (uint16_t)x1, (uint16_t)y1};

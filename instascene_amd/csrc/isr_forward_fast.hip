@@ -26,9 +26,9 @@ constexpr int FF_BATCH = 128;       // instances staged per round
 constexpr int FF_RS = 24;           // staged floats per instance (six float4)
 // staged record:  q0 = A.xyz, cx - X0              A = Tv x Tw
 //                 q1 = B.xyz, cy - Y0              B = Tw x Tu
-//                 q2 = C.xyz, skip                C = p at the tile origin (X0, Y0); skip: alpha < 1/255 for rho > skip
-//                 q3 = det, Tw.z, opacity, 1/det
-//                 q4 = 1/Tw.z, normal.xyz
+//                 q2 = C.xyz, band.hi             C = p at the tile origin (X0, Y0); alpha < 1/255 is certain for rho > band.hi
+//                 q3 = det, Tw.z, opacity, band.lo   ... and alpha >= 1/255 for rho <= band.lo (isr_fast_pair.hpp: guard bands)
+//                 q4 = band.bw, normal.xyz
 //                 q5 = rgb, unused
 
 // AUX = false ("feature-only forward", opt-in ISR_MODE_FEATURE_ONLY): colour, the seven auxiliary maps, the median
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
             }
             const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y}, Tw = {b.z, b.w, c.x};
             const float opa = d.z;
-            const float skip = fast_skip(opa);
+            const FastBand fb = fast_band(opa, e.w);
             // p(px, py) = (px - X0) A + (py - Y0) B + C,  C = (X0 Tw - Tu) x (Y0 Tw - Tv)     (isr_fast_pair.hpp)
             const FastSplat fs = fast_splat(Tu, Tv, Tw, X0, Y0);
             const F3 A = fs.A, B = fs.B, C = fs.C;
@@ -137,9 +137,9 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
             float4* s4 = reinterpret_cast<float4*>(s_rec + t * RS);
             s4[0] = make_float4(A.x, A.y, A.z, c.y - X0);
             s4[1] = make_float4(B.x, B.y, B.z, c.z - Y0);
-            s4[2] = make_float4(C.x, C.y, C.z, skip);
-            s4[3] = make_float4(det, Tw.z, opa, __builtin_amdgcn_rcpf(det));
-            s4[4] = make_float4(__builtin_amdgcn_rcpf(Tw.z), c.w, d.x, d.y);
+            s4[2] = make_float4(C.x, C.y, C.z, fb.hi);
+            s4[3] = make_float4(det, Tw.z, opa, fb.lo);
+            s4[4] = make_float4(fb.bw, c.w, d.x, d.y);
             s4[5] = make_float4(d.w, e.x, e.y, 0.0f);
             const float4 cb = reinterpret_cast<const float4*>(cull + (size_t)id * 8)[0];      // per-Gaussian bounds from K1
             s_box[t] = cb;
@@ -202,17 +202,24 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                 const float4 q0 = q[0], q1 = q[1], q2 = q[2];
                 // the pair's arithmetic is isr_fast_pair.hpp's, shared with the FAST backward kernels: both passes take the
                 // same decisions on the same pair, bit for bit
-                const FastRay fr = fast_ray(lx, ly, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, q0.w, q1.w);
-                const float p_z = fr.p_z;
-                // beyond `skip` alpha < 1/255 is certain: when that holds for the whole wave nothing else is needed
-                const unsigned long long m_near = __ballot(fr.rho <= q2.w) & __ballot(p_z != 0.0f) & ~m_done;
+                FastRay fr = fast_ray(lx, ly, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, q0.w, q1.w);
+                // beyond band.hi alpha < 1/255 is certain: when that holds for the whole wave nothing else is needed
+                const unsigned long long m_near = __ballot(fr.rho <= q2.w) & __ballot(fr.p_z != 0.0f) & ~m_done;
                 if (m_near == 0ull) continue;
-                const float4 q3 = q[3];
-                const FastHit fh = fast_hit(fr, q3.x, q3.y, q3.z);
-                const bool use3d = fh.use3d;
+                const float4 q3 = q[3], q4 = q[4];
+                FastHit fh = fast_hit(fr, q3.x, q3.y, q3.z);
+                // the same decisions as k_render_fwd_fast_w below (guard bands: isr_fast_pair.hpp)
+                const unsigned long long m_cand = m_near & __ballot(!(fh.depth < NEAR_N));
+                const unsigned long long m_band = (m_near & __ballot(fr.rho > q3.w)) | (m_cand & __ballot(fabsf(fr.rho3d - fr.rho2d) <= q4.x));
+                unsigned long long m_pass = m_cand & ~m_band;
+                if (m_band != 0ull) {
+                    FastRay er; FastHit eh;
+                    const bool ep = exact_pair_rec(X0 + lx, Y0 + ly, rec, __builtin_amdgcn_readfirstlane(s_id[j]), er, eh);
+                    fast_take((m_band >> lane) & 1ull, er, eh, fr, fh);
+                    m_pass |= m_band & __ballot(ep);
+                }
                 const float depth = fh.depth, alpha = fh.alpha;
                 const float test_T = __builtin_fmaf(-T, alpha, T);
-                const unsigned long long m_pass = m_near & __ballot(!(depth < NEAR_N)) & __ballot(!(alpha < 1.0f / 255.0f));
                 const unsigned long long m_stop = m_pass & __ballot(test_T < 0.0001f);
                 m_done |= m_stop;
                 const unsigned long long m_ok = m_pass & ~m_stop;
@@ -231,8 +238,8 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                     w_lane = w;
                     const unsigned contributor = cbase + (unsigned)j;
                     if (AUX && first_pass) {
-                        const float4 q4 = q[4], q5 = q[5];
-                        const float inv_depth = use3d ? p_z * q3.w : q4.x;
+                        const float4 q5 = q[5];
+                        const float inv_depth = __builtin_amdgcn_rcpf(depth);
                         const float m_ = __builtin_fmaf(-(mscale * NEAR_N), inv_depth, mshift);      // m - m_ref
                         const float mw = m_ * w;
                         D = __builtin_fmaf(depth, w, D);
@@ -407,7 +414,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     f32x16 accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA, accC = accA, accD = accA;     // C, D: NC == 2
     float w_pend = 0.0f, f_pend = 0.0f, f_pend2 = 0.0f;
     bool pending = false;
-    unsigned st_cull = 0, st_eval = 0, st_blend = 0, st_lanes = 0, st_sub = 0;
+    unsigned st_cull = 0, st_eval = 0, st_blend = 0, st_lanes = 0, st_sub = 0, st_slow = 0, st_viol = 0;
     const float mscale = FAR_N / (FAR_N - NEAR_N);
     // the distortion moments are kept relative to m_ref, the mapped depth of the TILE's nearest splat (as in the tile-wide kernel:
     // every block of a tile uses the same shift, and the two kernels produce the same bits)
@@ -490,14 +497,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             }
             const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y}, Tw = {b.z, b.w, c.x};
             const float opa = d.z;
-            const float skip = fast_skip(opa);
+            const FastBand fb = fast_band(opa, e.w);
             const FastSplat fs = fast_splat(Tu, Tv, Tw, X0, Y0);
             float4* s4 = reinterpret_cast<float4*>(s_rec + lane * RS);
             s4[0] = make_float4(fs.A.x, fs.A.y, fs.A.z, c.y - X0);
             s4[1] = make_float4(fs.B.x, fs.B.y, fs.B.z, c.z - Y0);
-            s4[2] = make_float4(fs.C.x, fs.C.y, fs.C.z, skip);
-            s4[3] = make_float4(fs.det, Tw.z, opa, __builtin_amdgcn_rcpf(fs.det));
-            s4[4] = make_float4(__builtin_amdgcn_rcpf(Tw.z), c.w, d.x, d.y);
+            s4[2] = make_float4(fs.C.x, fs.C.y, fs.C.z, fb.hi);
+            s4[3] = make_float4(fs.det, Tw.z, opa, fb.lo);
+            s4[4] = make_float4(fb.bw, c.w, d.x, d.y);
             s4[5] = make_float4(d.w, e.x, e.y, __int_as_float(hp.y));          // .w: position in the tile's list (1-based)
         }
         if (FEAT) {
@@ -536,21 +543,39 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             const float4 q0 = q[0], q1 = q[1], q2 = q[2];
             v4f q3v = reinterpret_cast<const v4f*>(q)[3];
             FastRay fr = fast_ray(lx, ly, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, q0.w, q1.w);
-            const float p_z = fr.p_z;
             asm volatile("" : "+v"(q3v), "+v"(fr.rho));          // q3 is requested with q0..q2, not after the first branch
-            const unsigned long long m_near = __ballot(fr.rho <= q2.w) & __ballot(p_z != 0.0f) & ~m_done;
-            if (m_near == 0ull) continue;
+            const unsigned long long m_near = __ballot(fr.rho <= q2.w) & __ballot(fr.p_z != 0.0f) & ~m_done;
+            if (!STATS && m_near == 0ull) continue;
             const float4 q3 = make_float4(q3v.x, q3v.y, q3v.z, q3v.w);
             v4f q4e = reinterpret_cast<const v4f*>(q)[4], q5e = reinterpret_cast<const v4f*>(q)[5];
             float f_early = FEAT ? s_feat[j * FCH + (lane & 31)] : 0.0f;
             float f_early2 = (FEAT && NC == 2) ? s_feat[j * FCH + 32 + (lane & 31)] : 0.0f;
-            const FastHit fh = fast_hit(fr, q3.x, q3.y, q3.z);
+            FastHit fh = fast_hit(fr, q3.x, q3.y, q3.z);
+            if (NC == 2) asm volatile("" : "+v"(f_early2));
+            asm volatile("" : "+v"(q4e), "+v"(q5e), "+v"(f_early), "+v"(fh.alpha));      // ... and the blend's operands before ITS branch
+            // decisions (isr_fast_pair.hpp): a near pair outside the guard bands certainly has alpha >= 1/255 and FAST's branch
+            // and near-plane test are EXACT's; a pair inside them is re-evaluated with EXACT's instruction sequence
+            const unsigned long long m_cand = m_near & __ballot(!(fh.depth < NEAR_N));
+            const unsigned long long m_band = (m_near & __ballot(fr.rho > q3.w)) | (m_cand & __ballot(fabsf(fr.rho3d - fr.rho2d) <= q4e.x));
+            unsigned long long m_pass = m_cand & ~m_band;
+            if (STATS || m_band != 0ull) {
+                const int gid = __builtin_amdgcn_readfirstlane(s_ring[(head + j) & (FW_RING - 1)].x);
+                FastRay er; FastHit eh;
+                const bool ep = exact_pair_rec(X0 + lx, Y0 + ly, rec, gid, er, eh);
+                if (STATS) {
+                    if (m_band != 0ull) st_slow++;
+                    // outside the band FAST's decisions must be EXACT's (near pairs: pass and branch; far pairs: skipped)
+                    const bool fpass = (m_pass >> lane) & 1ull, inb = (m_band >> lane) & 1ull, alive = !((m_done >> lane) & 1ull);
+                    const bool bad = alive && !inb && (fpass != ep || (ep && fh.use3d != eh.use3d));
+                    st_viol += (unsigned)__popcll(__ballot(bad));
+                }
+                fast_take((m_band >> lane) & 1ull, er, eh, fr, fh);
+                m_pass |= m_band & __ballot(ep);
+                if (STATS && m_near == 0ull) continue;
+            }
             const bool use3d = fh.use3d;
             const float depth = fh.depth, alpha = fh.alpha;
-            float test_T = __builtin_fmaf(-T, alpha, T);
-            if (NC == 2) asm volatile("" : "+v"(f_early2));
-            asm volatile("" : "+v"(q4e), "+v"(q5e), "+v"(f_early), "+v"(test_T));      // ... and the blend's operands before ITS branch
-            const unsigned long long m_pass = m_near & __ballot(!(depth < NEAR_N)) & __ballot(!(alpha < 1.0f / 255.0f));
+            const float test_T = __builtin_fmaf(-T, alpha, T);
             const unsigned long long m_stop = m_pass & __ballot(test_T < 0.0001f);
             m_done |= m_stop;
             const unsigned long long m_ok = m_pass & ~m_stop;
@@ -568,7 +593,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                 w_lane = w;
                 const unsigned contributor = __float_as_uint(q5e.w);
                 if (AUX && first_pass) {
-                    const float inv_depth = use3d ? p_z * q3.w : q4e.x;
+                    const float inv_depth = __builtin_amdgcn_rcpf(depth);
                     const float m_ = __builtin_fmaf(-(mscale * NEAR_N), inv_depth, mshift);      // m - m_ref
                     const float mw = m_ * w;
                     D = __builtin_fmaf(depth, w, D);
@@ -581,6 +606,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                 T = test_T;
                 last_contributor = contributor;
             }
+            (void)use3d;
             if (AUX && tracer != nullptr && first_pass) {
                 const unsigned long long m_tr = __ballot(w_lane >= 0.1f);     // (double)w > 0.1  <=>  w >= 0.1f
                 if (m_tr != 0ull) {
@@ -642,6 +668,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             atomicAdd(stats + 2, (unsigned long long)st_blend);
             atomicAdd(stats + 3, (unsigned long long)st_lanes);
             atomicAdd(stats + 5, (unsigned long long)st_sub);
+            atomicAdd(stats + 6, (unsigned long long)st_slow);      // (wave, splat) evaluations that took the EXACT path
+            atomicAdd(stats + 7, (unsigned long long)st_viol);      // pairs outside the guard bands whose decision differs from EXACT's
         }
     }
     if (!AUX && inside && first_pass) {

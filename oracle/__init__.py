@@ -29,15 +29,28 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libsurfel_oracle.so")
+_LIB_FMA_PATH = os.path.join(_HERE, "_build", "libsurfel_oracle_fma.so")
 _lib = None
+_lib_fma = None
 
 
 def build(force: bool = False) -> str:
     """Compile the C++ oracle with g++ (a few seconds)."""
     src = os.path.join(_HERE, "surfel_oracle.cpp")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    if force or any(not os.path.exists(q) or os.path.getmtime(q) < os.path.getmtime(src) for q in (_LIB_PATH, _LIB_FMA_PATH)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
+
+
+def lib_fma():
+    """The second build of the same source (``-ffp-contract=fast``, libm ``expf``): what a compiler with the reference's
+    defaults (nvcc ``--fmad=true``, libdevice ``expf``) may legitimately produce.  Only the per-pixel loops are taken from it
+    (``forward(..., fma=True)``): K1 and the binning stay the primary build's, so both see the same tile lists."""
+    global _lib_fma
+    if _lib_fma is None:
+        build()
+        _lib_fma = ctypes.CDLL(_LIB_FMA_PATH)
+    return _lib_fma
 
 
 def lib():
@@ -82,7 +95,7 @@ def dist2_3nn(points):
 
 def forward(means3D, opacities, view, proj, campos, bg, W, H, tanfovx, tanfovy, *, scales=None,
             rotations=None, shs=None, colors_precomp=None, transMat_precomp=None, extra=None,
-            sh_degree=0, scale_modifier=1.0, tracer=False):
+            sh_degree=0, scale_modifier=1.0, tracer=False, fma=False, margins=False):
     """Full forward (K1..K8).  Returns a dict with outputs and every intermediate
     the backward / parity tests need.  Argument meaning follows
     ``CudaRasterizer::Rasterizer::forward`` (rasterizer_impl.cu:198-351)."""
@@ -129,10 +142,11 @@ def forward(means3D, opacities, view, proj, campos, bg, W, H, tanfovx, tanfovy, 
     trace = np.full((N * 10, 2), -1, np.int32) if tracer else None
     tcount = c_int64(0)
     pl = point_list if R > 0 else np.zeros(1, np.uint32)
-    L.so_render_fwd(c_int(W), c_int(H), c_int(ED), _p(ranges), _p(pl), _p(means2D), _p(colors_used), _p(tm_used),
-                    _p(extra), _p(normal_opacity), _p(bg), _p(final_T), _p(n_contrib), _p(out_color),
-                    _p(out_others), _p(out_extra) if ED else None, _p(trace), c_int64(N * 10),
-                    ctypes.byref(tcount))
+    mg = np.zeros((4, N), np.float32) if margins else None
+    (lib_fma() if fma else L).so_render_fwd_margins(
+        c_int(W), c_int(H), c_int(ED), _p(ranges), _p(pl), _p(means2D), _p(colors_used), _p(tm_used),
+        _p(extra), _p(normal_opacity), _p(bg), _p(final_T), _p(n_contrib), _p(out_color),
+        _p(out_others), _p(out_extra) if ED else None, _p(trace), c_int64(N * 10), ctypes.byref(tcount), _p(mg))
     st = dict(P=P, W=W, H=H, ED=ED, M=M, R=R, sh_degree=sh_degree, scale_modifier=scale_modifier,
               tanfovx=tanfovx, tanfovy=tanfovy, radii=radii, means2D=means2D, depths=depths,
               transMats=transMats, rgb=rgb, normal_opacity=normal_opacity, tiles_touched=tiles_touched,
@@ -144,6 +158,8 @@ def forward(means3D, opacities, view, proj, campos, bg, W, H, tanfovx, tanfovy, 
                           view=view, proj=proj, campos=campos, bg=bg))
     if tracer:
         st["tracer"] = trace[: int(tcount.value)]
+    if margins:
+        st["margins"] = mg
     return st
 
 

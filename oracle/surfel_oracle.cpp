@@ -91,6 +91,11 @@ inline uint32_t sat_u32(float v) {
 // degree-5 polynomial, < 1 ulp) that is reproducible on any IEEE-754 machine —
 // the HIP kernels' "exact" mode evaluates the identical sequence.
 inline float exp_fixed(float x) {
+#ifdef ORACLE_FMA
+    // second build (libsurfel_oracle_fma.so: -ffp-contract=fast, libm expf): the latitude of the reference's own nvcc build
+    // (default --fmad=true, libdevice expf) - used by the tests to tell a decision that sits inside that latitude
+    return std::exp(x);
+#endif
     if (x < -87.0f) return 0.0f;
     float n = std::nearbyint(x * 1.44269504088896341f);
     float r = std::fmaf(n, -0.693359375f, x);
@@ -398,11 +403,16 @@ int64_t so_bin(int P, int W, int H, const int* radii, const float* means2D, cons
 // (exactly what each CUDA thread computes; the cooperative fetch is
 // irrelevant to the values).  tracer may be null; otherwise it receives
 // (gaussian, pixel) pairs with w > 0.1 and *tracer_count their number.
-void so_render_fwd(int W, int H, int ED, const uint32_t* ranges, const uint32_t* point_list,
+// margins (optional, [4,N]): how close the pixel's walk came to flipping a decision -
+//   [0] min |alpha * 255 - 1| over the pairs that reached the alpha < 1/255 test (forward.cu:386)
+//   [1] min |depth - near_n| over the pairs that reached the depth test (forward.cu:372)
+//   [2] min |rho3d - rho2d| over the pairs that blended (the branch of forward.cu:365-372)
+//   [3] min |test_T / 1e-4 - 1| over the pairs that reached the T < 1e-4 stop (forward.cu:389)
+void so_render_fwd_margins(int W, int H, int ED, const uint32_t* ranges, const uint32_t* point_list,
                    const float* means2D, const float* colors, const float* transMats, const float* extras,
                    const float* normal_opacity, const float* bg, float* final_T /*[3,N]*/,
                    uint32_t* n_contrib /*[2,N]*/, float* out_color, float* out_others, float* out_extra,
-                   int32_t* tracer, int64_t tracer_cap, int64_t* tracer_count) {
+                   int32_t* tracer, int64_t tracer_cap, int64_t* tracer_count, float* margins) {
     const int gx = tiles_x(W), gy = tiles_y(H);
     const size_t N = (size_t)W * H;
     const float mscale = FAR_N / (FAR_N - NEAR_N);
@@ -424,6 +434,7 @@ void so_render_fwd(int W, int H, int ED, const uint32_t* ranges, const uint32_t*
                 float D = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
                 float median_contributor = -1.0f;
                 std::fill(E.begin(), E.end(), 0.0f);
+                float mg[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
                 for (uint32_t k = r0; k < r1; k++) {
                     contributor++;
                     const uint32_t g = point_list[k];
@@ -439,15 +450,19 @@ void so_render_fwd(int W, int H, int ED, const uint32_t* ranges, const uint32_t*
                     float rho2d = FILTER_INV_SQ * (dx * dx + dy * dy);
                     float rho = std::min(rho3d, rho2d);
                     float depth = (rho3d <= rho2d) ? (sx * Tw.x + sy * Tw.y) + Tw.z : Tw.z;
+                    mg[1] = std::min(mg[1], std::fabs(depth - NEAR_N));
                     if (depth < NEAR_N) continue;
                     const float* no = normal_opacity + 4 * (size_t)g;
                     float opa = no[3];
                     float power = -0.5f * rho;
                     if (power > 0.0f) continue;
                     float alpha = std::min(0.99f, opa * exp_fixed(power));
+                    mg[0] = std::min(mg[0], std::fabs(alpha * 255.0f - 1.0f));
                     if (alpha < 1.0f / 255.0f) continue;
                     float test_T = T * (1 - alpha);
+                    mg[3] = std::min(mg[3], std::fabs(test_T * 10000.0f - 1.0f));
                     if (test_T < 0.0001f) break;   // `done = true` — nothing after it blends
+                    mg[2] = std::min(mg[2], std::fabs(rho3d - rho2d));
                     float w = alpha * T;
                     float A = 1 - T;
                     float m = mscale * (1 - NEAR_N / depth);
@@ -481,6 +496,8 @@ void so_render_fwd(int W, int H, int ED, const uint32_t* ranges, const uint32_t*
                 out_others[pix + 5 * N] = median_depth;
                 out_others[pix + 6 * N] = distortion;
                 for (int ch = 0; ch < ED; ch++) out_extra[ch * N + pix] = E[ch];
+                if (margins)
+                    for (int q = 0; q < 4; q++) margins[q * N + pix] = mg[q];
             }
     }
     if (tracer) {
@@ -492,6 +509,14 @@ void so_render_fwd(int W, int H, int ED, const uint32_t* ranges, const uint32_t*
             }
         *tracer_count = n;
     }
+}
+
+void so_render_fwd(int W, int H, int ED, const uint32_t* ranges, const uint32_t* point_list,
+                   const float* means2D, const float* colors, const float* transMats, const float* extras,
+                   const float* normal_opacity, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
+                   float* out_others, float* out_extra, int32_t* tracer, int64_t tracer_cap, int64_t* tracer_count) {
+    so_render_fwd_margins(W, H, ED, ranges, point_list, means2D, colors, transMats, extras, normal_opacity, bg, final_T, n_contrib,
+                          out_color, out_others, out_extra, tracer, tracer_cap, tracer_count, nullptr);
 }
 
 // ---------------------------------------------------------------------------

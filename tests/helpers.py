@@ -15,7 +15,7 @@ def small_scene(P=400, F=6, W=64, H=48, seed=3, mu_s=math.log(0.06), ncam=6, sh_
     return sc, cams, inp
 
 
-def oracle_forward(inp, cam, bg=(0.0, 0.0, 0.0), sh_degree=3, tracer=False, scale_modifier=1.0, **over):
+def oracle_forward(inp, cam, bg=(0.0, 0.0, 0.0), sh_degree=3, tracer=False, scale_modifier=1.0, fma=False, margins=False, **over):
     a = {k: (None if v is None else v.detach().cpu().numpy()) for k, v in inp.items()}
     a.update(over)
     return oracle.forward(a["means3D"], a["opacities"], cam.world_view_transform.numpy(),
@@ -24,7 +24,7 @@ def oracle_forward(inp, cam, bg=(0.0, 0.0, 0.0), sh_degree=3, tracer=False, scal
                           math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), scales=a.get("scales"),
                           rotations=a.get("rotations"), shs=a.get("shs"), colors_precomp=a.get("colors_precomp"),
                           transMat_precomp=a.get("transMat_precomp"), extra=a.get("extra"), sh_degree=sh_degree,
-                          scale_modifier=scale_modifier, tracer=tracer)
+                          scale_modifier=scale_modifier, tracer=tracer, fma=fma, margins=margins)
 
 
 def rel_err(a, b, eps=1e-12):
