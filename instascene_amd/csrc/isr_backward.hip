@@ -123,10 +123,10 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
     const uint32_t* __restrict__ point_offsets,
     const Rect16* __restrict__ rects, float* __restrict__ partial, uint8_t* __restrict__ row_flags,
     const uint8_t* __restrict__ tile_mode, int row_stride, int geom_off, int feat_off, int64_t capacity) {
-    // staged record, EXACT: Tu Tv Tw | centre normal | opacity skip.  FAST: the affine form of the intersection first
-    // (A.xyz, cx - X0 | B.xyz, cy - Y0 | C.xyz, det | Tw.z, opacity, skip: isr_fast_pair.hpp - the pair is evaluated exactly as
-    // k_render_fwd_fast did), and only for the geometry gradient also Tu Tv Tw | normal
-    constexpr int RS = (Math::fast && GEOM) ? 28 : 16;
+    // staged record, EXACT: Tu Tv Tw | centre normal | opacity skip.  FAST: the operand pairs of fast_ray (Tu.xy Tv.xy | Tw.xy Tu.z Tv.z |
+    // Tw.z det cx cy | opacity band.hi band.lo: isr_fast_pair.hpp - the pair is evaluated exactly as k_render_fwd_fast did), and
+    // only for the geometry gradient also the normal
+    constexpr int RS = (Math::fast && GEOM) ? 20 : 16;
     constexpr int SB = 128;                 // (id, cull box) pairs staged per barrier round: two 64-bit hit masks per wave
     constexpr int PART = (GEOM ? GEOM_ROW : 0) + (FEAT ? 32 : 0);   // floats per instance per wave in LDS
     __shared__ __attribute__((aligned(16))) float s_rec[BB * RS];      // records of the current sub-batch (hit instances only)
@@ -150,7 +150,6 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
     const size_t N = (size_t)W * H;
     const size_t pix = (size_t)W * py + px;
     const float pxf = (float)px, pyf = (float)py;
-    const float lxf = (float)((wv & 1) * 8 + (lane & 7)), lyf = (float)((wv >> 1) * 8 + (lane >> 3));     // tile-relative
 
     const int64_t r0 = tile_offset[tile];
     int64_t r1 = tile_offset[tile + 1];
@@ -358,13 +357,13 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
                 }
                 float4* s4 = reinterpret_cast<float4*>(s_rec + t * RS);
                 if constexpr (Math::fast) {
-                    const FastSplat fs = fast_splat({a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, (float)(tx * TILE), (float)(ty * TILE));
+                    const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y}, Tw = {b.z, b.w, c.x};
                     const FastBand fb = fast_band(opa, e.w);          // rec[19]: K1's guard band (isr_fast_pair.hpp)
-                    s4[0] = make_float4(fs.A.x, fs.A.y, fs.A.z, c.y - (float)(tx * TILE));
-                    s4[1] = make_float4(fs.B.x, fs.B.y, fs.B.z, c.z - (float)(ty * TILE));
-                    s4[2] = make_float4(fs.C.x, fs.C.y, fs.C.z, fs.det);
-                    s4[3] = make_float4(c.x, opa, fb.hi, fb.lo);
-                    if constexpr (GEOM) { s4[4] = a; s4[5] = b; s4[6] = make_float4(c.w, d.x, d.y, 0.0f); }
+                    s4[0] = make_float4(Tu.x, Tu.y, Tv.x, Tv.y);
+                    s4[1] = make_float4(Tw.x, Tw.y, Tu.z, Tv.z);
+                    s4[2] = make_float4(Tw.z, fast_det(Tu, Tv, Tw, c.y, c.z), c.y, c.z);
+                    s4[3] = make_float4(opa, fb.hi, fb.lo, 0.0f);
+                    if constexpr (GEOM) s4[4] = make_float4(c.w, d.x, d.y, 0.0f);
                 } else {
                     s4[0] = a; s4[1] = b; s4[2] = c; s4[3] = make_float4(d.x, d.y, opa, skip);
                 }
@@ -401,18 +400,19 @@ __global__ __launch_bounds__(256, (GEOM && !FEAT && QF == 0) ? 3 : 2) void k_ren
                     if constexpr (Math::fast) {
                         // the forward's own evaluation of the pair (isr_fast_pair.hpp): same decisions, bit for bit
                         const float4 qa = sj[0], qb = sj[1], qc = sj[2], qd = sj[3];
-                        d.z = qd.y;
-                        Tw.z = qd.x;
+                        d.z = qd.x;
+                        Tw = {qb.x, qb.y, qc.x};
+                        a = make_float4(qa.x, qa.y, qb.z, qa.z);          // Tu.xyz, Tv.x
+                        b = make_float4(qa.w, qb.w, qb.x, qb.y);          // Tv.yz, Tw.xy
                         if constexpr (GEOM) {
-                            a = sj[4]; b = sj[5];
-                            const float4 qn = sj[6];
-                            Tw = {b.z, b.w, qd.x};
+                            const float4 qn = sj[4];
                             nx = qn.x; ny = qn.y; nz = qn.z;
                         }
-                        FastRay fr = fast_ray(lxf, lyf, qa.x, qa.y, qa.z, qb.x, qb.y, qb.z, qc.x, qc.y, qc.z, qa.w, qb.w);
-                        FastHit fh = fast_hit(fr, qc.w, qd.x, qd.y);
-                        const bool near = act && fast_near(fr, qd.z);
-                        const bool inb = near && fast_in_band(fr, fast_band_of(qd.z, qd.w));
+                        FastRay fr = fast_ray((v2f){pxf, pyf}, (v2f){qa.x, qa.y}, (v2f){qa.z, qa.w}, (v2f){qb.x, qb.y}, (v2f){qb.z, qb.w}, qc.x,
+                                              (v2f){qc.z, qc.w});
+                        FastHit fh = fast_hit(fr, qc.y, qc.x, qd.x);
+                        const bool near = act && fast_near(fr, qd.y);
+                        const bool inb = near && fast_in_band(fr, fast_band_of(qd.y, qd.z));
                         act = near && fast_pass(fh);
                         if (__ballot(inb) != 0ull) {          // rare: the pair is re-evaluated as EXACT does (the forward did the same)
                             FastRay er; FastHit eh;
@@ -700,11 +700,10 @@ __device__ __forceinline__ float splat_alpha(const F3 Tu, const F3 Tv, const F3 
 
 // the same in FAST arithmetic: the forward's own evaluation of the pair (isr_fast_pair.hpp: EXACT inside the guard bands),
 // tile-relative pixel (lx, ly) = absolute pixel (pxf, pyf)
-__device__ __forceinline__ float splat_alpha_fast(const FastSplat& fs, const F3 Tu, const F3 Tv, const F3 Tw, float cx, float cy,
-                                                  float cxr, float cyr, float opa, const FastBand& fb, float lx, float ly,
-                                                  float pxf, float pyf) {
+__device__ __forceinline__ float splat_alpha_fast(const F3 Tu, const F3 Tv, const F3 Tw, float cx, float cy, float opa, float det,
+                                                  const FastBand& fb, float pxf, float pyf) {
     FastRay fr; FastHit fh;
-    return fast_pair_lane(fs, Tu, Tv, Tw, cx, cy, opa, fb, cxr, cyr, lx, ly, pxf, pyf, fr, fh) ? fh.alpha : 0.0f;
+    return fast_pair_lane(Tu, Tv, Tw, cx, cy, opa, det, fb, pxf, pyf, fr, fh) ? fh.alpha : 0.0f;
 }
 
 // Step 1 — which pixels carry an upstream gradient?  A streaming pass over dL/dE: one workgroup per strip of four
@@ -1001,10 +1000,9 @@ __global__ __launch_bounds__(64, ISR_SPARSE_WAVES) void k_render_bwd_sparse(
                     skip = 2.0f * l * 1.01f + 0.05f;
                 } else skip = __builtin_inff();
             }
-            FastSplat fs = {{0, 0, 0}, {0, 0, 0}, {0, 0, 1}, 0.0f};
+            float det = 0.0f;
             FastBand fb = {0.0f, 0.0f, 0.0f};
-            if constexpr (Math::fast) { fs = fast_splat(Tu, Tv, Tw, tile_x0, tile_y0); fb = fast_band(opa, band); }
-            const float cxr = cx - tile_x0, cyr = cy - tile_y0;
+            if constexpr (Math::fast) { det = fast_det(Tu, Tv, Tw, cx, cy); fb = fast_band(opa, band); }
             float acc[32];
 #pragma unroll
             for (int c2 = 0; c2 < 32; c2++) acc[c2] = 0.0f;
@@ -1015,8 +1013,7 @@ __global__ __launch_bounds__(64, ISR_SPARSE_WAVES) void k_render_bwd_sparse(
                 float alpha = 0.0f;
                 if ((hk >> k) & 1u) {
                     if constexpr (Math::fast)
-                        alpha = splat_alpha_fast(fs, Tu, Tv, Tw, cx, cy, cxr, cyr, opa, fb, (float)(xy & 255), (float)(xy >> 8),
-                                                 tile_x0 + (float)(xy & 255), tile_y0 + (float)(xy >> 8));
+                        alpha = splat_alpha_fast(Tu, Tv, Tw, cx, cy, opa, det, fb, tile_x0 + (float)(xy & 255), tile_y0 + (float)(xy >> 8));
                     else
                         alpha = splat_alpha<Math>(Tu, Tv, Tw, cx, cy, opa, skip, tile_x0 + (float)(xy & 255), tile_y0 + (float)(xy >> 8));
                 }

@@ -149,13 +149,12 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
                 const Rect16 rc = rects[id];
                 slot = point_offsets[id] + (unsigned)(ty - rc.y0) * (unsigned)(rc.x1 - rc.x0) + (unsigned)(tx - rc.x0);
             }
-            // The ray-splat intersection is affine in the pixel (see isr_forward_fast.hip): p = lx A + ly B + C with tile-relative
-            // pixel coordinates, and so is its adjoint: dL/dA = sum lx dL/dp, dL/dB = sum ly dL/dp, dL/dC = sum dL/dp.  The pixel
+            // The ray-splat intersection p = (px Tw - Tu) x (py Tw - Tv) is affine in the pixel: p = lx A + ly B + C with tile-relative
+            // pixel coordinates (A = Tv x Tw, B = Tw x Tu, C = p at the tile origin), and so is its adjoint: dL/dA = sum lx dL/dp, dL/dB = sum ly dL/dp, dL/dC = sum dL/dp.  The pixel
             // loop accumulates those nine sums (instead of two cross products and nine FMAs per pair for dL/dTu, dL/dTv, dL/dTw);
             // they are turned into the gradient of the three rows once per (block, splat), after the loop.
-            const FastSplat fs = fast_splat(Tu, Tv, Tw, tile_x0, tile_y0);
+            const float det = fast_det(Tu, Tv, Tw, cx, cy);
             const FastBand fb = fast_band(opa, band);
-            const float cxr = cx - tile_x0, cyr = cy - tile_y0;
             float aP0 = 0, aP1 = 0, aP2 = 0, aX0 = 0, aX1 = 0, aX2 = 0, aY0 = 0, aY1 = 0, aY2 = 0;     // sum dL/dp, sum lx dL/dp, sum ly dL/dp
             float aZ0 = 0, aZ1 = 0, aZ2 = 0;            // sum dL/dz (sx, sy, 1)
             float aC0 = 0, aC1 = 0;                     // dL/dcentre (low-pass branch)
@@ -171,7 +170,7 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
                     const float lx = (float)lxi, ly = (float)lyi;
                     // the forward's own evaluation of the pair (isr_fast_pair.hpp; EXACT inside the guard bands): same decisions, bit for bit
                     FastRay fr; FastHit fh;
-                    const bool pass = fast_pair_lane(fs, Tu, Tv, Tw, cx, cy, opa, fb, cxr, cyr, lx, ly, tile_x0 + lx, tile_y0 + ly, fr, fh);
+                    const bool pass = fast_pair_lane(Tu, Tv, Tw, cx, cy, opa, det, fb, tile_x0 + lx, tile_y0 + ly, fr, fh);
                     const float dx = fr.dx, dy = fr.dy, rz = fr.rz, sx = fr.sx, sy = fr.sy;
                     const bool use3d = fh.use3d;
                     const float c_d = fh.depth, G = fh.G, alpha = fh.alpha;

@@ -10,8 +10,14 @@
 // instruction sequence on the same inputs in both passes (the library is built with -ffp-contract=off, every fused
 // operation below is explicit, v_rcp_f32 / v_exp_f32 are deterministic), so the decisions replay bit for bit.
 //
-//   p(px, py) = (px Tw - Tu) x (py Tw - Tv) is affine in the pixel:  p = lx A + ly B + C  with tile-relative lx, ly,
-//   A = Tv x Tw,  B = Tw x Tu,  C = p at the tile origin;  depth = <p, Tw> / p.z = det / p.z  (A, B are orthogonal to Tw).
+//   p(px, py) = k x l,  k = px Tw - Tu,  l = py Tw - Tv  (forward.cu:340-352).  The two-rounding EXACT / oracle evaluation
+//   of k.z = fl(fl(px Tw.z) - Tu.z) cancels ~3 decimal digits (px Tw.z ~ Tu.z ~ 1e4, their difference a few pixels times the
+//   depth) and that rounding dominates everything else in rho by two orders of magnitude.  FAST therefore computes k.z and
+//   l.z with EXACTLY those two roundings (bit-identical to EXACT's), the well-conditioned k.xy, l.xy and the cross product
+//   with fused multiply-adds, two components per v_pk_* instruction (8 vector instructions for p), s = p.xy * rcp(p.z), and
+//   depth = <p, Tw> / p.z = det / p.z with the per-splat det = det[Tu, Tv, Tw]  (<k x l, Tw> = det[k, l, Tw], and adding
+//   multiples of Tw to the other two rows does not change it).  Its rho then follows EXACT's to ~1e-6 relative, so the guard
+//   bands below are narrow.
 #pragma once
 
 #include "isr_common.hpp"
@@ -19,9 +25,8 @@
 namespace isr {
 
 // ---- guard bands ----------------------------------------------------------------------------------------------------
-// FAST's rho differs from the two-rounding EXACT / oracle evaluation by rounding noise (dominated by EXACT's own
-// fl(px Tw.z) - Tu.z, an absolute error of ulp(px Tw.z) on a difference of a few pixels).  A pair whose rho lies within that
-// noise of a DECISION threshold - alpha = 1/255 (forward.cu:386), rho3d = rho2d (forward.cu:365-372), depth = near_n
+// FAST's rho still differs from the two-rounding EXACT / oracle evaluation by rounding noise (fma against mul + add in the
+// well-conditioned terms, rcp against IEEE division).  A pair whose rho lies within that noise of a DECISION threshold - alpha = 1/255 (forward.cu:386), rho3d = rho2d (forward.cu:365-372), depth = near_n
 // (forward.cu:372) - is re-evaluated with EXACT's instruction sequence (exact_pair below), in the forward and in every backward
 // kernel alike, so the decision taken is the oracle's.  The noise bound `band` is per Gaussian and view (splat_band, K1,
 // stored in rec[19]); band = +inf forces the EXACT sequence for every pair of the splat (ill-conditioned, near the near plane,
@@ -36,11 +41,22 @@ __device__ __forceinline__ FastBand fast_band(float opa, float band) {
 }
 __device__ __forceinline__ FastBand fast_band_of(float hi, float lo) { return {hi, lo, hi - lo}; }
 
+// det = <Tu, Tv x Tw> = <k x l, Tw> for every pixel; evaluated at the splat's centre (cx, cy), where k and l are small: no
+// cancellation of the large Tu.z ~ cx Tw.z, Tv.z ~ cy Tw.z
+__device__ __forceinline__ float fast_det(const F3 Tu, const F3 Tv, const F3 Tw, float cx, float cy) {
+    const F3 k = {__builtin_fmaf(cx, Tw.x, -Tu.x), __builtin_fmaf(cx, Tw.y, -Tu.y), __builtin_fmaf(cx, Tw.z, -Tu.z)};
+    const F3 l = {__builtin_fmaf(cy, Tw.x, -Tv.x), __builtin_fmaf(cy, Tw.y, -Tv.y), __builtin_fmaf(cy, Tw.z, -Tv.z)};
+    const F3 c = {__builtin_fmaf(k.y, l.z, -(k.z * l.y)), __builtin_fmaf(k.z, l.x, -(k.x * l.z)), __builtin_fmaf(k.x, l.y, -(k.y * l.x))};
+    return __builtin_fmaf(c.x, Tw.x, __builtin_fmaf(c.y, Tw.y, c.z * Tw.z));
+}
+
 // Bound on |rho_FAST - rho_EXACT| (both branches) over the splat's footprint - its alpha >= 1/255 box `cb` (splat_cull_box)
-// clipped to the image - plus the slack of exp / log / the threshold itself.  First-order worst-case rounding analysis:
-//   EXACT  k = fl(fl(px Tw) - Tu), l likewise, p = fl(fl(k.y l.z) - fl(k.z l.y)) ..., s = p.xy / p.z
-//   FAST   A, B, C (fast_splat) by fma, p = fma(lx, A, fma(ly, B, C)), s = p.xy * rcp(p.z)
-// u = 2^-24.  Returns +inf (always EXACT) when the bound is not small or a depth of the footprint may lie within it of near_n.
+// clipped to the image - plus the slack of exp / log / the threshold itself.  First-order worst-case rounding analysis, u = 2^-24:
+//   k.z, l.z                identical in both;
+//   k.x  EXACT fl(fl(px Tw.x) - Tu.x): u (|px Tw.x| + |k.x|);  FAST fma: u |k.x|   (k.y, l.x, l.y alike)
+//   p.x  EXACT fl(fl(k.y l.z) - fl(k.z l.y)), FAST fma(k.y, l.z, -fl(k.z l.y)): u (|k.y l.z| + 2 |k.z l.y| + 2 |p.x|) + inputs
+//   s    EXACT p.xy / p.z, FAST p.xy * rcp(p.z): 3 u |s|;   rho3d, rho2d: fma against mul + add, 3 u rho
+// Returns +inf (always EXACT) when the bound is not small or a depth of the footprint may lie within its error of near_n.
 __device__ __forceinline__ float splat_band(F3 Tu, F3 Tv, F3 Tw, float cx, float cy, float opa, float4 cb, int W, int H) {
     const float inf = __builtin_inff();
     const float u = 5.9604645e-8f;
@@ -49,24 +65,19 @@ __device__ __forceinline__ float splat_band(F3 Tu, F3 Tv, F3 Tw, float cx, float
     const float l0 = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
     const float S2 = l0 + l0 + 0.1f, S = __builtin_sqrtf(S2);
     const F3 aw = {fabsf(Tw.x), fabsf(Tw.y), fabsf(Tw.z)};
-    // pixels of the footprint and the origins of their tiles: [xa - 16, xb + 16]
-    const float PX = xb + 16.0f, PY = yb + 16.0f;
-    const F3 ek = {u * (2.0f * PX * aw.x + fabsf(Tu.x)), u * (2.0f * PX * aw.y + fabsf(Tu.y)), u * (2.0f * PX * aw.z + fabsf(Tu.z))};
-    const F3 el = {u * (2.0f * PY * aw.x + fabsf(Tv.x)), u * (2.0f * PY * aw.y + fabsf(Tv.y)), u * (2.0f * PY * aw.z + fabsf(Tv.z))};
     const F3 ka = {__builtin_fmaf(xa, Tw.x, -Tu.x), __builtin_fmaf(xa, Tw.y, -Tu.y), __builtin_fmaf(xa, Tw.z, -Tu.z)};
     const F3 kb = {__builtin_fmaf(xb, Tw.x, -Tu.x), __builtin_fmaf(xb, Tw.y, -Tu.y), __builtin_fmaf(xb, Tw.z, -Tu.z)};
     const F3 la = {__builtin_fmaf(ya, Tw.x, -Tv.x), __builtin_fmaf(ya, Tw.y, -Tv.y), __builtin_fmaf(ya, Tw.z, -Tv.z)};
     const F3 lb = {__builtin_fmaf(yb, Tw.x, -Tv.x), __builtin_fmaf(yb, Tw.y, -Tv.y), __builtin_fmaf(yb, Tw.z, -Tv.z)};
-    const F3 K = {fmaxf(fabsf(ka.x), fabsf(kb.x)) + 16.0f * aw.x, fmaxf(fabsf(ka.y), fabsf(kb.y)) + 16.0f * aw.y,
-                  fmaxf(fabsf(ka.z), fabsf(kb.z)) + 16.0f * aw.z};
-    const F3 L = {fmaxf(fabsf(la.x), fabsf(lb.x)) + 16.0f * aw.x, fmaxf(fabsf(la.y), fabsf(lb.y)) + 16.0f * aw.y,
-                  fmaxf(fabsf(la.z), fabsf(lb.z)) + 16.0f * aw.z};
+    // |k|, |l| over the footprint (affine: extremes at its ends; + a pixel for the clipping of the box to whole pixels)
+    const F3 K = {fmaxf(fabsf(ka.x), fabsf(kb.x)) + aw.x, fmaxf(fabsf(ka.y), fabsf(kb.y)) + aw.y, fmaxf(fabsf(ka.z), fabsf(kb.z)) + aw.z};
+    const F3 L = {fmaxf(fabsf(la.x), fabsf(lb.x)) + aw.x, fmaxf(fabsf(la.y), fabsf(lb.y)) + aw.y, fmaxf(fabsf(la.z), fabsf(lb.z)) + aw.z};
+    const float dkx = u * (xb * aw.x + 2.0f * K.x), dky = u * (xb * aw.y + 2.0f * K.y);
+    const float dlx = u * (yb * aw.x + 2.0f * L.x), dly = u * (yb * aw.y + 2.0f * L.y);
     const F3 aC = {K.y * L.z + K.z * L.y, K.z * L.x + K.x * L.z, K.x * L.y + K.y * L.x};
-    const F3 aA = {fabsf(Tv.y * Tw.z) + fabsf(Tv.z * Tw.y), fabsf(Tv.z * Tw.x) + fabsf(Tv.x * Tw.z), fabsf(Tv.x * Tw.y) + fabsf(Tv.y * Tw.x)};
-    const F3 aB = {fabsf(Tw.y * Tu.z) + fabsf(Tw.z * Tu.y), fabsf(Tw.z * Tu.x) + fabsf(Tw.x * Tu.z), fabsf(Tw.x * Tu.y) + fabsf(Tw.y * Tu.x)};
-    const float Px = (L.z * ek.y + K.y * el.z + L.y * ek.z + K.z * el.y) + u * (10.0f * aC.x + 64.0f * (aA.x + aB.x));
-    const float Py = (L.x * ek.z + K.z * el.x + L.z * ek.x + K.x * el.z) + u * (10.0f * aC.y + 64.0f * (aA.y + aB.y));
-    const float Pz = (L.y * ek.x + K.x * el.y + L.x * ek.y + K.y * el.x) + u * (10.0f * aC.z + 64.0f * (aA.z + aB.z));
+    const float Px = (L.z * dky + K.z * dly) + 4.0f * u * aC.x;
+    const float Py = (K.z * dlx + L.z * dkx) + 4.0f * u * aC.y;
+    const float Pz = (L.y * dkx + K.x * dly + L.x * dky + K.y * dlx) + 4.0f * u * aC.z;
     // p.z is affine in the pixel: its extremes over the footprint are at the corners
     const float z00 = __builtin_fmaf(ka.x, la.y, -(ka.y * la.x)), z10 = __builtin_fmaf(kb.x, la.y, -(kb.y * la.x));
     const float z01 = __builtin_fmaf(ka.x, lb.y, -(ka.y * lb.x)), z11 = __builtin_fmaf(kb.x, lb.y, -(kb.y * lb.x));
@@ -75,62 +86,60 @@ __device__ __forceinline__ float splat_band(F3 Tu, F3 Tv, F3 Tw, float cx, float
     const float zmin = fminf(fabsf(zlo), fabsf(zhi)) - (Pz + Pz);
     if (!(zmin > 0.0f)) return inf;
     const float r = 1.0f / zmin;
-    const float es = ((Px + Py) + 2.0f * S * Pz) * r;                   // |delta sx| + |delta sy|
-    const float e3 = 2.0f * S * es + 16.0f * u * S2;
-    const float Dm = __builtin_sqrtf(0.5f * S2);
-    const float ox = fmaxf(fabsf(cx - xa), fabsf(cx - xb)) + 16.0f, oy = fmaxf(fabsf(cy - ya), fabsf(cy - yb)) + 16.0f;
-    const float e2 = 4.0f * Dm * u * ((ox + oy) + 4.0f * Dm) + 4.0f * u * S2;
-    const float band = 1.25f * (e3 + e2) + 1e-5f;
+    const float es = ((Px + Py) + 2.0f * S * Pz) * r + 8.0f * u * S;      // |delta sx| + |delta sy|
+    const float e3 = 2.0f * S * es + 8.0f * u * S2;
+    const float e2 = 8.0f * u * S2;                     // dx, dy are EXACT's own; fma against mul + add
+    const float band = 1.5f * (e3 + e2) + 4e-6f;        // (+ exp2 / __logf / the product opa * G: < 2e-6 in rho)
     // depth = <p, Tw> / p.z = det / p.z (3-D branch) or Tw.z: may any depth of the footprint lie within its error of near_n?
-    const F3 c0 = {__builtin_fmaf(ka.y, la.z, -(ka.z * la.y)), __builtin_fmaf(ka.z, la.x, -(ka.x * la.z)), z00};
-    const float det = __builtin_fmaf(c0.x, Tw.x, __builtin_fmaf(c0.y, Tw.y, c0.z * Tw.z));
+    const float det = fast_det(Tu, Tv, Tw, cx, cy);
     const float d0 = det / z00, d1 = det / z10, d2 = det / z01, d3 = det / z11;
     const float dlo = fminf(fminf(fminf(d0, d1), fminf(d2, d3)), Tw.z), dhi = fmaxf(fmaxf(fmaxf(d0, d1), fmaxf(d2, d3)), Tw.z);
-    const float ddet = 16.0f * u * (aC.x * aw.x + aC.y * aw.y + aC.z * aw.z);
+    const float kc = fabsf(__builtin_fmaf(cx, Tw.z, -Tu.z)) + fabsf(__builtin_fmaf(cy, Tw.z, -Tv.z));      // conditioning of det
+    const float ddet = 16.0f * u * ((K.y + K.x + kc) * (L.x + L.y + kc) * (aw.x + aw.y + aw.z));
     const float derr = (ddet + fmaxf(fabsf(dlo), fabsf(dhi)) * 2.0f * Pz) * r + (aw.x + aw.y) * es +
-                       8.0f * u * (S * (aw.x + aw.y) + aw.z) + 1e-4f;
+                       8.0f * u * (S * (aw.x + aw.y) + aw.z) + 1e-5f;
     if (!(dlo - derr > NEAR_N || dhi + derr < NEAR_N)) return inf;
     if (!(band < 0.04f)) return inf;                    // (the hit masks' own margin is 0.05 in rho; also catches NaN)
     return band;
 }
 
-struct FastSplat { F3 A, B, C; float det; };
-
-// per (tile, splat) instance; X0, Y0 = pixel coordinates of the tile's origin
-__device__ __forceinline__ FastSplat fast_splat(const F3 Tu, const F3 Tv, const F3 Tw, float X0, float Y0) {
-    FastSplat f;
-    f.A = {__builtin_fmaf(Tv.y, Tw.z, -(Tv.z * Tw.y)), __builtin_fmaf(Tv.z, Tw.x, -(Tv.x * Tw.z)),
-           __builtin_fmaf(Tv.x, Tw.y, -(Tv.y * Tw.x))};
-    f.B = {__builtin_fmaf(Tw.y, Tu.z, -(Tw.z * Tu.y)), __builtin_fmaf(Tw.z, Tu.x, -(Tw.x * Tu.z)),
-           __builtin_fmaf(Tw.x, Tu.y, -(Tw.y * Tu.x))};
-    const F3 k0 = {__builtin_fmaf(X0, Tw.x, -Tu.x), __builtin_fmaf(X0, Tw.y, -Tu.y), __builtin_fmaf(X0, Tw.z, -Tu.z)};
-    const F3 l0 = {__builtin_fmaf(Y0, Tw.x, -Tv.x), __builtin_fmaf(Y0, Tw.y, -Tv.y), __builtin_fmaf(Y0, Tw.z, -Tv.z)};
-    f.C = {__builtin_fmaf(k0.y, l0.z, -(k0.z * l0.y)), __builtin_fmaf(k0.z, l0.x, -(k0.x * l0.z)),
-           __builtin_fmaf(k0.x, l0.y, -(k0.y * l0.x))};
-    f.det = __builtin_fmaf(f.C.x, Tw.x, __builtin_fmaf(f.C.y, Tw.y, f.C.z * Tw.z));
-    return f;
-}
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct FastRay { float p_x, p_y, p_z, dx, dy, rho2d, rz, sx, sy, rho3d, rho; };
 
-// first half: the intersection and the two squared distances.  lx, ly: tile-relative pixel (0..15 as float);
-// cxr, cyr: the splat's low-pass centre relative to the tile origin
-__device__ __forceinline__ FastRay fast_ray(float lx, float ly, float Ax, float Ay, float Az, float Bx, float By, float Bz,
-                                            float Cx, float Cy, float Cz, float cxr, float cyr) {
+// first half: the intersection and the two squared distances.  pq = the pixel (absolute x, y); operands as the register
+// pairs the packed instructions take them in (a staged record is laid out so that ds_read_b128 delivers exactly these):
+//   Tuxy = (Tu.x, Tu.y)  Tvxy = (Tv.x, Tv.y)  Twxy = (Tw.x, Tw.y)  Tuvz = (Tu.z, Tv.z)  cxy = the low-pass centre
+__device__ __forceinline__ FastRay fast_ray(v2f pq, v2f Tuxy, v2f Tvxy, v2f Twxy, v2f Tuvz, float Twz, v2f cxy) {
     FastRay r;
-    r.p_x = __builtin_fmaf(lx, Ax, __builtin_fmaf(ly, Bx, Cx));
-    r.p_y = __builtin_fmaf(lx, Ay, __builtin_fmaf(ly, By, Cy));
-    r.p_z = __builtin_fmaf(lx, Az, __builtin_fmaf(ly, Bz, Cz));
-    r.dx = cxr - lx;
-    r.dy = cyr - ly;
+    const v2f klz = pq * (v2f){Twz, Twz} - Tuvz;                         // (k.z, l.z): EXACT's two roundings (-ffp-contract=off)
+    const v2f kxy = __builtin_elementwise_fma((v2f){pq.x, pq.x}, Twxy, -Tuxy);
+    const v2f lxy = __builtin_elementwise_fma((v2f){pq.y, pq.y}, Twxy, -Tvxy);
+    // (p.x, p.y) = l.z (k.y, -k.x) - k.z (l.y, -l.x): two packed instructions whose operand swizzles and signs are instruction
+    // modifiers (the compiler materialises the swapped, half-negated pairs with four extra moves / xors)
+    //   t   = (k.z l.y, -k.z l.x)            src0 = klz.lo twice, src1 = (lxy.hi, -lxy.lo)
+    //   pxy = (l.z k.y - t.lo, -l.z k.x - t.hi)   src0 = klz.hi twice, src1 = (kxy.hi, -kxy.lo), src2 = -t
+    v2f t, pxy;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(t) : "v"(klz), "v"(lxy));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,1,1]" : "=v"(pxy) : "v"(klz), "v"(kxy), "v"(t));
+    r.p_x = pxy.x;
+    r.p_y = pxy.y;
+    r.p_z = __builtin_fmaf(kxy.x, lxy.y, -(kxy.y * lxy.x));
+    const v2f d = cxy - pq;
+    r.dx = d.x;
+    r.dy = d.y;
     const float hh = __builtin_fmaf(r.dy, r.dy, r.dx * r.dx);
     r.rho2d = hh + hh;                                  // FilterInvSquare = 2
     r.rz = __builtin_amdgcn_rcpf(r.p_z);
-    r.sx = r.p_x * r.rz;
-    r.sy = r.p_y * r.rz;
+    const v2f sxy = pxy * (v2f){r.rz, r.rz};
+    r.sx = sxy.x;
+    r.sy = sxy.y;
     r.rho3d = __builtin_fmaf(r.sy, r.sy, r.sx * r.sx);
     r.rho = fminf(r.rho3d, r.rho2d);
     return r;
+}
+__device__ __forceinline__ FastRay fast_ray(float pxf, float pyf, const F3 Tu, const F3 Tv, const F3 Tw, float cx, float cy) {
+    return fast_ray((v2f){pxf, pyf}, (v2f){Tu.x, Tu.y}, (v2f){Tv.x, Tv.y}, (v2f){Tw.x, Tw.y}, (v2f){Tu.z, Tv.z}, Tw.z, (v2f){cx, cy});
 }
 // decision 1 (forward.cu:358 and the certain alpha < 1/255): the pair can contribute at all
 __device__ __forceinline__ bool fast_near(const FastRay& r, float hi) { return r.rho <= hi && r.p_z != 0.0f; }
@@ -141,7 +150,7 @@ __device__ __forceinline__ bool fast_in_band(const FastRay& r, const FastBand& b
 
 struct FastHit { bool use3d; float depth, G, alpha; };
 
-// second half: depth along the ray, Gaussian weight, alpha.  det = FastSplat::det, Twz = Tw.z, opa = opacity
+// second half: depth along the ray, Gaussian weight, alpha.  det = fast_det, Twz = Tw.z, opa = opacity
 __device__ __forceinline__ FastHit fast_hit(const FastRay& r, float det, float Twz, float opa) {
     FastHit h;
     h.use3d = r.rho3d <= r.rho2d;
@@ -193,11 +202,10 @@ __device__ __forceinline__ void fast_take(bool inb, const FastRay& er, const Fas
 }
 // One pair for a lane that owns its splat's record (the splat-major backward kernels): FAST, EXACT inside the band.
 // Returns whether the pair blends (before the T < 1e-4 stop).
-__device__ __forceinline__ bool fast_pair_lane(const FastSplat& fs, const F3 Tu, const F3 Tv, const F3 Tw, float cx, float cy, float opa,
-                                               const FastBand& b, float cxr, float cyr, float lx, float ly, float pxf, float pyf,
-                                               FastRay& fr, FastHit& fh) {
-    fr = fast_ray(lx, ly, fs.A.x, fs.A.y, fs.A.z, fs.B.x, fs.B.y, fs.B.z, fs.C.x, fs.C.y, fs.C.z, cxr, cyr);
-    fh = fast_hit(fr, fs.det, Tw.z, opa);
+__device__ __forceinline__ bool fast_pair_lane(const F3 Tu, const F3 Tv, const F3 Tw, float cx, float cy, float opa, float det,
+                                               const FastBand& b, float pxf, float pyf, FastRay& fr, FastHit& fh) {
+    fr = fast_ray(pxf, pyf, Tu, Tv, Tw, cx, cy);
+    fh = fast_hit(fr, det, Tw.z, opa);
     const bool near = fast_near(fr, b.hi);
     bool pass = near && fast_pass(fh);
     if (near && fast_in_band(fr, b)) pass = exact_pair(pxf, pyf, Tu, Tv, Tw, cx, cy, opa, fr, fh);

@@ -24,11 +24,12 @@ namespace isr {
 
 constexpr int FF_BATCH = 128;       // instances staged per round
 constexpr int FF_RS = 24;           // staged floats per instance (six float4)
-// staged record:  q0 = A.xyz, cx - X0              A = Tv x Tw
-//                 q1 = B.xyz, cy - Y0              B = Tw x Tu
-//                 q2 = C.xyz, band.hi             C = p at the tile origin (X0, Y0); alpha < 1/255 is certain for rho > band.hi
-//                 q3 = det, Tw.z, opacity, band.lo   ... and alpha >= 1/255 for rho <= band.lo (isr_fast_pair.hpp: guard bands)
-//                 q4 = band.bw, normal.xyz
+// staged record (the pairs fast_ray's packed instructions take, each an aligned register pair of a ds_read_b128):
+//                 q0 = Tu.x, Tu.y, Tv.x, Tv.y
+//                 q1 = Tw.x, Tw.y, Tu.z, Tv.z
+//                 q2 = Tw.z, band.hi, cx, cy      alpha < 1/255 is certain for rho > band.hi
+//                 q3 = det, opacity, band.lo, band.bw   ... and alpha >= 1/255 for rho <= band.lo (isr_fast_pair.hpp: guard bands)
+//                 q4 = normal.xyz, -
 //                 q5 = rgb, unused
 
 // AUX = false ("feature-only forward", opt-in ISR_MODE_FEATURE_ONLY): colour, the seven auxiliary maps, the median
@@ -63,7 +64,8 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
     const bool inside = px < (unsigned)W && py < (unsigned)H;
     const size_t N = (size_t)W * H;
     const size_t pix = (size_t)W * py + px;
-    const float lx = (float)lxi, ly = (float)lyi;
+    const float pxf = (float)px, pyf = (float)py;
+    const v2f pq = {pxf, pyf};
     const float X0 = (float)(tx * TILE), Y0 = (float)(ty * TILE);
 
     const int64_t r0 = tile_offset[tile];
@@ -130,16 +132,12 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
             const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y}, Tw = {b.z, b.w, c.x};
             const float opa = d.z;
             const FastBand fb = fast_band(opa, e.w);
-            // p(px, py) = (px - X0) A + (py - Y0) B + C,  C = (X0 Tw - Tu) x (Y0 Tw - Tv)     (isr_fast_pair.hpp)
-            const FastSplat fs = fast_splat(Tu, Tv, Tw, X0, Y0);
-            const F3 A = fs.A, B = fs.B, C = fs.C;
-            const float det = fs.det;
             float4* s4 = reinterpret_cast<float4*>(s_rec + t * RS);
-            s4[0] = make_float4(A.x, A.y, A.z, c.y - X0);
-            s4[1] = make_float4(B.x, B.y, B.z, c.z - Y0);
-            s4[2] = make_float4(C.x, C.y, C.z, fb.hi);
-            s4[3] = make_float4(det, Tw.z, opa, fb.lo);
-            s4[4] = make_float4(fb.bw, c.w, d.x, d.y);
+            s4[0] = make_float4(Tu.x, Tu.y, Tv.x, Tv.y);
+            s4[1] = make_float4(Tw.x, Tw.y, Tu.z, Tv.z);
+            s4[2] = make_float4(Tw.z, fb.hi, c.y, c.z);
+            s4[3] = make_float4(fast_det(Tu, Tv, Tw, c.y, c.z), opa, fb.lo, fb.bw);
+            s4[4] = make_float4(c.w, d.x, d.y, 0.0f);
             s4[5] = make_float4(d.w, e.x, e.y, 0.0f);
             const float4 cb = reinterpret_cast<const float4*>(cull + (size_t)id * 8)[0];      // per-Gaussian bounds from K1
             s_box[t] = cb;
@@ -163,7 +161,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
             __syncthreads();
         }
         if (AUX && base == r0) {
-            const float z0 = s_rec[13];                  // Tw.z of the tile's nearest splat
+            const float z0 = s_rec[8];                   // Tw.z of the tile's nearest splat
             const float mr = fminf(1.0f, fmaxf(0.0f, mscale - mscale * NEAR_N * __builtin_amdgcn_rcpf(z0)));
             m_ref = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mr)));
             mshift = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mscale - mr)));
@@ -191,7 +189,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                     if (st_skip_next) st_skip_next = false;
                     else if (m != 0ull) {
                         const int j2 = c0 + __builtin_ctzll(m);
-                        const float fx = X0 + lx, fy = Y0 + ly;
+                        const float fx = pxf, fy = pyf;
                         const float4 b1 = s_box[j], d1 = s_diag[j], b2 = s_box[j2], d2 = s_diag[j2];
                         const bool in1 = fx >= b1.x && fx <= b1.y && fy >= b1.z && fy <= b1.w && fx + fy >= d1.x && fx + fy <= d1.y && fx - fy >= d1.z && fx - fy <= d1.w;
                         const bool in2 = fx >= b2.x && fx <= b2.y && fy >= b2.z && fy <= b2.w && fx + fy >= d2.x && fx + fy <= d2.y && fx - fy >= d2.z && fx - fy <= d2.w;
@@ -202,19 +200,19 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                 const float4 q0 = q[0], q1 = q[1], q2 = q[2];
                 // the pair's arithmetic is isr_fast_pair.hpp's, shared with the FAST backward kernels: both passes take the
                 // same decisions on the same pair, bit for bit
-                FastRay fr = fast_ray(lx, ly, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, q0.w, q1.w);
+                FastRay fr = fast_ray(pq, (v2f){q0.x, q0.y}, (v2f){q0.z, q0.w}, (v2f){q1.x, q1.y}, (v2f){q1.z, q1.w}, q2.x, (v2f){q2.z, q2.w});
                 // beyond band.hi alpha < 1/255 is certain: when that holds for the whole wave nothing else is needed
-                const unsigned long long m_near = __ballot(fr.rho <= q2.w) & __ballot(fr.p_z != 0.0f) & ~m_done;
+                const unsigned long long m_near = __ballot(fr.rho <= q2.y) & __ballot(fr.p_z != 0.0f) & ~m_done;
                 if (m_near == 0ull) continue;
                 const float4 q3 = q[3], q4 = q[4];
-                FastHit fh = fast_hit(fr, q3.x, q3.y, q3.z);
+                FastHit fh = fast_hit(fr, q3.x, q2.x, q3.y);
                 // the same decisions as k_render_fwd_fast_w below (guard bands: isr_fast_pair.hpp)
                 const unsigned long long m_cand = m_near & __ballot(!(fh.depth < NEAR_N));
-                const unsigned long long m_band = (m_near & __ballot(fr.rho > q3.w)) | (m_cand & __ballot(fabsf(fr.rho3d - fr.rho2d) <= q4.x));
+                const unsigned long long m_band = (m_near & __ballot(fr.rho > q3.z)) | (m_cand & __ballot(fabsf(fr.rho3d - fr.rho2d) <= q3.w));
                 unsigned long long m_pass = m_cand & ~m_band;
                 if (m_band != 0ull) {
                     FastRay er; FastHit eh;
-                    const bool ep = exact_pair_rec(X0 + lx, Y0 + ly, rec, __builtin_amdgcn_readfirstlane(s_id[j]), er, eh);
+                    const bool ep = exact_pair_rec(pxf, pyf, rec, __builtin_amdgcn_readfirstlane(s_id[j]), er, eh);
                     fast_take((m_band >> lane) & 1ull, er, eh, fr, fh);
                     m_pass |= m_band & __ballot(ep);
                 }
@@ -246,7 +244,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                         M1 += mw;
                         M2 = __builtin_fmaf(m_, mw, M2);
                         if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }
-                        N0 = __builtin_fmaf(q4.y, w, N0); N1 = __builtin_fmaf(q4.z, w, N1); N2 = __builtin_fmaf(q4.w, w, N2);
+                        N0 = __builtin_fmaf(q4.x, w, N0); N1 = __builtin_fmaf(q4.y, w, N1); N2 = __builtin_fmaf(q4.z, w, N2);
                         C0 = __builtin_fmaf(q5.x, w, C0); C1 = __builtin_fmaf(q5.y, w, C1); C2 = __builtin_fmaf(q5.z, w, C2);
                     }
                     T = test_T;
@@ -398,8 +396,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     const bool inside = px < (unsigned)W && py < (unsigned)H;
     const size_t N = (size_t)W * H;
     const size_t pix = (size_t)W * py + px;
-    const float lx = (float)lxi, ly = (float)lyi;
-    const float X0 = (float)(tx * TILE), Y0 = (float)(ty * TILE);
+    const float pxf = (float)px, pyf = (float)py;
+    const v2f pq = {pxf, pyf};
+
 
     const int64_t r0 = tile_offset[tile];
     int64_t r1 = tile_offset[tile + 1];
@@ -498,13 +497,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             const F3 Tu = {a.x, a.y, a.z}, Tv = {a.w, b.x, b.y}, Tw = {b.z, b.w, c.x};
             const float opa = d.z;
             const FastBand fb = fast_band(opa, e.w);
-            const FastSplat fs = fast_splat(Tu, Tv, Tw, X0, Y0);
             float4* s4 = reinterpret_cast<float4*>(s_rec + lane * RS);
-            s4[0] = make_float4(fs.A.x, fs.A.y, fs.A.z, c.y - X0);
-            s4[1] = make_float4(fs.B.x, fs.B.y, fs.B.z, c.z - Y0);
-            s4[2] = make_float4(fs.C.x, fs.C.y, fs.C.z, fb.hi);
-            s4[3] = make_float4(fs.det, Tw.z, opa, fb.lo);
-            s4[4] = make_float4(fb.bw, c.w, d.x, d.y);
+            s4[0] = make_float4(Tu.x, Tu.y, Tv.x, Tv.y);
+            s4[1] = make_float4(Tw.x, Tw.y, Tu.z, Tv.z);
+            s4[2] = make_float4(Tw.z, fb.hi, c.y, c.z);
+            s4[3] = make_float4(fast_det(Tu, Tv, Tw, c.y, c.z), opa, fb.lo, fb.bw);
+            s4[4] = make_float4(c.w, d.x, d.y, 0.0f);
             s4[5] = make_float4(d.w, e.x, e.y, __int_as_float(hp.y));          // .w: position in the tile's list (1-based)
         }
         if (FEAT) {
@@ -542,26 +540,26 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             const float4* q = reinterpret_cast<const float4*>(s_rec + j * RS);
             const float4 q0 = q[0], q1 = q[1], q2 = q[2];
             v4f q3v = reinterpret_cast<const v4f*>(q)[3];
-            FastRay fr = fast_ray(lx, ly, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z, q0.w, q1.w);
+            FastRay fr = fast_ray(pq, (v2f){q0.x, q0.y}, (v2f){q0.z, q0.w}, (v2f){q1.x, q1.y}, (v2f){q1.z, q1.w}, q2.x, (v2f){q2.z, q2.w});
             asm volatile("" : "+v"(q3v), "+v"(fr.rho));          // q3 is requested with q0..q2, not after the first branch
-            const unsigned long long m_near = __ballot(fr.rho <= q2.w) & __ballot(fr.p_z != 0.0f) & ~m_done;
+            const unsigned long long m_near = __ballot(fr.rho <= q2.y) & __ballot(fr.p_z != 0.0f) & ~m_done;
             if (!STATS && m_near == 0ull) continue;
             const float4 q3 = make_float4(q3v.x, q3v.y, q3v.z, q3v.w);
             v4f q4e = reinterpret_cast<const v4f*>(q)[4], q5e = reinterpret_cast<const v4f*>(q)[5];
             float f_early = FEAT ? s_feat[j * FCH + (lane & 31)] : 0.0f;
             float f_early2 = (FEAT && NC == 2) ? s_feat[j * FCH + 32 + (lane & 31)] : 0.0f;
-            FastHit fh = fast_hit(fr, q3.x, q3.y, q3.z);
+            FastHit fh = fast_hit(fr, q3.x, q2.x, q3.y);
             if (NC == 2) asm volatile("" : "+v"(f_early2));
             asm volatile("" : "+v"(q4e), "+v"(q5e), "+v"(f_early), "+v"(fh.alpha));      // ... and the blend's operands before ITS branch
             // decisions (isr_fast_pair.hpp): a near pair outside the guard bands certainly has alpha >= 1/255 and FAST's branch
             // and near-plane test are EXACT's; a pair inside them is re-evaluated with EXACT's instruction sequence
             const unsigned long long m_cand = m_near & __ballot(!(fh.depth < NEAR_N));
-            const unsigned long long m_band = (m_near & __ballot(fr.rho > q3.w)) | (m_cand & __ballot(fabsf(fr.rho3d - fr.rho2d) <= q4e.x));
+            const unsigned long long m_band = (m_near & __ballot(fr.rho > q3.z)) | (m_cand & __ballot(fabsf(fr.rho3d - fr.rho2d) <= q3.w));
             unsigned long long m_pass = m_cand & ~m_band;
             if (STATS || m_band != 0ull) {
                 const int gid = __builtin_amdgcn_readfirstlane(s_ring[(head + j) & (FW_RING - 1)].x);
                 FastRay er; FastHit eh;
-                const bool ep = exact_pair_rec(X0 + lx, Y0 + ly, rec, gid, er, eh);
+                const bool ep = exact_pair_rec(pxf, pyf, rec, gid, er, eh);
                 if (STATS) {
                     if (m_band != 0ull) st_slow++;
                     // outside the band FAST's decisions must be EXACT's (near pairs: pass and branch; far pairs: skipped)
@@ -600,7 +598,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                     M1 += mw;
                     M2 = __builtin_fmaf(m_, mw, M2);
                     if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }
-                    N0 = __builtin_fmaf(q4e.y, w, N0); N1 = __builtin_fmaf(q4e.z, w, N1); N2 = __builtin_fmaf(q4e.w, w, N2);
+                    N0 = __builtin_fmaf(q4e.x, w, N0); N1 = __builtin_fmaf(q4e.y, w, N1); N2 = __builtin_fmaf(q4e.z, w, N2);
                     C0 = __builtin_fmaf(q5e.x, w, C0); C1 = __builtin_fmaf(q5e.y, w, C1); C2 = __builtin_fmaf(q5e.z, w, C2);
                 }
                 T = test_T;
