@@ -142,7 +142,7 @@ def forward(means3D, opacities, view, proj, campos, bg, W, H, tanfovx, tanfovy, 
     trace = np.full((N * 10, 2), -1, np.int32) if tracer else None
     tcount = c_int64(0)
     pl = point_list if R > 0 else np.zeros(1, np.uint32)
-    mg = np.zeros((4, N), np.float32) if margins else None
+    mg = np.zeros((5, N), np.float32) if margins else None
     (lib_fma() if fma else L).so_render_fwd_margins(
         c_int(W), c_int(H), c_int(ED), _p(ranges), _p(pl), _p(means2D), _p(colors_used), _p(tm_used),
         _p(extra), _p(normal_opacity), _p(bg), _p(final_T), _p(n_contrib), _p(out_color),

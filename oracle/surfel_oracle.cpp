@@ -403,11 +403,12 @@ int64_t so_bin(int P, int W, int H, const int* radii, const float* means2D, cons
 // (exactly what each CUDA thread computes; the cooperative fetch is
 // irrelevant to the values).  tracer may be null; otherwise it receives
 // (gaussian, pixel) pairs with w > 0.1 and *tracer_count their number.
-// margins (optional, [4,N]): how close the pixel's walk came to flipping a decision -
+// margins (optional, [5,N]): how close the pixel's walk came to flipping a decision -
 //   [0] min |alpha * 255 - 1| over the pairs that reached the alpha < 1/255 test (forward.cu:386)
 //   [1] min |depth - near_n| over the pairs that reached the depth test (forward.cu:372)
 //   [2] min |rho3d - rho2d| over the pairs that blended (the branch of forward.cu:365-372)
 //   [3] min |test_T / 1e-4 - 1| over the pairs that reached the T < 1e-4 stop (forward.cu:389)
+//   [4] min |T / 0.5 - 1| over the pairs that blended (the median-depth test T > 0.5, forward.cu:406)
 void so_render_fwd_margins(int W, int H, int ED, const uint32_t* ranges, const uint32_t* point_list,
                    const float* means2D, const float* colors, const float* transMats, const float* extras,
                    const float* normal_opacity, const float* bg, float* final_T /*[3,N]*/,
@@ -434,7 +435,7 @@ void so_render_fwd_margins(int W, int H, int ED, const uint32_t* ranges, const u
                 float D = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
                 float median_contributor = -1.0f;
                 std::fill(E.begin(), E.end(), 0.0f);
-                float mg[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+                float mg[5] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY};
                 for (uint32_t k = r0; k < r1; k++) {
                     contributor++;
                     const uint32_t g = point_list[k];
@@ -463,6 +464,7 @@ void so_render_fwd_margins(int W, int H, int ED, const uint32_t* ranges, const u
                     mg[3] = std::min(mg[3], std::fabs(test_T * 10000.0f - 1.0f));
                     if (test_T < 0.0001f) break;   // `done = true` — nothing after it blends
                     mg[2] = std::min(mg[2], std::fabs(rho3d - rho2d));
+                    mg[4] = std::min(mg[4], std::fabs(T * 2.0f - 1.0f));
                     float w = alpha * T;
                     float A = 1 - T;
                     float m = mscale * (1 - NEAR_N / depth);
@@ -497,7 +499,7 @@ void so_render_fwd_margins(int W, int H, int ED, const uint32_t* ranges, const u
                 out_others[pix + 6 * N] = distortion;
                 for (int ch = 0; ch < ED; ch++) out_extra[ch * N + pix] = E[ch];
                 if (margins)
-                    for (int q = 0; q < 4; q++) margins[q * N + pix] = mg[q];
+                    for (int q = 0; q < 5; q++) margins[q * N + pix] = mg[q];
             }
     }
     if (tracer) {

@@ -21,7 +21,7 @@ from helpers import oracle_forward  # noqa: E402
 from instascene_amd import _lib  # noqa: E402
 
 T = Z.T
-T_TOL = 2e-3
+T_TOL = 1e-4
 
 
 def check(inp, cam, tag):
@@ -43,13 +43,15 @@ def check(inp, cam, tag):
         w = want.reshape(want.shape[0], -1)
         sc = np.abs(w).max(axis=1, keepdims=True) + 1e-30
         img_bad |= (np.abs(g - w) > 1e-4 * sc).any(axis=0)
-    tstop = st["margins"][3] < T_TOL
+    tm = np.minimum(st["margins"][3], st["margins"][4])          # the two T decisions (stop at 1e-4, median at 0.5)
+    tstop = tm < T_TOL
     two = (st2["n_contrib"] != st["n_contrib"]).any(axis=0)
     bad = diff | img_bad
     rec = dict(tag=tag, P=st["P"], N=N, R=st["R"], evals=c[1], blends=c[2], exact_path=c[6], outside_band_decision_differs=c[7],
                px_contrib_differs=int(diff.sum()), px_image_beyond_1e4=int(img_bad.sum()),
                explained_T_stop=int((bad & tstop).sum()), explained_two_builds=int((bad & ~tstop & two).sum()),
                unexplained=int((bad & ~tstop & ~two).sum()), px_two_builds_differ=int(two.sum()),
+               largest_T_margin_of_a_differing_pixel=float(tm[bad].max()) if bad.any() else 0.0,
                forced_splats=int(np.isinf(dbg["records"][:, 19][st["radii"] > 0]).sum()), visible=int((st["radii"] > 0).sum()))
     print(json.dumps(rec), flush=True)
     return rec
