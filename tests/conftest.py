@@ -4,7 +4,9 @@ import sys
 import pytest
 
 # the product's default arithmetic mode is "fast"; the parity tests compare against the CPU oracle bit for bit unless a test
-# selects a mode itself, so the suite's default is "exact" (read by instascene_amd.rasterizer at import)
+# selects a mode itself, so the suite's default is "exact" (read by instascene_amd.rasterizer at import).  The shipped default
+# is covered by the tests that select MODE_FAST themselves (test_gpu_fuzz.py: 40 scenes gated by cause; test_gpu_fullsize.py:
+# C1 / C3 at full size; test_gpu_rasterizer.py; the harness / drop-in tests run both)
 os.environ.setdefault("ISR_MODE", "exact")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
