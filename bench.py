@@ -514,10 +514,17 @@ def main():
                           "multi-view leg every 10th iteration, torch.optim.Adam; 30 steps = 3 multi-view iterations")
             sub("dropin_plain_fast", mode="fast", step="plain", steps=30, warmup=10, note=plain_note + "; the drop-in's default mode")
             sub("dropin_plain_exact", mode="exact", step="plain", steps=30, warmup=10, note=plain_note + "; ISR_MODE=exact")
+            from instascene_amd import dropin as _dropin
+            _dropin.empty_cache_under_pressure()          # what dropin.install() does for the unmodified driver
             sub("dropin_plain_fast_empty_cache", mode="fast", step="plain", steps=30, warmup=10, empty_cache=True,
-                note=plain_note + "; plus torch.cuda.empty_cache() every iteration like the reference (:206).  This record measures "
-                     "the driver as much as the library: every iteration hands all cached device memory back and requests it again; "
-                     "17 ms per iteration on most boxes of the pool, 55-90 ms on some (same build, same process history)")
+                note=plain_note + "; plus torch.cuda.empty_cache() every iteration like the reference (:206), under the drop-in as "
+                     "installed: the library's buffers live in its own arena (arena.py) and install() makes empty_cache() act only "
+                     "under memory pressure (dropin.empty_cache_under_pressure)")
+            _dropin.restore_empty_cache()
+            sub("dropin_plain_fast_empty_cache_honoured", mode="fast", step="plain", steps=30, warmup=10, empty_cache=True,
+                note=plain_note + "; ISR_KEEP_EMPTY_CACHE=1: torch's own empty_cache() every iteration - the library's buffers stay in "
+                     "the arena, the reference's torch temporaries (~9 device allocations per iteration) go back to the driver and "
+                     "are hipMalloc-ed again; this record measures the driver (it slows down with the process's allocation count)")
             sub("soak_500", steps=500, warmup=5, note="the headline configuration, one block of 500 steps")
             sub("C3_multiview", steps=40, warmup=10, multiview=True,
                 note="the reference's default step: the multi-view leg (5 more views rendered with gradients through the dense "
@@ -583,6 +590,13 @@ def main():
                               if args.step == "seg" else
                               ["targets = initial renders + noise", "the cameras' ray tables, each view's verified tile-instance count"])},
                "roofline": roof}
+        if subs.get("dropin_plain_fast") or subs.get("dropin_plain_fast_empty_cache"):
+            # what a maintainer gets who installs the drop-in and runs train_semantic.py unmodified (harness.PlainSegTrainer;
+            # details in sub_records): next to the headline, not only inside the long sub_records object
+            ud = {"views_per_s": (subs.get("dropin_plain_fast") or {}).get("value"),
+                  "views_per_s_with_the_reference's_empty_cache_every_iteration": (subs.get("dropin_plain_fast_empty_cache") or {}).get("value"),
+                  "workspace": "library-owned arena (instascene_amd/arena.py): empty_cache() frees none of the per-forward buffers"}
+            out = dict(list(out.items())[:9] + [("unmodified_driver", ud)] + list(out.items())[9:])
         if subs:
             out["sub_records"] = subs
         if world > 1:

@@ -1,0 +1,147 @@
+"""Library-owned workspace arena (the reference's ``resizeFunctional`` hook, rasterize_points.cu:31-37,107-109, re-thought).
+
+The reference obtains every per-forward buffer - geometry / binning / image state, the output maps, the 1.66 GB tracer list -
+through torch's caching allocator, and its drivers call ``torch.cuda.empty_cache()`` every iteration
+(train_semantic.py:208): everything is handed back to the driver and ``hipMalloc``-ed again on the next iteration (~1 GB per view
+at 1080p with a 32-channel feature: tens of milliseconds).  This arena keeps those buffers: a pool of live ``uint8`` base
+tensors per (device, stream, size class); ``empty()`` leases a view of a free block, and a block is free again when every tensor
+that views its storage has died - read from the storage's reference count, so the lease ends exactly when the caller (or the
+autograd graph holding the forward's state) drops the tensors; no hook, no explicit release.  ``empty_cache()`` frees nothing of it.
+
+* Ownership contract unchanged: the caller gets tensors that nobody else writes while any of them is alive.
+* Stream safety like the caching allocator's: a block is reused only by the stream that leased it; ``used_on(tensor, stream)``
+  (the analogue of ``Tensor.record_stream``) makes the next lease of the block wait for that stream first.
+* Size classes (x 1.25) bound the number of distinct blocks under a drifting size; at most ``MAX_FREE`` idle blocks per class
+  and ``ISR_ARENA_MAX_GB`` (default 64) in total are kept - beyond that idle blocks go back to the caching allocator.
+* ``ISR_ARENA=0`` disables it (plain ``torch.empty``).  Requests below ``MIN_BYTES`` are not pooled.
+"""
+from __future__ import annotations
+
+import bisect
+import os
+
+import torch
+
+ENABLED = os.environ.get("ISR_ARENA", "1") != "0"
+MIN_BYTES = 1 << 20
+MAX_FREE = 3
+MAX_BYTES = int(float(os.environ.get("ISR_ARENA_MAX_GB", "64")) * (1 << 30))
+
+_CLASSES = [MIN_BYTES]
+_POOLS = {}            # (device index, stream handle, class bytes) -> [_Block]
+_BY_PTR = {}           # base data_ptr -> _Block
+_TOTAL = [0]
+STATS = {"leases": 0, "new_blocks": 0, "dropped_blocks": 0}
+
+
+def _class_of(n: int) -> int:
+    while _CLASSES[-1] < n:
+        _CLASSES.append((int(_CLASSES[-1] * 1.25) + 4095) // 4096 * 4096)
+    return _CLASSES[bisect.bisect_left(_CLASSES, n)]
+
+
+def _use_count(t: torch.Tensor) -> int:
+    return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+
+
+class _Block:
+    __slots__ = ("base", "idle_count", "foreign", "nbytes")
+
+    def __init__(self, nbytes, dev):
+        self.base = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.idle_count = _use_count(self.base)          # the base tensor (+ the temporary handle the probe itself makes)
+        self.foreign = set()
+        self.nbytes = nbytes
+
+    def idle(self) -> bool:
+        return _use_count(self.base) == self.idle_count
+
+
+def empty(shape, dtype, device) -> torch.Tensor:
+    """``torch.empty(shape, dtype=dtype, device=device)`` out of the arena (uninitialised, 256-byte aligned)."""
+    if isinstance(shape, int):
+        shape = (shape,)
+    n = 1
+    for s in shape:
+        n *= int(s)
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    dev = torch.device(device)
+    if not ENABLED or nbytes < MIN_BYTES or dev.type != "cuda":
+        return torch.empty(shape, dtype=dtype, device=dev)
+    cls = _class_of(nbytes)
+    stream = torch.cuda.current_stream(dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream.cuda_stream, cls)
+    pool = _POOLS.setdefault(key, [])
+    blk = None
+    idle = 0
+    for b in pool:
+        if b.idle():
+            idle += 1
+            if blk is None:
+                blk = b
+    if idle > MAX_FREE:                                   # a burst is over: hand the surplus back
+        keep = []
+        for b in pool:
+            if b is not blk and idle > MAX_FREE and b.idle():
+                idle -= 1
+                _drop(b)
+            else:
+                keep.append(b)
+        pool[:] = keep
+    if blk is None:
+        if _TOTAL[0] + cls > MAX_BYTES:
+            trim(_TOTAL[0] + cls - MAX_BYTES)
+        blk = _Block(cls, dev)
+        pool.append(blk)
+        _BY_PTR[blk.base.data_ptr()] = blk
+        _TOTAL[0] += cls
+        STATS["new_blocks"] += 1
+    elif blk.foreign:
+        # other streams read (or wrote) the previous lease: whatever they have enqueued so far comes first
+        for s in blk.foreign:
+            if s.cuda_stream != stream.cuda_stream:
+                ev = torch.cuda.Event()
+                ev.record(s)
+                stream.wait_event(ev)
+        blk.foreign.clear()
+    STATS["leases"] += 1
+    return blk.base[:nbytes].view(dtype).view(*shape)
+
+
+def used_on(t: torch.Tensor, stream) -> None:
+    """``t`` (a lease, or any tensor) is used by kernels on ``stream``: the arena's analogue of ``Tensor.record_stream``."""
+    if t is None or not t.is_cuda:
+        return
+    blk = _BY_PTR.get(t.untyped_storage().data_ptr())
+    if blk is not None:
+        blk.foreign.add(stream)
+    else:
+        t.record_stream(stream)
+
+
+def _drop(b: _Block) -> None:
+    _BY_PTR.pop(b.base.data_ptr(), None)
+    _TOTAL[0] -= b.nbytes
+    STATS["dropped_blocks"] += 1
+
+
+def trim(nbytes: int = None) -> int:
+    """Give idle blocks back to the caching allocator (all of them, or at least ``nbytes`` worth).  Returns the bytes released."""
+    freed = 0
+    for key in list(_POOLS):
+        keep = []
+        for b in _POOLS[key]:
+            if (nbytes is None or freed < nbytes) and b.idle():
+                freed += b.nbytes
+                _drop(b)
+            else:
+                keep.append(b)
+        if keep:
+            _POOLS[key] = keep
+        else:
+            del _POOLS[key]
+    return freed
+
+
+def reserved_bytes() -> int:
+    return _TOTAL[0]

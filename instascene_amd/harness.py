@@ -546,9 +546,13 @@ class SegTrainer:
                                 num_labels=self.n_labels + 1) * self.lmv
 
     def _multiview_views(self, vi):
+        """The window of ``sample_mv_frames`` consecutive views of the cross-view leg (train_semantic.py:146 draws its start at
+        random; here a function of the step's view, so that the leg's chains can be issued ahead).  With no more views than the
+        window the reference's draw has no valid start either: the window is clamped to the views there are."""
         n = len(self.cams)
-        first = (vi + 1) % max(1, n - self.mv_frames)
-        return list(range(first, first + self.mv_frames))
+        k = min(self.mv_frames, n)
+        first = (vi + 1) % max(1, n - k + 1)
+        return list(range(first, first + k))
 
     def _issue_leg_chains(self, views, counts=None):
         """All of the cross-view leg's binning chains at once, spread over ``mv_chain_streams`` side streams: a chain cannot
@@ -749,7 +753,7 @@ class PlainSegTrainer:
                 idx = torch.randint(0, len(labels), size=(self.batch,), device=dev)
                 loss = loss + contrastive_loss(feats[:, idx].T, labels[idx], predef_u_list=m.class_feat if k == 1 else None) \
                     * self.lsv * (1 if k == 1 else 0.5)
-        if self.lmv > 0 and iteration % 10 == 0:
+        if self.lmv > 0 and iteration % 10 == 0 and len(self.cams) > self.mv_frames:      # (the reference's np.random.randint needs it too)
             first = self.rng.randint(0, len(self.cams) - self.mv_frames - 1)
             views = self.cams[first:first + self.mv_frames]
             maps = torch.stack([render(v, m, self.pipe, self.bg)["seg_feature"] for v in views], dim=0)

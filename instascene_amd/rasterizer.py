@@ -20,7 +20,7 @@ from typing import NamedTuple, Optional
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, arena
 from ._lib import GRAD_EXTRA, GRAD_GEOMETRY, MODE_EXACT, MODE_FAST, MODE_FEATURE_ONLY, MODE_PREBINNED, check, lib
 
 _ENV_MODE = os.environ.get("ISR_MODE", "fast").lower()
@@ -266,7 +266,7 @@ def _size_class(n: int) -> int:
 
 def _workspace(nbytes_of, count, dev):
     """A byte workspace for ``count`` units, sized for the count's class (``nbytes_of(count_class)`` bytes)."""
-    return torch.empty(nbytes_of(_size_class(max(1, int(count)))), dtype=torch.uint8, device=dev)
+    return arena.empty(nbytes_of(_size_class(max(1, int(count)))), torch.uint8, dev)
 
 
 def _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
@@ -362,9 +362,9 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
                 if t is not None:
                     t.record_stream(side)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            radii = arena.empty((P,), torch.int32, dev)
             geom = _workspace(L.isr_geom_bytes, P, dev)
-            img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
+            img = arena.empty(L.isr_image_bytes(W, H), torch.uint8, dev)
             st = _stream()
             R, _ = _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier,
                             rotations, transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered,
@@ -421,9 +421,11 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
     extra = _f32c(extra_attrs.to(dev) if (extra_attrs is not None and extra_attrs.numel() and not extra_attrs.is_cuda)
                   else extra_attrs, "extra_attrs") if F > 0 else None
 
-    out_color = torch.empty((0 if feature_only else 3, H, W), dtype=torch.float32, device=dev)
-    out_others = torch.empty((0 if feature_only else 7, H, W), dtype=torch.float32, device=dev)
-    out_extra = torch.empty((F, H, W), dtype=torch.float32, device=dev) if F > 0 else torch.empty(0, device=dev)
+    # outputs and state come out of the library's arena (arena.py): fresh tensors for the caller, but the memory behind them
+    # survives the reference driver's per-iteration torch.cuda.empty_cache()
+    out_color = arena.empty((0 if feature_only else 3, H, W), torch.float32, dev)
+    out_others = arena.empty((0 if feature_only else 7, H, W), torch.float32, dev)
+    out_extra = arena.empty((F, H, W), torch.float32, dev) if F > 0 else torch.empty(0, device=dev)
     M = sh.shape[1] if (sh is not None and sh.dim() == 3) else 0
     if P == 0:
         radii = torch.zeros((P,), dtype=torch.int32, device=dev)
@@ -465,21 +467,21 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
                 cur = torch.cuda.current_stream()
                 cur.wait_event(done)
                 for t in (radii, geom, img, binning):
-                    t.record_stream(cur)
+                    arena.used_on(t, cur)
             prebinned = MODE_PREBINNED
             sized_by_estimate = geom.data_ptr() in _PENDING or geom.data_ptr() in _OVERFLOWED
             global PREFETCH_HITS
             PREFETCH_HITS += 1
         else:
-            radii = torch.empty((P,), dtype=torch.int32, device=dev)      # K1 writes every entry
+            radii = arena.empty((P,), torch.int32, dev)      # K1 writes every entry
             geom = _workspace(L.isr_geom_bytes, P, dev)
-            img = torch.empty(L.isr_image_bytes(W, H), dtype=torch.uint8, device=dev)
+            img = arena.empty(L.isr_image_bytes(W, H), torch.uint8, dev)
             R, sized_by_estimate = _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales,
                                             scale_modifier, rotations, transMat_precomp, viewmatrix, projmatrix, campos,
                                             tan_fovx, tan_fovy, prefiltered, radii, geom, img, tight=tight)
             binning = _workspace(lambda c: L.isr_binning_bytes(c, W, H), R, dev)
         if tracer:
-            grp = torch.empty((H * W * 10, 2), dtype=torch.int32, device=dev)
+            grp = arena.empty((H * W * 10, 2), torch.int32, dev)
             gcount = torch.empty((1,), dtype=torch.int32, device=dev)
         else:
             grp, gcount = None, None
@@ -543,7 +545,7 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, 
     geomg = bool(grad_mask & GRAD_GEOMETRY)
 
     def new(*shape):
-        return torch.empty(shape, dtype=torch.float32, device=dev)
+        return arena.empty(shape, torch.float32, dev)
 
     g2 = new(P, 3) if geomg else None
     gn = new(P, 3) if geomg else None
@@ -637,7 +639,7 @@ def rasterize_gaussians_backward_sampled(P, F, W, H, R, pixels, dL_dsampled, tra
     if rows_only:
         out = None
     else:
-        out = accumulate_into if accumulate_into is not None else torch.empty((P, F), dtype=torch.float32, device=dev)
+        out = accumulate_into if accumulate_into is not None else arena.empty((P, F), torch.float32, dev)
     scratch = _workspace(lambda c: L.isr_backward_sampled_scratch_bytes(c, F, n, W, H), R, dev)
     nbytes = scratch.numel()
     with torch.cuda.device(dev):

@@ -172,3 +172,36 @@ def test_real_reference_packages_resolve_to_the_library():
     r = subprocess.run([sys.executable, "-c", code], cwd=REFERENCE, env=_env(os.path.join(ROOT, "dropin")),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
+
+
+def test_install_makes_empty_cache_act_only_under_memory_pressure(monkeypatch):
+    """train_semantic.py:208 calls torch.cuda.empty_cache() every iteration; under the drop-in that hands memory back only when
+    the device is short of it (dropin.empty_cache_under_pressure), ISR_KEEP_EMPTY_CACHE=1 opts out, uninstall() restores."""
+    import torch
+    from instascene_amd import dropin
+    real = torch.cuda.empty_cache
+    calls = []
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: calls.append(1))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    free = [200 << 30]
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda: (free[0], 288 << 30))
+    try:
+        dropin.install()
+        assert torch.cuda.empty_cache is not real
+        torch.cuda.empty_cache()
+        assert calls == []                      # plenty of free memory: nothing is handed back
+        free[0] = 10 << 30
+        torch.cuda.empty_cache()
+        assert calls == [1]                     # under pressure the real function runs
+    finally:
+        dropin.uninstall()
+    torch.cuda.empty_cache()
+    assert calls == [1, 1]                      # restored: the (patched-in) original again
+    monkeypatch.setenv("ISR_KEEP_EMPTY_CACHE", "1")
+    try:
+        dropin.install()
+        torch.cuda.empty_cache()
+        assert calls == [1, 1, 1]
+    finally:
+        dropin.uninstall()
