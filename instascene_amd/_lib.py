@@ -20,7 +20,7 @@ MODE_PREBINNED = 0x100
 MODE_FEATURE_ONLY = 0x200
 GRAD_EXTRA, GRAD_GEOMETRY = 1, 2
 
-# every exported symbol and its signature (checked by tests/test_abi.py against include/*.h)
+# every exported symbol and its signature (tests/test_abi.py static_asserts each one against include/*.h with g++)
 _P = c_void_p
 SIGNATURES = {
     "isr_last_error": (c_char_p, []),

@@ -815,6 +815,7 @@ __global__ __launch_bounds__(1024) void rows_compact_kernel(int n, int F, long l
 //   rows_merge_kernel   a wave per sample: a row drawn twice gets its second occurrence added by that occurrence's wave, a row
 //                       drawn three times or more by its head's wave in ascending position - the order of
 //                       index_put_(accumulate=True) and of rows_compact_kernel, hence the same bits; the count is cleared.
+static_assert(ROWS_COMPACT_MAX <= 0x3fff + 1, "a row position must fit the slot's 14 position bits");
 constexpr unsigned ROWS_POS_MASK = 0x3fffu, ROWS_REPEAT_ONE = 0x4000u;       // slot while the three kernels run: repeats << 14 | first position (n <= 16 384)
 __global__ __launch_bounds__(256) void rows_first_kernel(int n, long long P, const long long* __restrict__ idx, unsigned* __restrict__ slot) {
     const int i = blockIdx.x * 256 + threadIdx.x;

@@ -70,7 +70,10 @@ int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binni
         const int big = (binning_capacity / (T > 0 ? T : 1)) > 1500 ? 1 : 0;
         static const bool wave_sort = [] { const char* e = getenv("ISR_WAVE_SORT"); return !(e && e[0] == '0'); }();
         // buckets of up to 2 048 keys: one wave each, in registers; the LDS network takes the rest
-        static const int wave_max = [] { const char* e = getenv("ISR_WAVE_SORT_MAX"); return e ? atoi(e) : 64; }();
+        // (only 32, 64 and 128 keys per lane exist as kernels: anything else falls back to 64 - a value without a kernel would
+        // leave the buckets between the LDS network's range and the big kernel's unsorted)
+        static const int wave_max = [] { const char* e = getenv("ISR_WAVE_SORT_MAX"); const int v = e ? atoi(e) : 64;
+                                         return (v == 32 || v == 64 || v == 128) ? v : 64; }();
         const int wk = !wave_sort ? 0 : (!big ? 32 : wave_max);           // keys per lane of the widest variant launched
         const int wflags = wk == 0 ? 0 : wk == 32 ? 2 : wk == 64 ? 6 : 14;
         if (wk == 128)
