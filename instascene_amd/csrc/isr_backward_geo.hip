@@ -44,6 +44,11 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
     const unsigned long long* __restrict__ hit_mask) {
     __shared__ __attribute__((aligned(16))) float s_pix[64 * 16];
     __shared__ int s_q[GEO_QCAP];
+    // A splat whose every pair takes EXACT's instruction sequence (band = +inf: edge-on, horizon inside its footprint; ~0.4 % of
+    // the splats, i.e. one in a quarter of all chunks of 64) would make the whole wave run that sequence - for one lane - at every
+    // pixel of its box.  It is evaluated here instead, once per chunk, a lane per PIXEL of the block, and handed to its lane
+    // through LDS: 12 floats per pixel (dx dy rz sx | sy depth G alpha | pass, use3d).
+    __shared__ __attribute__((aligned(16))) float s_ex[64 * 12];
 
     const int tile = tile_order != nullptr ? (int)tile_order[blockIdx.x >> 2] : (int)(blockIdx.x >> 2), blk = blockIdx.x & 3;
     const int tx = tile % gx, ty = tile / gx;
@@ -155,12 +160,35 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
             // they are turned into the gradient of the three rows once per (block, splat), after the loop.
             const float det = fast_det(Tu, Tv, Tw, cx, cy);
             const FastBand fb = fast_band(opa, band);
+            const unsigned long long m_forced = __ballot(li >= 0 && !(band < __builtin_inff()));
+            const bool pre = __popcll(m_forced) == 1;              // (two or more in one chunk: the per-pair path below, as before)
+            const int f_lane = pre ? __builtin_ctzll(m_forced) : 0;
+            if (pre) {
+                auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), f_lane)); };
+                const F3 fTu = {bc(Tu.x), bc(Tu.y), bc(Tu.z)}, fTv = {bc(Tv.x), bc(Tv.y), bc(Tv.z)}, fTw = {bc(Tw.x), bc(Tw.y), bc(Tw.z)};
+                FastRay er; FastHit eh;
+                const bool ep = exact_pair(tile_x0 + (float)(bxo + (lane & 7)), tile_y0 + (float)(byo + (lane >> 3)), fTu, fTv, fTw, bc(cx), bc(cy),
+                                           bc(opa), er, eh);
+                wave_lds_sync();                                   // (the previous chunk's readers are done)
+                float4* o = reinterpret_cast<float4*>(s_ex + lane * 12);
+                o[0] = make_float4(er.dx, er.dy, er.rz, er.sx);
+                o[1] = make_float4(er.sy, eh.depth, eh.G, eh.alpha);
+                o[2] = make_float4(ep ? 1.0f : 0.0f, eh.use3d ? 1.0f : 0.0f, 0.0f, 0.0f);
+                wave_lds_sync();
+            }
+            const bool pre_mine = pre && lane == f_lane;
             float aP0 = 0, aP1 = 0, aP2 = 0, aX0 = 0, aX1 = 0, aX2 = 0, aY0 = 0, aY1 = 0, aY2 = 0;     // sum dL/dp, sum lx dL/dp, sum ly dL/dp
             float aZ0 = 0, aZ1 = 0, aZ2 = 0;            // sum dL/dz (sx, sy, 1)
             float aC0 = 0, aC1 = 0;                     // dL/dcentre (low-pass branch)
             float aN0 = 0, aN1 = 0, aN2 = 0, aO = 0, aR = 0, aG = 0, aB = 0;
             bool touched = false;
+            FastHalf lrow = {{0.0f, 0.0f}, 0.0f};
+            float pyf_row = 0.0f;
             for (int p = 0; p < 64; p++) {
+                if ((p & 7) == 0) {             // a new pixel row: l = py Tw - Tv once per row and splat
+                    pyf_row = tile_y0 + (float)(byo + (p >> 3));
+                    lrow = fast_l(pyf_row, Tv, Tw);
+                }
                 const float4* pq = reinterpret_cast<const float4*>(s_pix + p * 16);
                 const float4 q3 = pq[3];
                 const unsigned last_p = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q3.y));
@@ -170,7 +198,14 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
                     const float lx = (float)lxi, ly = (float)lyi;
                     // the forward's own evaluation of the pair (isr_fast_pair.hpp; EXACT inside the guard bands): same decisions, bit for bit
                     FastRay fr; FastHit fh;
-                    const bool pass = fast_pair_lane(Tu, Tv, Tw, cx, cy, opa, det, fb, tile_x0 + lx, tile_y0 + ly, fr, fh);
+                    bool pass = fast_pair_lane(Tu, Tv, Tw, cx, cy, opa, det, fb, tile_x0 + lx, pyf_row, fr, fh, pre_mine, &lrow);
+                    if (pre_mine && cand) {                        // the chunk's always-EXACT splat: evaluated above
+                        const float4* e4 = reinterpret_cast<const float4*>(s_ex + p * 12);
+                        const float4 e0 = e4[0], e1 = e4[1], e2 = e4[2];
+                        fr.dx = e0.x; fr.dy = e0.y; fr.rz = e0.z; fr.sx = e0.w; fr.sy = e1.x;
+                        fh.depth = e1.y; fh.G = e1.z; fh.alpha = e1.w;
+                        pass = e2.x != 0.0f; fh.use3d = e2.y != 0.0f;
+                    }
                     const float dx = fr.dx, dy = fr.dy, rz = fr.rz, sx = fr.sx, sy = fr.sy;
                     const bool use3d = fh.use3d;
                     const float c_d = fh.depth, G = fh.G, alpha = fh.alpha;

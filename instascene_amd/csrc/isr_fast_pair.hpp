@@ -138,6 +138,36 @@ __device__ __forceinline__ FastRay fast_ray(v2f pq, v2f Tuxy, v2f Tvxy, v2f Twxy
     r.rho = fminf(r.rho3d, r.rho2d);
     return r;
 }
+// The same split by pixel column and row, for a kernel that walks the pixels of a block for one splat per lane (k depends on
+// the column only, l on the row only): bit-identical to fast_ray (the packed instructions round each half like the scalar ones).
+struct FastHalf { v2f xy; float z; };
+__device__ __forceinline__ FastHalf fast_k(float pxf, const F3 Tu, const F3 Tw) {
+    return {__builtin_elementwise_fma((v2f){pxf, pxf}, (v2f){Tw.x, Tw.y}, -(v2f){Tu.x, Tu.y}), pxf * Tw.z - Tu.z};
+}
+__device__ __forceinline__ FastHalf fast_l(float pyf, const F3 Tv, const F3 Tw) {
+    return {__builtin_elementwise_fma((v2f){pyf, pyf}, (v2f){Tw.x, Tw.y}, -(v2f){Tv.x, Tv.y}), pyf * Tw.z - Tv.z};
+}
+__device__ __forceinline__ FastRay fast_ray_kl(const FastHalf& k, const FastHalf& l, float dx, float dy) {
+    FastRay r;
+    const v2f klz = {k.z, l.z};
+    v2f t, pxy;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(t) : "v"(klz), "v"(l.xy));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,1,1]" : "=v"(pxy) : "v"(klz), "v"(k.xy), "v"(t));
+    r.p_x = pxy.x;
+    r.p_y = pxy.y;
+    r.p_z = __builtin_fmaf(k.xy.x, l.xy.y, -(k.xy.y * l.xy.x));
+    r.dx = dx;
+    r.dy = dy;
+    const float hh = __builtin_fmaf(r.dy, r.dy, r.dx * r.dx);
+    r.rho2d = hh + hh;
+    r.rz = __builtin_amdgcn_rcpf(r.p_z);
+    const v2f sxy = pxy * (v2f){r.rz, r.rz};
+    r.sx = sxy.x;
+    r.sy = sxy.y;
+    r.rho3d = __builtin_fmaf(r.sy, r.sy, r.sx * r.sx);
+    r.rho = fminf(r.rho3d, r.rho2d);
+    return r;
+}
 __device__ __forceinline__ FastRay fast_ray(float pxf, float pyf, const F3 Tu, const F3 Tv, const F3 Tw, float cx, float cy) {
     return fast_ray((v2f){pxf, pyf}, (v2f){Tu.x, Tu.y}, (v2f){Tv.x, Tv.y}, (v2f){Tw.x, Tw.y}, (v2f){Tu.z, Tv.z}, Tw.z, (v2f){cx, cy});
 }
@@ -202,13 +232,18 @@ __device__ __forceinline__ void fast_take(bool inb, const FastRay& er, const Fas
 }
 // One pair for a lane that owns its splat's record (the splat-major backward kernels): FAST, EXACT inside the band.
 // Returns whether the pair blends (before the T < 1e-4 stop).
+// `elsewhere`: this lane's EXACT evaluation is supplied by the caller (k_render_bwd_geo's always-EXACT splat of a chunk).
 __device__ __forceinline__ bool fast_pair_lane(const F3 Tu, const F3 Tv, const F3 Tw, float cx, float cy, float opa, float det,
-                                               const FastBand& b, float pxf, float pyf, FastRay& fr, FastHit& fh) {
-    fr = fast_ray(pxf, pyf, Tu, Tv, Tw, cx, cy);
+                                               const FastBand& b, float pxf, float pyf, FastRay& fr, FastHit& fh, bool elsewhere = false,
+                                               const FastHalf* row = nullptr) {
+    if (row != nullptr) fr = fast_ray_kl(fast_k(pxf, Tu, Tw), *row, cx - pxf, cy - pyf);       // (row = fast_l(pyf, Tv, Tw), hoisted by the caller)
+    else fr = fast_ray(pxf, pyf, Tu, Tv, Tw, cx, cy);
     fh = fast_hit(fr, det, Tw.z, opa);
     const bool near = fast_near(fr, b.hi);
     bool pass = near && fast_pass(fh);
-    if (near && fast_in_band(fr, b)) pass = exact_pair(pxf, pyf, Tu, Tv, Tw, cx, cy, opa, fr, fh);
+#ifndef ISR_AB_NO_LANE_EXACT        // (A/B builds only, tools/build_variant.sh: what the EXACT path costs the splat-major kernels)
+    if (!elsewhere && near && fast_in_band(fr, b)) pass = exact_pair(pxf, pyf, Tu, Tv, Tw, cx, cy, opa, fr, fh);
+#endif
     return pass;
 }
 

@@ -376,8 +376,14 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
                 done.record()
     # the entry keeps the converted inputs alive until it is consumed or dropped
     _PREFETCHED[sig] = _Prefetched(sig, _refs(originals), radii, geom, img, R, binning, done, inputs)
-    while len(_PREFETCHED) > 12:                # entries nobody came for
+    # entries nobody came for: bounded by count AND by bytes (an entry pins radii + geom + img + binning - ~0.4 GB per view at
+    # C3, ~1 GB at C5; ISR_PREFETCH_MAX_GB, default 8); the newest entry always stays
+    limit = int(float(os.environ.get("ISR_PREFETCH_MAX_GB", "8")) * (1 << 30))
+    nbytes = lambda e: sum(t.numel() * t.element_size() for t in (e.radii, e.geom, e.img, e.binning))
+    total = sum(nbytes(e) for e in _PREFETCHED.values())
+    while len(_PREFETCHED) > 1 and (len(_PREFETCHED) > 12 or total > limit):
         old = _PREFETCHED.pop(next(iter(_PREFETCHED)))
+        total -= nbytes(old)
         _PENDING.pop(old.geom.data_ptr(), None)
     return True
 
