@@ -31,6 +31,21 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md); measured co
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
 
 
+SIMDS, CLOCK_GHZ = 1024, 2.4      # MI355X: 256 CUs x 4 SIMDs; a wave64 vector instruction occupies its SIMD's issue port for 4 cycles
+
+
+def csrc_tree_hash():
+    """sha256 over the library's sources: profiles/roofline_traffic.json records the tree its PMC counters were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "instascene_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _self_launch(n):
     """``python bench.py --gpus N`` with no launcher: become ``torch.distributed.run`` with N ranks on this node."""
     with socket.socket() as s:
@@ -190,6 +205,8 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
         trainer.split_tail = bool(args.split_tail)
         if args.sharded_tail is not None:
             trainer.sharded_tail = bool(args.sharded_tail)
+        if getattr(args, "exchange", None):
+            trainer.exchange = args.exchange
         trainer.pipe.lazy_maps = bool(args.lazy_maps)
         trainer.pipe.feature_only_forward = feature_only
         trainer.warm_view_caches()       # per-view constants (ray tables, visible pools, instance counts): setup
@@ -301,16 +318,18 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
         launches = max(1, int(round(kern[dom]["launches_per_view"]))) if dom_key in ("k_render_fwd", "k_render_bwd_dense") else 1
         dom_bytes = bm.get(dom_key, 0) / launches
         gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic, tsrc = None, None
+        traffic, tsrc, issue, stale = None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get(args.config + ":" + args.step + ":" + mode, {}).get(dom)
                 tsrc = tj.get("source")
+                issue = tj.get(args.config + ":" + args.step + ":" + mode + ":" + dom + ":issue")
+                stale = tj.get("csrc_tree_hash") != csrc_tree_hash()      # the counters were taken on another tree
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": dom, "traffic_stale": stale, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                 "traffic_over_algorithmic_bytes": (round(traffic / dom_bytes, 3) if (traffic and dom_bytes) else None),
                 "avg_launch_ms": round(dom_ms, 4), "launches_per_view": launches,
@@ -342,12 +361,34 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
                 "flops": int(flops_eval), "flops_upper_bound_256R": int(flops_model),
                 "TFLOP/s": round(tf, 2), "peak_TFLOP/s": VALU_PEAK_TFLOPS, "frac": round(tf / VALU_PEAK_TFLOPS, 4),
                 "frac_with_256R_bound": round(flops_model / (dom_ms * launches * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}
+        if dom == "k_render_fwd" and issue and issue.get("SQ_INSTS_VALU"):
+            # what bounds the blend kernel: vector-instruction ISSUE.  A wave64 vector instruction holds its SIMD's port for 4
+            # cycles, so the chip issues at most SIMDS * clock / 4 of them per second; the count per launch is the committed PMC
+            # counter (profiles/roofline_traffic.json, taken on the tree named there), the time is this run's.
+            peak = SIMDS * CLOCK_GHZ / 4.0                            # G wave-instructions / s
+            ach = issue["SQ_INSTS_VALU"] / (dom_ms * 1e-3) / 1e9
+            roof.update({"bound": "valu_issue", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "G wave-instructions/s",
+                         "frac": round(ach / peak, 4),
+                         "issue": dict({k: v for k, v in issue.items() if k != "source"}, source=issue.get("source"),
+                                       model="achieved = SQ_INSTS_VALU per launch / this run's launch time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles "
+                                             "per wave64 instruction"),
+                         "frac_hbm": roof["hbm"]["frac"], "frac_fp32_flops": (roof.get("valu") or {}).get("frac")})
         rec["roofline"] = roof
         rec["cfg"] = cfg
     if world > 1 and args.step == "seg":
         ms = time_allreduce(cfg["P"] * cfg["F"], dev, world)
         rec["allreduce_ms"] = None if ms is None else round(ms, 3)
-        if not getattr(trainer, "sharded_tail", False):
+        P_, F_ = cfg["P"], cfg["F"]
+        rec["exchange"] = {"kind": "RCCL all-reduce of the [P,F] gradient in %d row ranges" % getattr(trainer, "tail_chunks", 1),
+                           "bytes": {"buffer": 4 * P_ * F_, "per_link_ring_model": int(2 * (world - 1) / world * 4 * P_ * F_)}}
+        if getattr(trainer, "exchange", "rccl") in ("peer", "peer_compact") and not getattr(trainer, "sharded_tail", False):
+            trainer.phase_timing = True
+            trainer.step(it0 + extra_steps + 100)
+            trainer.phase_timing = False
+            sync()
+            if trainer.last_exchange:
+                rec["exchange"] = trainer.last_exchange
+        elif not getattr(trainer, "sharded_tail", False):
             # per-phase device times of the multi-rank tail over a few extra (untimed) steps: how much of the collective the
             # row-range pipeline hides
             trainer.phase_timing = True
@@ -411,6 +452,9 @@ def main():
                          "before the timed region; a pure relabelling of rows); 0: keep the generator's random order")
     ap.add_argument("--fused-sampling", type=int, default=1,
                     help="1 (default): one kernel draws every index of a step (iso_sample_step); 0: torch.randint + gathers")
+    ap.add_argument("--exchange", default=os.environ.get("ISR_EXCHANGE", "rccl"), choices=["rccl", "peer", "peer_compact"],
+                    help="N > 1, seg step: how dL/dparam is summed - RCCL all-reduce (default), or the direct exchange over peer-mapped "
+                         "buffers, dense or compacted to the touched rows (peer_exchange.PeerExchange; opt-in, untimed on a multi-GPU node)")
     ap.add_argument("--sharded-tail", type=int, default=None,
                     help="1: several ranks exchange dL/dparam by reduce-scatter, run Adam on their shard of the rows and all-gather "
                          "the parameter rows (SegTrainer.sharded_tail; default: ISR_SHARDED_TAIL or off)")
@@ -567,6 +611,7 @@ def main():
                           "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
                           "allreduce_ms_per_step_alone": head.get("allreduce_ms"),
                           "multi_rank_tail_phases": head.get("multi_rank_tail"),
+                          "gradient_exchange": head.get("exchange"),
                           "gaussian_order": "z-order of the centres, sorted once at load" if args.spatial_sort else "as generated (random)",
                           "derived_render_maps": "on first access (never read by the seg step)" if args.lazy_maps else "inside render(), like the reference",
                           "multi_rank_tail": ("sharded: reduce-scatter, owner-only Adam, all-gather of the parameter rows"

@@ -192,6 +192,27 @@ int iso_sample_step(unsigned long long seed, unsigned long long step, int B, lon
  * is the caller's (instascene_amd/peer_exchange.py). */
 int iso_peer_sum(int W, const float* const* sources, long long begin, long long count, float* dst, void* stream);
 
+/* ---- the direct exchange's control plane on the device (instascene_amd/peer_exchange.py) ------------
+ * iso_ipc_alloc: `bytes` of zeroed fine-grained device memory (plain device memory where the driver has no fine-grained pool)
+ * and its 64-byte hipIpcMemHandle, which another process turns into a mapping with iso_ipc_open; iso_ipc_close unmaps (owner = 0)
+ * or frees (owner = 1).  iso_enable_peer_access: hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess from the current device.
+ * iso_flag_set: after everything enqueued on `stream` so far, *flag = value (release, system scope).
+ * iso_flag_wait: `stream` stalls until *flags[w] >= value (generation counters; signed distance) for every w < W except `skip`
+ * (acquire, system scope; no host involvement); a flag that does not arrive within timeout_ms sets bit w of *status (device
+ * memory, 32 bits) instead of hanging the device.
+ * iso_rows_pack: the rows r with touched[r] != 0 of grad[P,F] -> idx[n], rows[n,F], *count = n (the buffers hold up to P rows).
+ * iso_rows_scatter_add: dst[idx[e]] += rows[e] (or = with assign != 0) for e < *count; count / idx / rows may be a peer's memory;
+ * max_rows bounds the launch (the list's capacity). */
+int iso_ipc_alloc(size_t bytes, void** ptr, void* handle64);
+int iso_ipc_open(const void* handle64, void** ptr);
+int iso_ipc_close(void* ptr, int owner);
+int iso_enable_peer_access(int peer_device);
+int iso_flag_set(void* flag, unsigned value, void* stream);
+int iso_flag_wait(int W, const void* const* flags, int skip, unsigned value, void* status, int timeout_ms, void* stream);
+int iso_rows_pack(int P, int F, const unsigned char* touched, const float* grad, int* idx, float* rows, int* count, void* stream);
+int iso_rows_scatter_add(int F, int P, long long max_rows, const int* count, const int* idx, const float* rows, float* dst, int assign,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,14 @@ SIGNATURES = {
                                   ctypes.c_longlong, c_float,
                                   c_float, _P, _P, _P, _P, _P, _P, _P]),
     "iso_peer_sum": (c_int, [c_int, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P]),
+    "iso_ipc_alloc": (c_int, [c_size_t, _P, _P]),
+    "iso_ipc_open": (c_int, [_P, _P]),
+    "iso_ipc_close": (c_int, [_P, c_int]),
+    "iso_enable_peer_access": (c_int, [c_int]),
+    "iso_flag_set": (c_int, [_P, c_uint, _P]),
+    "iso_flag_wait": (c_int, [c_int, _P, c_int, c_uint, _P, c_int, _P]),
+    "iso_rows_pack": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "iso_rows_scatter_add": (c_int, [c_int, c_int, ctypes.c_longlong, _P, _P, _P, _P, c_int, _P]),
     "iso_rownorm2": (c_int, [ctypes.c_longlong, c_int, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P]),
 }
 

@@ -142,4 +142,80 @@ __global__ __launch_bounds__(256) void peer_sum_kernel(int W, PeerPtrs p, long l
         }
     }
 }
+
+// ---- device-side phase flags of the direct exchange -------------------------------------------------------------------------------
+// Every rank owns a small array of 32-bit generation counters in fine-grained device memory that its peers have mapped
+// (iso_ipc_alloc / iso_ipc_open).  A rank publishes "phase ph of call g is complete on my stream" by a one-thread kernel on that
+// stream (release at system scope, then the store), and consumes its peers' progress by a one-wave kernel on its own stream that
+// polls their counters (acquire at system scope): the kernels enqueued behind it read what the peers wrote before their publish.
+// No host round trip; the host only enqueues.  A poll gives up after `timeout_ms` (a peer died): it sets *status and returns, so a
+// broken run ends with an error on the next host check instead of a wedged GPU.
+__global__ void flag_set_kernel(unsigned* flag, unsigned value) {
+    __threadfence_system();
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+struct FlagPtrs { const unsigned* f[16]; };
+__global__ __launch_bounds__(64) void flag_wait_kernel(int W, FlagPtrs p, int skip, unsigned value, unsigned* status, long long timeout_ticks) {
+    const int w = threadIdx.x;
+    if (w < W && w != skip) {
+        const long long t0 = wall_clock64();
+        // generations only grow; compared as a signed distance so that the counter may wrap
+        while ((int)(__hip_atomic_load(p.f[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
+            __builtin_amdgcn_s_sleep(32);
+            if (wall_clock64() - t0 > timeout_ticks) { atomicOr(status, 1u << w); break; }
+        }
+    }
+    __threadfence_system();
+}
+
+// ---- compacted exchange: only the rows a rank touched -------------------------------------------------------------------------
+// pack: the rows r with touched[r] != 0 of grad[P,F] -> idx[n], rows[n,F], *count = n (order = the order of the position atomics:
+// irrelevant, every row appears once).  One wave per 64 rows; a lane copies a float4 column of a row.
+__global__ __launch_bounds__(256) void rows_pack_kernel(int P, int F, const unsigned char* __restrict__ touched, const float* __restrict__ grad,
+                                                        int* __restrict__ idx, float* __restrict__ rows, int* __restrict__ count) {
+    __shared__ int s_base;
+    __shared__ int s_n;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const bool on = r < P && touched[r] != 0;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    int at = 0;
+    if (on) at = atomicAdd(&s_n, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = atomicAdd(count, s_n);
+    __syncthreads();
+    if (on) {
+        const int pos = s_base + at;
+        idx[pos] = r;
+        const float* src = grad + (size_t)r * F;
+        float* dst = rows + (size_t)pos * F;
+        if ((F & 3) == 0)
+            for (int c = 0; c < F; c += 4) *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
+        else
+            for (int c = 0; c < F; c++) dst[c] = src[c];
+    }
+}
+// dst[idx[e]][:] += rows[e][:] for e < *count (count, idx, rows may live in a peer's memory): rows of one list are distinct, so no
+// atomics; lists are applied one launch after the other in rank order, i.e. every row is summed in rank order on every rank.
+__global__ __launch_bounds__(256) void rows_scatter_add_kernel(int F, int P, const int* __restrict__ count, const int* __restrict__ idx,
+                                                               const float* __restrict__ rows, float* __restrict__ dst, int assign) {
+    const int n = *count;
+    const int q4 = (F + 3) / 4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < (long long)n * q4; e += (long long)gridDim.x * 256) {
+        const int i = (int)(e / q4), c = (int)(e - (long long)i * q4) * 4;
+        const int r = idx[i];
+        if (r < 0 || r >= P) continue;
+        if ((F & 3) == 0) {
+            const float4 v = *reinterpret_cast<const float4*>(rows + (size_t)i * F + c);
+            float4* d = reinterpret_cast<float4*>(dst + (size_t)r * F + c);
+            if (assign) *d = v;
+            else { float4 o = *d; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; *d = o; }
+        } else {
+            for (int k = c; k < F && k < c + 4; k++) {
+                const float v = rows[(size_t)i * F + k];
+                if (assign) dst[(size_t)r * F + k] = v; else dst[(size_t)r * F + k] += v;
+            }
+        }
+    }
+}
 }  // namespace iso

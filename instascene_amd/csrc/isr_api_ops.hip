@@ -3,6 +3,7 @@
 // caller's stream.  No torch types, no allocation, no hidden synchronisation except
 // where the header says so.
 #include <algorithm>
+#include <cstring>
 #include "isr_host.hpp"
 #include "iso_knn.hip"
 #include "iso_contrastive.hip"
@@ -464,6 +465,87 @@ int iso_peer_sum(int W, const float* const* sources, long long begin, long long 
     }
     hipLaunchKernelGGL(iso::peer_sum_kernel, dim3((unsigned)((count + 1023) / 1024)), dim3(256), 0, s, W, p, begin, count, dst);
     ISR_LAUNCH_CHECK("iso_peer_sum");
+    return ISR_OK;
+}
+
+
+// ---- fine-grained, IPC-shareable device memory for the exchange's flags / headers ---------------------------------------------
+int iso_ipc_alloc(size_t bytes, void** ptr, void* handle64) {
+    if (!ptr || !handle64 || bytes == 0) return fail(ISR_EINVAL, "ipc_alloc: null pointer or zero size");
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, bytes); }          // (no fine-grained pool: plain device memory)
+    if (e != hipSuccess) return fail(ISR_EHIP, "ipc_alloc: %s", hipGetErrorString(e));
+    if ((e = hipMemset(p, 0, bytes)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) { (void)hipFree(p); return fail(ISR_EHIP, "ipc_alloc: %s", hipGetErrorString(e)); }
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+    hipIpcMemHandle_t h;
+    if ((e = hipIpcGetMemHandle(&h, p)) != hipSuccess) { (void)hipFree(p); return fail(ISR_EHIP, "ipc_alloc: hipIpcGetMemHandle: %s", hipGetErrorString(e)); }
+    memcpy(handle64, &h, 64);
+    *ptr = p;
+    return ISR_OK;
+}
+int iso_ipc_open(const void* handle64, void** ptr) {
+    if (!ptr || !handle64) return fail(ISR_EINVAL, "ipc_open: null pointer");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, 64);
+    const hipError_t e = hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail(ISR_EHIP, "ipc_open: hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+    return ISR_OK;
+}
+int iso_ipc_close(void* ptr, int owner) {
+    const hipError_t e = owner ? hipFree(ptr) : hipIpcCloseMemHandle(ptr);
+    if (e != hipSuccess) return fail(ISR_EHIP, "ipc_close: %s", hipGetErrorString(e));
+    return ISR_OK;
+}
+int iso_enable_peer_access(int peer_device) {
+    int dev = 0, can = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(ISR_EHIP, "enable_peer_access: no current device");
+    if (peer_device == dev) return ISR_OK;
+    if (hipDeviceCanAccessPeer(&can, dev, peer_device) != hipSuccess || !can)
+        return fail(ISR_EHIP, "device %d cannot access device %d", dev, peer_device);
+    const hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(ISR_EHIP, "hipDeviceEnablePeerAccess(%d): %s", peer_device, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return ISR_OK;
+}
+int iso_flag_set(void* flag, unsigned value, void* stream) {
+    if (!flag) return fail(ISR_EINVAL, "flag_set: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(iso::flag_set_kernel, dim3(1), dim3(1), 0, s, (unsigned*)flag, value);
+    ISR_LAUNCH_CHECK("iso_flag_set");
+    return ISR_OK;
+}
+int iso_flag_wait(int W, const void* const* flags, int skip, unsigned value, void* status, int timeout_ms, void* stream) {
+    if (W < 1 || W > 16 || !flags || !status) return fail(ISR_EINVAL, "flag_wait: 1..16 flags and a status word");
+    iso::FlagPtrs p = {};
+    for (int w = 0; w < W; w++) {
+        if (!flags[w]) return fail(ISR_EINVAL, "flag_wait: flag %d is null", w);
+        p.f[w] = (const unsigned*)flags[w];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(iso::flag_wait_kernel, dim3(1), dim3(64), 0, s, W, p, skip, value, (unsigned*)status,
+                       (long long)timeout_ms * 100000ll);           // wall_clock64: 100 MHz
+    ISR_LAUNCH_CHECK("iso_flag_wait");
+    return ISR_OK;
+}
+int iso_rows_pack(int P, int F, const unsigned char* touched, const float* grad, int* idx, float* rows, int* count, void* stream) {
+    if (P < 0 || F < 1) return fail(ISR_EINVAL, "rows_pack: P >= 0, F >= 1");
+    if (!touched || !grad || !idx || !rows || !count) return fail(ISR_EINVAL, "rows_pack: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(count, 0, sizeof(int), s) != hipSuccess) return fail(ISR_EHIP, "rows_pack: memset");
+    if (P > 0) hipLaunchKernelGGL(iso::rows_pack_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, F, touched, grad, idx, rows, count);
+    ISR_LAUNCH_CHECK("iso_rows_pack");
+    return ISR_OK;
+}
+int iso_rows_scatter_add(int F, int P, long long max_rows, const int* count, const int* idx, const float* rows, float* dst, int assign, void* stream) {
+    if (F < 1 || P < 0 || max_rows < 0) return fail(ISR_EINVAL, "rows_scatter_add: F >= 1, P >= 0");
+    if (!count || !idx || !rows || !dst) return fail(ISR_EINVAL, "rows_scatter_add: null pointer");
+    if (max_rows == 0) return ISR_OK;
+    const long long work = max_rows * ((F + 3) / 4);
+    const unsigned grid = (unsigned)(work + 255 < 256ll * 8192 ? (work + 255) / 256 : 8192);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(iso::rows_scatter_add_kernel, dim3(grid), dim3(256), 0, s, F, P, count, idx, rows, dst, assign);
+    ISR_LAUNCH_CHECK("iso_rows_scatter_add");
     return ISR_OK;
 }
 

@@ -175,6 +175,12 @@ class SegTrainer:
         self.prefetch_mode = _os.environ.get("ISR_PREFETCH_MODE", "behind" if _pe is None else ("early" if _pe == "1" else "after"))
         self.high_priority_main = _os.environ.get("ISR_MAIN_PRIORITY", "1") == "1"     # measured: 2.03 -> 1.995 ms per C3 step
         self.sharded_tail = _os.environ.get("ISR_SHARDED_TAIL", "0") == "1"    # opt-in (unmeasured on hardware): _tail_sharded
+        # how the multi-rank tail sums dL/dparam: "rccl" (default: torch.distributed all-reduce in row ranges), "peer" (direct
+        # reduce-scatter / all-gather over peer-mapped buffers) or "peer_compact" (only the rows this step touched) -
+        # peer_exchange.PeerExchange, device-side phase flags; opt-in (ISR_EXCHANGE): never timed on a multi-GPU node
+        self.exchange = _os.environ.get("ISR_EXCHANGE", "rccl")
+        self._peer = None
+        self.last_exchange = None
         self.phase_timing = False    # multi-rank tail: record per-phase device times of each step into self.last_phases
         self.last_phases = None
         self.split_tail = False      # tests: take the multi-rank form of the tail (dL/dx, all-reduce, Adam) with one rank
@@ -492,6 +498,8 @@ class SegTrainer:
                 return loss.detach()
             if self.sharded_tail and m._seg_feature.shape[0] % self.world == 0:
                 self._tail_sharded(sink)
+            elif self.exchange in ("peer", "peer_compact") and self.world > 1 and self.device.type == "cuda":
+                self._tail_with_peer_exchange(sink)
             else:
                 self._tail_with_allreduce(sink)
             m._seg_cache = None
@@ -602,6 +610,36 @@ class SegTrainer:
         opt.renormalize_range(r1, P)
         opt.end_step()
         opt.zero_grad(set_to_none=True)
+
+    def _tail_with_peer_exchange(self, sink):
+        """Several ranks, opt-in (``exchange`` = "peer" / "peer_compact"): dL/dparam is reduced into a persistent ``[P,F]`` buffer
+        that all ranks have mapped, summed by the direct exchange (peer_exchange.PeerExchange: generation counters in device
+        memory, no host round trip; every row summed in rank order, so the replicas stay bit-identical), then Adam on every rank.
+        "peer_compact" exchanges only the rows this rank's step touched (a row is touched when its gradient is non-zero)."""
+        from .peer_exchange import PeerExchange
+        opt, p = self.opt, self.model._seg_feature
+        P, F = p.shape
+        if self._peer is None:
+            self._xgrad = torch.zeros(P, F, dtype=torch.float32, device=self.device)
+            self._peer = PeerExchange(self._xgrad, rows=(P, F) if self.exchange == "peer_compact" else None)
+        tail = opt.begin_tail(sink.rows, sink.row_grads, sink.dense)
+        p.grad = self._xgrad
+        if tail is None:
+            self._xgrad.zero_()
+        else:
+            opt.tail_gradient(tail, 0, P)
+        if self.exchange == "peer_compact":
+            touched = self._xgrad.abs().amax(dim=1) > 0
+            self._peer.all_reduce_compact_(touched)
+        else:
+            self._peer.all_reduce_()
+        opt.begin_step()
+        opt.step_range(0, P)
+        opt.end_step()
+        p.grad = None
+        if self.phase_timing:
+            self.last_exchange = {"kind": self._peer.last_kind,
+                                  "bytes": self._peer.compact_bytes() if self.exchange == "peer_compact" else self._peer.last_bytes}
 
     def _tail_with_allreduce(self, sink):
         """Several ranks: dL/dparam must be summed before Adam.  The [P,F] table is walked in ``tail_chunks`` row ranges:

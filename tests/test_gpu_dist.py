@@ -34,7 +34,7 @@ def _trainer(rank, world):
                       world=world)
 
 
-def _worker(rank, world, port, steps, out, sharded=False):
+def _worker(rank, world, port, steps, out, sharded=False, exchange="rccl"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -43,6 +43,7 @@ def _worker(rank, world, port, steps, out, sharded=False):
     from instascene_amd.dist_utils import replicas_in_sync
     tr = _trainer(rank, world)
     tr.sharded_tail = bool(sharded)
+    tr.exchange = exchange
     tr.warm_view_caches()
     tr.prime()
     grads = []
@@ -91,6 +92,24 @@ def test_sharded_tail_equals_the_all_reduce_tail(tmp_path):
         assert torch.equal(sh[r]["m"][r0:r1], ar[r]["m"][r0:r1])
         other = torch.cat([sh[r]["m"][:r0], sh[r]["m"][r1:]])
         assert float(other.abs().max()) == 0.0            # the shard owner is the only rank that keeps those moments
+
+
+@pytest.mark.timeout(300)
+def test_direct_exchanges_in_the_trainer_equal_the_all_reduce_tail(tmp_path):
+    """SegTrainer.exchange = "peer" (dense reduce-scatter / all-gather over peer-mapped buffers) and "peer_compact" (only the rows
+    the step touched), synchronised on the device: parameters and Adam moments bit-identical to the all-reduce tail's on both
+    ranks after four steps (two ranks: every sum is a + b, whatever the exchange)."""
+    world, steps = 2, 4
+    runs = {}
+    for kind in ("rccl", "peer", "peer_compact"):
+        d = tmp_path / kind
+        d.mkdir()
+        mp.spawn(_worker, args=(world, _free_port(), steps, str(d), False, kind), nprocs=world, join=True)
+        runs[kind] = [torch.load(d / f"r{r}.pt") for r in range(world)]
+    for kind in ("peer", "peer_compact"):
+        for r in range(world):
+            assert torch.equal(runs[kind][r]["p"], runs["rccl"][r]["p"]), (kind, r)
+            assert torch.equal(runs[kind][r]["m"], runs["rccl"][r]["m"]), (kind, r)
 
 
 def _single_process_reference(world, steps, r0):
@@ -257,6 +276,15 @@ def test_bench_launches_itself_for_several_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["multi_rank_tail"].startswith("sharded")
+    # ... and with the compacted direct exchange: the line says which exchange ran and what it moved
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--submodes", "", "--exchange", "peer_compact"], env=env, capture_output=True, text=True,
+                       timeout=560, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    ex = rec["config"]["gradient_exchange"]
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and ex["kind"].startswith("compacted")
+    assert len(ex["bytes"]["rows_per_rank"]) == 2 and 0 < ex["bytes"]["pulled_per_rank"] < ex["bytes"]["buffer"]
 
 
 def _peer_worker(rank, world, port, out):
@@ -269,27 +297,67 @@ def _peer_worker(rank, world, port, out):
     g = torch.Generator(device="cuda").manual_seed(100 + rank)
     P, F = 6001, 20                                     # odd row count: ragged last shard, unaligned tail
     buf = torch.empty(P, F, device="cuda")
-    ex = PeerExchange(buf)
-    results = []
+    ex = PeerExchange(buf, rows=(P, F))
+    results, compact, fractions = [], [], []
     for step in range(3):
         buf.copy_(torch.randn(P, F, device="cuda", generator=g))
         want = buf.clone()
         dist.all_reduce(want)                           # the reference collective (gloo here, RCCL on a real node)
-        ex.all_reduce_()
+        ex.all_reduce_()                                # enqueues only: no host synchronisation inside
         results.append(bool(torch.equal(buf, want)))
-    torch.save({"ok": results, "sum": buf.cpu()}, os.path.join(out, f"p{rank}.pt"))
+    for step in range(3):
+        # a sparse gradient: a third of the rows touched, a different third on every rank and step
+        touched = (torch.rand(P, device="cuda", generator=g) < 0.33)
+        buf.copy_(torch.randn(P, F, device="cuda", generator=g) * touched[:, None])
+        want = buf.clone()
+        dist.all_reduce(want)
+        ex.all_reduce_compact_(touched)
+        compact.append(bool(torch.equal(buf, want)))
+        fractions.append(ex.compact_bytes())
+    ex.check_status()
+    torch.save({"ok": results, "compact": compact, "bytes": fractions, "sum": buf.cpu()}, os.path.join(out, f"p{rank}.pt"))
     dist.barrier()
-    del ex
+    ex.close()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
 def test_direct_peer_exchange_equals_the_collective(tmp_path):
-    """SURVEY section 5's direct reduce-scatter / all-gather over IPC-mapped peer buffers (peer_exchange.PeerExchange,
-    iso_peer_sum), two ranks sharing one GPU: the summed buffer is bit-identical to torch.distributed's all-reduce of the
-    same buffers, on both ranks, three steps in a row (buffers reused, as a training loop would)."""
+    """SURVEY section 5's direct exchange over IPC-mapped peer buffers (peer_exchange.PeerExchange), two ranks sharing one GPU,
+    synchronised by generation counters in device memory (no host barrier inside a call): the dense reduce-scatter / all-gather
+    AND the compacted exchange of the touched rows give sums bit-identical to torch.distributed's all-reduce of the same
+    buffers, on both ranks, three steps in a row each (buffers reused, as a training loop would); the compacted call moves
+    about a third of the dense one's bytes."""
     world = 2
     mp.spawn(_peer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     r0, r1 = torch.load(tmp_path / "p0.pt"), torch.load(tmp_path / "p1.pt")
     assert r0["ok"] == [True] * 3 and r1["ok"] == [True] * 3
+    assert r0["compact"] == [True] * 3 and r1["compact"] == [True] * 3
     assert torch.equal(r0["sum"], r1["sum"])
+    for b in r0["bytes"] + r1["bytes"]:
+        assert all(0.25 < f < 0.42 for f in b["touched_fraction"]) and b["pulled_per_rank"] < 0.5 * b["buffer"]
+
+
+def test_a_peer_that_never_arrives_times_out_instead_of_hanging():
+    """iso_flag_wait gives up after its timeout and reports the late rank in the status word; the device stays usable."""
+    import ctypes
+    from instascene_amd._lib import lib, check
+    L = lib()
+    torch.cuda.set_device(0)
+    mem, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+    check(L.iso_ipc_alloc(64, ctypes.byref(mem), handle), "iso_ipc_alloc")
+    try:
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        flags = (ctypes.c_void_p * 2)(mem.value, mem.value + 4)
+        check(L.iso_flag_set(ctypes.c_void_p(mem.value), 7, st), "iso_flag_set")           # "rank 0" publishes generation 7
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        check(L.iso_flag_wait(2, flags, -1, 7, ctypes.c_void_p(mem.value + 32), 50, st), "iso_flag_wait")   # "rank 1" never does
+        t1.record()
+        out = torch.zeros(4, device="cuda")
+        check(L.iso_peer_sum(1, (ctypes.c_void_p * 1)(mem.value), 8, 1, ctypes.c_void_p(out.data_ptr()), st), "read")
+        torch.cuda.synchronize()
+        assert int(out[:1].view(torch.int32).item()) == 0b10
+        assert 40.0 <= t0.elapsed_time(t1) <= 2000.0
+    finally:
+        L.iso_ipc_close(mem, 1)

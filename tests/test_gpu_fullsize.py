@@ -322,6 +322,55 @@ def test_c3_trainer_formulations_agree_bit_for_bit():
         rz.set_tracer(True)
 
 
+def test_c5_full_size_against_the_oracle():
+    """BASELINE config 5 in its 1-GPU form (5 M Gaussians, 1296 x 968, F = 64: ~15 M tile instances, lists of ~3 100 per tile -
+    the dense-scene paths of the binning: k_tile_sort_big, two-chunk feature passes) at FULL size against the CPU oracle: the
+    EXACT forward bit-identical on every output and all integer state; the sampled feature backward within 1e-3 of the tensor's
+    maximum on every row in EXACT mode; FAST gated by cause like C3."""
+    import oracle
+    import test_gpu_rasterizer as TR
+    from helpers import oracle_forward, assert_rows_close
+    scene, cams, cfg = scenes.config_scene("C5")
+    P, W, H, F = cfg["P"], cfg["W"], cfg["H"], cfg["F"]
+    assert (P, W, H, F) == (5_000_000, 1296, 968, 64)
+    cpu = scenes.activated_inputs(scene)
+    inp = {k: (None if v is None else v.cuda()) for k, v in cpu.items()}
+    cam = cams[4]
+    st = oracle_forward(cpu, cam, margins=True)
+    st2 = oracle_forward(cpu, cam, fma=True)
+    a, o = _forward(inp, cam, cfg, MODE_EXACT)
+    assert o[0] == st["R"] and st["R"] > 12_000_000
+    np.testing.assert_array_equal(o[3].cpu().numpy(), st["radii"])
+    dbg = rz.debug_state(P, W, H, o[0], o[5], o[6], o[7])
+    for k in ("tiles_touched", "point_list", "ranges", "n_contrib", "final_T"):
+        np.testing.assert_array_equal(dbg[k], st[k], err_msg=k)
+    np.testing.assert_array_equal(o[1].cpu().numpy(), st["color"])
+    np.testing.assert_array_equal(o[2].cpu().numpy(), st["others"])
+    np.testing.assert_array_equal(o[4].cpu().numpy(), st["extra"])
+    del dbg
+    g = torch.Generator(device="cuda").manual_seed(37)
+    pix = torch.randint(0, W * H, (16384,), device="cuda", generator=g)
+    rows = torch.randn(16384, F, device="cuda", generator=g)
+    Gs = torch.zeros(F, H * W, device="cuda")
+    Gs.index_add_(1, pix, rows.t().contiguous())
+    want = oracle.backward(st, np.zeros((3, H, W), np.float32), np.zeros((7, H, W), np.float32),
+                           Gs.reshape(F, H, W).cpu().numpy())["dL_dextra"]
+    del Gs
+    scale = np.abs(want).max()
+    got = rz.rasterize_gaussians_backward_sampled(P, F, W, H, o[0], pix, rows, None, o[5], o[6], o[7], mode=MODE_EXACT).cpu().numpy()
+    dev = np.abs(got - want).max(axis=1) / scale
+    assert dev.max() <= 1e-3, float(dev.max())
+    assert_rows_close(got, want, "C5 exact dL_dextra")
+    del a, o
+    a, o, counters = TR.hip_forward_fast_counted(cpu, cam)
+    df = rz.debug_state(P, W, H, o[0], o[5], o[6], o[7])
+    explained, differ = TR.fast_forward_by_cause(st, st2, o, df, counters)
+    assert differ.sum() <= 2e-5 * W * H, int(differ.sum())
+    got = rz.rasterize_gaussians_backward_sampled(P, F, W, H, o[0], pix, rows, None, o[5], o[6], o[7], mode=MODE_FAST).cpu().numpy()
+    out_rows = TR.rows_by_cause("dL_dextra", got, want, st, explained, differ)
+    assert len(out_rows) <= 1e-5 * P, out_rows
+
+
 def test_c5_two_feature_passes_adjoint_and_trainer():
     """Config C5 (5 M Gaussians, 1296x968, F = 64): the feature channels take two 32-channel passes through every blend
     kernel.  Adjoint identity of the sampled backward, and the trainer's fused tail against the plain formulation."""

@@ -45,5 +45,21 @@ for cfg, step in (("C3", "seg"), ("C2", "rgb"), ("C5", "seg")):
     if rec:
         out[f"{cfg}:{step}:fast"] = rec
         out[f"{cfg}:{step}:fast:instances"] = inst
+# the blend kernel's vector-instruction count per launch (its binding roofline is instruction issue): tools/pmc_fwd.sh's passes
+issue = os.path.join(d, "pmc_issue_k_render_fwd.txt")
+if os.path.exists(issue):
+    cnt = {}
+    for line in open(issue):
+        for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_MFMA", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"):
+            m = re.search(r"\b" + k + r"=([0-9.e+]+)\(n=", line)
+            if m and "k_render_fwd_fast_w" in line:
+                cnt[k] = float(m.group(1))
+    if cnt:
+        out["C3:seg:fast:k_render_fwd:issue"] = dict(cnt, source=f"rocprofv3 --pmc, one counter group per run, tools/pmc_fwd.sh over tools/run_raster.py "
+                                                                  f"--config C3 (profiles/{tag}_pmc_issue_k_render_fwd.txt); wave-instructions per launch")
+# the tree the counters were taken on: bench.py prints "traffic_stale": true when csrc/ has changed since
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_tree_hash
+out["csrc_tree_hash"] = csrc_tree_hash()
 json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "roofline_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:2000])
