@@ -56,7 +56,8 @@ __device__ __forceinline__ float fast_det(const F3 Tu, const F3 Tv, const F3 Tw,
 //   k.x  EXACT fl(fl(px Tw.x) - Tu.x): u (|px Tw.x| + |k.x|);  FAST fma: u |k.x|   (k.y, l.x, l.y alike)
 //   p.x  EXACT fl(fl(k.y l.z) - fl(k.z l.y)), FAST fma(k.y, l.z, -fl(k.z l.y)): u (|k.y l.z| + 2 |k.z l.y| + 2 |p.x|) + inputs
 //   s    EXACT p.xy / p.z, FAST p.xy * rcp(p.z): 3 u |s|;   rho3d, rho2d: fma against mul + add, 3 u rho
-// Returns +inf (always EXACT) when the bound is not small or a depth of the footprint may lie within its error of near_n.
+// Returns +inf (always EXACT) when the bound is not small, the horizon crosses the footprint, or a depth of the footprint may
+// lie below near_n + its error - so that a finite band also certifies p.z != 0 and depth >= near_n for every pair (fast_near, fast_pass).
 __device__ __forceinline__ float splat_band(F3 Tu, F3 Tv, F3 Tw, float cx, float cy, float opa, float4 cb, int W, int H) {
     const float inf = __builtin_inff();
     const float u = 5.9604645e-8f;
@@ -98,7 +99,7 @@ __device__ __forceinline__ float splat_band(F3 Tu, F3 Tv, F3 Tw, float cx, float
     const float ddet = 16.0f * u * ((K.y + K.x + kc) * (L.x + L.y + kc) * (aw.x + aw.y + aw.z));
     const float derr = (ddet + fmaxf(fabsf(dlo), fabsf(dhi)) * 2.0f * Pz) * r + (aw.x + aw.y) * es +
                        8.0f * u * (S * (aw.x + aw.y) + aw.z) + 1e-5f;
-    if (!(dlo - derr > NEAR_N || dhi + derr < NEAR_N)) return inf;
+    if (!(dlo - derr > NEAR_N)) return inf;             // (with a finite band every depth of the footprint passes the near-plane test)
     if (!(band < 0.04f)) return inf;                    // (the hit masks' own margin is 0.05 in rho; also catches NaN)
     return band;
 }
@@ -171,8 +172,11 @@ __device__ __forceinline__ FastRay fast_ray_kl(const FastHalf& k, const FastHalf
 __device__ __forceinline__ FastRay fast_ray(float pxf, float pyf, const F3 Tu, const F3 Tv, const F3 Tw, float cx, float cy) {
     return fast_ray((v2f){pxf, pyf}, (v2f){Tu.x, Tu.y}, (v2f){Tv.x, Tv.y}, (v2f){Tw.x, Tw.y}, (v2f){Tu.z, Tv.z}, Tw.z, (v2f){cx, cy});
 }
-// decision 1 (forward.cu:358 and the certain alpha < 1/255): the pair can contribute at all
-__device__ __forceinline__ bool fast_near(const FastRay& r, float hi) { return r.rho <= hi && r.p_z != 0.0f; }
+// decision 1 (forward.cu:358 and the certain alpha < 1/255): the pair can contribute at all.  The reference's p.z == 0 test needs
+// no instruction here: a splat with a finite band has |p.z| >= zmin > 0 on its whole footprint (splat_band), outside of it
+// rho2d > hi, and p.z = 0 makes rho3d inf or NaN, never the smaller of the two; a splat whose horizon crosses its footprint has
+// band = +inf and every pair of it takes exact_pair, which tests p.z itself.
+__device__ __forceinline__ bool fast_near(const FastRay& r, float hi) { return r.rho <= hi; }
 // ... and lies within the rounding noise of the alpha threshold or of the branch rho3d = rho2d (only asked of `near` pairs)
 __device__ __forceinline__ bool fast_in_band(const FastRay& r, const FastBand& b) {
     return r.rho > b.lo || fabsf(r.rho3d - r.rho2d) <= b.bw;
@@ -189,8 +193,10 @@ __device__ __forceinline__ FastHit fast_hit(const FastRay& r, float det, float T
     h.alpha = fminf(0.99f, opa * h.G);
     return h;
 }
-// decision 2 (forward.cu:372) of a near pair outside the band (there alpha >= 1/255 is certain)
-__device__ __forceinline__ bool fast_pass(const FastHit& h) { return !(h.depth < NEAR_N); }
+// decision 2 (forward.cu:372, depth < near_n) of a near pair outside the band needs no instruction either: a splat with a finite
+// band has every depth of its footprint above near_n by more than its error (splat_band returns +inf otherwise), and alpha >= 1/255
+// is certain there.  (Kept as a function so that the call sites read like the reference's sequence of tests.)
+__device__ __forceinline__ bool fast_pass(const FastHit&) { return true; }
 
 // The pair in EXACT arithmetic - k_render_fwd_w<ExactMath>'s instruction sequence (the reference's operation order,
 // forward.cu:340-393; bit-identical to the oracle) - written into the FAST structures.  pxf, pyf: absolute pixel.

@@ -202,12 +202,12 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                 // same decisions on the same pair, bit for bit
                 FastRay fr = fast_ray(pq, (v2f){q0.x, q0.y}, (v2f){q0.z, q0.w}, (v2f){q1.x, q1.y}, (v2f){q1.z, q1.w}, q2.x, (v2f){q2.z, q2.w});
                 // beyond band.hi alpha < 1/255 is certain: when that holds for the whole wave nothing else is needed
-                const unsigned long long m_near = __ballot(fr.rho <= q2.y) & __ballot(fr.p_z != 0.0f) & ~m_done;
+                const unsigned long long m_near = __ballot(fr.rho <= q2.y) & ~m_done;
                 if (m_near == 0ull) continue;
                 const float4 q3 = q[3], q4 = q[4];
                 FastHit fh = fast_hit(fr, q3.x, q2.x, q3.y);
                 // the same decisions as k_render_fwd_fast_w below (guard bands: isr_fast_pair.hpp)
-                const unsigned long long m_cand = m_near & __ballot(!(fh.depth < NEAR_N));
+                const unsigned long long m_cand = m_near;          // (depth >= near_n is certain outside the bands: fast_pass)
                 const unsigned long long m_band = (m_near & __ballot(fr.rho > q3.z)) | (m_cand & __ballot(fabsf(fr.rho3d - fr.rho2d) <= q3.w));
                 unsigned long long m_pass = m_cand & ~m_band;
                 if (m_band != 0ull) {
@@ -542,7 +542,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             v4f q3v = reinterpret_cast<const v4f*>(q)[3];
             FastRay fr = fast_ray(pq, (v2f){q0.x, q0.y}, (v2f){q0.z, q0.w}, (v2f){q1.x, q1.y}, (v2f){q1.z, q1.w}, q2.x, (v2f){q2.z, q2.w});
             asm volatile("" : "+v"(q3v), "+v"(fr.rho));          // q3 is requested with q0..q2, not after the first branch
-            const unsigned long long m_near = __ballot(fr.rho <= q2.y) & __ballot(fr.p_z != 0.0f) & ~m_done;
+            const unsigned long long m_near = __ballot(fr.rho <= q2.y) & ~m_done;
             if (!STATS && m_near == 0ull) continue;
             const float4 q3 = make_float4(q3v.x, q3v.y, q3v.z, q3v.w);
             v4f q4e = reinterpret_cast<const v4f*>(q)[4], q5e = reinterpret_cast<const v4f*>(q)[5];
@@ -553,7 +553,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             asm volatile("" : "+v"(q4e), "+v"(q5e), "+v"(f_early), "+v"(fh.alpha));      // ... and the blend's operands before ITS branch
             // decisions (isr_fast_pair.hpp): a near pair outside the guard bands certainly has alpha >= 1/255 and FAST's branch
             // and near-plane test are EXACT's; a pair inside them is re-evaluated with EXACT's instruction sequence
-            const unsigned long long m_cand = m_near & __ballot(!(fh.depth < NEAR_N));
+            const unsigned long long m_cand = m_near;          // (depth >= near_n is certain outside the bands: fast_pass)
             const unsigned long long m_band = (m_near & __ballot(fr.rho > q3.z)) | (m_cand & __ballot(fabsf(fr.rho3d - fr.rho2d) <= q3.w));
             unsigned long long m_pass = m_cand & ~m_band;
             if (STATS || m_band != 0ull) {
