@@ -338,7 +338,7 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
                         "frac_of_measured_copy_peak_6290": round(gbs / 6290.0, 5)},
                 "note": "the blend kernel is bound by vector-instruction issue (PMC: vector pipe 72-75 % busy, LDS array 38 %, matrix "
                         "pipe 16 %), not by HBM: one wave per 8x8 block walks its hit list serially (~830 cycles per splat at 4 waves per SIMD: 79 % of a wave's life; staging the next 32 hits 14 %, "
-                        "finding them 4 % - DESIGN 9.11); `valu` is the work model",
+                        "finding them 4 % - docs/history/DESIGN_rounds_1-3.md 9.11); `valu` is the work model",
                 "timing": timing, "kernels": kern,
                 "workload": {"P": P, "V": V, "R": R, "N": N, "F": F, "tiles": tiles}}
         if dom == "k_render_fwd" and pairs_eval:

@@ -9,8 +9,10 @@ that views its storage has died - read from the storage's reference count, so th
 autograd graph holding the forward's state) drops the tensors; no hook, no explicit release.  ``empty_cache()`` frees nothing of it.
 
 * Ownership contract unchanged: the caller gets tensors that nobody else writes while any of them is alive.
-* Stream safety like the caching allocator's: a block is reused only by the stream that leased it; ``used_on(tensor, stream)``
-  (the analogue of ``Tensor.record_stream``) makes the next lease of the block wait for that stream first.
+* Stream safety like the caching allocator's: a block is reused only by the stream that leased it; after
+  ``used_on(tensor, stream)`` (the analogue of ``Tensor.record_stream``) the block is not handed out again until that stream has
+  passed the point where the block was found idle (an event per such stream, polled - no stream ever WAITS for another because of
+  the arena: a lease that would have to wait takes another block).
 * Size classes (x 1.25) bound the number of distinct blocks under a drifting size; at most ``MAX_FREE`` idle blocks per class
   and ``ISR_ARENA_MAX_GB`` (default 64) in total are kept - beyond that idle blocks go back to the caching allocator.
 * ``ISR_ARENA=0`` disables it (plain ``torch.empty``).  Requests below ``MIN_BYTES`` are not pooled.
@@ -45,16 +47,35 @@ def _use_count(t: torch.Tensor) -> int:
 
 
 class _Block:
-    __slots__ = ("base", "idle_count", "foreign", "nbytes")
+    __slots__ = ("base", "idle_count", "foreign", "events", "nbytes")
 
     def __init__(self, nbytes, dev):
         self.base = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.idle_count = _use_count(self.base)          # the base tensor (+ the temporary handle the probe itself makes)
         self.foreign = set()
+        self.events = None
         self.nbytes = nbytes
 
     def idle(self) -> bool:
         return _use_count(self.base) == self.idle_count
+
+    def reusable(self, stream) -> bool:
+        """Idle, and every other stream that used the last lease has passed the point where that was first seen."""
+        if not self.idle():
+            return False
+        if self.foreign:
+            self.events = []
+            for s in self.foreign:
+                if s.cuda_stream != stream.cuda_stream:
+                    ev = torch.cuda.Event()
+                    ev.record(s)
+                    self.events.append(ev)
+            self.foreign.clear()
+        if self.events:
+            self.events = [e for e in self.events if not e.query()]
+            if self.events:
+                return False
+        return True
 
 
 def empty(shape, dtype, device) -> torch.Tensor:
@@ -75,14 +96,14 @@ def empty(shape, dtype, device) -> torch.Tensor:
     blk = None
     idle = 0
     for b in pool:
-        if b.idle():
+        if b.reusable(stream):
             idle += 1
             if blk is None:
                 blk = b
     if idle > MAX_FREE:                                   # a burst is over: hand the surplus back
         keep = []
         for b in pool:
-            if b is not blk and idle > MAX_FREE and b.idle():
+            if b is not blk and idle > MAX_FREE and b.reusable(stream):
                 idle -= 1
                 _drop(b)
             else:
@@ -96,14 +117,6 @@ def empty(shape, dtype, device) -> torch.Tensor:
         _BY_PTR[blk.base.data_ptr()] = blk
         _TOTAL[0] += cls
         STATS["new_blocks"] += 1
-    elif blk.foreign:
-        # other streams read (or wrote) the previous lease: whatever they have enqueued so far comes first
-        for s in blk.foreign:
-            if s.cuda_stream != stream.cuda_stream:
-                ev = torch.cuda.Event()
-                ev.record(s)
-                stream.wait_event(ev)
-        blk.foreign.clear()
     STATS["leases"] += 1
     return blk.base[:nbytes].view(dtype).view(*shape)
 
@@ -131,7 +144,7 @@ def trim(nbytes: int = None) -> int:
     for key in list(_POOLS):
         keep = []
         for b in _POOLS[key]:
-            if (nbytes is None or freed < nbytes) and b.idle():
+            if (nbytes is None or freed < nbytes) and b.reusable(torch.cuda.current_stream(b.base.device)):
                 freed += b.nbytes
                 _drop(b)
             else:

@@ -1822,9 +1822,17 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
     if (R > 0 && geo_splat) {
         if (hipMemsetAsync(flags, 0, (size_t)R * rpi, s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }
         ProfScope ps_("k_render_bwd", s);
-        hipLaunchKernelGGL(k_render_bwd_geo, dim3(T * 4), dim3(64), 0, s, W, H, gx, iv.tile_offset, bv.point_list, bv.box4, g.rec,
-                           col_pre, tm_pre, bg, iv.final_T, iv.n_contrib, dC, dO, g.point_offsets, g.rect, partial, flags, stride,
-                           geom_off, R, geo_heavy_first() ? iv.tile_order : (const uint32_t*)nullptr, bv.hit_mask);
+        // small grids (fewer blocks than ~2 rounds of the chip's wave slots): two waves per 8x8 block - the kernel's time there is
+        // the longest list's, and half the pixels per wave halves it; large grids are throughput-bound: one wave per block
+        static const int geo_two = [] { const char* e = getenv("ISR_GEO_TWO_WAVES_BELOW"); return e ? atoi(e) : 12000; }();
+        if (T * 4 < geo_two)
+            hipLaunchKernelGGL(k_render_bwd_geo<2>, dim3(T * 4), dim3(128), 0, s, W, H, gx, iv.tile_offset, bv.point_list, bv.box4, g.rec,
+                               col_pre, tm_pre, bg, iv.final_T, iv.n_contrib, dC, dO, g.point_offsets, g.rect, partial, flags, stride,
+                               geom_off, R, geo_heavy_first() ? iv.tile_order : (const uint32_t*)nullptr, bv.hit_mask);
+        else
+            hipLaunchKernelGGL(k_render_bwd_geo<1>, dim3(T * 4), dim3(64), 0, s, W, H, gx, iv.tile_offset, bv.point_list, bv.box4, g.rec,
+                               col_pre, tm_pre, bg, iv.final_T, iv.n_contrib, dC, dO, g.point_offsets, g.rect, partial, flags, stride,
+                               geom_off, R, geo_heavy_first() ? iv.tile_order : (const uint32_t*)nullptr, bv.hit_mask);
         ISR_CHECK_LAUNCH_B("k_render_bwd_geo");
     } else if (R > 0) {
         if (hipMemsetAsync(flags, 0, (size_t)R * npass, s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }

@@ -34,7 +34,11 @@ __device__ __forceinline__ float wave_scan_add(float v) {      // inclusive sum 
     return v;
 }
 
-__global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
+// NW = waves per 8x8 block: 1, or 2 on small grids (a 779x519 view is 6 468 blocks for 4 096 wave slots: its time is the
+// longest list's) - the two waves of a workgroup take the upper and the lower four pixel rows of the block, walk the same
+// chunks of 64 splats in lockstep, and wave 1 hands its 21 partial sums per splat to wave 0 through LDS before the row is stored.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
     int W, int H, int gx, const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ point_list,
     const uint32_t* __restrict__ box4, const float* __restrict__ rec, const float* __restrict__ col_pre,
     const float* __restrict__ tm_pre, const float* __restrict__ bg, const float* __restrict__ final_T,
@@ -42,18 +46,24 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
     const uint32_t* __restrict__ point_offsets, const Rect16* __restrict__ rects, float* __restrict__ partial,
     uint8_t* __restrict__ row_flags, int row_stride, int geom_off, int64_t capacity, const uint32_t* __restrict__ tile_order,
     const unsigned long long* __restrict__ hit_mask) {
-    __shared__ __attribute__((aligned(16))) float s_pix[64 * 16];
+    constexpr int NP = 64 / NW;         // pixels per wave
+    __shared__ __attribute__((aligned(16))) float s_pix_all[64 * 16];
     __shared__ int s_q[GEO_QCAP];
+    __shared__ __attribute__((aligned(16))) float s_acc[NW > 1 ? 64 * 24 : 4];
+    __shared__ unsigned s_last[2];
     // A splat whose every pair takes EXACT's instruction sequence (band = +inf: edge-on, horizon inside its footprint; ~0.4 % of
     // the splats, i.e. one in a quarter of all chunks of 64) would make the whole wave run that sequence - for one lane - at every
     // pixel of its box.  It is evaluated here instead, once per chunk, a lane per PIXEL of the block, and handed to its lane
     // through LDS: 12 floats per pixel (dx dy rz sx | sy depth G alpha | pass, use3d).
-    __shared__ __attribute__((aligned(16))) float s_ex[64 * 12];
+    __shared__ __attribute__((aligned(16))) float s_ex_all[64 * 12];
 
     const int tile = tile_order != nullptr ? (int)tile_order[blockIdx.x >> 2] : (int)(blockIdx.x >> 2), blk = blockIdx.x & 3;
     const int tx = tile % gx, ty = tile / gx;
-    const int lane = threadIdx.x;
-    const int bxo = (blk & 1) * 8, byo = (blk >> 1) * 8;            // block origin inside the tile
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int bxo = (blk & 1) * 8, byo = (blk >> 1) * 8 + wv * (8 / NW);            // origin of this wave's pixels inside the tile
+    float* const s_pix = s_pix_all + wv * NP * 16;
+    float* const s_ex = s_ex_all + wv * NP * 12;
+    auto block_sync = [&]() { if constexpr (NW > 1) __syncthreads(); else wave_lds_sync(); };
     const int64_t r0 = tile_offset[tile];
     int64_t r1 = tile_offset[tile + 1];
     if (r1 > capacity) r1 = capacity;
@@ -67,7 +77,7 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
         float v[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = 0.0f;
-        if (px < (unsigned)W && py < (unsigned)H) {
+        if (lane < NP && px < (unsigned)W && py < (unsigned)H) {
             const size_t pix = (size_t)W * py + px;
             if (dC) { v[0] = dC[pix]; v[1] = dC[N + pix]; v[2] = dC[2 * N + pix]; }
             if (dO) {
@@ -83,22 +93,29 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
             v[14] = __uint_as_float(n_contrib[pix + N]);
             v[15] = (bg[0] * v[0] + bg[1] * v[1]) + bg[2] * v[2];
         }
-        float4* dst = reinterpret_cast<float4*>(s_pix + lane * 16);
-        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
-        dst[2] = make_float4(v[8], v[9], v[10], v[11]);
-        dst[3] = make_float4(v[12], v[13], v[14], v[15]);
+        if (lane < NP) {
+            float4* dst = reinterpret_cast<float4*>(s_pix + lane * 16);
+            dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+            dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+            dst[2] = make_float4(v[8], v[9], v[10], v[11]);
+            dst[3] = make_float4(v[12], v[13], v[14], v[15]);
+        }
     }
     unsigned block_last = mylast;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) block_last = max(block_last, (unsigned)__shfl_xor((int)block_last, o));
+    if constexpr (NW > 1) {             // the two waves walk the same list prefix: the deeper of their last contributors
+        if (lane == 0) s_last[wv] = block_last;
+        __syncthreads();
+        block_last = max(s_last[0], s_last[1]);
+    }
     if (block_last == 0u) return;
-    wave_lds_sync();
+    block_sync();
     const int len_eff = min(len, (int)block_last);
     const float mscale = FAR_N / (FAR_N - NEAR_N);
     const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
     float carryT = 0.0f, carryR = 0.0f;      // lane p: transmittance behind / sum of w S behind the splats walked so far, pixel p
-    carryT = s_pix[lane * 16 + 10];
+    carryT = lane < NP ? s_pix[lane * 16 + 10] : 0.0f;
 
     int n_q = 0;                    // queued entries (uniform); s_q holds tile-list positions in DESCENDING order
     int seg_hi = len_eff;           // entries [0, seg_hi) are still to be culled
@@ -121,7 +138,7 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
             }
             seg_hi = seg_lo;
         }
-        wave_lds_sync();
+        block_sync();
         const bool drained = seg_hi == 0;
         int done = 0;
         while (n_q - done >= 64 || (drained && done < n_q)) {
@@ -167,13 +184,15 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
                 auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), f_lane)); };
                 const F3 fTu = {bc(Tu.x), bc(Tu.y), bc(Tu.z)}, fTv = {bc(Tv.x), bc(Tv.y), bc(Tv.z)}, fTw = {bc(Tw.x), bc(Tw.y), bc(Tw.z)};
                 FastRay er; FastHit eh;
-                const bool ep = exact_pair(tile_x0 + (float)(bxo + (lane & 7)), tile_y0 + (float)(byo + (lane >> 3)), fTu, fTv, fTw, bc(cx), bc(cy),
+                const bool ep = exact_pair(tile_x0 + (float)(bxo + (lane & 7)), tile_y0 + (float)(byo + ((lane & (NP - 1)) >> 3)), fTu, fTv, fTw, bc(cx), bc(cy),
                                            bc(opa), er, eh);
-                wave_lds_sync();                                   // (the previous chunk's readers are done)
-                float4* o = reinterpret_cast<float4*>(s_ex + lane * 12);
-                o[0] = make_float4(er.dx, er.dy, er.rz, er.sx);
-                o[1] = make_float4(er.sy, eh.depth, eh.G, eh.alpha);
-                o[2] = make_float4(ep ? 1.0f : 0.0f, eh.use3d ? 1.0f : 0.0f, 0.0f, 0.0f);
+                wave_lds_sync();                                   // (the previous chunk's readers - this wave - are done)
+                if (lane < NP) {
+                    float4* o = reinterpret_cast<float4*>(s_ex + lane * 12);
+                    o[0] = make_float4(er.dx, er.dy, er.rz, er.sx);
+                    o[1] = make_float4(er.sy, eh.depth, eh.G, eh.alpha);
+                    o[2] = make_float4(ep ? 1.0f : 0.0f, eh.use3d ? 1.0f : 0.0f, 0.0f, 0.0f);
+                }
                 wave_lds_sync();
             }
             const bool pre_mine = pre && lane == f_lane;
@@ -184,7 +203,7 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
             bool touched = false;
             FastHalf lrow = {{0.0f, 0.0f}, 0.0f};
             float pyf_row = 0.0f;
-            for (int p = 0; p < 64; p++) {
+            for (int p = 0; p < NP; p++) {
                 if ((p & 7) == 0) {             // a new pixel row: l = py Tw - Tv once per row and splat
                     pyf_row = tile_y0 + (float)(byo + (p >> 3));
                     lrow = fast_l(pyf_row, Tv, Tw);
@@ -275,6 +294,23 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
                     }
                 }
             }
+            if constexpr (NW > 1) {             // wave 1's partial sums -> wave 0 (fixed order: upper rows + lower rows)
+                float4* a4 = reinterpret_cast<float4*>(s_acc + lane * 24);
+                if (wv == 1) {
+                    a4[0] = make_float4(aP0, aP1, aP2, aX0); a4[1] = make_float4(aX1, aX2, aY0, aY1);
+                    a4[2] = make_float4(aY2, aZ0, aZ1, aZ2); a4[3] = make_float4(aC0, aC1, aN0, aN1);
+                    a4[4] = make_float4(aN2, aO, aR, aG); a4[5] = make_float4(aB, touched ? 1.0f : 0.0f, 0.0f, 0.0f);
+                }
+                __syncthreads();
+                if (wv == 0) {
+                    const float4 q0 = a4[0], q1 = a4[1], q2 = a4[2], q3 = a4[3], q4 = a4[4], q5 = a4[5];
+                    aP0 += q0.x; aP1 += q0.y; aP2 += q0.z; aX0 += q0.w; aX1 += q1.x; aX2 += q1.y; aY0 += q1.z; aY1 += q1.w;
+                    aY2 += q2.x; aZ0 += q2.y; aZ1 += q2.z; aZ2 += q2.w; aC0 += q3.x; aC1 += q3.y; aN0 += q3.z; aN1 += q3.w;
+                    aN2 += q4.x; aO += q4.y; aR += q4.z; aG += q4.w; aB += q5.x;
+                    touched = touched || q5.y != 0.0f;
+                } else touched = false;
+                __syncthreads();
+            }
             if (touched) {
                 // adjoint of  A = Tv x Tw,  B = Tw x Tu,  C = (X0 Tw - Tu) x (Y0 Tw - Tv),  with the pixel sums taken to absolute
                 // coordinates:  SP = sum dL/dp,  SX = sum px dL/dp,  SY = sum py dL/dp:
@@ -297,11 +333,19 @@ __global__ __launch_bounds__(64, 4) void k_render_bwd_geo(
         // what is left (less than a chunk, unless the list is drained) moves to the front of the queue
         const int rem = n_q - done;                    // < 64
         const int keep = lane < rem ? s_q[done + lane] : 0;
-        wave_lds_sync();
+        block_sync();
         if (lane < rem) s_q[lane] = keep;
         n_q = rem > 0 ? rem : 0;
-        wave_lds_sync();
+        block_sync();
     }
 }
+template __global__ void k_render_bwd_geo<1>(int, int, int, const uint32_t*, const uint32_t*, const uint32_t*, const float*, const float*,
+                                              const float*, const float*, const float*, const uint32_t*, const float*, const float*,
+                                              const uint32_t*, const Rect16*, float*, uint8_t*, int, int, int64_t, const uint32_t*,
+                                              const unsigned long long*);
+template __global__ void k_render_bwd_geo<2>(int, int, int, const uint32_t*, const uint32_t*, const uint32_t*, const float*, const float*,
+                                              const float*, const float*, const float*, const uint32_t*, const float*, const float*,
+                                              const uint32_t*, const Rect16*, float*, uint8_t*, int, int, int64_t, const uint32_t*,
+                                              const unsigned long long*);
 
 }  // namespace isr

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
                 unsigned long long m_pass = m_cand & ~m_band;
                 if (m_band != 0ull) {
                     FastRay er; FastHit eh;
-                    const bool ep = exact_pair_rec(pxf, pyf, rec, __builtin_amdgcn_readfirstlane(s_id[j]), er, eh);
+                    // (the staged record holds the splat's raw rows: no second trip to memory)
+                    const bool ep = exact_pair(pxf, pyf, {q0.x, q0.y, q1.z}, {q0.z, q0.w, q1.w}, {q1.x, q1.y, q2.x}, q2.z, q2.w, q3.y, er, eh);
                     fast_take((m_band >> lane) & 1ull, er, eh, fr, fh);
                     m_pass |= m_band & __ballot(ep);
                 }
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
 // The same blend with the four 8x8 blocks of a tile DECOUPLED: one wave = one workgroup = one 8x8 pixel block that culls,
 // stages and walks its own hit list.  In the tile-wide kernel above a wave waits in workgroup barriers (its block's hit count
 // differs from its neighbours' in every 128-instance round) and in the staging phase between them for about as long as it walks
-// hits (cycle counters); here there is no barrier at all:
+// hits (cycle counters, docs/history/DESIGN_rounds_1-3.md 9.11); here there is no barrier at all:
 //   scan:   64 entries of the tile's list per step: k_pack_hits' 64-bit word for (chunk, block) says which of them meet the
 //           block (one scalar load; ids by one coalesced load); hits are appended (id, position in the tile's list) to a ring
 //           in LDS until 32 are pending or the list ends;
@@ -378,7 +379,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
 #define ISR_WCAP 512
 #endif
     // tracer pairs buffered per wave, ONE atomic on the list's counter per flush (that counter bounded the kernel while a wave
-    // flushed every 64 pairs: DESIGN 9.11).  A pair is packed into 32 bits - pixel of the block << 26 | gaussian (the launcher
+    // flushed every 64 pairs: docs/history/DESIGN_rounds_1-3.md 9.11).  A pair is packed into 32 bits - pixel of the block << 26 | gaussian (the launcher
     // sends scenes of more than 2^26 Gaussians to the tile-wide kernel) - so 2 KB hold 512: a block has ~214, its wave flushes
     // once, at its end, and that flush's atomic is issued BEFORE the output maps are stored and consumed after them.
     constexpr int WCAP = ISR_WCAP;
@@ -557,9 +558,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             const unsigned long long m_band = (m_near & __ballot(fr.rho > q3.z)) | (m_cand & __ballot(fabsf(fr.rho3d - fr.rho2d) <= q3.w));
             unsigned long long m_pass = m_cand & ~m_band;
             if (STATS || m_band != 0ull) {
-                const int gid = __builtin_amdgcn_readfirstlane(s_ring[(head + j) & (FW_RING - 1)].x);
-                FastRay er; FastHit eh;
-                const bool ep = exact_pair_rec(pxf, pyf, rec, gid, er, eh);
+                FastRay er; FastHit eh;          // (the staged record holds the splat's raw rows: no second trip to memory)
+                const bool ep = exact_pair(pxf, pyf, {q0.x, q0.y, q1.z}, {q0.z, q0.w, q1.w}, {q1.x, q1.y, q2.x}, q2.z, q2.w, q3.y, er, eh);
                 if (STATS) {
                     if (m_band != 0ull) st_slow++;
                     // outside the band FAST's decisions must be EXACT's (near pairs: pass and branch; far pairs: skipped)

@@ -262,3 +262,33 @@ def test_trainer_defaults_are_the_reference_defaults(golden_dir):
                 opacity_cull=z["opacity_cull"], percent_dense=z["percent_dense"])
     for k, v in dens.items():
         assert f"{k}={v:_}" in src.replace("15_000", "15_000") or f"{k}={v}" in src, (k, v)
+
+
+def test_arena_lease_ends_with_the_last_view_of_the_block():
+    """instascene_amd/arena.py: a block is free again exactly when every tensor viewing its storage has died - views of views
+    and tensors saved by an autograd graph included - read from the storage's reference count (no hook, no explicit release)."""
+    import torch
+    from instascene_amd import arena
+    b = arena._Block.__new__(arena._Block)
+    b.base = torch.empty(4096, dtype=torch.uint8)
+    b.idle_count, b.foreign, b.events, b.nbytes = arena._use_count(b.base), set(), None, 4096
+    assert b.idle()
+    v = b.base[:100].view(torch.float32).view(5, 5)
+    assert not b.idle()
+    w = v.t()
+    del v
+    assert not b.idle()                 # a view of the view keeps the lease
+    del w
+    assert b.idle()
+    x = torch.ones(5, 5, requires_grad=True)
+    v = b.base[:100].view(torch.float32).view(5, 5)
+    y = (x * v).sum()                   # the graph saves v for the backward
+    del v
+    assert not b.idle()
+    y.backward()
+    del y
+    assert b.idle()
+    # size classes grow by x1.25 and requests below MIN_BYTES / on the CPU are plain torch.empty
+    assert arena._class_of(arena.MIN_BYTES + 1) <= int(arena.MIN_BYTES * 1.26)
+    t = arena.empty((3, 4), torch.float32, "cpu")
+    assert t.shape == (3, 4) and arena.reserved_bytes() == 0

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Long-run check of a trainer: step time, loss and workload every BLOCK iterations - what found item 34 of DESIGN section 3
+"""Long-run check of a trainer: step time, loss and workload every BLOCK iterations - what found item 34 of docs/history/DESIGN_rounds_1-3.md section 3
 (a train.py-style run slowing 2.4x over 3 000 iterations because sixteen surfels had grown over the whole view).
 usage: soak_train.py [--config C2|C3] [--step rgb|seg|plain] [--blocks 6] [--block 500] [--scale 1.0] [--empty-cache 1]
 (--step plain: harness.PlainSegTrainer = the reference's unmodified train_semantic.py iteration on the drop-in functions; --empty-cache 1:
