@@ -34,9 +34,9 @@ __device__ __forceinline__ float wave_scan_add(float v) {      // inclusive sum 
     return v;
 }
 
-// NW = waves per 8x8 block: 1, or 2 on small grids (a 779x519 view is 6 468 blocks for 4 096 wave slots: its time is the
-// longest list's) - the two waves of a workgroup take the upper and the lower four pixel rows of the block, walk the same
-// chunks of 64 splats in lockstep, and wave 1 hands its 21 partial sums per splat to wave 0 through LDS before the row is stored.
+// NW = waves per 8x8 block: 1, or 2 on small grids (4 measured: no further gain at 779x519, 0.304 against 0.298 ms) (a 779x519 view is 6 468 blocks for 4 096 wave slots: its time is the
+// longest list's) - the waves of a workgroup take 8 / NW pixel rows of the block each, walk the same chunks of 64 splats in
+// lockstep, and hand their 21 partial sums per splat to wave 0 through LDS before the row is stored.
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
     int W, int H, int gx, const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ point_list,
@@ -49,8 +49,8 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
     constexpr int NP = 64 / NW;         // pixels per wave
     __shared__ __attribute__((aligned(16))) float s_pix_all[64 * 16];
     __shared__ int s_q[GEO_QCAP];
-    __shared__ __attribute__((aligned(16))) float s_acc[NW > 1 ? 64 * 24 : 4];
-    __shared__ unsigned s_last[2];
+    __shared__ __attribute__((aligned(16))) float s_acc[NW > 1 ? (NW - 1) * 64 * 24 : 4];
+    __shared__ unsigned s_last[4];
     // A splat whose every pair takes EXACT's instruction sequence (band = +inf: edge-on, horizon inside its footprint; ~0.4 % of
     // the splats, i.e. one in a quarter of all chunks of 64) would make the whole wave run that sequence - for one lane - at every
     // pixel of its box.  It is evaluated here instead, once per chunk, a lane per PIXEL of the block, and handed to its lane
@@ -107,7 +107,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
     if constexpr (NW > 1) {             // the two waves walk the same list prefix: the deeper of their last contributors
         if (lane == 0) s_last[wv] = block_last;
         __syncthreads();
-        block_last = max(s_last[0], s_last[1]);
+        block_last = s_last[0];
+#pragma unroll
+        for (int w = 1; w < NW; w++) block_last = max(block_last, s_last[w]);
     }
     if (block_last == 0u) return;
     block_sync();
@@ -294,20 +296,24 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
                     }
                 }
             }
-            if constexpr (NW > 1) {             // wave 1's partial sums -> wave 0 (fixed order: upper rows + lower rows)
-                float4* a4 = reinterpret_cast<float4*>(s_acc + lane * 24);
-                if (wv == 1) {
+            if constexpr (NW > 1) {             // the other waves' partial sums -> wave 0 (fixed order: pixel rows top to bottom)
+                if (wv > 0) {
+                    float4* a4 = reinterpret_cast<float4*>(s_acc + ((wv - 1) * 64 + lane) * 24);
                     a4[0] = make_float4(aP0, aP1, aP2, aX0); a4[1] = make_float4(aX1, aX2, aY0, aY1);
                     a4[2] = make_float4(aY2, aZ0, aZ1, aZ2); a4[3] = make_float4(aC0, aC1, aN0, aN1);
                     a4[4] = make_float4(aN2, aO, aR, aG); a4[5] = make_float4(aB, touched ? 1.0f : 0.0f, 0.0f, 0.0f);
                 }
                 __syncthreads();
                 if (wv == 0) {
-                    const float4 q0 = a4[0], q1 = a4[1], q2 = a4[2], q3 = a4[3], q4 = a4[4], q5 = a4[5];
-                    aP0 += q0.x; aP1 += q0.y; aP2 += q0.z; aX0 += q0.w; aX1 += q1.x; aX2 += q1.y; aY0 += q1.z; aY1 += q1.w;
-                    aY2 += q2.x; aZ0 += q2.y; aZ1 += q2.z; aZ2 += q2.w; aC0 += q3.x; aC1 += q3.y; aN0 += q3.z; aN1 += q3.w;
-                    aN2 += q4.x; aO += q4.y; aR += q4.z; aG += q4.w; aB += q5.x;
-                    touched = touched || q5.y != 0.0f;
+#pragma unroll
+                    for (int w = 1; w < NW; w++) {
+                        const float4* a4 = reinterpret_cast<const float4*>(s_acc + ((w - 1) * 64 + lane) * 24);
+                        const float4 q0 = a4[0], q1 = a4[1], q2 = a4[2], q3 = a4[3], q4 = a4[4], q5 = a4[5];
+                        aP0 += q0.x; aP1 += q0.y; aP2 += q0.z; aX0 += q0.w; aX1 += q1.x; aX2 += q1.y; aY0 += q1.z; aY1 += q1.w;
+                        aY2 += q2.x; aZ0 += q2.y; aZ1 += q2.z; aZ2 += q2.w; aC0 += q3.x; aC1 += q3.y; aN0 += q3.z; aN1 += q3.w;
+                        aN2 += q4.x; aO += q4.y; aR += q4.z; aG += q4.w; aB += q5.x;
+                        touched = touched || q5.y != 0.0f;
+                    }
                 } else touched = false;
                 __syncthreads();
             }
