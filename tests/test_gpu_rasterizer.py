@@ -383,6 +383,14 @@ def test_fast_mode_keeps_the_reference_binning_bit_for_bit(P, F, W, H, seed):
         # images within 1e-4 and the last / median contributors equal, except where the oracle itself sits on a T decision
         explained, differ = fast_forward_by_cause(st, st2, out, dbg, counters)
         assert differ.sum() <= 2
+        # the instrumented build of the blend kernel (the one that checks every pair against EXACT) and the production build
+        # produce the same bits
+        args_p, out_p = hip_forward(inp, cam, bg=(0.1, 0.2, 0.3), mode=MODE_FAST)
+        for k in (1, 2, 4):
+            assert torch.equal(out_p[k], out[k]), k
+        dbg_p = rz.debug_state(st["P"], st["W"], st["H"], out_p[0], out_p[5], out_p[6], out_p[7])
+        np.testing.assert_array_equal(dbg_p["n_contrib"], dbg["n_contrib"])
+        np.testing.assert_array_equal(dbg_p["final_T"], dbg["final_T"])
 
 
 @pytest.mark.parametrize("P,F,W,H,seed", [(1500, 16, 100, 70, 41), (3000, 32, 160, 112, 42)])
