@@ -165,7 +165,9 @@ int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int hei
  * (all [P, ED] pointers are the tables' base addresses; a data-parallel caller walks the table in a few row ranges so that
  * the all-reduce of one range overlaps the kernels of the others):
  *   dL/dz  = sum of its flagged partial rows (+ gz_dense[P, ED] if not NULL)
- *   dL/dy  = gy[P, ED] (or NULL) + the sparse part (gy_slot[P], gy_merged) made by iso_rows_compact (or NULL, NULL)
+ *   dL/dy  = gy[P, ED] (or NULL) + the sparse part (gy_slot[P], gy_merged) made by iso_rows_compact (or NULL, NULL);
+ *            every slot entry the pass reads is reset to -1: once all rows have been walked the table is clean again and the
+ *            next iso_rows_compact may be told so (slot_is_clean) instead of filling 4 P bytes
  *   dL/dx  = chain of dL/dz and dL/dy through  y = x/(|x|+eps1), z = y/(|y|+eps2)
  *            (scene/gaussian_model.py:122-125 and gaussian_renderer/__init__.py:61-62)
  *   grad_out != NULL:  grad_out = dL/dx, nothing else is written (a data-parallel caller all-reduces it);
@@ -174,7 +176,7 @@ int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int hei
  *                      (y may be NULL: not stored; iso_gather_rownorm recomputes the rows a caller needs). */
 int isr_feature_rows_step(int P, int row_begin, int row_count, int64_t num_rendered, int ED, const void* geom_buffer,
                           const void* rows_scratch,
-                          const float* gz_dense, const float* gy, const int* gy_slot, const float* gy_merged, float eps1,
+                          const float* gz_dense, const float* gy, int* gy_slot, const float* gy_merged, float eps1,
                           float eps2, float* x, float* grad_out, double lr, double beta1, double beta2, double eps,
                           long long step, float* exp_avg, float* exp_avg_sq, float* y, float* z, void* stream);
 

@@ -276,17 +276,53 @@ class _GatherRows(torch.autograd.Function):
 _ROW_SOURCE_ATTR = "_isr_row_source"
 
 
+class _SlotTable:
+    """A persistent ``slot[P]`` table (int32) per (device, P, stream).  ``isr_feature_rows_step`` resets every entry it reads,
+    so after a pass over all P rows the table is all -1 again and the next ``iso_rows_compact`` needs no 4 P-byte fill (6 MB, ~20 us
+    on the step's main chain at C3).  ``dirty``: filled and not yet walked completely - the next fill then clears it the slow way."""
+    __slots__ = ("slot", "dirty", "covered")
+
+    def __init__(self, P, device):
+        self.slot = torch.full((P,), -1, dtype=torch.int32, device=device)
+        self.dirty, self.covered = False, 0
+
+
+_SLOT_TABLES = {}
+
+
+def _slot_table(P: int, device) -> _SlotTable:
+    key = (device.index, int(P), torch.cuda.current_stream(device).cuda_stream)
+    t = _SLOT_TABLES.get(key)
+    if t is None:
+        if len(_SLOT_TABLES) > 8:
+            _SLOT_TABLES.clear()
+        t = _SLOT_TABLES[key] = _SlotTable(P, device)
+    return t
+
+
 def compact_row_grads(idx: torch.Tensor, vals: torch.Tensor, P: int):
     """``(slot[P] int32, merged[n,F])``: the sparse gradient ``(idx, vals)`` of a row gather with repeated rows summed in
-    index order (``iso_rows_compact``); ``slot[row]`` = position of the row's sum in ``merged`` or -1."""
+    index order (``iso_rows_compact``); ``slot[row]`` = position of the row's sum in ``merged`` or -1.  ``slot`` is the
+    persistent table of this (device, P, stream) - valid until the next call; ``isr_feature_rows_step`` consumes it."""
     idx = idx.contiguous().to(torch.int64)
     vals = vals.contiguous().float()
-    slot = torch.empty(P, dtype=torch.int32, device=vals.device)
+    table = _slot_table(P, vals.device)
     merged = torch.empty_like(vals)
     with torch.cuda.device(vals.device):
-        check(lib().iso_rows_compact(idx.shape[0], vals.shape[1], P, _p(idx), _p(vals), _p(slot), _p(merged), _stream()),
-              "iso_rows_compact")
-    return slot, merged
+        check(lib().iso_rows_compact(idx.shape[0], vals.shape[1], P, _p(idx), _p(vals), _p(table.slot), _p(merged),
+                                     0 if table.dirty else 1, _stream()), "iso_rows_compact")
+    table.dirty, table.covered = idx.shape[0] > 0, 0
+    return table.slot, merged
+
+
+def _slot_consumed(slot: torch.Tensor, P: int, n_rows: int):
+    """``isr_feature_rows_step`` walked ``n_rows`` more rows with this slot table (it reset what it read)."""
+    for t in _SLOT_TABLES.values():
+        if t.slot is slot:
+            t.covered += int(n_rows)
+            if t.covered >= P:
+                t.dirty = False
+            return
 
 
 def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
@@ -390,6 +426,8 @@ class FeatureAdam:
                                               _p(grad_out), self.lr, float(self.betas[0]), float(self.betas[1]), self.eps,
                                               max(1, self.step_count), _p(self.exp_avg), _p(self.exp_avg_sq), _p(y), _p(z),
                                               _stream()), "isr_feature_rows_step")
+        if slot is not None:
+            _slot_consumed(slot, P, n)
 
     def tail_gradient(self, tail, r0: int, r1: int):
         """``param.grad[r0:r1]`` = dL/dparam of those rows (allocated on first use)."""

@@ -74,7 +74,7 @@ int isr_backward_sampled(int P, int64_t num_rendered, int ED, int width, int hei
 
 int isr_feature_rows_step(int P, int row_begin, int row_count, int64_t num_rendered, int ED, const void* geom_buffer,
                           const void* rows_scratch,
-                          const float* gz_dense, const float* gy, const int* gy_slot, const float* gy_merged, float eps1,
+                          const float* gz_dense, const float* gy, int* gy_slot, const float* gy_merged, float eps1,
                           float eps2, float* x, float* grad_out, double lr, double beta1, double beta2, double eps,
                           long long step, float* exp_avg, float* exp_avg_sq, float* y, float* z, void* stream) {
     if (P < 0 || ED <= 0 || (ED & 3) != 0 || ED > 256) return fail(ISR_EINVAL, "feature_rows_step needs ED % 4 == 0 and ED <= 256");

@@ -412,12 +412,12 @@ int iso_sample_step(unsigned long long seed, unsigned long long step, int B, lon
 }
 
 int iso_rows_compact(int n, int F, long long P, const long long* idx, const float* vals, int* slot, float* merged,
-                     void* stream) {
+                     int slot_is_clean, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (n < 0 || F <= 0 || P < 0) return fail(ISR_EINVAL, "rows_compact: bad sizes");
     if (P > 0 && !slot) return fail(ISR_EINVAL, "rows_compact: null slot table");
     if (n > 0 && (!idx || !vals || !merged)) return fail(ISR_EINVAL, "rows_compact: null pointer");
-    if (P > 0 && hipMemsetAsync(slot, 0xFF, sizeof(int) * (size_t)P, s) != hipSuccess) return fail(ISR_EHIP, "rows_compact: memset failed");
+    if (P > 0 && !slot_is_clean && hipMemsetAsync(slot, 0xFF, sizeof(int) * (size_t)P, s) != hipSuccess) return fail(ISR_EHIP, "rows_compact: memset failed");
     if (n == 0 || P == 0) return ISR_OK;
     if (n > iso::ROWS_COMPACT_MAX) return fail(ISR_EINVAL, "rows_compact: at most %d rows", iso::ROWS_COMPACT_MAX);
     static const bool lds_form = [] { const char* e = getenv("ISR_ROWS_COMPACT"); return e && e[0] == 'l'; }();    // "lds": the one-launch form

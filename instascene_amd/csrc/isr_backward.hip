@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(256) void k_feature_rows_step(
     int row0, int P, int F, const uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ tiles_touched,
     const unsigned long long* __restrict__ row_mask, const float* __restrict__ partial,
     const uint8_t* __restrict__ row_flags, int64_t R, int row_stride,
-    const float* __restrict__ gz_dense, const float* __restrict__ gy, const int* __restrict__ gy_slot,
+    const float* __restrict__ gz_dense, const float* __restrict__ gy, int* __restrict__ gy_slot,
     const float* __restrict__ gy_merged, float eps1, float eps2, float* __restrict__ x,
     float* __restrict__ grad_out, float lr_over_bc1, float om1, float beta2, float om2, float inv_sqrt_bc2, float eps,
     float* __restrict__ m, float* __restrict__ v, float* __restrict__ y, float* __restrict__ z) {
@@ -1325,6 +1325,7 @@ __global__ __launch_bounds__(256) void k_feature_rows_step(
     if (ok) xv = *reinterpret_cast<const float4*>(x + off);
     if (ok && gy != nullptr) a = *reinterpret_cast<const float4*>(gy + off);
     const int gslot = (ok && gy_slot != nullptr) ? gy_slot[row] : -1;       // dL/dy as (row -> merged entry), iso_rows_compact
+    if (gslot >= 0 && sub == 0) gy_slot[row] = -1;      // consumed: the table is clean again after the pass (no 4 P-byte fill per step)
     float4 m4 = z4, v4 = z4;
     if (ADAM && ok) { m4 = nt_load4(m + off); v4 = nt_load4(v + off); }      // (moments: read once per step)
     // (1) dL/dz row: flagged per-tile partial rows in row order (+ a dense contribution, if any)
@@ -1959,7 +1960,7 @@ static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int
 }
 
 int launch_feature_rows_step(int P, int row_begin, int row_count, int64_t R, int F, const void* geom, const void* rows_scratch, const float* gz_dense,
-                             const float* gy, const int* gy_slot, const float* gy_merged, float eps1, float eps2, float* x, float* grad_out, float lr_over_bc1,
+                             const float* gy, int* gy_slot, const float* gy_merged, float eps1, float eps2, float* x, float* grad_out, float lr_over_bc1,
                              float om1, float beta2, float om2, float inv_sqrt_bc2, float eps, float* m, float* v, float* y,
                              float* z, hipStream_t s) {
     if (P <= 0 || row_count <= 0) return 0;
