@@ -210,7 +210,7 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
         trainer.pipe.lazy_maps = bool(args.lazy_maps)
         trainer.pipe.feature_only_forward = feature_only
         trainer.warm_view_caches()       # per-view constants (ray tables, visible pools, instance counts): setup
-        trainer.prime()                  # code objects, allocator pools, side stream: two steps whose effect is undone
+        trainer.prime(steps=n_views)     # code objects, allocator / arena pools, side stream, clocks: one pass over the views whose effect is undone
         view_index = trainer.view_index
     else:
         scene.seg_feature = None
@@ -237,7 +237,9 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
         for it in range(args.warmup):
             trainer.step(it)
     sync()
-    dbg0 = (rasterizer.PREFETCH_HITS, torch.cuda.memory_stats().get("num_device_alloc", 0), len(rasterizer._R_ESTIMATE))
+    from instascene_amd import arena as _arena
+    dbg0 = (rasterizer.PREFETCH_HITS, torch.cuda.memory_stats().get("num_device_alloc", 0), len(rasterizer._R_ESTIMATE),
+            _arena.STATS["new_blocks"])
     dt, it_next = None, args.warmup
     for rep in range(repeats):       # the headline: exactly one block of K steps; sub-records: the better of two blocks
         L.isr_profile_enable(2)      # HIP events around the forward blend kernel only inside the timed region
@@ -255,7 +257,8 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
     if os.environ.get("ISR_BENCH_DEBUG"):
         print(f"[bench debug] mode={mode} prefetch hits {rasterizer.PREFETCH_HITS - dbg0[0]} / {args.steps} steps, device allocs "
               f"{torch.cuda.memory_stats().get('num_device_alloc', 0) - dbg0[1]}, estimates {dbg0[2]} -> {len(rasterizer._R_ESTIMATE)}, "
-              f"pending {len(rasterizer._PENDING)}, reserved {torch.cuda.memory_reserved() / 2**30:.2f} GB", file=sys.stderr)
+              f"pending {len(rasterizer._PENDING)}, reserved {torch.cuda.memory_reserved() / 2**30:.2f} GB, arena new blocks "
+              f"{_arena.STATS['new_blocks'] - dbg0[3]} ({_arena.reserved_bytes() / 2**30:.2f} GB)", file=sys.stderr)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -628,7 +631,9 @@ def main():
                               ["activations of the frozen parameters (exp / sigmoid / normalize, SH concat): evaluated once",
                                "per-view pools of labelled pixels and of visible labelled Gaussians, the cameras' ray tables, each "
                                "view's verified tile-instance count (SegTrainer.warm_view_caches: one untrained render per view)",
-                               "two priming steps whose effect on parameters / optimiser / RNG is undone (SegTrainer.prime)",
+                               "one priming pass over the 16 views whose effect on parameters / optimiser / RNG is undone (SegTrainer.prime: code objects, "
+                               "allocator and arena pools at their steady-state size, GPU clocks up - a fresh process otherwise spends its first ~20 "
+                               "steps 3-5 % slow)",
                                "render()'s `visibility_filter` (radii > 0, one elementwise kernel) and the tracer list's slice are "
                                "evaluated on first access of the dict entry; a warmed-up step reads neither",
                                "the next step's index draw (a function of seed, iteration and view) is issued behind this step's forward"]
