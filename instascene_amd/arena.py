@@ -24,7 +24,9 @@ import os
 
 import torch
 
-ENABLED = os.environ.get("ISR_ARENA", "1") != "0"
+# (the lease bookkeeping reads the storage's reference count through torch._C._storage_Use_Count - the call torch's own CUDA-graph
+# trees use for the same purpose; a torch without it gets plain torch.empty)
+ENABLED = os.environ.get("ISR_ARENA", "1") != "0" and hasattr(torch._C, "_storage_Use_Count")
 MIN_BYTES = 1 << 20
 MAX_FREE = 3
 MAX_BYTES = int(float(os.environ.get("ISR_ARENA_MAX_GB", "64")) * (1 << 30))
