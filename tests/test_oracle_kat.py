@@ -125,3 +125,34 @@ def test_dist2_3nn_regular_grid_interior_is_one():
     d = oracle.dist2_3nn(g.astype(np.float32)).reshape(5, 5, 5)
     assert d[2, 2, 2] == 1.0 and d[1, 3, 2] == 1.0
     assert d[0, 0, 0] == 1.0                       # corner: 3 axis neighbours at distance 1
+
+
+def test_the_two_oracle_builds_differ_only_where_a_decision_has_no_margin():
+    """oracle/surfel_oracle.cpp is built twice: the primary build (-ffp-contract=off, fixed exp: what the library's EXACT mode
+    reproduces bit for bit) and a second one with FMA contraction and libm expf - what a compiler with the reference's defaults
+    (nvcc --fmad=true, libdevice expf) may legitimately produce.  They bracket the reference's own build: on a seeded scene every
+    map agrees to 1e-4 of its maximum (the parity clause) on every pixel whose decisions have a margin (the per-pixel margins the primary build
+    reports: alpha against 1/255, depth against near_n, rho3d against rho2d, T against 1e-4 and 0.5), and the last / median
+    contributors differ only on pixels without one."""
+    import math
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import small_scene, oracle_forward
+    sc, cams, inp = small_scene(P=6000, F=8, W=160, H=112, seed=17, mu_s=math.log(0.05))
+    cam = cams[2]
+    a = oracle_forward(inp, cam, margins=True)
+    b = oracle_forward(inp, cam, fma=True)
+    m = a["margins"]                                      # [5, N]
+    assert m.shape == (5, 160 * 112) and np.isfinite(m[:, a["n_contrib"][0] > 0]).any()
+    tight = (m[0] < 1e-3) | (m[2] < 1e-4) | (m[3] < 1e-3) | (m[4] < 1e-3)
+    differ = (a["n_contrib"] != b["n_contrib"]).any(axis=0)
+    assert not (differ & ~tight).any(), int((differ & ~tight).sum())
+    assert tight.mean() < 0.2                             # (the margins are informative: most pixels have one)
+    for k in ("color", "others", "extra"):
+        x, y = a[k].reshape(a[k].shape[0], -1), b[k].reshape(a[k].shape[0], -1)
+        scale = np.abs(x).max(axis=1, keepdims=True) + 1e-30
+        bad = (np.abs(x - y) > 1e-4 * scale)
+        if k == "others":
+            bad = bad[:6]                                 # (the distortion map's fp32 cancellation: see helpers.assert_close)
+        assert not (bad.any(axis=0) & ~tight).any(), (k, int((bad.any(axis=0) & ~tight).sum()))
