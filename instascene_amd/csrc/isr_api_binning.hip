@@ -74,6 +74,7 @@ int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binni
         // leave the buckets between the LDS network's range and the big kernel's unsorted)
         static const int wave_max = [] { const char* e = getenv("ISR_WAVE_SORT_MAX"); const int v = e ? atoi(e) : 64;
                                          return (v == 32 || v == 64 || v == 128) ? v : 64; }();
+        static const bool radix = [] { const char* e = getenv("ISR_SORT_RADIX"); return !(e && e[0] == '0'); }();
         const int wk = !wave_sort ? 0 : (!big ? 32 : wave_max);           // keys per lane of the widest variant launched
         const int wflags = wk == 0 ? 0 : wk == 32 ? 2 : wk == 64 ? 6 : 14;
         if (wk == 128)
@@ -85,13 +86,21 @@ int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binni
         hipLaunchKernelGGL(k_tile_sort, dim3(T), dim3(256), 0, s, iv.tile_offset, bv.keys, bv.point_list, binning_capacity,
                            big | wflags);
         if (big) {
+            // buckets beyond the wave kernels' range: LDS radix sort up to 8 192 keys, the bitonic network in 128 KB of LDS beyond
+            constexpr int RADIX_LDS = 2 * SORT_RADIX_KEYS * (int)sizeof(unsigned long long) + 16 * 256 * (int)sizeof(uint32_t);
             static const bool attr_ok = [] {
                 return hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           SORT_BIG_KEYS * (int)sizeof(unsigned long long)) == hipSuccess;
+                                           SORT_BIG_KEYS * (int)sizeof(unsigned long long)) == hipSuccess &&
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_radix), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           RADIX_LDS) == hipSuccess;
             }();
-            if (!attr_ok) return fail(ISR_EHIP, "k_tile_sort_big: cannot reserve %d bytes of LDS", SORT_BIG_KEYS * 8);
+            if (!attr_ok) return fail(ISR_EHIP, "k_tile_sort_big / _radix: cannot reserve %d bytes of LDS", RADIX_LDS);
+            const int beyond_wave = wk > 64 ? wk * 64 : SORT_LDS_KEYS;
+            if (radix)
+                hipLaunchKernelGGL(k_tile_sort_radix, dim3(T), dim3(1024), RADIX_LDS, s, iv.tile_offset, bv.keys, bv.point_list,
+                                   binning_capacity, beyond_wave);
             hipLaunchKernelGGL(k_tile_sort_big, dim3(T), dim3(1024), SORT_BIG_KEYS * sizeof(unsigned long long), s, iv.tile_offset,
-                               bv.keys, bv.point_list, binning_capacity, wk > 64 ? wk * 64 : SORT_LDS_KEYS);
+                               bv.keys, bv.point_list, binning_capacity, radix && SORT_RADIX_KEYS > beyond_wave ? SORT_RADIX_KEYS : beyond_wave);
         } }
         ISR_LAUNCH_CHECK("k_tile_sort");
         { ProfScope ps_("k_pack_hits", s);

@@ -520,6 +520,114 @@ __global__ __launch_bounds__(1024) void k_tile_sort_big(const uint32_t* __restri
     for (int i = threadIdx.x; i < n; i += blockDim.x) point_list[r0 + i] = (uint32_t)s_big[i];
 }
 
+// Buckets of radix_min < n <= SORT_RADIX_KEYS keys: a stable LSD radix sort in LDS instead of the O(n log^2 n) network (dense
+// scenes: C5's lists average 3 100 entries, and the side chain that holds this kernel is that step's critical path).
+//   * Only the 32 depth bits are sorted by radix passes (8 bits each); a pass whose digit is the same for all keys - the high
+//     byte(s) of the depths of one tile - is skipped.  Keys of EQUAL depth (a third of C5's tiles have a pair) are then put into
+//     ascending id order by odd-even transposition inside their runs (runs of 2 or 3: as many phases).  Together that is the order
+//     of the reference's stable radix sort on (tile, depth) over keys emitted in id order (rasterizer_impl.cu:70-111,309-314).
+//   * A pass: every wave owns a contiguous segment of the array (stability = segment order, then position inside it); per wave a
+//     256-bin histogram (LDS atomics); the bins are scanned digit-major / wave-minor; then every wave re-walks its segment, 64
+//     keys at a time: the lanes holding the same digit find each other with eight ballots, rank themselves by lane order, and the
+//     group's first lane advances the wave's running offset of that digit.
+// 1024 threads, two key buffers of SORT_RADIX_KEYS u64 + 16 KB of counters = 144 KB of dynamic LDS, one workgroup per CU.
+// Measured at C5 (tools/fwd_ab.py, the sort kernels of a view together): 0.381 ms against 0.586 with the network for these
+// buckets; taking the (2 048, 4 096] buckets from the one-wave register sort as well: 0.415 - not done.
+constexpr int SORT_RADIX_KEYS = 8192;
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__global__ __launch_bounds__(1024) void k_tile_sort_radix(const uint32_t* __restrict__ tile_offset, const unsigned long long* __restrict__ keys,
+                                                          uint32_t* __restrict__ point_list, int64_t capacity, int min_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_big[];
+    unsigned long long* buf0 = s_big;
+    unsigned long long* buf1 = s_big + SORT_RADIX_KEYS;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(s_big + 2 * SORT_RADIX_KEYS);       // [16 waves][256 bins]
+    __shared__ uint32_t s_total[256];
+    __shared__ int s_flag;
+    const uint32_t t = blockIdx.x;
+    const int64_t r0 = tile_offset[t];
+    int64_t r1 = tile_offset[t + 1];
+    if (r1 > capacity) r1 = capacity;
+    const int n = (int)(r1 - r0);
+    if (n <= min_n || n > SORT_RADIX_KEYS) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int S = (n + 1023) / 1024 * 64;                     // keys per wave segment (a multiple of 64)
+    const int seg0 = wv * S, nchunk = S / 64;
+    for (int i = threadIdx.x; i < n; i += 1024) buf0[i] = keys[r0 + i];
+    unsigned long long* src = buf0;
+    unsigned long long* dst = buf1;
+    for (int shift = 32; shift < 64; shift += 8) {
+        for (int e = threadIdx.x; e < 16 * 256; e += 1024) hist[e] = 0u;
+        __syncthreads();                                      // (also: the loads above / the previous pass's scatter)
+        for (int c = 0; c < nchunk; c++) {
+            const int i = seg0 + c * 64 + lane;
+            if (i < n) atomicAdd(&hist[wv * 256 + (int)((src[i] >> shift) & 255ull)], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {                              // digit d: exclusive offsets of the 16 waves inside the digit, and its total
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < 16; w++) { const uint32_t v = hist[w * 256 + threadIdx.x]; hist[w * 256 + threadIdx.x] = run; run += v; }
+            s_total[threadIdx.x] = run;
+        }
+        if (threadIdx.x == 0) s_flag = 0;
+        __syncthreads();
+        if (wv == 0) {                                        // exclusive scan of the 256 totals (four per lane)
+            uint32_t c4[4], run = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) { c4[u] = s_total[lane * 4 + u]; if (c4[u] == (uint32_t)n) s_flag = 1; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t x = c4[u]; c4[u] = run; run += x; }
+            uint32_t inc = run;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += y; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) s_total[lane * 4 + u] = inc - run + c4[u];
+        }
+        __syncthreads();
+        if (s_flag) { __syncthreads(); continue; }            // every key has the same digit: nothing moves
+        for (int c = 0; c < nchunk; c++) {
+            const int i = seg0 + c * 64 + lane;
+            const bool valid = i < n;
+            const unsigned long long key = valid ? src[i] : 0ull;
+            const int d = (int)((key >> shift) & 255ull);
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool bit = (d >> k) & 1;
+                const unsigned long long b = __ballot(bit);
+                peers &= bit ? b : ~b;
+            }
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0u));
+            if (valid) {
+                const uint32_t at = s_total[d] + hist[wv * 256 + d] + (uint32_t)rank;
+                dst[at] = key;
+            }
+            wave_lds_fence();                                 // (every lane has read the running offset)
+            if (valid && rank == 0) hist[wv * 256 + d] += (uint32_t)__popcll(peers);
+            wave_lds_fence();
+        }
+        __syncthreads();
+        unsigned long long* tmp = src; src = dst; dst = tmp;
+    }
+    // equal depths -> ascending id: odd-even transposition inside the runs, until an even and an odd phase in a row moved nothing
+    int clean = 0;
+    for (int phase = 0; phase < n + 2 && clean < 2; phase++) {
+        if (threadIdx.x == 0) s_flag = 0;
+        __syncthreads();
+        for (int j = (phase & 1) + 2 * (int)threadIdx.x; j + 1 < n; j += 2048) {
+            const unsigned long long a = src[j], b = src[j + 1];
+            if ((a >> 32) == (b >> 32) && (uint32_t)a > (uint32_t)b) { src[j] = b; src[j + 1] = a; s_flag = 1; }
+        }
+        __syncthreads();
+        clean = s_flag ? 0 : clean + 1;                       // (uniform: every thread reads the same flag)
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += 1024) point_list[r0 + i] = (uint32_t)src[i];
+}
+
 // Buckets of up to SORT_WAVE_KEYS keys (all but the densest tiles of a 1080p view) are sorted by ONE WAVE in registers:
 // lane l holds K consecutive elements of the (virtual) array, so the network's strides below K are compare-exchanges between
 // a lane's own registers and the strides of K and more are exchanges with lane l ^ (stride / K) (two ds_bpermute per key) -

@@ -117,6 +117,23 @@ def test_forward_bucket_larger_than_lds_sort_budget(P, lo, hi):
     check_forward_exact(st, args, out)
 
 
+def test_radix_sorted_buckets_with_depth_ties():
+    """4 096 < n <= 8 192 keys: k_tile_sort_radix (LDS radix passes on the depth bits, then equal depths into id order).  A
+    tenth of the splats are exact copies of others' positions - runs of two and three equal depths in every list - and the order
+    is still the oracle's (= the reference's stable sort over keys emitted in id order) bit for bit."""
+    sc, cams, inp = small_scene(P=6500, F=0, W=32, H=32, seed=14, mu_s=math.log(0.4))
+    inp = dict(inp)
+    xyz = inp["means3D"].clone()
+    xyz[3000:3400] = xyz[100:500]
+    xyz[5000:5200] = xyz[100:300]           # triples
+    inp["means3D"] = xyz
+    st = oracle_forward(inp, cams[0])
+    lens = st["ranges"][:, 1].astype(np.int64) - st["ranges"][:, 0]
+    assert 4096 < lens.max() <= 8192
+    args, out = hip_forward(inp, cams[0], mode=MODE_EXACT)
+    check_forward_exact(st, args, out)
+
+
 def test_tile_counter_aggregation_overflow_path():
     """K1 and the key scatter merge a workgroup's tile counters in a 2048-entry LDS hash table; a workgroup that touches
     more distinct tiles than fit (splats covering a 4800-tile image) must fall back to direct global atomics for the
