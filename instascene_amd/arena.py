@@ -24,6 +24,8 @@ import os
 
 import torch
 
+from . import _hot
+
 # (the lease bookkeeping reads the storage's reference count through torch._C._storage_Use_Count - the call torch's own CUDA-graph
 # trees use for the same purpose; a torch without it gets plain torch.empty)
 ENABLED = os.environ.get("ISR_ARENA", "1") != "0" and hasattr(torch._C, "_storage_Use_Count")
@@ -44,31 +46,36 @@ def _class_of(n: int) -> int:
     return _CLASSES[bisect.bisect_left(_CLASSES, n)]
 
 
-def _use_count(t: torch.Tensor) -> int:
-    return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+_COUNT = getattr(torch._C, "_storage_Use_Count", None)
 
 
 class _Block:
-    __slots__ = ("base", "idle_count", "foreign", "events", "nbytes")
+    __slots__ = ("base", "idle_count", "foreign", "events", "nbytes", "_st", "_cd")
 
     def __init__(self, nbytes, dev):
-        self.base = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        self.idle_count = _use_count(self.base)          # the base tensor (+ the temporary handle the probe itself makes)
+        self._adopt(torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes)
+
+    def _adopt(self, base, nbytes):
+        self.base = base
+        self._st = base.untyped_storage()       # held for good: the probe then makes no temporary handle of its own
+        self._cd = self._st._cdata
+        self.idle_count = _COUNT(self._cd)      # the base tensor + that handle
         self.foreign = set()
         self.events = None
         self.nbytes = nbytes
 
     def idle(self) -> bool:
-        return _use_count(self.base) == self.idle_count
+        return _COUNT(self._cd) == self.idle_count
 
-    def reusable(self, stream) -> bool:
-        """Idle, and every other stream that used the last lease has passed the point where that was first seen."""
+    def reusable(self, stream: int) -> bool:
+        """Idle, and every other stream that used the last lease has passed the point where that was first seen
+        (``stream``: the raw handle of the stream that asks)."""
         if not self.idle():
             return False
         if self.foreign:
             self.events = []
             for s in self.foreign:
-                if s.cuda_stream != stream.cuda_stream:
+                if s.cuda_stream != stream:
                     ev = torch.cuda.Event()
                     ev.record(s)
                     self.events.append(ev)
@@ -87,21 +94,26 @@ def empty(shape, dtype, device) -> torch.Tensor:
     n = 1
     for s in shape:
         n *= int(s)
-    nbytes = n * torch.empty((), dtype=dtype).element_size()
-    dev = torch.device(device)
+    nbytes = n * dtype.itemsize
+    dev = device if isinstance(device, torch.device) else torch.device(device)
     if not ENABLED or nbytes < MIN_BYTES or dev.type != "cuda":
         return torch.empty(shape, dtype=dtype, device=dev)
     cls = _class_of(nbytes)
-    stream = torch.cuda.current_stream(dev)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream.cuda_stream, cls)
-    pool = _POOLS.setdefault(key, [])
+    stream = _hot.raw_stream(dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream, cls)
+    pool = _POOLS.get(key)
+    if pool is None:
+        pool = _POOLS[key] = []
     blk = None
     idle = 0
+    surplus = len(pool) > MAX_FREE            # (only then is the number of idle blocks of interest: stop at the first otherwise)
     for b in pool:
         if b.reusable(stream):
             idle += 1
             if blk is None:
                 blk = b
+                if not surplus:
+                    break
     if idle > MAX_FREE:                                   # a burst is over: hand the surplus back
         keep = []
         for b in pool:
@@ -146,7 +158,7 @@ def trim(nbytes: int = None) -> int:
     for key in list(_POOLS):
         keep = []
         for b in _POOLS[key]:
-            if (nbytes is None or freed < nbytes) and b.reusable(torch.cuda.current_stream(b.base.device)):
+            if (nbytes is None or freed < nbytes) and b.reusable(_hot.raw_stream(b.base.device)):
                 freed += b.nbytes
                 _drop(b)
             else:

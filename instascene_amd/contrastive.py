@@ -10,6 +10,7 @@ import ctypes
 
 import torch
 
+from . import _hot
 from ._lib import check, lib
 
 
@@ -18,7 +19,7 @@ def _p(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _hot.stream_ptr()
 
 
 class _ProtoNCE(torch.autograd.Function):
@@ -34,7 +35,7 @@ class _ProtoNCE(torch.autograd.Function):
         nbytes = L.iso_contrastive_scratch_bytes(N, F, K)
         state = torch.empty(nbytes, dtype=torch.uint8, device=feats.device)
         loss = torch.empty(1, dtype=torch.float32, device=feats.device)
-        with torch.cuda.device(feats.device):
+        with _hot.on_device(feats.device):
             check(L.iso_contrastive_forward(N, F, K, _p(feats), _p(labels), int(labels.dtype == torch.int64), _p(pre),
                                             int(bool(consider_negative)), int(min_pixnum), float(temp_lambda), _p(loss),
                                             _p(state), nbytes, _stream()), "iso_contrastive_forward")
@@ -49,7 +50,7 @@ class _ProtoNCE(torch.autograd.Function):
         N, F, K, nbytes, has_pre = ctx.dims
         g = grad_loss.reshape(1).contiguous().float()
         out = torch.empty((N, F), dtype=torch.float32, device=state.device)
-        with torch.cuda.device(state.device):
+        with _hot.on_device(state.device):
             check(L.iso_contrastive_backward(N, F, K, int(has_pre), _p(g), _p(out), _p(state), nbytes, _stream()),
                   "iso_contrastive_backward")
         return out, None, None, None, None, None, None
@@ -98,7 +99,7 @@ class _ProtoNCEBatch(torch.autograd.Function):
         loss = torch.empty(nb + 1, dtype=torch.float32, device=dev)
         ptrs = lambda ts: (ctypes.c_void_p * nb)(*[None if t is None else t.data_ptr() for t in ts])
         w = (ctypes.c_float * nb)(*[float(x) for x in weights])
-        with torch.cuda.device(dev):
+        with _hot.on_device(dev):
             check(L.iso_contrastive_forward_batch(nb, N, F, K, ptrs(feats), ptrs(labs), 1, ptrs(pres),
                                                   int(bool(consider_negative)), int(min_pixnum), float(temp_lambda), w,
                                                   _p(loss), ctypes.c_void_p(loss.data_ptr() + 4 * nb), _p(state), one * nb,
@@ -129,7 +130,7 @@ class _ProtoNCEBatch(torch.autograd.Function):
         flags = (ctypes.c_int * nb)(*[int(h) for h in has_pre])
         w = (ctypes.c_float * nb)(*weights)
         optr = (ctypes.c_void_p * nb)(*[o.data_ptr() for o in outs])
-        with torch.cuda.device(state.device):
+        with _hot.on_device(state.device):
             check(L.iso_contrastive_backward_batch(nb, N, F, K, flags, _p(g), w, optr, _p(state), nbytes, _stream()),
                   "iso_contrastive_backward_batch")
         return (None,) * 8 + tuple(ret)
@@ -167,7 +168,7 @@ class _RowNorm(torch.autograd.Function):
         L = lib()
         xc = x.contiguous().float()
         out = torch.empty_like(xc)
-        with torch.cuda.device(xc.device):
+        with _hot.on_device(xc.device):
             check(L.iso_rownorm(xc.shape[0], xc.shape[1], float(eps), 0, _p(xc), None, _p(out), _stream()), "iso_rownorm")
         ctx.save_for_backward(xc)
         ctx.eps = float(eps)
@@ -179,7 +180,7 @@ class _RowNorm(torch.autograd.Function):
         (xc,) = ctx.saved_tensors
         dyc = dy.contiguous().float()
         out = torch.empty_like(xc)
-        with torch.cuda.device(xc.device):
+        with _hot.on_device(xc.device):
             check(L.iso_rownorm(xc.shape[0], xc.shape[1], ctx.eps, 1, _p(xc), _p(dyc), _p(out), _stream()), "iso_rownorm")
         return out, None
 
@@ -192,7 +193,7 @@ class _RowNorm2(torch.autograd.Function):
         L = lib()
         xc = x.contiguous().float()
         y, z = torch.empty_like(xc), torch.empty_like(xc)
-        with torch.cuda.device(xc.device):
+        with _hot.on_device(xc.device):
             check(L.iso_rownorm2(xc.shape[0], xc.shape[1], float(eps1), float(eps2), 0, _p(xc), None, None, _p(y), _p(z),
                                  _stream()), "iso_rownorm2")
         ctx.save_for_backward(xc)
@@ -209,7 +210,7 @@ class _RowNorm2(torch.autograd.Function):
         gy = None if gy is None else gy.contiguous().float()
         gz = None if gz is None else gz.contiguous().float()
         out = torch.empty_like(xc)
-        with torch.cuda.device(xc.device):
+        with _hot.on_device(xc.device):
             check(L.iso_rownorm2(xc.shape[0], xc.shape[1], ctx.eps[0], ctx.eps[1], 1, _p(xc), _p(gy), _p(gz), _p(out), None,
                                  _stream()), "iso_rownorm2")
         return out, None, None
@@ -249,7 +250,7 @@ class _GatherRows(torch.autograd.Function):
         x, eps = src
         ix = idx.contiguous().to(torch.int64)
         out = torch.empty((ix.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _hot.on_device(x.device):
             check(lib().iso_gather_rownorm(ix.shape[0], x.shape[1], x.shape[0], float(eps), _p(x), _p(ix), _p(out), _stream()),
                   "iso_gather_rownorm")
         return out
@@ -291,7 +292,7 @@ _SLOT_TABLES = {}
 
 
 def _slot_table(P: int, device) -> _SlotTable:
-    key = (device.index, int(P), torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, int(P), _hot.raw_stream(device))
     t = _SLOT_TABLES.get(key)
     if t is None:
         if len(_SLOT_TABLES) > 8:
@@ -308,7 +309,7 @@ def compact_row_grads(idx: torch.Tensor, vals: torch.Tensor, P: int):
     vals = vals.contiguous().float()
     table = _slot_table(P, vals.device)
     merged = torch.empty_like(vals)
-    with torch.cuda.device(vals.device):
+    with _hot.on_device(vals.device):
         check(lib().iso_rows_compact(idx.shape[0], vals.shape[1], P, _p(idx), _p(vals), _p(table.slot), _p(merged),
                                      0 if table.dirty else 1, _stream()), "iso_rows_compact")
     table.dirty, table.covered = idx.shape[0] > 0, 0
@@ -363,7 +364,7 @@ class FeatureAdam:
         g = p.grad.contiguous().float()
         y, z = torch.empty_like(p.data), torch.empty_like(p.data)
         self.step_count += 1
-        with torch.cuda.device(p.device):
+        with _hot.on_device(p.device):
             check(L.iso_adam_rownorm2(p.shape[0], p.shape[1], self.lr, float(self.betas[0]), float(self.betas[1]), self.eps,
                                       self.step_count, float(self.norm_eps[0]), float(self.norm_eps[1]), _p(p.data), _p(g),
                                       _p(self.exp_avg), _p(self.exp_avg_sq), _p(y), _p(z), _stream()), "iso_adam_rownorm2")
@@ -418,7 +419,7 @@ class FeatureAdam:
         rows, gy, gz, slot, merged = tail
         p = self.param
         P, F = p.shape
-        with torch.cuda.device(p.device):
+        with _hot.on_device(p.device):
             check(lib().isr_feature_rows_step(P, int(r0), int(n), rows.R if rows is not None else 0, F,
                                               _p(rows.geom) if rows is not None else None,
                                               _p(rows.scratch) if rows is not None else None, _p(gz), _p(gy), _p(slot),
@@ -462,7 +463,7 @@ class FeatureAdam:
         y, z = self._pending_yz
         at = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr() + 4 * F * int(r0))
         g = at(p.grad) if grad_rows is None else _p(grad_rows.contiguous())
-        with torch.cuda.device(p.device):
+        with _hot.on_device(p.device):
             check(lib().iso_adam_rownorm2(int(r1 - r0), F, self.lr, float(self.betas[0]), float(self.betas[1]), self.eps,
                                           self.step_count, float(self.norm_eps[0]), float(self.norm_eps[1]), at(p.data),
                                           g, at(self.exp_avg), at(self.exp_avg_sq), at(y), at(z), _stream()),
@@ -477,7 +478,7 @@ class FeatureAdam:
         F = p.shape[1]
         y, z = self._pending_yz
         at = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr() + 4 * F * int(r0))
-        with torch.cuda.device(p.device):
+        with _hot.on_device(p.device):
             check(lib().iso_rownorm2(int(r1 - r0), F, float(self.norm_eps[0]), float(self.norm_eps[1]), 0, at(p.data), None, None,
                                      at(y), at(z), _stream()), "iso_rownorm2")
 

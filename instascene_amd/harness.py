@@ -299,6 +299,7 @@ class SegTrainer:
         kernel (``iso_sample_step``) instead of two ``randint`` and six gathers; the 3-D part needs the view's pool of
         visible labelled Gaussians (``warm_view_caches`` or a first visit), else it is drawn later the torch way."""
         import ctypes
+        from . import _hot
         from ._lib import check, lib
         B, dev = self.batch, self.device
         cam = self.cams[vi]
@@ -308,11 +309,11 @@ class SegTrainer:
         out = torch.empty(6 * B, dtype=torch.int64, device=dev)
         pix, la, lb, pick3d, lab3d = out[:2 * B], out[2 * B:3 * B], out[3 * B:4 * B], out[4 * B:5 * B], out[5 * B:]
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
-        with torch.cuda.device(dev):
+        with _hot.on_device(dev):
             check(lib().iso_sample_step(self.sample_seed, int(it), B, int(pool2d.numel()), p(pool2d), p(cam.segmap.reshape(-1)),
                                         p(cam.sorted_segmap.reshape(-1)), n3, p(pool3d) if n3 else None,
                                         p(self.labels3d) if n3 else None, p(pix), p(la), p(lb), p(pick3d), p(lab3d),
-                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "iso_sample_step")
+                                        _hot.stream_ptr(dev)), "iso_sample_step")
         return (pix, la, lb, pick3d if n3 else None, lab3d if n3 else None)
 
     def _sample_view_loss(self, vi, seg_feature, segmap, predef, weight):

@@ -20,6 +20,7 @@ from typing import Dict, Optional
 
 import torch
 
+from . import _hot
 from ._lib import check, lib
 
 GROUPS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
@@ -67,13 +68,13 @@ class GaussianAdam:
         lr = (ctypes.c_double * 6)(*[float(g["lr"]) for g in self.param_groups])
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         g = [None if t is None else t.contiguous().float() for t in grads]
-        with torch.cuda.device(dev):
+        with _hot.on_device(dev):
             check(lib().iso_gaussian_adam_step(
                 P, M, _table([t.data for t in ps]), _table([self.exp_avg[k] for k in GROUPS]),
                 _table([self.exp_avg_sq[k] for k in GROUPS]), lr, float(self.betas[0]), float(self.betas[1]), self.eps,
                 max(1, self.step_count), p(g[0]), p(g[1]), p(g[2]), p(g[3]), p(g[4]),
                 *(p(a) for a in (acts if acts is not None else (None,) * 4)),
-                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "iso_gaussian_adam_step")
+                _hot.stream_ptr(dev)), "iso_gaussian_adam_step")
         return acts
 
     def begin(self):

@@ -20,7 +20,7 @@ from typing import NamedTuple, Optional
 import torch
 import torch.nn as nn
 
-from . import _lib, arena
+from . import _hot, _lib, arena
 from ._lib import GRAD_EXTRA, GRAD_GEOMETRY, MODE_EXACT, MODE_FAST, MODE_FEATURE_ONLY, MODE_PREBINNED, check, lib
 
 _ENV_MODE = os.environ.get("ISR_MODE", "fast").lower()
@@ -184,7 +184,7 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _hot.stream_ptr()
 
 
 def _f32c(t: Optional[torch.Tensor], name: str):
@@ -198,6 +198,7 @@ def _f32c(t: Optional[torch.Tensor], name: str):
 
 
 _TIGHT_RECTS = 0x100  # ISR_PREPARE_TIGHT_RECTS
+_PREFETCH_LIMIT = int(float(os.environ.get("ISR_PREFETCH_MAX_GB", "8")) * (1 << 30))
 _PREFETCHED = {}      # signature -> _Prefetched: geometry pass + binning issued ahead of its forward
 PREFETCH_HITS = 0     # forwards that found their geometry pass already issued (statistics / tests)
 
@@ -345,9 +346,9 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
     viewmatrix, projmatrix = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix")
     sh, campos = _f32c(sh, "sh"), _f32c(campos, "campos")
     inputs = (means3D, sh, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix, campos)
-    with torch.cuda.device(dev):
+    with _hot.on_device(dev):
         done = None
-        side = stream if (stream is not None and stream != torch.cuda.current_stream()) else None
+        side = stream if (stream is not None and stream.cuda_stream != _hot.raw_stream()) else None
         if side is not None:
             if after is None or after is False:
                 # `after=False` used to mean "start at once"; temporaries made above on the caller's stream must be
@@ -378,7 +379,7 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
     _PREFETCHED[sig] = _Prefetched(sig, _refs(originals), radii, geom, img, R, binning, done, inputs)
     # entries nobody came for: bounded by count AND by bytes (an entry pins radii + geom + img + binning - ~0.4 GB per view at
     # C3, ~1 GB at C5; ISR_PREFETCH_MAX_GB, default 8); the newest entry always stays
-    limit = int(float(os.environ.get("ISR_PREFETCH_MAX_GB", "8")) * (1 << 30))
+    limit = _PREFETCH_LIMIT
     nbytes = lambda e: sum(t.numel() * t.element_size() for t in (e.radii, e.geom, e.img, e.binning))
     total = sum(nbytes(e) for e in _PREFETCHED.values())
     while len(_PREFETCHED) > 1 and (len(_PREFETCHED) > 12 or total > limit):
@@ -444,7 +445,7 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
             out_extra.zero_()
         return (0, out_color, out_others, radii, out_extra, geom, torch.empty(0, dtype=torch.uint8, device=dev), img,
                 torch.empty((0, 2), dtype=torch.int32, device=dev), torch.full((1,), -1, dtype=torch.int32, device=dev))
-    with torch.cuda.device(dev):
+    with _hot.on_device(dev):
         st = _stream()
         key = (dev.index, P, W, H)
         sig = _geometry_signature(mode, tight, P, W, H, degree, M, scale_modifier, tan_fovx, tan_fovy, prefiltered, originals)
@@ -568,7 +569,7 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, 
     _verify_pending(geomBuffer.data_ptr())
     scratch = _workspace(lambda c: L.isr_backward_scratch_bytes(c, F, grad_mask), R, dev)
     nbytes = scratch.numel()
-    with torch.cuda.device(dev):
+    with _hot.on_device(dev):
         check(L.isr_backward(P, int(degree), M, int(R), F, W, H, int(mode), grad_mask, _ptr(bg), _ptr(means3D), _ptr(sh),
                              _ptr(colors), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(transMat_precomp),
                              _ptr(extra), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx),
@@ -586,7 +587,7 @@ def sample_extra(out_extra: torch.Tensor, pixels: torch.Tensor) -> torch.Tensor:
     F, H, W = out_extra.shape
     pix = pixels.contiguous().to(torch.int64)
     out = torch.empty((pix.shape[0], F), dtype=torch.float32, device=out_extra.device)
-    with torch.cuda.device(out_extra.device):
+    with _hot.on_device(out_extra.device):
         check(lib().isr_sample_extra(F, W, H, pix.shape[0], _ptr(out_extra), _ptr(pix), _ptr(out), _stream()), "isr_sample_extra")
     return out
 
@@ -648,7 +649,7 @@ def rasterize_gaussians_backward_sampled(P, F, W, H, R, pixels, dL_dsampled, tra
         out = accumulate_into if accumulate_into is not None else arena.empty((P, F), torch.float32, dev)
     scratch = _workspace(lambda c: L.isr_backward_sampled_scratch_bytes(c, F, n, W, H), R, dev)
     nbytes = scratch.numel()
-    with torch.cuda.device(dev):
+    with _hot.on_device(dev):
         check(L.isr_backward_sampled(P, int(R), F, W, H, int(mode), n, _ptr(pix), _ptr(g), _ptr(_f32c(transMat_precomp, "transMat_precomp")),
                                      _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(out),
                                      1 if accumulate_into is not None else 0, _ptr(scratch), nbytes, _stream()),
@@ -665,7 +666,7 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
     if P:
         means3D = _f32c(means3D, "means3D")
-        with torch.cuda.device(means3D.device):
+        with _hot.on_device(means3D.device):
             check(L.isr_mark_visible(P, _ptr(means3D), _ptr(_f32c(viewmatrix, "viewmatrix")),
                                      _ptr(_f32c(projmatrix, "projmatrix")), _ptr(present), _stream()), "isr_mark_visible")
     return present

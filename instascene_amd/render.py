@@ -11,12 +11,13 @@ import os
 
 import torch
 
-from . import _lib
+from . import _hot, _lib
 from .contrastive import row_normalize
 from . import rasterizer as _rz
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
+_ENV_LAZY_MAPS = os.environ.get("ISR_LAZY_MAPS", "0") == "1"
 _LAZY_KEYS = ("rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal", "rend_depth", "rend_median_depth")
 
 
@@ -117,7 +118,7 @@ class _RenderPost(torch.autograd.Function):
         alpha, normal, dist, surf, snorm, depth, median = torch.empty((11, H, W), dtype=torch.float32,
                                                                       device=am.device).split((1, 3, 1, 1, 3, 1, 1))
         vm = viewmatrix.contiguous().float()
-        with torch.cuda.device(am.device):
+        with _hot.on_device(am.device):
             _lib.check(L.iso_render_post_forward(W, H, float(depth_ratio), _ptr(am), _ptr(vm), _ptr(rays_d), _ptr(rays_o),
                                                  _ptr(alpha), _ptr(normal), _ptr(dist), _ptr(surf), _ptr(snorm),
                                                  _ptr(depth), _ptr(median), _stream()), "iso_render_post_forward")
@@ -138,7 +139,7 @@ class _RenderPost(torch.autograd.Function):
         g_snorm, g_depth, g_median = c(g_snorm), c(g_depth), c(g_median)
         scratch = torch.empty((6, H, W), dtype=torch.float32, device=am.device) if g_snorm is not None else None
         out = torch.empty_like(am)
-        with torch.cuda.device(am.device):
+        with _hot.on_device(am.device):
             _lib.check(L.iso_render_post_backward(W, H, ctx.ratio, _ptr(am), _ptr(vm), _ptr(rays_d), _ptr(rays_o), _ptr(surf),
                                                   _ptr(g_alpha), _ptr(g_normal), _ptr(g_dist), _ptr(g_surf), _ptr(g_snorm),
                                                   _ptr(g_depth), _ptr(g_median), _ptr(scratch), _ptr(out), _stream()),
@@ -151,7 +152,7 @@ def _ptr(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _hot.stream_ptr()
 
 
 def post_process(viewpoint_camera, allmap, depth_ratio):
@@ -268,7 +269,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if len(res) > 5:
         # extension: ``seg_feature.reshape(F, -1)[:, sample_pixels].T`` without a dense gradient map in the backward
         rets["sampled_seg_feature"] = res[5]
-    if getattr(pipe, "lazy_maps", False) or os.environ.get("ISR_LAZY_MAPS", "0") == "1":
+    if getattr(pipe, "lazy_maps", False) or _ENV_LAZY_MAPS:
         dict.update(rets, dict.fromkeys(_LAZY_KEYS))
         rets._pending = (viewpoint_camera, allmap, pipe.depth_ratio, torch.is_grad_enabled())
     else:

@@ -270,8 +270,7 @@ def test_arena_lease_ends_with_the_last_view_of_the_block():
     import torch
     from instascene_amd import arena
     b = arena._Block.__new__(arena._Block)
-    b.base = torch.empty(4096, dtype=torch.uint8)
-    b.idle_count, b.foreign, b.events, b.nbytes = arena._use_count(b.base), set(), None, 4096
+    b._adopt(torch.empty(4096, dtype=torch.uint8), 4096)
     assert b.idle()
     v = b.base[:100].view(torch.float32).view(5, 5)
     assert not b.idle()
