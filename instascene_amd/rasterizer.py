@@ -33,13 +33,18 @@ _CONFIG = {
     # of a decision (alpha = 1/255, rho3d = rho2d, depth = near): those decisions are EXACT's by construction, checked on the
     # device for every pair by the STATS build.  Measured (tests/test_gpu_fuzz.py, profiles/r04_fuzz_340_scenes.jsonl, 340 scenes):
     # 1 of 2.3 M pixels differs from the oracle in its last / median contributor or beyond 1e-4 (a T < 1e-4 stop; the full-size
-    # C3 view: 4 of 2 073 600), no gradient row beyond 1e-3.  Forward and backward take identical per-pixel decisions.  Both modes
-    # keep the reference's tile rectangles: radii, tiles_touched, point_list and ranges are bit-identical to the reference's.
+    # C3 view: 4 of 2 073 600), no gradient row beyond 1e-3.  Forward and backward take identical per-pixel decisions.
     "mode": MODE_EXACT if _ENV_MODE == "exact" else MODE_FAST,
-    # opt-in on top of "fast" (mode name "fast_tight", or ISR_TIGHT_RECTS=1): bin a splat only into the tiles its
-    # alpha >= 1/255 bound reaches (ISR_PREPARE_TIGHT_RECTS).  Tile lists are then order-preserving SUBSEQUENCES of the
-    # reference's - same images, but not the reference's point_list / ranges.
-    "tight_rects": _ENV_MODE == "fast_tight" or os.environ.get("ISR_TIGHT_RECTS", "0") == "1",
+    # FAST bins a splat only into the tiles its alpha >= 1/255 box reaches (ISR_PREPARE_TIGHT_RECTS) - the box the blend and
+    # backward kernels already apply per 8x8 block (k_pack_hits' masks), so they walk exactly the same (block, splat) pairs in the
+    # same order as with the reference's square rectangles: image, allmap channels 0-5, feature map, radii, tracer pairs and the
+    # dense geometry gradients are the same bits (tests/test_gpu_rasterizer.py::test_tight_rectangles_change_no_output_bit, every
+    # fuzz scene, and at full C3 / C2 size in test_gpu_fullsize.py); the distortion channel is evaluated relative to the depth of
+    # the tile's first list entry and moves in its last bits, and the backward kernels that scan over chunks of 64 list positions
+    # associate their products differently (1e-7 of the maximum).  Tile lists are order-preserving SUBSEQUENCES of the
+    # reference's (8-19 % fewer instances to count, scatter, sort and pack at C2 / C3), num_rendered is their total.  "fast_reflists" (or ISR_TIGHT_RECTS=0) keeps the reference's
+    # rectangles: tiles_touched, point_list and ranges then equal the reference's bit for bit, as they always do in EXACT mode.
+    "tight_rects": _ENV_MODE != "fast_reflists" and os.environ.get("ISR_TIGHT_RECTS", "1") != "0",
     # produce the (gaussian, pixel) tracer list like the reference does on every forward
     "tracer": os.environ.get("ISR_TRACER", "1") != "0",
     # size the binning workspace from the previous view's instance count (+25 %) instead of a blocking
@@ -56,15 +61,15 @@ LAST_NUM_RENDERED = 0   # instance count of the most recent forward (reporting o
 
 
 def set_mode(mode: str):
-    """"exact" | "fast" | "fast_tight" (see _CONFIG)."""
-    _CONFIG["mode"] = {"exact": MODE_EXACT, "fast": MODE_FAST, "fast_tight": MODE_FAST}[mode]
-    _CONFIG["tight_rects"] = mode == "fast_tight"
+    """"exact" | "fast" | "fast_reflists" (see _CONFIG; "fast_tight", the former opt-in name of today's "fast", is accepted)."""
+    _CONFIG["mode"] = {"exact": MODE_EXACT, "fast": MODE_FAST, "fast_tight": MODE_FAST, "fast_reflists": MODE_FAST}[mode]
+    _CONFIG["tight_rects"] = mode in ("fast", "fast_tight")
 
 
 def get_mode() -> str:
     if _CONFIG["mode"] != MODE_FAST:
         return "exact"
-    return "fast_tight" if _CONFIG["tight_rects"] else "fast"
+    return "fast" if _CONFIG["tight_rects"] else "fast_reflists"
 
 
 def set_tracer(enabled: bool):

@@ -116,6 +116,21 @@ def test_fuzz_parity(case):
         if t is None or name not in want or want[name].size == 0:
             continue
         rows += T.rows_by_cause(name, t.cpu().numpy(), want[name], st, explained, differ, ROW_DEV)
+    # ---- FAST on its default tile lists (a splat binned only where its alpha >= 1/255 box reaches): the same bits as on the
+    # reference's rectangles above - outputs bit for bit (distortion channel: its last bits), gradients to rounding
+    args_t, out_t = T.hip_forward(inp, cam, mode=T.MODE_FAST, tight=True)
+    assert out_t[0] <= out[0]
+    for k in (1, 3, 4):
+        assert torch.equal(out_t[k], out[k]), k
+    assert torch.equal(out_t[2][:6], out[2][:6])
+    assert float((out_t[2][6] - out[2][6]).abs().max()) <= 2e-6 * max(1.0, float(out[2][6].abs().max()))
+    dO_t = dO.copy()
+    dO_t[6] = 0.0
+    got_r = T.hip_backward(args, out, dC, dO_t, dE, mask, T.MODE_FAST)
+    got_t = T.hip_backward(args_t, out_t, dC, dO_t, dE, mask, T.MODE_FAST)
+    for name, x, y in zip(T.GRAD_NAMES, got_r, got_t):
+        if x is not None and x.numel():       # (to rounding: scans over chunks of list positions associate differently)
+            assert float((x - y).abs().max()) <= 1e-6 * max(float(x.abs().max()), 1e-30), f"default lists vs reference rectangles: {name}"
     path = os.environ.get("ISR_FUZZ_REPORT")
     if path:
         with open(path, "a") as f:
