@@ -546,3 +546,11 @@ def test_default_fast_lists_change_no_output_bit_at_full_size():
     for x, y in zip(_backward_c2(a0, o0, dC, dO, MODE_FAST), _backward_c2(a1, o1, dC, dO, MODE_FAST)):
         if x is not None and x.numel():
             assert torch.equal(x, y)
+    del a0, o0, a1, o1
+    # C5 (lists of ~3 000 per tile: the radix-sorted buckets, two feature passes of 32 channels): forward outputs
+    scene, cams, cfg = scenes.config_scene("C5")
+    inp = {k: (None if v is None else v.cuda()) for k, v in scenes.activated_inputs(scene).items()}
+    _, o0 = _forward(inp, cams[4], cfg, MODE_FAST, tight=False)
+    _, o1 = _forward(inp, cams[4], cfg, MODE_FAST, tight=True)
+    assert o1[0] < o0[0]
+    _same_outputs(o0, o1)
