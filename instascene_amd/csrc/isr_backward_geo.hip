@@ -29,8 +29,11 @@ __device__ __forceinline__ float wave_scan_add(float v) {      // inclusive sum 
     v += dpp_fetch<0x112, 0xF>(v, 0.0f);     // row_shr:2
     v += dpp_fetch<0x114, 0xF>(v, 0.0f);     // row_shr:4
     v += dpp_fetch<0x118, 0xF>(v, 0.0f);     // row_shr:8
-    v += dpp_fetch<0x142, 0xA>(v, 0.0f);     // row_bcast:15 into rows 1 and 3
-    v += dpp_fetch<0x143, 0xC>(v, 0.0f);     // row_bcast:31 into rows 2 and 3
+    // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 - as adds that write only those rows (the builtin form is a
+    // move into a zeroed register plus an add: two instructions more per step, in a loop that is bound by instruction issue);
+    // s_nop 1 = the two wait states between a vector write of a register and its read through DPP
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
     return v;
 }
 
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
 
     const int tile = tile_order != nullptr ? (int)tile_order[blockIdx.x >> 2] : (int)(blockIdx.x >> 2), blk = blockIdx.x & 3;
     const int tx = tile % gx, ty = tile / gx;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (uniform: scalar row arithmetic)
     const int bxo = (blk & 1) * 8, byo = (blk >> 1) * 8 + wv * (8 / NW);            // origin of this wave's pixels inside the tile
     float* const s_pix = s_pix_all + wv * NP * 16;
     float* const s_ex = s_ex_all + wv * NP * 12;
@@ -198,25 +201,35 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
                 wave_lds_sync();
             }
             const bool pre_mine = pre && lane == f_lane;
-            float aP0 = 0, aP1 = 0, aP2 = 0, aX0 = 0, aX1 = 0, aX2 = 0, aY0 = 0, aY1 = 0, aY2 = 0;     // sum dL/dp, sum lx dL/dp, sum ly dL/dp
-            float aZ0 = 0, aZ1 = 0, aZ2 = 0;            // sum dL/dz (sx, sy, 1)
-            float aC0 = 0, aC1 = 0;                     // dL/dcentre (low-pass branch)
-            float aN0 = 0, aN1 = 0, aN2 = 0, aO = 0, aR = 0, aG = 0, aB = 0;
+            // The sums a lane keeps for its splat, as the register PAIRS the packed fp32 instructions take (v_pk_fma_f32 / v_pk_add_f32:
+            // one instruction for two sums, the same IEEE operation per component); the pairing follows the operands that are
+            // already neighbours - (dx, dy), (sx, sy), dL/dp.xy, the even-aligned halves of the pixel's float4s - so that no
+            // register has to be moved to form a pair.
+            v2f P01 = {0, 0}, X01 = {0, 0}, Y01 = {0, 0};      // sum dL/dp.xy, sum lx dL/dp.xy, sum ly dL/dp.xy
+            v2f XY2 = {0, 0};                                  // (sum lx dL/dp.z, sum ly dL/dp.z)
+            v2f PZ2 = {0, 0};                                  // (sum dL/dp.z, sum dL/dz)
+            v2f Z01 = {0, 0};                                  // sum dL/dz (sx, sy)
+            v2f C01 = {0, 0};                                  // dL/dcentre (low-pass branch)
+            v2f N12 = {0, 0}, RG = {0, 0};                     // dL/dnormal.yz, dL/dcolour.rg
+            float aN0 = 0, aO = 0, aB = 0;
             bool touched = false;
-            FastHalf lrow = {{0.0f, 0.0f}, 0.0f};
-            float pyf_row = 0.0f;
-            for (int p = 0; p < NP; p++) {
-                if ((p & 7) == 0) {             // a new pixel row: l = py Tw - Tv once per row and splat
-                    pyf_row = tile_y0 + (float)(byo + (p >> 3));
-                    lrow = fast_l(pyf_row, Tv, Tw);
-                }
+            for (int prow = 0; prow < NP / 8; prow++) {
+              // a pixel row: l = py Tw - Tv, the row's float coordinate and "does my box reach this row" once per row and splat
+              const int lyi = byo + prow;
+              const bool row_in = li >= 0 && byl <= lyi && byh >= lyi;
+              if (__ballot(row_in) == 0ull) continue;             // no splat of the chunk reaches the row: its eight pixels at once
+              const float ly = (float)lyi;
+              const float pyf_row = tile_y0 + ly;
+              const FastHalf lrow = fast_l(pyf_row, Tv, Tw);
+              for (int pc = 0; pc < 8; pc++) {
+                const int p = prow * 8 + pc;
                 const float4* pq = reinterpret_cast<const float4*>(s_pix + p * 16);
                 const float4 q3 = pq[3];
                 const unsigned last_p = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q3.y));
-                const int lxi = bxo + (p & 7), lyi = byo + (p >> 3);
-                const bool cand = li >= 0 && (unsigned)li < last_p && bxl <= lxi && bxh >= lxi && byl <= lyi && byh >= lyi;
+                const int lxi = bxo + pc;
+                const bool cand = row_in && (unsigned)li < last_p && bxl <= lxi && bxh >= lxi;
                 if (__ballot(cand) != 0ull) {       // (one latch for the loop: `continue`s here made the compiler rotate the accumulators)
-                    const float lx = (float)lxi, ly = (float)lyi;
+                    const float lx = (float)lxi;
                     // the forward's own evaluation of the pair (isr_fast_pair.hpp; EXACT inside the guard bands): same decisions, bit for bit
                     FastRay fr; FastHit fh;
                     bool pass = fast_pair_lane(Tu, Tv, Tw, cx, cy, opa, det, fb, tile_x0 + lx, pyf_row, fr, fh, pre_mine, &lrow);
@@ -280,22 +293,31 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
                         const bool a3 = act && use3d;
                         const float dsx = __builtin_fmaf(gG, sx, dL_dz * Tw.x);
                         const float dsy = __builtin_fmaf(gG, sy, dL_dz * Tw.y);
-                        const float ssx = a3 ? sx : 0.0f, ssy = a3 ? sy : 0.0f;
-                        const float dpx_ = a3 ? dsx * rz : 0.0f, dpy_ = a3 ? dsy * rz : 0.0f;
-                        const float dpz_ = -__builtin_fmaf(dpx_, ssx, dpy_ * ssy);
-                        aP0 += dpx_; aP1 += dpy_; aP2 += dpz_;
-                        aX0 = __builtin_fmaf(lx, dpx_, aX0); aX1 = __builtin_fmaf(lx, dpy_, aX1); aX2 = __builtin_fmaf(lx, dpz_, aX2);
-                        aY0 = __builtin_fmaf(ly, dpx_, aY0); aY1 = __builtin_fmaf(ly, dpy_, aY1); aY2 = __builtin_fmaf(ly, dpz_, aY2);
+                        const v2f ss = {a3 ? sx : 0.0f, a3 ? sy : 0.0f};
+                        const v2f dp = {a3 ? dsx * rz : 0.0f, a3 ? dsy * rz : 0.0f};
+                        const float dpz_ = -__builtin_fmaf(dp.x, ss.x, dp.y * ss.y);
+                        const v2f lxy = {lx, ly}, lx2 = {lx, lx}, ly2 = {ly, ly};
+                        P01 = P01 + dp;
+                        X01 = __builtin_elementwise_fma(lx2, dp, X01);
+                        Y01 = __builtin_elementwise_fma(ly2, dp, Y01);
+                        XY2 = __builtin_elementwise_fma(lxy, (v2f){dpz_, dpz_}, XY2);
+                        PZ2 = PZ2 + (v2f){dpz_, dL_dz};
                         const float dz3 = a3 ? dL_dz : 0.0f;
-                        aZ0 = __builtin_fmaf(dz3, ssx, aZ0); aZ1 = __builtin_fmaf(dz3, ssy, aZ1); aZ2 += dL_dz;
+                        Z01 = __builtin_elementwise_fma((v2f){dz3, dz3}, ss, Z01);
                         const float g2 = (act && !use3d) ? gG * FILTER_INV_SQ : 0.0f;
-                        aC0 = __builtin_fmaf(g2, dx, aC0); aC1 = __builtin_fmaf(g2, dy, aC1);
-                        aN0 = __builtin_fmaf(w, q1.y, aN0); aN1 = __builtin_fmaf(w, q1.z, aN1); aN2 = __builtin_fmaf(w, q1.w, aN2);
+                        C01 = __builtin_elementwise_fma((v2f){g2, g2}, (v2f){dx, dy}, C01);
+                        const v2f w2 = {w, w};
+                        aN0 = __builtin_fmaf(w, q1.y, aN0);
+                        N12 = __builtin_elementwise_fma(w2, (v2f){q1.z, q1.w}, N12);
                         aO = __builtin_fmaf(G, dL_dalpha, aO);
-                        aR = __builtin_fmaf(w, q0.x, aR); aG = __builtin_fmaf(w, q0.y, aG); aB = __builtin_fmaf(w, q0.z, aB);
+                        RG = __builtin_elementwise_fma(w2, (v2f){q0.x, q0.y}, RG);
+                        aB = __builtin_fmaf(w, q0.z, aB);
                     }
                 }
+              }
             }
+            float aP0 = P01.x, aP1 = P01.y, aP2 = PZ2.x, aX0 = X01.x, aX1 = X01.y, aX2 = XY2.x, aY0 = Y01.x, aY1 = Y01.y, aY2 = XY2.y;
+            float aZ0 = Z01.x, aZ1 = Z01.y, aZ2 = PZ2.y, aC0 = C01.x, aC1 = C01.y, aN1 = N12.x, aN2 = N12.y, aR = RG.x, aG = RG.y;
             if constexpr (NW > 1) {             // the other waves' partial sums -> wave 0 (fixed order: pixel rows top to bottom)
                 if (wv > 0) {
                     float4* a4 = reinterpret_cast<float4*>(s_acc + ((wv - 1) * 64 + lane) * 24);
