@@ -2,7 +2,7 @@
 
 ``torch.cuda.current_stream()`` builds a Stream object and, without a device argument, walks ``_get_device_index ->
 is_available -> os.getenv``; a train step asked for it ~24 times (0.19 ms of a 1.1 ms host budget, profiles/
-r04d_host_profile.txt).  The raw handle is one C call."""
+r04_host_profile_before.txt).  The raw handle is one C call."""
 from __future__ import annotations
 
 import contextlib
