@@ -54,6 +54,10 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
     __shared__ int s_q[GEO_QCAP];
     __shared__ __attribute__((aligned(16))) float s_acc[NW > 1 ? (NW - 1) * 64 * 24 : 4];
     __shared__ unsigned s_last[4];
+    // per pixel: (transmittance behind, sum of w S behind) the splats walked so far - read by every lane (one broadcast LDS read),
+    // rewritten by the chunk's front-most lane; as registers of "lane p" they cost two v_readlane, two moves and two selects per
+    // (chunk, pixel) in a loop that is bound by vector-instruction issue
+    __shared__ __attribute__((aligned(8))) float2 s_carry_all[64];
     // A splat whose every pair takes EXACT's instruction sequence (band = +inf: edge-on, horizon inside its footprint; ~0.4 % of
     // the splats, i.e. one in a quarter of all chunks of 64) would make the whole wave run that sequence - for one lane - at every
     // pixel of its box.  It is evaluated here instead, once per chunk, a lane per PIXEL of the block, and handed to its lane
@@ -66,6 +70,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
     const int bxo = (blk & 1) * 8, byo = (blk >> 1) * 8 + wv * (8 / NW);            // origin of this wave's pixels inside the tile
     float* const s_pix = s_pix_all + wv * NP * 16;
     float* const s_ex = s_ex_all + wv * NP * 12;
+    float2* const s_carry = s_carry_all + wv * NP;
     auto block_sync = [&]() { if constexpr (NW > 1) __syncthreads(); else wave_lds_sync(); };
     const int64_t r0 = tile_offset[tile];
     int64_t r1 = tile_offset[tile + 1];
@@ -75,6 +80,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
     const size_t N = (size_t)W * H;
     // ---- the block's pixels: lane p loads pixel p, LDS hands them to everybody (wave-uniform reads in the pixel loop)
     unsigned mylast = 0u;
+    bool reg_here = false;
     {
         const unsigned px = tx * TILE + bxo + (lane & 7), py = ty * TILE + byo + (lane >> 3);
         float v[16];
@@ -92,6 +98,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
             for (int k = 0; k < 10; k++) any = any || (v[k] != 0.0f);
             v[10] = final_T[pix]; v[11] = final_T[pix + N]; v[12] = final_T[pix + 2 * N];
             mylast = any ? n_contrib[pix] : 0u;          // a pixel without upstream gradient contributes exact zeros
+            reg_here = v[9] != 0.0f;
             v[13] = __uint_as_float(mylast);
             v[14] = __uint_as_float(n_contrib[pix + N]);
             v[15] = (bg[0] * v[0] + bg[1] * v[1]) + bg[2] * v[2];
@@ -119,8 +126,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
     const int len_eff = min(len, (int)block_last);
     const float mscale = FAR_N / (FAR_N - NEAR_N);
     const float tile_x0 = (float)(tx * TILE), tile_y0 = (float)(ty * TILE);
-    float carryT = 0.0f, carryR = 0.0f;      // lane p: transmittance behind / sum of w S behind the splats walked so far, pixel p
-    carryT = lane < NP ? s_pix[lane * 16 + 10] : 0.0f;
+    const bool any_reg = __ballot(reg_here) != 0ull;       // (lambda_dist = 0: no pixel carries a distortion gradient)
+    if (lane < NP) s_carry[lane] = make_float2(s_pix[lane * 16 + 10], 0.0f);
+    wave_lds_sync();
 
     int n_q = 0;                    // queued entries (uniform); s_q holds tile-list positions in DESCENDING order
     int seg_hi = len_eff;           // entries [0, seg_hi) are still to be culled
@@ -247,18 +255,18 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
                     if (__ballot(act) != 0ull) {
                         const float4 q0 = pq[0], q1 = pq[1], q2 = pq[2];
                         // q0 = dC.rgb, d_depth   q1 = d_accum, dN.xyz   q2 = d_median, d_reg, T_final, final_D   q3 = final_D2, last, median, bg_dot
+                        const float2 cc = s_carry[p];
                         const float om = act ? 1.0f - alpha : 1.0f;
                         // transmittance in front of this lane's splat: carry / prod_{lanes <= l} (1 - alpha), the product
                         // as a SUM scan of logarithms (6 fused DPP adds + v_log + v_exp instead of 18 instructions)
                         const float lg = __builtin_amdgcn_logf(om);                      // log2, <= 0
                         const float Linc = wave_scan_add(lg);
-                        const float cT = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(carryT), p));
-                        const float cR = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(carryR), p));
+                        const float cT = cc.x, cR = cc.y;
                         const float Tb = cT * __builtin_amdgcn_exp2f(-Linc);
                         const float w = act ? alpha * Tb : 0.0f;
                         const float T_final = q2.z, final_A = 1.0f - q2.z, final_D = q2.w, final_D2 = q3.x;
                         const float dL_dreg = q2.y;
-                        const bool has_reg = __builtin_amdgcn_readfirstlane((int)__float_as_uint(dL_dreg)) != 0;    // uniform
+                        const bool has_reg = any_reg && __builtin_amdgcn_readfirstlane((int)__float_as_uint(dL_dreg)) != 0;    // uniform
                         float dL_dweight = 0.0f, dz_reg = 0.0f;
                         if (has_reg) {          // the pixel's distortion gradient (lambda_dist = 0: never)
                             const float inv_cd = __builtin_amdgcn_rcpf(c_d);
@@ -274,11 +282,8 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
                         const float wS = w * S;             // (0 for an inactive lane: w is)
                         const float incl = wave_scan_add(wS);
                         const float Rl = cR + (incl - wS);                               // sum of w S over the splats behind this one
-                        const float Tfront = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tb), 63));
-                        const float Stot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
-                        const bool mine = lane == p;
-                        carryT = mine ? Tfront : carryT;     // (lane 63 is the chunk's front-most splat: its T_before is what the next chunk sees behind it)
-                        carryR = mine ? cR + Stot : carryR;
+                        // (lane 63 is the chunk's front-most splat: its T_before is what the next chunk sees behind it)
+                        if (lane == 63) s_carry[p] = make_float2(Tb, cR + incl);
                         touched = touched || act;
                         // every addend below is selected to zero for an inactive lane (its inputs may be inf / NaN)
                         const float inv_om = __builtin_amdgcn_exp2f(-lg);                // 1 / (1 - alpha)
