@@ -282,7 +282,7 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
         L.isr_profile_enable(0)
     if rank == 0 and detail:
         # workload statistics + work counters of the blend kernel on the last timed view (one extra, untimed render)
-        counters = torch.zeros(8, dtype=torch.int64, device=dev)
+        counters = torch.zeros(16, dtype=torch.int64, device=dev)
         with torch.no_grad():
             was = rasterizer._CONFIG["async_binning"]
             rasterizer.set_async_binning(False)             # exact instance count for the byte model
@@ -295,6 +295,7 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
             R = int(rasterizer.LAST_NUM_RENDERED)
             rasterizer.set_async_binning(was)
         cull_tests, pairs_eval, pairs_blend, lane_pairs, pairs_mergeable, sub_blocks, pairs_exact, band_violations = (int(v) for v in counters.tolist()[:8])
+        sublists = [int(v) for v in counters.tolist()[8:16]]
         P, N, F = cfg["P"], cfg["W"] * cfg["H"], (cfg["F"] if args.step in ("seg", "plain") else 0)
         tiles = ((cfg["W"] + 15) // 16) * ((cfg["H"] + 15) // 16)
         bm = byte_model(P, V, R, N, F, tiles)
@@ -362,6 +363,12 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
                 "lane_utilisation_of_blending_pairs": round(lane_pairs / max(1, 64 * pairs_blend), 4),
                 "blending_4x4_sub_blocks_per_blending_pair": round(sub_blocks / max(1, pairs_blend), 4),
                 "lane_utilisation_at_4x4_granularity": round(lane_pairs / max(1, 16 * sub_blocks), 4),
+                # what a per-8x4-half / per-4x4-quad walk would iterate (lower bounds: the longest sub-list of a wave, counting only
+                # evaluations with a lane inside band.hi; the octagon test would put more into the lists)
+                "walk_iterations_if_each_8x4_half_walked_its_own_list": sublists[0],
+                "walk_iterations_if_each_4x4_quad_walked_its_own_list": sublists[1],
+                "half_and_quad_sub_list_entries": [sublists[2], sublists[3]],
+                "the_same_counting_only_blending_evaluations": sublists[4:8],
                 "flop_model": "SURVEY 8(d): 40 flop per evaluated (pixel, splat) pair + 2*(3+7+F) per contributing pair",
                 "flops": int(flops_eval), "flops_upper_bound_256R": int(flops_model),
                 "TFLOP/s": round(tf, 2), "peak_TFLOP/s": VALU_PEAK_TFLOPS, "frac": round(tf / VALU_PEAK_TFLOPS, 4),

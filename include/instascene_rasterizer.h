@@ -66,10 +66,12 @@ int isr_set_debug(int on, int fault_after);
  * "kernel_name launches total_ms" line per kernel into buf (returns bytes written). */
 void isr_profile_enable(int on);
 /* Work counters of the forward blend kernel (bench.py's `roofline.valu`): the NEXT isr_forward_render call of this host
- * thread in ISR_MODE_FAST also adds, into device_counters[0..4] (u64[8], device memory, zeroed by the caller): (wave, splat)
- * cull tests, (wave, splat) pairs evaluated, pairs with at least one blending lane, blending (pixel, splat) pairs, and
- * consecutive evaluated pairs whose alpha >= 1/255 bounds share no pixel of the wave's block (greedy).
- * One extra atomic per wave; not meant for timed runs. */
+ * thread in ISR_MODE_FAST also adds, into device_counters (u64[16], device memory, zeroed by the caller): [0] (wave, splat)
+ * cull tests, [1] (wave, splat) pairs evaluated, [2] pairs with at least one blending lane, [3] blending (pixel, splat) pairs,
+ * [4] consecutive evaluated pairs whose alpha >= 1/255 bounds share no pixel of the wave's block (greedy; tile-wide kernel),
+ * [5] 4x4 sub-blocks with a blending pixel, [6] evaluations on the EXACT path, [7] pairs outside the guard bands deciding unlike
+ * EXACT (must be 0), [8..15] the walk lengths of a per-8x4-half / per-4x4-quad decomposition (isr_forward_fast.hip).
+ * A few extra atomics per wave; not meant for timed runs. */
 void isr_forward_set_counters(unsigned long long* device_counters);
 size_t isr_profile_summary(char* buf, size_t len);
 

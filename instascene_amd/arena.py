@@ -14,13 +14,19 @@ autograd graph holding the forward's state) drops the tensors; no hook, no expli
   passed the point where the block was found idle (an event per such stream, polled - no stream ever WAITS for another because of
   the arena: a lease that would have to wait takes another block).
 * Size classes (x 1.25) bound the number of distinct blocks under a drifting size; at most ``MAX_FREE`` idle blocks per class
-  and ``ISR_ARENA_MAX_GB`` (default 64) in total are kept - beyond that idle blocks go back to the caching allocator.
+  and ``ISR_ARENA_MAX_GB`` (default: half of the device's memory) in total are kept - beyond that idle blocks go back to the
+  caching allocator.  Under memory pressure the arena lets go: an out-of-memory error while a block is created trims every idle
+  block, empties torch's cache and retries once; the drop-in's pressure-gated ``empty_cache()`` trims it too (``dropin.py``).
+* Leases are NOT autograd views of the block (``Tensor.set_`` on the block's storage): an in-place operation on a render output
+  created inside the rasterizer's ``autograd.Function`` behaves like on the reference's fresh tensors.  (``torch.save`` of a
+  lease serialises the whole block; clone first.)
 * ``ISR_ARENA=0`` disables it (plain ``torch.empty``).  Requests below ``MIN_BYTES`` are not pooled.
 """
 from __future__ import annotations
 
 import bisect
 import os
+import threading
 
 import torch
 
@@ -31,7 +37,12 @@ from . import _hot
 ENABLED = os.environ.get("ISR_ARENA", "1") != "0" and hasattr(torch._C, "_storage_Use_Count")
 MIN_BYTES = 1 << 20
 MAX_FREE = 3
-MAX_BYTES = int(float(os.environ.get("ISR_ARENA_MAX_GB", "64")) * (1 << 30))
+# cap on the bytes the arena keeps: ISR_ARENA_MAX_GB, else half of the device's memory (read at the first lease on a device)
+_MAX_GB_ENV = os.environ.get("ISR_ARENA_MAX_GB")
+MAX_BYTES = int(float(_MAX_GB_ENV) * (1 << 30)) if _MAX_GB_ENV else None
+MAX_FRACTION = 0.5
+_DEVICE_CAP = {}
+_LOCK = threading.RLock()      # empty() runs on the main thread in forward and on autograd's device threads in backward
 
 _CLASSES = [MIN_BYTES]
 _POOLS = {}            # (device index, stream handle, class bytes) -> [_Block]
@@ -53,7 +64,14 @@ class _Block:
     __slots__ = ("base", "idle_count", "foreign", "events", "nbytes", "_st", "_cd")
 
     def __init__(self, nbytes, dev):
-        self._adopt(torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes)
+        try:
+            base = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        except torch.OutOfMemoryError:
+            # the arena's idle blocks are invisible to torch's own out-of-memory retry: let them go, then torch's cache, once
+            trim()
+            _real_empty_cache()
+            base = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._adopt(base, nbytes)
 
     def _adopt(self, base, nbytes):
         self.base = base
@@ -87,6 +105,25 @@ class _Block:
         return True
 
 
+def _real_empty_cache():
+    """torch's own ``empty_cache`` even when the drop-in has replaced the public name (dropin.py keeps the original here)."""
+    fn = getattr(torch.cuda, "_isr_real_empty_cache", None) or torch.cuda.empty_cache
+    fn()
+
+
+def _cap(dev_index: int) -> int:
+    if MAX_BYTES is not None:
+        return MAX_BYTES
+    c = _DEVICE_CAP.get(dev_index)
+    if c is None:
+        try:
+            c = int(torch.cuda.mem_get_info(dev_index)[1] * MAX_FRACTION)
+        except Exception:
+            c = 64 << 30
+        _DEVICE_CAP[dev_index] = c
+    return c
+
+
 def empty(shape, dtype, device) -> torch.Tensor:
     """``torch.empty(shape, dtype=dtype, device=device)`` out of the arena (uninitialised, 256-byte aligned)."""
     if isinstance(shape, int):
@@ -98,6 +135,11 @@ def empty(shape, dtype, device) -> torch.Tensor:
     dev = device if isinstance(device, torch.device) else torch.device(device)
     if not ENABLED or nbytes < MIN_BYTES or dev.type != "cuda":
         return torch.empty(shape, dtype=dtype, device=dev)
+    with _LOCK:
+        return _lease(shape, dtype, dev, nbytes)
+
+
+def _lease(shape, dtype, dev, nbytes) -> torch.Tensor:
     cls = _class_of(nbytes)
     stream = _hot.raw_stream(dev)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream, cls)
@@ -124,15 +166,18 @@ def empty(shape, dtype, device) -> torch.Tensor:
                 keep.append(b)
         pool[:] = keep
     if blk is None:
-        if _TOTAL[0] + cls > MAX_BYTES:
-            trim(_TOTAL[0] + cls - MAX_BYTES)
+        cap = _cap(key[0])
+        if _TOTAL[0] + cls > cap:
+            trim(_TOTAL[0] + cls - cap)
         blk = _Block(cls, dev)
         pool.append(blk)
         _BY_PTR[blk.base.data_ptr()] = blk
         _TOTAL[0] += cls
         STATS["new_blocks"] += 1
     STATS["leases"] += 1
-    return blk.base[:nbytes].view(dtype).view(*shape)
+    # a tensor of its own on the block's storage, not a view of `base`: the storage's reference count still says when the lease
+    # has ended, and autograd sees what the reference hands out - a fresh tensor (in-place operations on the render outputs)
+    return torch.empty(0, dtype=dtype, device=dev).set_(blk._st, 0, tuple(int(v) for v in shape))
 
 
 def used_on(t: torch.Tensor, stream) -> None:
@@ -141,7 +186,8 @@ def used_on(t: torch.Tensor, stream) -> None:
         return
     blk = _BY_PTR.get(t.untyped_storage().data_ptr())
     if blk is not None:
-        blk.foreign.add(stream)
+        with _LOCK:
+            blk.foreign.add(stream)
     else:
         t.record_stream(stream)
 
@@ -155,18 +201,21 @@ def _drop(b: _Block) -> None:
 def trim(nbytes: int = None) -> int:
     """Give idle blocks back to the caching allocator (all of them, or at least ``nbytes`` worth).  Returns the bytes released."""
     freed = 0
-    for key in list(_POOLS):
-        keep = []
-        for b in _POOLS[key]:
-            if (nbytes is None or freed < nbytes) and b.reusable(_hot.raw_stream(b.base.device)):
-                freed += b.nbytes
-                _drop(b)
+    with _LOCK:
+        for key in list(_POOLS):
+            keep = []
+            for b in _POOLS[key]:
+                # key[1]: the stream that OWNS the pool - a block used on another stream (used_on) stays until that stream has
+                # passed it, whichever stream happens to be current where trim() is called
+                if (nbytes is None or freed < nbytes) and b.reusable(key[1]):
+                    freed += b.nbytes
+                    _drop(b)
+                else:
+                    keep.append(b)
+            if keep:
+                _POOLS[key] = keep
             else:
-                keep.append(b)
-        if keep:
-            _POOLS[key] = keep
-        else:
-            del _POOLS[key]
+                del _POOLS[key]
     return freed
 
 

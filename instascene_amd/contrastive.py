@@ -261,7 +261,7 @@ class _GatherRows(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         sink = _rz._ROWS_SINK
         n = idx.shape[0]
-        if sink is not None and sink.row_grads is None and g.is_cuda and n <= 16384:
+        if sink is not None and sink.row_grads is None and g.is_cuda:
             # merged per distinct row right away (iso_rows_compact), early in the backward: by the time the per-Gaussian
             # tail runs the table is ready and the small kernel does not queue up behind the next view's binning
             sink.row_grads = compact_row_grads(idx, g, ctx.shape[0])
@@ -289,6 +289,7 @@ class _SlotTable:
 
 
 _SLOT_TABLES = {}
+ROWS_COMPACT_MAX = 65536         # iso_rows_compact's limit (csrc/iso_contrastive.hip: ROWS_SPLIT_MAX)
 
 
 def _slot_table(P: int, device) -> _SlotTable:
@@ -308,6 +309,18 @@ def compact_row_grads(idx: torch.Tensor, vals: torch.Tensor, P: int):
     idx = idx.contiguous().to(torch.int64)
     vals = vals.contiguous().float()
     table = _slot_table(P, vals.device)
+    if idx.shape[0] > ROWS_COMPACT_MAX:
+        # beyond the kernels' 65 536 samples (the reference's default sample_batchsize is 32 768): one entry per distinct row by
+        # torch (unique + index_add_: the sum of a repeated row is in atomic order, not in index order - the only difference)
+        ok = (idx >= 0) & (idx < P)
+        rows, inverse = torch.unique(idx[ok], return_inverse=True)
+        merged = torch.zeros((max(int(rows.shape[0]), 1), vals.shape[1]), dtype=torch.float32, device=vals.device)
+        merged.index_add_(0, inverse, vals[ok])
+        if table.dirty:
+            table.slot.fill_(-1)
+        table.slot[rows] = torch.arange(rows.shape[0], dtype=torch.int32, device=vals.device)
+        table.dirty, table.covered = rows.shape[0] > 0, 0
+        return table.slot, merged
     merged = torch.empty_like(vals)
     with _hot.on_device(vals.device):
         check(lib().iso_rows_compact(idx.shape[0], vals.shape[1], P, _p(idx), _p(vals), _p(table.slot), _p(merged),

@@ -815,8 +815,11 @@ __global__ __launch_bounds__(1024) void rows_compact_kernel(int n, int F, long l
 //   rows_merge_kernel   a wave per sample: a row drawn twice gets its second occurrence added by that occurrence's wave, a row
 //                       drawn three times or more by its head's wave in ascending position - the order of
 //                       index_put_(accumulate=True) and of rows_compact_kernel, hence the same bits; the count is cleared.
-static_assert(ROWS_COMPACT_MAX <= 0x3fff + 1, "a row position must fit the slot's 14 position bits");
-constexpr unsigned ROWS_POS_MASK = 0x3fffu, ROWS_REPEAT_ONE = 0x4000u;       // slot while the three kernels run: repeats << 14 | first position (n <= 16 384)
+// slot while the three kernels run: repeats << pos_bits | first position.  pos_bits = 14 up to 16 384 samples (the rounds 3-4 layout)
+// and ceil(log2 n) beyond: a row has at most n - 1 < 2^pos_bits repeats, so both fields fit 32 bits up to ROWS_SPLIT_MAX samples
+// (the reference's default sample_batchsize is 32 768, arguments/__init__.py:103), and 0xFFFFFFFF stays "no entry".
+constexpr int ROWS_SPLIT_MAX = 65536;
+inline int rows_pos_bits(int n) { int b = 14; while ((1 << b) < n) b++; return b; }
 __global__ __launch_bounds__(256) void rows_first_kernel(int n, long long P, const long long* __restrict__ idx, unsigned* __restrict__ slot) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -825,7 +828,8 @@ __global__ __launch_bounds__(256) void rows_first_kernel(int n, long long P, con
 }
 __global__ __launch_bounds__(256) void rows_copy_kernel(int n, int F, long long P, const long long* __restrict__ idx,
                                                         const float* __restrict__ vals, unsigned* __restrict__ slot,
-                                                        float* __restrict__ merged) {
+                                                        float* __restrict__ merged, int pos_bits) {
+    const unsigned ROWS_POS_MASK = (1u << pos_bits) - 1u, ROWS_REPEAT_ONE = 1u << pos_bits;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x, total = (long long)n * F;
     if ((F & 3) == 0) {
         if (4 * e < total) reinterpret_cast<float4*>(merged)[e] = reinterpret_cast<const float4*>(vals)[e];
@@ -839,13 +843,14 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(int n, int F, long long 
 }
 __global__ __launch_bounds__(256) void rows_merge_kernel(int n, int F, long long P, const long long* __restrict__ idx,
                                                          const float* __restrict__ vals, unsigned* __restrict__ slot,
-                                                         float* __restrict__ merged) {
+                                                         float* __restrict__ merged, int pos_bits) {
+    const unsigned ROWS_POS_MASK = (1u << pos_bits) - 1u;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
     const long long v = idx[i];
     if (v < 0 || v >= P) return;
     const unsigned sv = slot[v];
-    const unsigned first = sv & ROWS_POS_MASK, repeats = sv >> 14;
+    const unsigned first = sv & ROWS_POS_MASK, repeats = sv >> pos_bits;
     if (repeats == 0u) return;                                   // the row was drawn once
     if (repeats == 1u) {
         // drawn twice (nearly every repeat): the SECOND occurrence adds itself to the head's row - four dependent memory round

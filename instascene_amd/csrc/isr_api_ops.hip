@@ -419,20 +419,21 @@ int iso_rows_compact(int n, int F, long long P, const long long* idx, const floa
     if (n > 0 && (!idx || !vals || !merged)) return fail(ISR_EINVAL, "rows_compact: null pointer");
     if (P > 0 && !slot_is_clean && hipMemsetAsync(slot, 0xFF, sizeof(int) * (size_t)P, s) != hipSuccess) return fail(ISR_EHIP, "rows_compact: memset failed");
     if (n == 0 || P == 0) return ISR_OK;
-    if (n > iso::ROWS_COMPACT_MAX) return fail(ISR_EINVAL, "rows_compact: at most %d rows", iso::ROWS_COMPACT_MAX);
+    if (n > iso::ROWS_SPLIT_MAX) return fail(ISR_EINVAL, "rows_compact: at most %d rows", iso::ROWS_SPLIT_MAX);
     static const bool lds_form = [] { const char* e = getenv("ISR_ROWS_COMPACT"); return e && e[0] == 'l'; }();    // "lds": the one-launch form
-    if (lds_form) {
+    if (lds_form && n <= iso::ROWS_COMPACT_MAX) {
         hipLaunchKernelGGL(iso::rows_compact_kernel, dim3((n + 63) / 64), dim3(1024), 0, s, n, F, P, idx, vals, slot, merged);
         ISR_LAUNCH_CHECK("iso_rows_compact");
         return ISR_OK;
     }
     unsigned* us = reinterpret_cast<unsigned*>(slot);
+    const int pos_bits = iso::rows_pos_bits(n);
     hipLaunchKernelGGL(iso::rows_first_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, P, idx, us);
     ISR_LAUNCH_CHECK("rows_first_kernel");
     const long long quads = ((long long)n * F + 3) / 4;
-    hipLaunchKernelGGL(iso::rows_copy_kernel, dim3((unsigned)((std::max<long long>(quads, n) + 255) / 256)), dim3(256), 0, s, n, F, P, idx, vals, us, merged);
+    hipLaunchKernelGGL(iso::rows_copy_kernel, dim3((unsigned)((std::max<long long>(quads, n) + 255) / 256)), dim3(256), 0, s, n, F, P, idx, vals, us, merged, pos_bits);
     ISR_LAUNCH_CHECK("rows_copy_kernel");
-    hipLaunchKernelGGL(iso::rows_merge_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, F, P, idx, vals, us, merged);
+    hipLaunchKernelGGL(iso::rows_merge_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, F, P, idx, vals, us, merged, pos_bits);
     ISR_LAUNCH_CHECK("rows_merge_kernel");
     return ISR_OK;
 }

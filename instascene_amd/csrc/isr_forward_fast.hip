@@ -415,6 +415,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     float w_pend = 0.0f, f_pend = 0.0f, f_pend2 = 0.0f;
     bool pending = false;
     unsigned st_cull = 0, st_eval = 0, st_blend = 0, st_lanes = 0, st_sub = 0, st_slow = 0, st_viol = 0;
+    // (STATS) what a finer decomposition would walk: near / blending evaluations per 8x4 half and per 4x4 quad of the block
+    unsigned st_hn[2] = {0, 0}, st_qn[4] = {0, 0, 0, 0}, st_hb[2] = {0, 0}, st_qb[4] = {0, 0, 0, 0};
     const float mscale = FAR_N / (FAR_N - NEAR_N);
     // the distortion moments are kept relative to m_ref, the mapped depth of the TILE's nearest splat (as in the tile-wide kernel:
     // every block of a tile uses the same shift, and the two kernels produce the same bits)
@@ -569,6 +571,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                 }
                 fast_take((m_band >> lane) & 1ull, er, eh, fr, fh);
                 m_pass |= m_band & __ballot(ep);
+                if (STATS) {
+                    constexpr unsigned long long QM[4] = {0x0f0f0f0full, 0xf0f0f0f0ull, 0x0f0f0f0f00000000ull, 0xf0f0f0f000000000ull};
+                    for (int k = 0; k < 2; k++) st_hn[k] += (m_near & (0xffffffffull << (32 * k))) != 0ull;
+                    for (int k = 0; k < 4; k++) st_qn[k] += (m_near & QM[k]) != 0ull;
+                }
                 if (STATS && m_near == 0ull) continue;
             }
             const bool use3d = fh.use3d;
@@ -584,6 +591,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                 const int sb = ((lyi >> 2) & 1) * 2 + ((lxi >> 2) & 1);
                 const bool okl = (m_ok >> lane) & 1ull;
                 for (int k = 0; k < 4; k++) st_sub += __ballot(okl && sb == k) != 0ull ? 1u : 0u;
+                constexpr unsigned long long QM[4] = {0x0f0f0f0full, 0xf0f0f0f0ull, 0x0f0f0f0f00000000ull, 0xf0f0f0f000000000ull};
+                for (int k = 0; k < 2; k++) st_hb[k] += (m_ok & (0xffffffffull << (32 * k))) != 0ull;
+                for (int k = 0; k < 4; k++) st_qb[k] += (m_ok & QM[k]) != 0ull;
             }
             float w_lane = 0.0f;
             if (__builtin_amdgcn_inverse_ballot_w64(m_ok)) {
@@ -668,6 +678,16 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             atomicAdd(stats + 5, (unsigned long long)st_sub);
             atomicAdd(stats + 6, (unsigned long long)st_slow);      // (wave, splat) evaluations that took the EXACT path
             atomicAdd(stats + 7, (unsigned long long)st_viol);      // pairs outside the guard bands whose decision differs from EXACT's
+            // 8..15: iterations a wave would need if each 8x4 half / 4x4 quad walked its own sub-list (the longest sub-list) and the
+            // sub-lists' total length, counting the evaluations with a lane inside band.hi (8..11) or with a blending lane (12..15)
+            atomicAdd(stats + 8, (unsigned long long)max(st_hn[0], st_hn[1]));
+            atomicAdd(stats + 9, (unsigned long long)max(max(st_qn[0], st_qn[1]), max(st_qn[2], st_qn[3])));
+            atomicAdd(stats + 10, (unsigned long long)(st_hn[0] + st_hn[1]));
+            atomicAdd(stats + 11, (unsigned long long)(st_qn[0] + st_qn[1] + st_qn[2] + st_qn[3]));
+            atomicAdd(stats + 12, (unsigned long long)max(st_hb[0], st_hb[1]));
+            atomicAdd(stats + 13, (unsigned long long)max(max(st_qb[0], st_qb[1]), max(st_qb[2], st_qb[3])));
+            atomicAdd(stats + 14, (unsigned long long)(st_hb[0] + st_hb[1]));
+            atomicAdd(stats + 15, (unsigned long long)(st_qb[0] + st_qb[1] + st_qb[2] + st_qb[3]));
         }
     }
     if (!AUX && inside && first_pass) {

@@ -32,6 +32,7 @@ from __future__ import annotations
 import importlib.abc
 import importlib.machinery
 import importlib.util
+import logging
 import os
 import sys
 
@@ -132,6 +133,7 @@ def empty_cache_under_pressure(min_free_fraction: float = None):
         return
     frac = float(os.environ.get("ISR_EMPTY_CACHE_MIN_FREE", "0.25")) if min_free_fraction is None else float(min_free_fraction)
     real = _REAL_EMPTY_CACHE = torch.cuda.empty_cache
+    torch.cuda._isr_real_empty_cache = real            # (arena.py's out-of-memory retry calls the original)
 
     def empty_cache():
         EMPTY_CACHE["calls"] += 1
@@ -140,9 +142,16 @@ def empty_cache_under_pressure(min_free_fraction: float = None):
             if free >= frac * total:
                 return
         EMPTY_CACHE["honoured"] += 1
+        from . import arena
+        arena.trim()                                   # the library's idle workspaces first, then torch's cache
         real()
     empty_cache.__doc__ = real.__doc__
     torch.cuda.empty_cache = empty_cache
+    # a library that changes what a torch call does says so, once (review item 11)
+    logging.getLogger("instascene_amd").warning(
+        "instascene_amd.dropin: torch.cuda.empty_cache() now returns cached memory only when less than %.0f%% of the device is free "
+        "(the reference's drivers call it every iteration; on an MI355X that costs more than the iteration). "
+        "ISR_KEEP_EMPTY_CACHE=1 or dropin.restore_empty_cache() keeps torch's behaviour.", 100 * frac)
 
 
 def restore_empty_cache():
@@ -150,6 +159,8 @@ def restore_empty_cache():
     if _REAL_EMPTY_CACHE is not None:
         import torch
         torch.cuda.empty_cache = _REAL_EMPTY_CACHE
+        if hasattr(torch.cuda, "_isr_real_empty_cache"):
+            del torch.cuda._isr_real_empty_cache
         _REAL_EMPTY_CACHE = None
 
 

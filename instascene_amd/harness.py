@@ -18,6 +18,7 @@ Geometry parameters are frozen, exactly like ``GaussianModel.training_setup`` do
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -180,6 +181,7 @@ class SegTrainer:
         # peer_exchange.PeerExchange, device-side phase flags; opt-in (ISR_EXCHANGE): never timed on a multi-GPU node
         self.exchange = _os.environ.get("ISR_EXCHANGE", "rccl")
         self._peer = None
+        self.peer_check_every = max(1, int(os.environ.get("ISR_PEER_CHECK_EVERY", "50")))
         self.last_exchange = None
         self.phase_timing = False    # multi-rank tail: record per-phase device times of each step into self.last_phases
         self.last_phases = None
@@ -638,6 +640,11 @@ class SegTrainer:
         opt.step_range(0, P)
         opt.end_step()
         p.grad = None
+        # a wait that timed out only sets a status bit and lets the stream run on (a dead peer must not wedge the GPU): read the
+        # word every `peer_check_every` steps (one blocking 4-byte read), so that replicas never diverge silently for long
+        self._peer_calls = getattr(self, "_peer_calls", 0) + 1
+        if self._peer_calls % self.peer_check_every == 0 or self.phase_timing:
+            self._peer.check_status()
         if self.phase_timing:
             self.last_exchange = {"kind": self._peer.last_kind,
                                   "bytes": self._peer.compact_bytes() if self.exchange == "peer_compact" else self._peer.last_bytes}

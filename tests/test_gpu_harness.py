@@ -280,6 +280,28 @@ def test_fused_tail_reproduces_the_separate_kernels(mode):
     rz.set_tracer(True)
 
 
+def test_seg_trainer_reference_defaults():
+    """The reference's default training configuration (arguments/__init__.py:65,103-104; train_semantic.py:115-129,143-172):
+    sample_batchsize = 32 768, seg_feat_dim = 16, multi-view leg on.  Round 4's fused tail raised at this batch size (the sparse
+    row gradient of the 3-D loss was limited to 16 384 samples); it must step, and reproduce the separate kernels bit for bit."""
+    rz.set_mode("fast")
+    rz.set_tracer(False)
+    outs = []
+    for ft in (False, True):
+        sc, cams = _scene(P=20000, F=16, W=512, H=384)     # (<= 512 samples per tile: the sampled backward's fixed-order regime)
+        tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=32 * 1024, n_labels=12, use_class_feat=True, multiview=True,
+                        sample_mv_frames=2, seed=3, fused_tail=ft)
+        assert tr.fused_tail == ft and tr.batch == 32768
+        p0 = tr.model._seg_feature.detach().clone()
+        losses = [float(tr.step(it)) for it in range(12)]          # the multi-view branch runs at it == 0 and 10
+        assert all(np.isfinite(losses)) and not torch.equal(tr.model._seg_feature.detach(), p0)
+        outs.append((losses, tr.model._seg_feature.detach().clone(), tr.opt.exp_avg.clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    rz.set_mode("exact")
+    rz.set_tracer(True)
+
+
 def test_batched_losses_change_nothing():
     """SegTrainer(batched_losses=True) evaluates the step's three contrastive losses with one sequence of launches:
     same losses, same parameters as one call per loss."""

@@ -134,6 +134,30 @@ def test_render_returns_reference_dict_and_matches_oracle():
         assert_close(out[k].cpu().numpy(), v.numpy(), 1e-4, k)
 
 
+def test_inplace_operations_on_render_outputs():
+    """The reference's rasterizer returns fresh tensors; user code may clamp or scale them in place.  With the arena on, the
+    outputs must behave the same (round 4 leased them as views created inside the autograd.Function: `image.clamp_()` raised)."""
+    import copy
+    from instascene_amd import arena
+    sc, cams, inp = small_scene(P=3000, F=8, W=640, H=480, seed=72)       # maps above arena.MIN_BYTES: leased, not torch.empty
+    pc = _PC({k: (v.cuda().requires_grad_(True) if (v is not None and v.is_floating_point()) else v) for k, v in inp.items()})
+    camg = copy.deepcopy(cams[0]).to("cuda")
+    rz.set_mode("fast")
+    before = arena.STATS["leases"]
+    out = render(camg, pc, _Pipe(), torch.zeros(3, device="cuda"))
+    assert not arena.ENABLED or arena.STATS["leases"] > before
+    img, feat = out["render"], out["seg_feature"]
+    assert img.requires_grad and img._base is None
+    ref = img.detach().clone()
+    img.clamp_(0.0, 0.5)
+    feat[1:2].mul_(2.0)
+    out["rend_alpha"].add_(1.0)
+    assert torch.equal(img.detach(), ref.clamp(0.0, 0.5))
+    (img.sum() + feat.sum()).backward()
+    assert pc._i["extra"].grad is not None and torch.isfinite(pc._i["extra"].grad).all()
+    rz.set_mode("exact")
+
+
 @pytest.mark.parametrize("N,F,eps", [(5000, 32, 1e-6), (777, 16, 1e-9), (300, 6, 1e-6), (100, 64, 1e-9)])
 def test_row_normalize_matches_torch(N, F, eps):
     from instascene_amd.contrastive import row_normalize

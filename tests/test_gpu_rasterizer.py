@@ -303,7 +303,7 @@ def hip_forward_fast_counted(inp, cam, **kw):
     EXACT's (csrc/isr_fast_pair.hpp) - the band's bound, checked on the device for every pair: must be 0."""
     import ctypes
     from instascene_amd import _lib
-    counters = torch.zeros(8, dtype=torch.int64, device="cuda")
+    counters = torch.zeros(16, dtype=torch.int64, device="cuda")
     _lib.lib().isr_forward_set_counters(ctypes.c_void_p(counters.data_ptr()))
     args, out = hip_forward(inp, cam, mode=MODE_FAST, **kw)
     torch.cuda.synchronize()
@@ -810,6 +810,43 @@ def test_sparse_row_gradient_equals_dense_index_put():
         outs.append(p.grad.clone())
     assert torch.equal(outs[0], outs[1])
     assert outs[0].abs().max() > 0
+
+
+@pytest.mark.parametrize("n,pool", [(16384, 6000), (32768, 20000), (32768, 3), (65536, 40000), (70000, 40000)])
+def test_rows_compact_at_the_reference_default_batch(n, pool):
+    """iso_rows_compact beyond round 4's 16 384 samples (the reference draws sample_batchsize = 32 768 Gaussians with replacement,
+    arguments/__init__.py:103, train_semantic.py:183-190): one entry per distinct row, repeats summed in index order = the bits of
+    index_put_(accumulate=True).  `pool = 3`: rows drawn ~11 000 times each (the repeat count needs the position field's width).
+    Beyond 65 536 the torch fallback sums in atomic order: compared to 1e-6 there."""
+    from instascene_amd.contrastive import compact_row_grads
+    P, F = 50000, 16
+    rng = np.random.RandomState(n + pool)
+    idx = rng.randint(0, pool, n)
+    idx[[5, n // 2, n - 1]] = P - 1
+    idx[[9, n // 3]] = [-4, P + 7]                    # out of range: ignored
+    vals = torch.tensor(rng.randn(n, F).astype(np.float32)).cuda()
+    idx_t = torch.tensor(idx, dtype=torch.int64).cuda()
+    ok = (idx_t >= 0) & (idx_t < P)
+    dense = torch.zeros(P, F).cuda().index_put_((idx_t[ok],), vals[ok], accumulate=True)
+    slot, merged = compact_row_grads(idx_t, vals, P)
+    slot = slot.clone().long()
+    got = torch.zeros(P, F).cuda()
+    rows = (slot >= 0).nonzero().squeeze(1)
+    got[rows] = merged[slot[rows]]
+    assert rows.numel() == len(set(int(v) for v in idx if 0 <= v < P))
+    if n <= 65536:
+        assert torch.equal(got, dense)
+        first = {}
+        for i, v in enumerate(idx):
+            first.setdefault(int(v), i)
+        assert all(int(slot[r]) == first[int(r)] for r in rows[:200].tolist())
+    else:
+        assert (got - dense).abs().max().item() <= 1e-6 * max(1.0, dense.abs().max().item()) * 64
+    # the table is the persistent one: hand it back clean for the next test
+    from instascene_amd import contrastive as _c
+    for t in _c._SLOT_TABLES.values():
+        if t.slot.shape[0] == P:
+            t.slot.fill_(-1); t.dirty = False
 
 
 def test_sampled_feature_path_through_autograd():

@@ -291,3 +291,80 @@ def test_arena_lease_ends_with_the_last_view_of_the_block():
     assert arena._class_of(arena.MIN_BYTES + 1) <= int(arena.MIN_BYTES * 1.26)
     t = arena.empty((3, 4), torch.float32, "cpu")
     assert t.shape == (3, 4) and arena.reserved_bytes() == 0
+
+
+def test_arena_leases_are_not_autograd_views():
+    """A lease is a tensor of its own on the block's storage (Tensor.set_), not a view of the block: an output of a custom
+    autograd.Function built that way takes in-place operations like the reference's fresh tensors do (round 4 handed out
+    `base[:n].view(dtype).view(shape)`, on which `image.clamp_()` raised "is a view and is being modified inplace"), and the
+    storage's reference count still ends the lease with the last tensor on it."""
+    import torch
+    from instascene_amd import arena
+    b = arena._Block.__new__(arena._Block)
+    b._adopt(torch.empty(4096, dtype=torch.uint8), 4096)
+
+    def lease(shape):
+        return torch.empty(0, dtype=torch.float32).set_(b._st, 0, shape)
+
+    class F(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            out = lease((3, 4))
+            out.copy_(x * 2)
+            return out
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2
+
+    x = torch.ones(3, 4, requires_grad=True)
+    y = F.apply(x)
+    assert not b.idle() and y._base is None and y.requires_grad
+    y.clamp_(0, 1)                       # in-place on the output
+    y[1:2].mul_(3)                       # ... and on a slice of it
+    y.sum().backward()
+    assert x.grad is not None
+    del y
+    assert b.idle()
+    # the round-4 form, for the record: it raises
+    class G(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            out = b.base[:48].view(torch.float32).view(3, 4)
+            out.copy_(x * 2)
+            return out
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2
+    z = G.apply(x)
+    import pytest
+    with pytest.raises(RuntimeError):
+        z.clamp_(0, 1)
+
+
+def test_arena_trim_asks_the_pools_own_stream():
+    """trim() must judge a block by the stream that OWNS its pool (the pool key), not by the caller's current stream: a block
+    used on a foreign stream would otherwise count as free the moment trim runs on that stream (advisor finding, round 4)."""
+    import torch
+    from instascene_amd import arena
+
+    class FakeBlock:
+        nbytes = 4096
+
+        def __init__(self):
+            self.asked = []
+            self.base = torch.empty(1)
+
+        def reusable(self, stream):
+            self.asked.append(stream)
+            return False
+
+    fb = FakeBlock()
+    key = (0, 0xABCDEF, 1 << 20)
+    arena._POOLS[key] = [fb]
+    try:
+        assert arena.trim() == 0
+        assert fb.asked == [0xABCDEF]
+    finally:
+        arena._POOLS.pop(key, None)

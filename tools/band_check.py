@@ -27,7 +27,7 @@ T_TOL = 1e-4
 def check(inp, cam, tag):
     st = oracle_forward(inp, cam, margins=True)
     st2 = oracle_forward(inp, cam, fma=True)
-    counters = torch.zeros(8, dtype=torch.int64, device="cuda")
+    counters = torch.zeros(16, dtype=torch.int64, device="cuda")
     _lib.lib().isr_forward_set_counters(ctypes.c_void_p(counters.data_ptr()))
     args, out = T.hip_forward(inp, cam, mode=T.MODE_FAST)
     torch.cuda.synchronize()
