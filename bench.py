@@ -33,7 +33,16 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md); measured co
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
 
 
-SIMDS, CLOCK_GHZ = 1024, 2.4      # MI355X: 256 CUs x 4 SIMDs; a wave64 vector instruction occupies its SIMD's issue port for 4 cycles
+SIMDS, CLOCK_GHZ = 1024, 2.4      # MI355X: 256 CUs x 4 SIMDs
+# Vector-instruction issue, MEASURED on this part (tools/micro/valu_issue.hip, profiles/r05_valu_issue.txt): wave-instructions per
+# second the whole chip sustains at 4-8 waves per SIMD.  Plain single-issue fp32 (v_fma / v_mul / v_add / v_mov): 820-850 G/s
+# (= 2.9 cycles per instruction and SIMD at the nominal 2.4 GHz; the in-kernel cycle counter says 2.1 at the 2.0-2.3 GHz the part
+# really runs at under that load - the guide's "2 cycles", MI355X_MICROARCH.md:52-54,430 - round 4 assumed 4).  Packed
+# (v_pk_fma_f32), SGPR-writing compares, v_cndmask with an SGPR mask, DPP, v_readlane: 500-570 G/s (x1.5); v_rcp / v_exp /
+# v_permlane32_swap: 290-300 G/s (x2.9); ds_read_b128: 150 G/s for any address pattern (4 cycles per CU).
+ISSUE_PEAK_PLAIN_G = 850.0
+# the blend kernel's walk, counted by class in its ISA: ~77 plain-equivalent issue slots for 66 vector instructions
+ISSUE_MIX_WEIGHT = 77.0 / 66.0
 
 
 def csrc_tree_hash():
@@ -102,6 +111,7 @@ def cpu_baseline(cfg, step, n_samples, seconds_budget=25.0):
     import numpy as np
     import oracle
     from instascene_amd import scenes
+    flags = oracle.use_native_build()          # g++ -O3 -march=native on this box; same bits as the tests' build
     F = cfg["F"] if step == "seg" else 0
 
     def build(scale):
@@ -152,7 +162,8 @@ def cpu_baseline(cfg, step, n_samples, seconds_budget=25.0):
             "(the reference does not exploit that sparsity, the GPU path does; the three losses and Adam are not in the sample)"
             if step == "seg" else "forward + dense full backward (colour + aux maps) of one view (losses and Adam not in the sample)")
     return {"value": frac / dt, "unit": "views/s", "cores": oracle.num_threads(), "cpu": cpu_model(), "kind": "port",
-            "sample": f"oracle {what}; {cfg['name']} at scale {scale:g} (P={P}, {W}x{H}, F={F}, R={R}): {n} view(s) in "
+            "build": "g++ " + flags,
+            "sample": f"oracle (g++ {flags.split(' -std')[0]}) {what}; {cfg['name']} at scale {scale:g} (P={P}, {W}x{H}, F={F}, R={R}): {n} view(s) in "
                       f"{dt * n:.1f} s" + ("" if scale == 1.0 else f"; value = measured {1.0 / dt:.3f} views/s x {frac:g} "
                                            "(work scales with P and pixels)")}
 
@@ -190,6 +201,10 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
     rasterizer.set_view_cache(args.view_cache_gb)
     scene, cams, cfg = scenes.config_scene(args.config)
     cfg["name"] = args.config
+    if getattr(args, "feat_dim", None) and args.step in ("seg", "plain") and int(args.feat_dim) != cfg["F"]:
+        # the same scene with another feature width (the reference's default seg_feat_dim is 16)
+        cfg = dict(cfg, F=int(args.feat_dim))
+        scene, cams = scenes.synthetic_scene(cfg["P"], cfg["F"], scenes.SEED_BASE + scenes.CONFIGS[args.config]["index"], cfg["mu_s"]), cams
     n_views = 16
     plain = args.step == "plain"
     if plain:
@@ -201,7 +216,8 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
                                   empty_cache=bool(getattr(args, "empty_cache", False)))
         view_index = lambda it: trainer.last_view
     elif args.step == "seg":
-        trainer = SegTrainer(scene, cams[:n_views], device=dev, sample_batchsize=8192, use_class_feat=True, rank=rank, world=world,
+        trainer = SegTrainer(scene, cams[:n_views], device=dev, sample_batchsize=int(getattr(args, "sample_batchsize", 8192)),
+                             use_class_feat=True, rank=rank, world=world,
                              spatial_sort=bool(args.spatial_sort), fused_sampling=bool(args.fused_sampling),
                              multiview=bool(getattr(args, "multiview", False)))
         trainer.split_tail = bool(args.split_tail)
@@ -342,9 +358,9 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
                 "launches_per_step": kern[dom]["launches_per_view"],
                 "hbm": {"bytes": int(dom_bytes), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 5),
                         "frac_of_measured_copy_peak_6290": round(gbs / 6290.0, 5)},
-                "note": "the blend kernel is bound by vector-instruction issue (PMC: vector pipe 72-75 % busy, LDS array 38 %, matrix "
-                        "pipe 16 %), not by HBM: one wave per 8x8 block walks its hit list serially (~830 cycles per splat at 4 waves per SIMD: 79 % of a wave's life; staging the next 32 hits 14 %, "
-                        "finding them 4 % - docs/history/DESIGN_rounds_1-3.md 9.11); `valu` is the work model",
+                "note": "frac = SURVEY 8(d): max(algorithmic bytes / 8 TB/s, model flops / 157.3 TF) of the dominant kernel.  The blend kernel "
+                        "is bound by neither but by vector-instruction issue (`issue`): one wave per 8x8 block walks its hit list "
+                        "serially with a third of the lanes of a blending evaluation blending (`valu`); DESIGN.md section 3",
                 "timing": timing, "kernels": kern,
                 "workload": {"P": P, "V": V, "R": R, "N": N, "F": F, "tiles": tiles}}
         if dom == "k_render_fwd" and pairs_eval:
@@ -373,18 +389,33 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
                 "flops": int(flops_eval), "flops_upper_bound_256R": int(flops_model),
                 "TFLOP/s": round(tf, 2), "peak_TFLOP/s": VALU_PEAK_TFLOPS, "frac": round(tf / VALU_PEAK_TFLOPS, 4),
                 "frac_with_256R_bound": round(flops_model / (dom_ms * launches * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}
+        if dom == "k_render_bwd" and args.step in ("rgb", "plain") and lane_pairs:
+            # K9 with geometry gradients (k_render_bwd_geo): SURVEY 8(d)'s flop model, 90 + 4 (16 + F) per contributing pair (the pairs
+            # the forward blended - the backward replays exactly those) + 40 per evaluated pair for the re-evaluation of alpha
+            per_c = 90.0 + 4.0 * (16 + F)
+            fl = per_c * lane_pairs + 40.0 * 64 * pairs_eval
+            tf = fl / (dom_ms * launches * 1e-3) / 1e12
+            roof["valu"] = {"pixel_splat_pairs_contributing": lane_pairs, "pixel_splat_pairs_evaluated_by_the_forward": 64 * pairs_eval,
+                            "flop_model": "SURVEY 8(d): 90 + 4*(16+F) flop per contributing pair + 40 per evaluated pair",
+                            "flops": int(fl), "TFLOP/s": round(tf, 2), "peak_TFLOP/s": VALU_PEAK_TFLOPS, "frac": round(tf / VALU_PEAK_TFLOPS, 4)}
+        # SURVEY 8(d)'s fraction: the larger of the HBM and the fp32 fraction of the dominant kernel
+        f_hbm, f_flop = roof["hbm"]["frac"], (roof.get("valu") or {}).get("frac") or 0.0
+        if f_flop > f_hbm:
+            roof.update({"bound": "fp32", "achieved": roof["valu"]["TFLOP/s"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f_flop})
+        roof["frac_hbm"], roof["frac_fp32_flops"] = f_hbm, f_flop
         if dom == "k_render_fwd" and issue and issue.get("SQ_INSTS_VALU"):
-            # what bounds the blend kernel: vector-instruction ISSUE.  A wave64 vector instruction holds its SIMD's port for 4
-            # cycles, so the chip issues at most SIMDS * clock / 4 of them per second; the count per launch is the committed PMC
-            # counter (profiles/roofline_traffic.json, taken on the tree named there), the time is this run's.
-            peak = SIMDS * CLOCK_GHZ / 4.0                            # G wave-instructions / s
+            # secondary: how close the blend kernel is to the chip's vector-instruction ISSUE rate - the count per launch is the
+            # committed PMC counter (profiles/roofline_traffic.json, taken on the tree named there), the time is this run's, the
+            # peak the measured one above
             ach = issue["SQ_INSTS_VALU"] / (dom_ms * 1e-3) / 1e9
-            roof.update({"bound": "valu_issue", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "G wave-instructions/s",
-                         "frac": round(ach / peak, 4),
-                         "issue": dict({k: v for k, v in issue.items() if k != "source"}, source=issue.get("source"),
-                                       model="achieved = SQ_INSTS_VALU per launch / this run's launch time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles "
-                                             "per wave64 instruction"),
-                         "frac_hbm": roof["hbm"]["frac"], "frac_fp32_flops": (roof.get("valu") or {}).get("frac")})
+            roof["issue"] = dict({k: v for k, v in issue.items() if k != "source"}, source=issue.get("source"),
+                                 achieved_G_wave_instructions_per_s=round(ach, 1), peak_plain_fp32_G_per_s=ISSUE_PEAK_PLAIN_G,
+                                 issue_frac=round(ach / ISSUE_PEAK_PLAIN_G, 4),
+                                 issue_frac_mix_weighted=round(ach * ISSUE_MIX_WEIGHT / ISSUE_PEAK_PLAIN_G, 4),
+                                 model="achieved = SQ_INSTS_VALU per launch / this run's launch time; peak = the chip's measured rate of "
+                                       "plain fp32 vector instructions (tools/micro/valu_issue.hip, profiles/r05_valu_issue.txt); "
+                                       "mix_weighted prices the kernel's packed / SGPR-writing / transcendental instructions at their "
+                                       "measured cost (x1.5 / x1.5 / x2.9)")
         rec["roofline"] = roof
         rec["cfg"] = cfg
     if world > 1 and args.step == "seg":
@@ -446,6 +477,9 @@ def main():
     ap.add_argument("--multiview", type=int, default=0,
                     help="seg step: 1 = with the reference's multi-view leg every 10th iteration (5 more views rendered with "
                          "gradients, train_semantic.py:143-172); the headline is the single-view step, this is sub_records.C3_multiview")
+    ap.add_argument("--sample-batchsize", dest="sample_batchsize", type=int, default=8192,
+                    help="seg step: samples per loss (BASELINE config 3 names 8 192; the reference's default is 32 768)")
+    ap.add_argument("--feat-dim", dest="feat_dim", type=int, default=None, help="seg step: feature width instead of the config's")
     ap.add_argument("--empty-cache", dest="empty_cache", type=int, default=0, help="plain step: torch.cuda.empty_cache() every iteration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tracer", type=int, default=1, help="produce gau_related_pixels each forward like the reference")
@@ -537,9 +571,11 @@ def main():
         r["dominant_kernel"] = roof.get("kernel")
         r["dominant_kernel_ms"] = roof.get("avg_launch_ms")
         r["dominant_kernel_launches_per_step"] = roof.get("launches_per_step")
-        r["dominant_kernel_frac_hbm"] = roof.get("frac")
+        r["dominant_kernel_roofline_frac"] = roof.get("frac")        # max(HBM, fp32) fraction
+        r["dominant_kernel_frac_hbm"] = roof.get("frac_hbm")
+        r["dominant_kernel_frac_fp32_flops"] = roof.get("frac_fp32_flops")
         if "valu" in roof:
-            r["dominant_kernel_frac_valu"] = roof["valu"].get("frac")
+            r["dominant_kernel_flop_model"] = {k: roof["valu"].get(k) for k in ("flop_model", "flops", "TFLOP/s", "pixel_splat_pairs_contributing")}
         r["R"] = roof.get("workload", {}).get("R")
         r["V"] = roof.get("workload", {}).get("V")
         r["kernels_ms_x_launches_per_step"] = {k: [v["ms_per_launch"], v["launches_per_view"]] for k, v in roof.get("kernels", {}).items()}
@@ -592,6 +628,9 @@ def main():
             sub("C2_rgb", config="C2", step="rgb", steps=200, warmup=10, note="BASELINE config 2: the train.py step")
             sub("C3_rgb", config="C3", step="rgb", steps=50, warmup=5, note="the train.py step at C3 size")
             sub("C5_seg", config="C5", step="seg", steps=50, warmup=5, note="BASELINE config 5 in its 1-GPU form (F = 64: one 64-channel feature pass)")
+            sub("reference_defaults", steps=40, warmup=10, multiview=True, sample_batchsize=32 * 1024, feat_dim=16,
+                note="the reference's default training configuration at C3 size (arguments/__init__.py:65,103-104): seg_feat_dim = 16, "
+                     "sample_batchsize = 32 768, multi-view leg on (every 10th iteration); 40 steps = 4 such iterations")
 
     if rank == 0:
         cfg = head.pop("cfg")
@@ -656,6 +695,21 @@ def main():
                               if args.step == "seg" else
                               ["targets = initial renders + noise", "the cameras' ray tables, each view's verified tile-instance count"])},
                "roofline": roof}
+        # the contract numbers as NUMERIC keys of `config` (the driver's record keeps `config`, not `sub_records`)
+        val = lambda k: (subs.get(k) or {}).get("value")
+        out["config"].update({
+            "integer_state": {"fast": "tiles_touched / point_list / ranges / num_rendered / n_contrib are order-preserving "
+                                      "subsequences of the reference's (same output bits as on the reference's lists)",
+                              "fast_tight": "as fast", "fast_reflists": "the reference's, bit for bit",
+                              "exact": "the reference's, bit for bit"}[args.mode],
+            "views_per_s_exact": val("exact"), "views_per_s_reference_tile_lists": val("fast_reflists"),
+            "views_per_s_unmodified_driver": val("dropin_plain_fast"),
+            "views_per_s_unmodified_driver_with_empty_cache": val("dropin_plain_fast_empty_cache"),
+            "views_per_s_C2_rgb": val("C2_rgb"), "views_per_s_C3_rgb": val("C3_rgb"), "views_per_s_C5_seg": val("C5_seg"),
+            "views_per_s_C3_multiview": val("C3_multiview"), "views_per_s_reference_defaults": val("reference_defaults"),
+            "views_per_s_soak_500": val("soak_500"),
+            "roofline_frac_C2_rgb_k_render_bwd_geo": (subs.get("C2_rgb") or {}).get("dominant_kernel_roofline_frac"),
+            "roofline_frac_C5_seg": (subs.get("C5_seg") or {}).get("dominant_kernel_roofline_frac")})
         if subs.get("dropin_plain_fast") or subs.get("dropin_plain_fast_empty_cache"):
             # what a maintainer gets who installs the drop-in and runs train_semantic.py unmodified (harness.PlainSegTrainer;
             # details in sub_records): next to the headline, not only inside the long sub_records object

@@ -114,9 +114,15 @@ class _RenderPost(torch.autograd.Function):
         L = _lib.lib()
         am = allmap.contiguous().float()
         _, H, W = am.shape
-        # one allocation, seven [C,H,W] views
-        alpha, normal, dist, surf, snorm, depth, median = torch.empty((11, H, W), dtype=torch.float32,
-                                                                      device=am.device).split((1, 3, 1, 1, 3, 1, 1))
+        # one allocation, seven [C,H,W] tensors on it - tensors of their own on the block's storage (Tensor.set_), NOT views of
+        # it: autograd forbids in-place operations on views a custom Function returns, and user code may clamp / scale the
+        # maps in place as it can with the reference's (gaussian_renderer/__init__.py:127-167 builds them with torch ops)
+        block = torch.empty((11, H, W), dtype=torch.float32, device=am.device)
+        st, parts, ch = block.untyped_storage(), [], 0
+        for c in (1, 3, 1, 1, 3, 1, 1):
+            parts.append(torch.empty(0, dtype=torch.float32, device=am.device).set_(st, block.storage_offset() + ch * H * W, (c, H, W)))
+            ch += c
+        alpha, normal, dist, surf, snorm, depth, median = parts
         vm = viewmatrix.contiguous().float()
         with _hot.on_device(am.device):
             _lib.check(L.iso_render_post_forward(W, H, float(depth_ratio), _ptr(am), _ptr(vm), _ptr(rays_d), _ptr(rays_o),

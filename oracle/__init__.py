@@ -63,6 +63,39 @@ def lib():
     return _lib
 
 
+NATIVE_FLAGS = "-O3 -march=native -std=c++17 -fPIC -shared -fopenmp -ffp-contract=off -fno-fast-math"
+BUILD_FLAGS = "-O2 -std=c++17 -fPIC -shared -fopenmp -mfma -ffp-contract=off -fno-fast-math"
+_native = None
+
+
+def use_native_build() -> str:
+    """bench.py's cpu_baseline only: rebuild the same source ON THIS MACHINE with the flags SURVEY 8(d) names (-O3 -march=native;
+    contraction still off, so the results keep their bits) and route forward / backward through it.  The default build (-O2,
+    portable: it travels prebuilt to another box) stays what the tests check against.  Returns the flags in use."""
+    global _lib, _native
+    if _native is not None:
+        return _native
+    import hashlib
+    try:
+        cpu = [l for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        cpu = "unknown"
+    out = os.path.join(_HERE, "_build", "libsurfel_oracle_native_%s.so" % hashlib.sha1(cpu.encode()).hexdigest()[:8])
+    src = os.path.join(_HERE, "surfel_oracle.cpp")
+    try:
+        if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            subprocess.check_call([os.environ.get("CXX", "g++")] + NATIVE_FLAGS.split() + [src, "-o", out])
+        nat = ctypes.CDLL(out)
+        nat.so_bin.restype = c_int64
+        nat.so_num_threads.restype = c_int
+        _lib, _native = nat, NATIVE_FLAGS
+    except Exception:
+        lib()
+        _native = BUILD_FLAGS + " (the -O3 -march=native build failed on this machine)"
+    return _native
+
+
 def _p(a, ty=None):
     if a is None:
         return None
