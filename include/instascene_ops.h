@@ -151,10 +151,11 @@ int iso_adam_rownorm2(long long N, int F, double lr, double beta1, double beta2,
  * features with replacement) kept sparse: slot[P] (int32) is set to -1, then for every distinct valid idx[i] the FIRST
  * position i becomes slot[idx[i]] = i and merged[i, :] = sum of vals[j, :] over all j with idx[j] == idx[i], ascending j
  * (the order of index_put_(accumulate=True)).  Rows of `merged` that are not a slot target are not written.
- * n <= 65536 (the reference's default sample_batchsize is 32 768).  Consumed by isr_feature_rows_step(gy_slot, gy_merged), which resets the entries it reads: slot_is_clean != 0
+ * n <= 65536 (the reference's default sample_batchsize is 32 768).  Consumed by isr_feature_rows_step(gy_slot, gy_merged), which resets the entries it reads.
+ * `chain`: n ints of scratch (the occurrences of a repeated row find each other through it).  slot_is_clean != 0
  * says the table is all -1 already (a persistent table whose last contents were consumed) and skips the fill. */
 int iso_rows_compact(int n, int F, long long P, const long long* idx, const float* vals, int* slot /*[P]*/,
-                     float* merged /*[n,F]*/, int slot_is_clean, void* stream);
+                     float* merged /*[n,F]*/, int* chain /*[n] scratch*/, int slot_is_clean, void* stream);
 
 /* The optimiser step of the train.py loop (scene/gaussian_model.py:206-253: torch.optim.Adam(lr = 0, eps = 1e-15) over six
  * parameter groups; train.py:153-156) as ONE pass, with the chain rule in front of it and the next forward's activations

@@ -79,7 +79,7 @@ SIGNATURES = {
     "iso_gather_rownorm": (c_int, [c_int, c_int, ctypes.c_longlong, c_float, _P, _P, _P, _P]),
     "iso_sample_step": (c_int, [ctypes.c_ulonglong, ctypes.c_ulonglong, c_int, ctypes.c_longlong, _P, _P, _P, ctypes.c_longlong, _P,
                                 _P, _P, _P, _P, _P, _P, _P]),
-    "iso_rows_compact": (c_int, [c_int, c_int, ctypes.c_longlong, _P, _P, _P, _P, c_int, _P]),
+    "iso_rows_compact": (c_int, [c_int, c_int, ctypes.c_longlong, _P, _P, _P, _P, _P, c_int, _P]),
     "iso_adam_rownorm2": (c_int, [ctypes.c_longlong, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                   ctypes.c_longlong, c_float,
                                   c_float, _P, _P, _P, _P, _P, _P, _P]),

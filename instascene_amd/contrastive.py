@@ -322,8 +322,9 @@ def compact_row_grads(idx: torch.Tensor, vals: torch.Tensor, P: int):
         table.dirty, table.covered = rows.shape[0] > 0, 0
         return table.slot, merged
     merged = torch.empty_like(vals)
+    chain = torch.empty(max(1, idx.shape[0]), dtype=torch.int32, device=vals.device)       # scratch of the call
     with _hot.on_device(vals.device):
-        check(lib().iso_rows_compact(idx.shape[0], vals.shape[1], P, _p(idx), _p(vals), _p(table.slot), _p(merged),
+        check(lib().iso_rows_compact(idx.shape[0], vals.shape[1], P, _p(idx), _p(vals), _p(table.slot), _p(merged), _p(chain),
                                      0 if table.dirty else 1, _stream()), "iso_rows_compact")
     table.dirty, table.covered = idx.shape[0] > 0, 0
     return table.slot, merged

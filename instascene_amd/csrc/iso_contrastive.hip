@@ -811,14 +811,19 @@ __global__ __launch_bounds__(1024) void rows_compact_kernel(int n, int F, long l
 // the step - 59 us on average in the C3 step against 16 us alone, profiles/r03c_kernel_stats_C3_seg.csv):
 //   rows_first_kernel   slot[row] = min i over the occurrences of the row (unsigned atomicMin on the 0xFFFFFFFF-filled table:
 //                       -1 stays "no entry");
-//   rows_copy_kernel    merged = vals, and every later occurrence counts itself in bits 14.. of its row's slot;
-//   rows_merge_kernel   a wave per sample: a row drawn twice gets its second occurrence added by that occurrence's wave, a row
-//                       drawn three times or more by its head's wave in ascending position - the order of
-//                       index_put_(accumulate=True) and of rows_compact_kernel, hence the same bits; the count is cleared.
-// slot while the three kernels run: repeats << pos_bits | first position.  pos_bits = 14 up to 16 384 samples (the rounds 3-4 layout)
-// and ceil(log2 n) beyond: a row has at most n - 1 < 2^pos_bits repeats, so both fields fit 32 bits up to ROWS_SPLIT_MAX samples
-// (the reference's default sample_batchsize is 32 768, arguments/__init__.py:103), and 0xFFFFFFFF stays "no entry".
+//   rows_copy_kernel    merged = vals, and every later occurrence e of a row hangs itself into the row's chain: the slot's
+//                       upper field becomes e, chain[e] = what it held before (0 = end of the chain: position 0 is always a
+//                       first occurrence);
+//   rows_merge_kernel   a wave per sample; only heads with a chain work: they walk it (<= ROWS_CHAIN_MAX hops), put the
+//                       positions in ascending order - the order of index_put_(accumulate=True) and of rows_compact_kernel,
+//                       hence the same bits - and add those rows; a longer chain falls back to a scan of the index list.
+// Round 4 counted the repeats in the upper field and let the head of a row drawn three times or more scan the whole list for
+// them: one such row (expected: four per launch at the reference's 32 768 samples) held the launch for 110-190 us.
+// slot while the three kernels run: last chained position << pos_bits | first position.  pos_bits = 14 up to 16 384 samples
+// and ceil(log2 n) beyond: both fields fit 32 bits up to ROWS_SPLIT_MAX samples (the reference's default sample_batchsize is
+// 32 768, arguments/__init__.py:103), and 0xFFFFFFFF stays "no entry" (last > first).
 constexpr int ROWS_SPLIT_MAX = 65536;
+constexpr int ROWS_CHAIN_MAX = 48;          // occurrences of one row merged from its chain (one lane each); more: the scan
 inline int rows_pos_bits(int n) { int b = 14; while ((1 << b) < n) b++; return b; }
 __global__ __launch_bounds__(256) void rows_first_kernel(int n, long long P, const long long* __restrict__ idx, unsigned* __restrict__ slot) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -828,8 +833,8 @@ __global__ __launch_bounds__(256) void rows_first_kernel(int n, long long P, con
 }
 __global__ __launch_bounds__(256) void rows_copy_kernel(int n, int F, long long P, const long long* __restrict__ idx,
                                                         const float* __restrict__ vals, unsigned* __restrict__ slot,
-                                                        float* __restrict__ merged, int pos_bits) {
-    const unsigned ROWS_POS_MASK = (1u << pos_bits) - 1u, ROWS_REPEAT_ONE = 1u << pos_bits;
+                                                        float* __restrict__ merged, int pos_bits, unsigned* __restrict__ chain) {
+    const unsigned POS_MASK = (1u << pos_bits) - 1u;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x, total = (long long)n * F;
     if ((F & 3) == 0) {
         if (4 * e < total) reinterpret_cast<float4*>(merged)[e] = reinterpret_cast<const float4*>(vals)[e];
@@ -838,46 +843,69 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(int n, int F, long long 
     }
     if (e < n) {
         const long long v = idx[e];
-        if (v >= 0 && v < P && (slot[v] & ROWS_POS_MASK) != (unsigned)e) atomicAdd(slot + v, ROWS_REPEAT_ONE);
+        unsigned before = 0u;
+        if (v >= 0 && v < P) {
+            unsigned old = slot[v];
+            if ((old & POS_MASK) != (unsigned)e) {           // a later occurrence: the new end of its row's chain
+                while (true) {
+                    const unsigned seen = atomicCAS(slot + v, old, ((unsigned)e << pos_bits) | (old & POS_MASK));
+                    if (seen == old) break;
+                    old = seen;
+                }
+                before = old >> pos_bits;
+            }
+        }
+        chain[e] = before;
     }
 }
 __global__ __launch_bounds__(256) void rows_merge_kernel(int n, int F, long long P, const long long* __restrict__ idx,
                                                          const float* __restrict__ vals, unsigned* __restrict__ slot,
-                                                         float* __restrict__ merged, int pos_bits) {
-    const unsigned ROWS_POS_MASK = (1u << pos_bits) - 1u;
+                                                         float* __restrict__ merged, int pos_bits, const unsigned* __restrict__ chain) {
+    const unsigned POS_MASK = (1u << pos_bits) - 1u;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
     const long long v = idx[i];
     if (v < 0 || v >= P) return;
     const unsigned sv = slot[v];
-    const unsigned first = sv & ROWS_POS_MASK, repeats = sv >> pos_bits;
-    if (repeats == 0u) return;                                   // the row was drawn once
-    if (repeats == 1u) {
-        // drawn twice (nearly every repeat): the SECOND occurrence adds itself to the head's row - four dependent memory round
-        // trips instead of the head's scan of the whole index list for it
-        if ((unsigned)i != first) {
-            for (int c = lane; c < F; c += 64) merged[(size_t)first * F + c] += vals[(size_t)i * F + c];
-            if (lane == 0) slot[v] = first;
-        }
-        return;
-    }
-    if ((unsigned)i != first) return;                            // three or more: the head adds them in ascending position
+    const unsigned first = sv & POS_MASK;
+    unsigned e = sv >> pos_bits;
+    if (e == 0u || (unsigned)i != first) return;                  // drawn once, or not the row's head
     float* dst = merged + (size_t)i * F;
-    constexpr int U = 16;                       // index loads in flight per lane (one dependent round trip per 1 024 entries)
-    for (int j0 = i + 1; j0 < n; j0 += 64 * U) {
-        long long w[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int j = j0 + 64 * u + lane;
-            w[u] = j < n ? idx[j] : -1;
+    // walk the chain (arrival order); lane k keeps the k-th position
+    unsigned mine = 0xffffffffu;
+    int cnt = 0;
+    while (e != 0u && cnt < ROWS_CHAIN_MAX) {
+        if (lane == cnt) mine = e;
+        cnt++;
+        e = chain[e];
+    }
+    if (e == 0u) {
+        // ascending position: rank of every kept position among the kept ones (positions are distinct)
+        int rank = 0;
+        for (int k = 0; k < cnt; k++) rank += (unsigned)__shfl((int)mine, k) < mine ? 1 : 0;
+        for (int r = 0; r < cnt; r++) {
+            const unsigned long long who = __ballot(lane < cnt && rank == r);
+            const unsigned jj = (unsigned)__shfl((int)mine, __builtin_ctzll(who));
+            for (int c = lane; c < F; c += 64) dst[c] += vals[(size_t)jj * F + c];
         }
+    } else {
+        // a row drawn more than ROWS_CHAIN_MAX times: scan the rest of the index list, U loads in flight per lane
+        constexpr int U = 32;
+        for (int j0 = i + 1; j0 < n; j0 += 64 * U) {
+            long long w[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            unsigned long long m = __ballot(w[u] == v);
-            while (m != 0ull) {                 // ascending position
-                const int jj = j0 + 64 * u + __builtin_ctzll(m);
-                m &= m - 1ull;
-                for (int c = lane; c < F; c += 64) dst[c] += vals[(size_t)jj * F + c];
+            for (int u = 0; u < U; u++) {
+                const int j = j0 + 64 * u + lane;
+                w[u] = j < n ? idx[j] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                unsigned long long m = __ballot(w[u] == v);
+                while (m != 0ull) {                 // ascending position
+                    const int jj = j0 + 64 * u + __builtin_ctzll(m);
+                    m &= m - 1ull;
+                    for (int c = lane; c < F; c += 64) dst[c] += vals[(size_t)jj * F + c];
+                }
             }
         }
     }

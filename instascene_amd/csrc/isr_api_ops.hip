@@ -412,11 +412,11 @@ int iso_sample_step(unsigned long long seed, unsigned long long step, int B, lon
 }
 
 int iso_rows_compact(int n, int F, long long P, const long long* idx, const float* vals, int* slot, float* merged,
-                     int slot_is_clean, void* stream) {
+                     int* chain, int slot_is_clean, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (n < 0 || F <= 0 || P < 0) return fail(ISR_EINVAL, "rows_compact: bad sizes");
     if (P > 0 && !slot) return fail(ISR_EINVAL, "rows_compact: null slot table");
-    if (n > 0 && (!idx || !vals || !merged)) return fail(ISR_EINVAL, "rows_compact: null pointer");
+    if (n > 0 && (!idx || !vals || !merged || !chain)) return fail(ISR_EINVAL, "rows_compact: null pointer");
     if (P > 0 && !slot_is_clean && hipMemsetAsync(slot, 0xFF, sizeof(int) * (size_t)P, s) != hipSuccess) return fail(ISR_EHIP, "rows_compact: memset failed");
     if (n == 0 || P == 0) return ISR_OK;
     if (n > iso::ROWS_SPLIT_MAX) return fail(ISR_EINVAL, "rows_compact: at most %d rows", iso::ROWS_SPLIT_MAX);
@@ -431,9 +431,9 @@ int iso_rows_compact(int n, int F, long long P, const long long* idx, const floa
     hipLaunchKernelGGL(iso::rows_first_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, P, idx, us);
     ISR_LAUNCH_CHECK("rows_first_kernel");
     const long long quads = ((long long)n * F + 3) / 4;
-    hipLaunchKernelGGL(iso::rows_copy_kernel, dim3((unsigned)((std::max<long long>(quads, n) + 255) / 256)), dim3(256), 0, s, n, F, P, idx, vals, us, merged, pos_bits);
+    hipLaunchKernelGGL(iso::rows_copy_kernel, dim3((unsigned)((std::max<long long>(quads, n) + 255) / 256)), dim3(256), 0, s, n, F, P, idx, vals, us, merged, pos_bits, reinterpret_cast<unsigned*>(chain));
     ISR_LAUNCH_CHECK("rows_copy_kernel");
-    hipLaunchKernelGGL(iso::rows_merge_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, F, P, idx, vals, us, merged, pos_bits);
+    hipLaunchKernelGGL(iso::rows_merge_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, F, P, idx, vals, us, merged, pos_bits, reinterpret_cast<const unsigned*>(chain));
     ISR_LAUNCH_CHECK("rows_merge_kernel");
     return ISR_OK;
 }

@@ -406,6 +406,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     if (r1 > capacity) r1 = capacity;
     const int len = (int)(r1 - r0);
     const int nfeat = FEAT ? min(FCH, ED - ch_base) : 0;
+    if (FEAT && nfeat < FCH && (ED & 3) == 0 && (nfeat & 3) == 0) {      // narrow chunk: the channels the staging never writes
+        for (int e = lane; e < NH * FCH / 4; e += 64) reinterpret_cast<float4*>(s_feat)[e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
 
     unsigned long long m_done = __ballot(!inside);
     float T = 1.0f;
@@ -525,7 +528,17 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                     const int e = lane + 64 * k;
                     if (e < nh * (FCH / 4)) reinterpret_cast<float4*>(s_feat)[e] = fv[k];
                 }
-            } else {                    // narrow or ragged chunk: zero-padded to 32 channels
+            } else if ((ED & 3) == 0 && (nfeat & 3) == 0) {
+                // a narrow chunk of whole float4s (the reference's default seg_feat_dim = 16, arguments/__init__.py:65): 16-byte
+                // requests for the channels that exist; the rows' upper channels were zeroed once, before the first round
+                const int q4 = nfeat >> 2;
+                for (int e = lane; e < nh * q4; e += 64) {
+                    const int inst = e / q4, part = e - inst * q4;
+                    const int id = s_ring[(head + inst) & (FW_RING - 1)].x;
+                    reinterpret_cast<float4*>(s_feat)[inst * (FCH / 4) + part] =
+                        *reinterpret_cast<const float4*>(extras + (size_t)id * ED + ch_base + part * 4);
+                }
+            } else {                    // ragged chunk: zero-padded to 32 channels
                 for (int e = lane; e < nh * FCH; e += 64) {
                     const int inst = e / FCH, c = e - inst * FCH;
                     const int id = s_ring[(head + inst) & (FW_RING - 1)].x;
