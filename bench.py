@@ -7,12 +7,12 @@
   forward, two single-view contrastive losses on 8 192 sampled pixels each, the 3-D contrastive loss, backward, Adam on
   the [P,F] feature.  ``--step rgb`` (C2 = BASELINE config 2, also C1 / C3): the train.py step - render, L1 + SSIM +
   normal consistency, full geometry backward, Adam on the six parameter groups.
-* ``--mode fast`` (default, the headline): FAST arithmetic in the per-pixel loops (decisions are EXACT's by construction,
-  images within 1e-4, gradients within 1e-3) on tile lists that hold a splat only where its alpha >= 1/255 box reaches - the
-  kernels walk the same (block, splat) pairs as with the reference's rectangles, so every output except the last bits of the
-  distortion channel is the same.  At one GPU the same line also carries ``sub_records`` for ``exact`` (op-for-op IEEE, all
-  integer state and images bit-identical to the CPU oracle) and ``fast_reflists`` (FAST on the reference's rectangles:
-  radii, tiles_touched, point_list and ranges bit-identical to the reference's), timed the same way.
+* ``--mode fast_reflists`` (default, the headline, = the library's shipped default): FAST arithmetic in the per-pixel loops
+  (decisions are EXACT's by construction, images within 1e-4, gradients within 1e-3) on the REFERENCE's tile rectangles: radii,
+  tiles_touched, point_list, ranges and num_rendered bit-identical to the reference's.  At one GPU the same line also carries
+  ``sub_records`` for ``exact`` (op-for-op IEEE, all integer state and images bit-identical to the CPU oracle) and ``fast``
+  (opt-in: tile lists that hold a splat only where its alpha >= 1/255 box reaches - the kernels walk the same (block, splat)
+  pairs, so every output except the last bits of the distortion channel is the same; ~2 % faster), timed the same way.
 * ``--gpus N`` > 1 without a launcher re-executes itself under ``torch.distributed.run`` (one rank per GPU, RCCL); under
   a launcher (WORLD_SIZE set) it is a rank.  Every rank renders a different view per step (weak scaling); the parameter
   gradients are summed across ranks.  Rank 0 prints ONE JSON line.
@@ -29,6 +29,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+DEFAULT_MODE = "fast_reflists"  # the library's shipped default: FAST arithmetic on the reference's tile lists (integer state bit-exact)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md); measured copy peak ~6290 GB/s
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
 
@@ -468,8 +469,8 @@ def main():
     ap.add_argument("--step", default=None, choices=[None, "seg", "rgb", "plain"],
                     help="seg: train_semantic.py step (needs a feature channel: C3, C5); rgb: train.py step (C1, C2, C3); "
                          "plain (sub-records): the reference's train_semantic.py iteration on the drop-in functions alone")
-    ap.add_argument("--mode", default=os.environ.get("ISR_MODE", "fast"), choices=["fast", "exact", "fast_reflists", "fast_tight"])
-    ap.add_argument("--submodes", default="exact,fast_reflists,fast+feature_only",
+    ap.add_argument("--mode", default=os.environ.get("ISR_MODE", DEFAULT_MODE), choices=["fast", "exact", "fast_reflists", "fast_tight"])
+    ap.add_argument("--submodes", default="exact,fast,fast+feature_only",
                     help="at one GPU: further modes timed the same way and reported as sub_records ('' = none)")
     ap.add_argument("--more", type=int, default=1,
                     help="1 (default, C3 seg at one GPU): also time the other BASELINE configs (C2 rgb, C5 seg), the step with the "
@@ -607,16 +608,16 @@ def main():
             plain_note = ("harness.PlainSegTrainer: the reference's iteration as the reference writes it (train_semantic.py:95-208) on "
                           "render() and contrastive_loss() alone, library defaults (blocking instance-count read, tracer on), "
                           "multi-view leg every 10th iteration, torch.optim.Adam; 30 steps = 3 multi-view iterations")
-            sub("dropin_plain_fast", mode="fast", step="plain", steps=30, warmup=10, note=plain_note + "; the drop-in's default mode")
+            sub("dropin_plain_fast", mode=DEFAULT_MODE, step="plain", steps=30, warmup=10, note=plain_note + "; the drop-in's default mode (fast_reflists)")
             sub("dropin_plain_exact", mode="exact", step="plain", steps=30, warmup=10, note=plain_note + "; ISR_MODE=exact")
             from instascene_amd import dropin as _dropin
             _dropin.empty_cache_under_pressure()          # what dropin.install() does for the unmodified driver
-            sub("dropin_plain_fast_empty_cache", mode="fast", step="plain", steps=30, warmup=10, empty_cache=True,
+            sub("dropin_plain_fast_empty_cache", mode=DEFAULT_MODE, step="plain", steps=30, warmup=10, empty_cache=True,
                 note=plain_note + "; plus torch.cuda.empty_cache() every iteration like the reference (:206), under the drop-in as "
                      "installed: the library's buffers live in its own arena (arena.py) and install() makes empty_cache() act only "
                      "under memory pressure (dropin.empty_cache_under_pressure)")
             _dropin.restore_empty_cache()
-            sub("dropin_plain_fast_empty_cache_honoured", mode="fast", step="plain", steps=30, warmup=10, empty_cache=True,
+            sub("dropin_plain_fast_empty_cache_honoured", mode=DEFAULT_MODE, step="plain", steps=30, warmup=10, empty_cache=True,
                 note=plain_note + "; ISR_KEEP_EMPTY_CACHE=1: torch's own empty_cache() every iteration - the library's buffers stay in "
                      "the arena, the reference's torch temporaries (~9 device allocations per iteration) go back to the driver and "
                      "are hipMalloc-ed again; this record measures the driver (it slows down with the process's allocation count)")
@@ -702,7 +703,9 @@ def main():
                                       "subsequences of the reference's (same output bits as on the reference's lists)",
                               "fast_tight": "as fast", "fast_reflists": "the reference's, bit for bit",
                               "exact": "the reference's, bit for bit"}[args.mode],
-            "views_per_s_exact": val("exact"), "views_per_s_reference_tile_lists": val("fast_reflists"),
+            "views_per_s_exact": val("exact"),
+            "views_per_s_reference_tile_lists": head["value"] if args.mode == "fast_reflists" else val("fast_reflists"),
+            "views_per_s_tight_tile_lists": head["value"] if args.mode in ("fast", "fast_tight") else val("fast"),
             "views_per_s_unmodified_driver": val("dropin_plain_fast"),
             "views_per_s_unmodified_driver_with_empty_cache": val("dropin_plain_fast_empty_cache"),
             "views_per_s_C2_rgb": val("C2_rgb"), "views_per_s_C3_rgb": val("C3_rgb"), "views_per_s_C5_seg": val("C5_seg"),

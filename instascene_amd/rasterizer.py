@@ -15,6 +15,7 @@ import contextlib
 import ctypes
 import weakref
 import os
+import sys
 from typing import NamedTuple, Optional
 
 import torch
@@ -23,9 +24,12 @@ import torch.nn as nn
 from . import _hot, _lib, arena
 from ._lib import GRAD_EXTRA, GRAD_GEOMETRY, MODE_EXACT, MODE_FAST, MODE_FEATURE_ONLY, MODE_PREBINNED, check, lib
 
-_ENV_MODE = os.environ.get("ISR_MODE", "fast").lower()
+# The shipped default is "fast_reflists": FAST arithmetic on the REFERENCE's tile rectangles, so that radii, tiles_touched, point_list,
+# ranges and num_rendered are the reference's bit for bit (north-star: "bit-exact tile/sort indices").  ISR_MODE=fast selects the
+# shorter lists described below (same output bits, ~2 % faster step, integer state = subsequences of the reference's).
+_ENV_MODE = os.environ.get("ISR_MODE", "fast_reflists").lower()
 _CONFIG = {
-    # arithmetic mode of the per-pixel loops: "fast" (the default) or "exact" (ISR_MODE=exact: op-for-op IEEE in the reference's
+    # arithmetic mode of the per-pixel loops: FAST (the default) or "exact" (ISR_MODE=exact: op-for-op IEEE in the reference's
     # operation order, bit-identical to the CPU oracle, 1.9x slower blend).  FAST (csrc/isr_fast_pair.hpp) keeps EXACT's own two
     # roundings where they dominate (k.z, l.z of the ray-splat intersection), uses fused multiply-adds, v_rcp_f32 and v_exp_f32
     # elsewhere (the reference's nvcc build contracts to FMA too but keeps IEEE division and libdevice expf: FAST goes beyond
@@ -35,7 +39,7 @@ _CONFIG = {
     # 1 of 2.3 M pixels differs from the oracle in its last / median contributor or beyond 1e-4 (a T < 1e-4 stop; the full-size
     # C3 view: 4 of 2 073 600), no gradient row beyond 1e-3.  Forward and backward take identical per-pixel decisions.
     "mode": MODE_EXACT if _ENV_MODE == "exact" else MODE_FAST,
-    # FAST bins a splat only into the tiles its alpha >= 1/255 box reaches (ISR_PREPARE_TIGHT_RECTS) - the box the blend and
+    # opt-in (ISR_MODE=fast / set_mode("fast")): FAST bins a splat only into the tiles its alpha >= 1/255 box reaches (ISR_PREPARE_TIGHT_RECTS) - the box the blend and
     # backward kernels already apply per 8x8 block (k_pack_hits' masks), so they walk exactly the same (block, splat) pairs in the
     # same order as with the reference's square rectangles: image, allmap channels 0-5, feature map, radii, tracer pairs and the
     # dense geometry gradients are the same bits (tests/test_gpu_rasterizer.py::test_tight_rectangles_change_no_output_bit, every
@@ -44,7 +48,7 @@ _CONFIG = {
     # associate their products differently (1e-7 of the maximum).  Tile lists are order-preserving SUBSEQUENCES of the
     # reference's (8-19 % fewer instances to count, scatter, sort and pack at C2 / C3), num_rendered is their total.  "fast_reflists" (or ISR_TIGHT_RECTS=0) keeps the reference's
     # rectangles: tiles_touched, point_list and ranges then equal the reference's bit for bit, as they always do in EXACT mode.
-    "tight_rects": _ENV_MODE != "fast_reflists" and os.environ.get("ISR_TIGHT_RECTS", "1") != "0",
+    "tight_rects": _ENV_MODE in ("fast", "fast_tight") and os.environ.get("ISR_TIGHT_RECTS", "1") != "0",
     # produce the (gaussian, pixel) tracer list like the reference does on every forward
     "tracer": os.environ.get("ISR_TRACER", "1") != "0",
     # size the binning workspace from the previous view's instance count (+25 %) instead of a blocking
@@ -61,9 +65,13 @@ LAST_NUM_RENDERED = 0   # instance count of the most recent forward (reporting o
 
 
 def set_mode(mode: str):
-    """"exact" | "fast" | "fast_reflists" (see _CONFIG; "fast_tight", the former opt-in name of today's "fast", is accepted)."""
+    """"exact" | "fast_reflists" (the shipped default: FAST arithmetic, the reference's tile lists) | "fast" (= "fast_tight": FAST
+    arithmetic on the shorter lists, see _CONFIG)."""
     _CONFIG["mode"] = {"exact": MODE_EXACT, "fast": MODE_FAST, "fast_tight": MODE_FAST, "fast_reflists": MODE_FAST}[mode]
     _CONFIG["tight_rects"] = mode in ("fast", "fast_tight")
+    ext = sys.modules.get("instascene_amd._C_hip")          # the compiled boundary follows, when it is loaded
+    if ext is not None:
+        ext.set_mode("fast" if mode == "fast_tight" else mode)
 
 
 def get_mode() -> str:

@@ -53,7 +53,10 @@ def _skeleton(tmp_path):
             "own_pkg": gaussian_renderer.STUB,
             "l1": l1_loss(0, 0),
             "rasterizer": diff_surfel_rasterization.GaussianRasterizer is instascene_amd.rasterizer.GaussianRasterizer,
-            "c_ext": diff_surfel_rasterization._C.rasterize_gaussians is instascene_amd.rasterizer.rasterize_gaussians,
+            # the compiled extension (instascene_amd/_C_hip.so) when it is built, else the Python mirror over the same C ABI
+            "c_ext": (diff_surfel_rasterization._C.rasterize_gaussians is sys.modules["instascene_amd._C_hip"].rasterize_gaussians)
+                     if diff_surfel_rasterization._C.COMPILED else
+                     (diff_surfel_rasterization._C.rasterize_gaussians is instascene_amd.rasterizer.rasterize_gaussians),
             "knn": distCUDA2 is instascene_amd.knn.distCUDA2,
             "argv": sys.argv[1:],
         }))

@@ -14,7 +14,7 @@ ap.add_argument("--delay-us", type=float, default=0.0, help="busy-wait on the ho
 ap.add_argument("--delay-at", default="render")
 ap.add_argument("--scale", type=float, default=1.0, help="shrink the scene: the step becomes host-bound")
 a = ap.parse_args()
-rasterizer.set_mode("fast"); rasterizer.set_tracer(True); rasterizer.set_async_binning(True)
+rasterizer.set_mode(os.environ.get("ISR_MODE", "fast_reflists")); rasterizer.set_tracer(True); rasterizer.set_async_binning(True)
 scene, cams, cfg = scenes.config_scene("C3", a.scale)
 tr = SegTrainer(scene, cams[:16], device="cuda", sample_batchsize=8192, use_class_feat=True)
 tr.pipe.lazy_maps = bool(a.lazy_maps)

@@ -14,7 +14,7 @@ ap.add_argument("--scale", type=float, default=1.0, help="shrink the scene: a sm
 ap.add_argument("--profile", type=int, default=1)
 ap.add_argument("--st-autograd", type=int, default=0, help="run the backward on the calling thread")
 a = ap.parse_args()
-rasterizer.set_mode("fast"); rasterizer.set_tracer(True); rasterizer.set_async_binning(True)
+rasterizer.set_mode(os.environ.get("ISR_MODE", "fast_reflists")); rasterizer.set_tracer(True); rasterizer.set_async_binning(True)
 scene, cams, cfg = scenes.config_scene("C3", a.scale)
 tr = SegTrainer(scene, cams[:16], device="cuda", sample_batchsize=8192, use_class_feat=True)
 tr.warm_view_caches()

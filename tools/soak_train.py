@@ -21,7 +21,7 @@ ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--empty-cache", dest="empty_cache", type=int, default=0)
 ap.add_argument("--densify", type=int, default=0, help="rgb step: 1 = density control on (clone / split / prune every 100 iterations)")
 a = ap.parse_args()
-rasterizer.set_mode("fast"); rasterizer.set_tracer(True); rasterizer.set_async_binning(a.step != "plain")
+rasterizer.set_mode(os.environ.get("ISR_MODE", "fast_reflists")); rasterizer.set_tracer(True); rasterizer.set_async_binning(a.step != "plain")
 scene, cams, cfg = scenes.config_scene(a.config, a.scale)
 step = a.step or ("seg" if cfg["F"] > 0 else "rgb")
 dev = torch.device("cuda")
