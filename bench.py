@@ -346,9 +346,11 @@ def run(args, mode, rank, world, dev, detail, repeats=1):
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(args.config + ":" + args.step + ":" + mode, {}).get(dom)
+                # (the counters are taken in the default mode; the FAST modes run the same kernels on lists of slightly different length)
+                tmode = mode if (args.config + ":" + args.step + ":" + mode) in tj else DEFAULT_MODE
+                traffic = tj.get(args.config + ":" + args.step + ":" + tmode, {}).get(dom)
                 tsrc = tj.get("source")
-                issue = tj.get(args.config + ":" + args.step + ":" + mode + ":" + dom + ":issue")
+                issue = tj.get(args.config + ":" + args.step + ":" + tmode + ":" + dom + ":issue")
                 stale = tj.get("csrc_tree_hash") != csrc_tree_hash()      # the counters were taken on another tree
             except Exception:
                 traffic = None

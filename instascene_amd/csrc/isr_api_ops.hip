@@ -91,11 +91,19 @@ static int contrastive_forward_impl(int nb, int N, int F, int K, const float* co
                        ticket_phi, st.phi, st.Us, bt);
     ISR_STAGE("ck_phi", s);
     if (F <= 32 && K <= 96) {
-#define ISO_SIM(NT)                                                                                                       \
-    hipLaunchKernelGGL((iso::ck_similarity_small<NT>), dim3(nblk, nb), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, \
-                       st.col, st.G, st.part, ticket_loss, loss, loss_total, ticket_total, bt)
+        static const int last_max = [] { const char* e = getenv("ISR_CK_LAST_MAX"); return e ? atoi(e) : 512; }();
+        const bool by_last = nblk <= last_max;       // (workgroups per problem)
+#define ISO_SIM(NT)                                                                                                                \
+    do { if (by_last)                                                                                                               \
+    hipLaunchKernelGGL((iso::ck_similarity_small<NT, true>), dim3(nblk, nb), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, \
+                       st.col, st.G, st.part, ticket_loss, loss, loss_total, ticket_total, bt);                                   \
+    else                                                                                                                            \
+    hipLaunchKernelGGL((iso::ck_similarity_small<NT, false>), dim3(nblk, nb), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, \
+                       st.col, st.G, st.part, ticket_loss, loss, loss_total, ticket_total, bt); } while (0)
         if (K <= 32) ISO_SIM(1); else if (K <= 64) ISO_SIM(2); else ISO_SIM(3);
 #undef ISO_SIM
+        if (!by_last)
+            hipLaunchKernelGGL(iso::ck_loss_reduce, dim3(1, nb), dim3(256), 0, s, nblk, st.part, loss, loss_total, ticket_total, bt);
     } else {
         hipLaunchKernelGGL(iso::ck_similarity, dim3(nblk, nb), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, st.col, st.G,
                            st.part, bt);

@@ -4,6 +4,8 @@
 (calibrated in round 1 on torch copy / add kernels over a 192 MB tensor: WRITE_SIZE = 1.00 x bytes, FETCH_SIZE = 0.50 x).
 usage: make_traffic_json.py gpurun_out/prof_TAG [tag-for-the-source-note]"""
 import json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import DEFAULT_MODE as MODE          # the passes run bench.py / run_raster.py in the library's default mode
 d = sys.argv[1]
 tag = sys.argv[2] if len(sys.argv) > 2 else os.path.basename(d.rstrip("/"))
 out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `python bench.py --config C --step S --steps 3 "
@@ -43,8 +45,8 @@ for cfg, step in (("C3", "seg"), ("C2", "rgb"), ("C5", "seg")):
                 inst.setdefault(key, full.split("(")[0])
     rec = {k: int((2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024) for k, v in vals.items()}
     if rec:
-        out[f"{cfg}:{step}:fast"] = rec
-        out[f"{cfg}:{step}:fast:instances"] = inst
+        out[f"{cfg}:{step}:{MODE}"] = rec
+        out[f"{cfg}:{step}:{MODE}:instances"] = inst
 # the blend kernel's vector-instruction count per launch (its binding roofline is instruction issue): tools/pmc_fwd.sh's passes
 issue = os.path.join(d, "pmc_issue_k_render_fwd.txt")
 if os.path.exists(issue):
@@ -55,7 +57,7 @@ if os.path.exists(issue):
             if m and "k_render_fwd_fast_w" in line:
                 cnt[k] = float(m.group(1))
     if cnt:
-        out["C3:seg:fast:k_render_fwd:issue"] = dict(cnt, source=f"rocprofv3 --pmc, one counter group per run, tools/pmc_fwd.sh over tools/run_raster.py "
+        out[f"C3:seg:{MODE}:k_render_fwd:issue"] = dict(cnt, source=f"rocprofv3 --pmc, one counter group per run, tools/pmc_fwd.sh over tools/run_raster.py "
                                                                   f"--config C3 (profiles/{tag}_pmc_issue_k_render_fwd.txt); wave-instructions per launch")
 # the tree the counters were taken on: bench.py prints "traffic_stale": true when csrc/ has changed since
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
