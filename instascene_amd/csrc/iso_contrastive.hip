@@ -413,9 +413,10 @@ __device__ __forceinline__ void ck_publish_loss(float t, int pb, int nb, float w
     loss_total[0] = tot;
 }
 
-// LAST: the last workgroup to finish adds the loss partials (saves a launch; every workgroup then pays an agent-scope release
-// fence + an atomic on one ticket - fine for the 256 workgroups of 8 192 samples, 150 us at the 1 024 x 3 of the reference's
-// default 32 768: there the partials are added by ck_loss_reduce in a launch of its own).
+// LAST (rounds 3-4, now opt-in ISR_CK_LAST_MAX): the last workgroup to finish adds the loss partials and saves a launch - but every
+// workgroup then pays an agent-scope release fence (on this part: a write-back of its XCD's L2) and an atomic on one ticket:
+// 13 us of the C3 step at the 256 x 3 workgroups of 8 192 samples, 100 us at the 1 024 x 3 of the reference's default 32 768.
+// Default: the partials are added by ck_loss_reduce in a launch of its own.
 template <int NT, bool LAST>
 __global__ __launch_bounds__(64) void ck_similarity_small(int N, int F, int K, const float* __restrict__ f,
                                                            const float* __restrict__ U, const float* __restrict__ phi,

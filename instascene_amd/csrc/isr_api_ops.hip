@@ -91,7 +91,9 @@ static int contrastive_forward_impl(int nb, int N, int F, int K, const float* co
                        ticket_phi, st.phi, st.Us, bt);
     ISR_STAGE("ck_phi", s);
     if (F <= 32 && K <= 96) {
-        static const int last_max = [] { const char* e = getenv("ISR_CK_LAST_MAX"); return e ? atoi(e) : 512; }();
+        static const int last_max = [] { const char* e = getenv("ISR_CK_LAST_MAX"); return e ? atoi(e) : 0; }();
+        // (default: never - A/B on one box at the headline's 256 x 3 workgroups: 1.660 / 1.664 ms per step with the last-workgroup
+        // form, 1.650 / 1.647 with ck_loss_reduce; at 1 024 x 3 the kernel takes 135 us against 32)
         const bool by_last = nblk <= last_max;       // (workgroups per problem)
 #define ISO_SIM(NT)                                                                                                                \
     do { if (by_last)                                                                                                               \
