@@ -417,7 +417,9 @@ __device__ __forceinline__ void ck_publish_loss(float t, int pb, int nb, float w
 // workgroup then pays an agent-scope release fence (on this part: a write-back of its XCD's L2) and an atomic on one ticket:
 // 13 us of the C3 step at the 256 x 3 workgroups of 8 192 samples, 100 us at the 1 024 x 3 of the reference's default 32 768.
 // Default: the partials are added by ck_loss_reduce in a launch of its own.
-template <int NT, bool LAST>
+// FS = MFMA steps over the channels (two channels per step): 16 for F <= 32, 32 for F <= 64 (C5's feature width; the generic
+// kernel reloads its operands from memory inside the channel loop and sweeps the columns twice: 58 us alone against 25).
+template <int NT, bool LAST, int FS = 16>
 __global__ __launch_bounds__(64) void ck_similarity_small(int N, int F, int K, const float* __restrict__ f,
                                                            const float* __restrict__ U, const float* __restrict__ phi,
                                                            const float* __restrict__ cnt, const int* __restrict__ colid,
@@ -430,9 +432,9 @@ __global__ __launch_bounds__(64) void ck_similarity_small(int N, int F, int K, c
     const int lane = threadIdx.x & 63;
     const int i0 = blockIdx.x * 32;
     const int arow = i0 + (lane & 31), kk = lane >> 5;
-    float a[16];
+    float a[FS];
 #pragma unroll
-    for (int s = 0; s < 16; s++) {
+    for (int s = 0; s < FS; s++) {
         const int ch = 2 * s + kk;
         a[s] = (arow < N && ch < F) ? f[(size_t)arow * F + ch] : 0.0f;
     }
@@ -448,9 +450,9 @@ __global__ __launch_bounds__(64) void ck_similarity_small(int N, int F, int K, c
 #pragma unroll
     for (int jt = 0; jt < NT; jt++) {
         const int col = jt * 32 + (lane & 31);
-        float b[16];
+        float b[FS];
 #pragma unroll
-        for (int s = 0; s < 16; s++) {
+        for (int s = 0; s < FS; s++) {
             const int ch = 2 * s + kk;
             b[s] = (col < K && ch < F) ? U[(size_t)col * F + ch] : 0.0f;
         }
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(64) void ck_similarity_small(int N, int F, int K, c
         ph[jt] = present[jt] ? phi[col] : 1.0f;
         f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < 16; s++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], c, 0, 0, 0);
+        for (int s = 0; s < FS; s++) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], c, 0, 0, 0);
         acc[jt] = c;
     }
     float lpart = 0.0f;

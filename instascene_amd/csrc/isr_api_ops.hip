@@ -90,21 +90,20 @@ static int contrastive_forward_impl(int nb, int N, int F, int K, const float* co
     hipLaunchKernelGGL(iso::ck_phi, dim3(nt, nb), dim3(256), 0, s, N, F, K, st.f, st.col, st.U, st.cnt, temp_lambda, st.phi_part,
                        ticket_phi, st.phi, st.Us, bt);
     ISR_STAGE("ck_phi", s);
-    if (F <= 32 && K <= 96) {
+    if (F <= 64 && K <= 96) {
         static const int last_max = [] { const char* e = getenv("ISR_CK_LAST_MAX"); return e ? atoi(e) : 0; }();
         // (default: never - A/B on one box at the headline's 256 x 3 workgroups: 1.660 / 1.664 ms per step with the last-workgroup
         // form, 1.650 / 1.647 with ck_loss_reduce; at 1 024 x 3 the kernel takes 135 us against 32)
         const bool by_last = nblk <= last_max;       // (workgroups per problem)
+#define ISO_SIM2(NT, LAST_, FS_)                                                                                                          \
+    hipLaunchKernelGGL((iso::ck_similarity_small<NT, LAST_, FS_>), dim3(nblk, nb), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, \
+                       st.col, st.G, st.part, ticket_loss, loss, loss_total, ticket_total, bt)
 #define ISO_SIM(NT)                                                                                                                \
-    do { if (by_last)                                                                                                               \
-    hipLaunchKernelGGL((iso::ck_similarity_small<NT, true>), dim3(nblk, nb), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, \
-                       st.col, st.G, st.part, ticket_loss, loss, loss_total, ticket_total, bt);                                   \
-    else                                                                                                                            \
-    hipLaunchKernelGGL((iso::ck_similarity_small<NT, false>), dim3(nblk, nb), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, \
-                       st.col, st.G, st.part, ticket_loss, loss, loss_total, ticket_total, bt); } while (0)
+    do { if (F > 32) ISO_SIM2(NT, false, 32); else if (by_last) ISO_SIM2(NT, true, 16); else ISO_SIM2(NT, false, 16); } while (0)
         if (K <= 32) ISO_SIM(1); else if (K <= 64) ISO_SIM(2); else ISO_SIM(3);
 #undef ISO_SIM
-        if (!by_last)
+#undef ISO_SIM2
+        if (!by_last || F > 32)
             hipLaunchKernelGGL(iso::ck_loss_reduce, dim3(1, nb), dim3(256), 0, s, nblk, st.part, loss, loss_total, ticket_total, bt);
     } else {
         hipLaunchKernelGGL(iso::ck_similarity, dim3(nblk, nb), dim3(64), 0, s, N, F, K, st.f, st.U, st.phi, st.cnt, st.col, st.G,
