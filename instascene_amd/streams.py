@@ -15,7 +15,10 @@ def side_stream(device) -> "torch.cuda.Stream":
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+        # ISR_SIDE_PRIORITY=-1: a high-priority side stream (A/B in DESIGN section 8: the chain's kernels then take their wave slots
+        # ahead of the blend's instead of filling in behind them)
+        import os
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("ISR_SIDE_PRIORITY", "0")))
     return st
 
 
