@@ -11,7 +11,7 @@ if os.environ.get("ISR_COMPILED_C", "1") != "0":
         _lib()                  # libinstascene_hip.so, found by the extension through its rpath, with every symbol checked
         from instascene_amd._C_hip import mark_visible, rasterize_gaussians, rasterize_gaussians_backward, set_mode  # noqa: F401
         COMPILED = True
-    except ImportError:
+    except Exception:       # not built, or built against another torch / library: the Python mirror serves the same names
         COMPILED = False
 if not COMPILED:
     from instascene_amd.rasterizer import mark_visible, rasterize_gaussians, rasterize_gaussians_backward, set_mode  # noqa: F401
