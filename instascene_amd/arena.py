@@ -212,10 +212,9 @@ def trim(nbytes: int = None) -> int:
                     _drop(b)
                 else:
                     keep.append(b)
-            if keep:
-                _POOLS[key] = keep
-            else:
-                del _POOLS[key]
+            # in place: _lease() may hold this very list (it trims on the cap path and through _Block's out-of-memory retry) and
+            # appends its new block to it afterwards - a rebound or deleted list would orphan that block for good
+            _POOLS[key][:] = keep
     return freed
 
 

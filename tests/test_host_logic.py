@@ -368,3 +368,95 @@ def test_arena_trim_asks_the_pools_own_stream():
         assert fb.asked == [0xABCDEF]
     finally:
         arena._POOLS.pop(key, None)
+
+
+def test_arena_block_created_after_a_trim_stays_in_its_pool(monkeypatch):
+    """Advisor finding, round 5: _lease() holds its pool's list while trim() runs (cap path, out-of-memory retry); trim() used to
+    rebind / delete that list, so the new block was appended to a dead list - never reused, never trimmed, counted forever.
+    Lease past a 3 MiB cap on the CPU and check that every live block is in a pool and the total stays bounded."""
+    import torch
+    from instascene_amd import arena, _hot
+    monkeypatch.setattr(_hot, "raw_stream", lambda dev: 0)
+    monkeypatch.setattr(arena, "MAX_BYTES", 3 << 20)
+    monkeypatch.setattr(arena, "_POOLS", {})
+    monkeypatch.setattr(arena, "_BY_PTR", {})
+    monkeypatch.setattr(arena, "_TOTAL", [0])
+    dev = torch.device("cpu", 0)
+    n = arena.MIN_BYTES
+    for i in range(12):
+        t = arena._lease((n,), torch.uint8, dev, n)      # the previous lease died: its block is idle when the next one asks
+        u = arena._lease((n,), torch.uint8, dev, n)
+        v = arena._lease((n,), torch.uint8, dev, n)
+        w = arena._lease((n,), torch.uint8, dev, n)      # the fourth live block: past the cap, trim() runs inside _lease
+        in_pools = {id(b) for pool in arena._POOLS.values() for b in pool}
+        assert {id(b) for b in arena._BY_PTR.values()} == in_pools, "a block is in no pool"
+        assert arena.reserved_bytes() == sum(b.nbytes for pool in arena._POOLS.values() for b in pool)
+        assert arena.reserved_bytes() <= 4 * arena._class_of(n)
+        del t, u, v, w
+    # and the out-of-memory retry path: trim() from inside _Block.__init__
+    real_empty, calls = torch.empty, [0]
+
+    def flaky_empty(*a, **k):
+        if k.get("dtype") == torch.uint8 and a and a[0] >= n:
+            calls[0] += 1
+            if calls[0] == 1:
+                raise torch.OutOfMemoryError("simulated")
+        return real_empty(*a, **k)
+    monkeypatch.setattr(arena, "_real_empty_cache", lambda: None)
+    keep = [arena._lease((n,), torch.uint8, dev, n) for _ in range(2)]
+    monkeypatch.setattr(torch, "empty", flaky_empty)
+    extra = arena._lease((2 * n,), torch.uint8, dev, 2 * n)     # a new size class: needs a new block, whose first attempt "fails"
+    monkeypatch.setattr(torch, "empty", real_empty)
+    assert calls[0] >= 2
+    in_pools = {id(b) for pool in arena._POOLS.values() for b in pool}
+    assert {id(b) for b in arena._BY_PTR.values()} == in_pools
+    del keep, extra
+
+
+def test_bench_final_line_is_compact_and_round_trips():
+    """bench.py prints ONE compact JSON line (round 5's 24.8 KB line was lost by the driver's parser): from a canned full record of
+    the size bench.py really produces, the line stays below 8 KB, round-trips through json, and carries the contract keys, the
+    dominant kernel's roofline and the CPU baseline."""
+    import json
+    import bench
+    kern = {("k_%02d" % i): {"ms_per_launch": 0.1234, "launches_per_view": 1.0, "algorithmic_bytes": 1 << 30, "GB/s": 1234.5,
+                               "frac_hbm": 0.1543} for i in range(40)}
+    sub = {"value": 123.456, "ms_per_step": 8.1, "note": "n" * 600, "kernels_ms_x_launches_per_step": {k: [0.1, 1.0] for k in kern}}
+    full = {"metric": "train-step views/sec (fwd+bwd) @1.5M Gaussians, 1080p, 32-d feat", "value": 618.01, "unit": "views/s",
+            "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 1.6181, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "unmodified_driver": {"views_per_s": 63.7, "workspace": "w" * 300},
+            "config": {"workload": "C3: " + "w" * 400, "parallelism": "dp1 (one view per rank)", "arithmetic_mode": "fast_reflists",
+                       "integer_state": "the reference's, bit for bit", "view_order": "v" * 900,
+                       "hoisted_out_of_the_timed_region": ["h" * 300] * 5, "rccl_world_size": 1, "tracer": True,
+                       "views_per_s_exact": 400.7, "views_per_s_C2_rgb": 1307.4, "views_per_s_C5_seg": 247.9,
+                       "views_per_s_unmodified_driver": 63.7, "views_per_s_reference_defaults": 404.2,
+                       "gradient_exchange": {"kind": "RCCL all-reduce", "bytes": {"buffer": 192000000}}},
+            "roofline": {"bound": "hbm", "kernel": "k_render_fwd", "achieved": 1748.05, "peak": 8000.0, "unit": "GB/s", "frac": 0.2185,
+                         "frac_hbm": 0.2185, "frac_fp32_flops": 0.1886, "avg_launch_ms": 0.9088, "launches_per_step": 1.0,
+                         "traffic": 1545011200, "traffic_stale": False, "traffic_over_algorithmic_bytes": 0.973,
+                         "hbm": {"bytes": 1588683804}, "note": "x" * 500, "kernels": kern,
+                         "workload": {"P": 1500000, "V": 1280051, "R": 5876701, "N": 2073600, "F": 32, "tiles": 8160},
+                         "valu": {"pixel_splat_pairs_evaluated": 445911232, "pixel_splat_pairs_contributing": 108699966,
+                                  "flops": 26967246424, "lane_utilisation_of_blending_pairs": 0.33, "flop_model": "m" * 200},
+                         "issue": {"issue_frac": 0.49, "model": "m" * 400}},
+            "sub_records": {("s%d" % i): sub for i in range(14)},
+            "cpu_baseline": {"value": 0.185, "unit": "views/s", "cores": 128, "cpu": "AMD EPYC 9575F 64-Core Processor", "kind": "port",
+                             "build": "g++ -O3 -march=native", "sample": "s" * 700}}
+    assert len(json.dumps(full)) > 20000                      # the canned record is as big as the real one
+    line = json.dumps(bench.compact_record(full), separators=(",", ":"))
+    assert len(line) < 8192 and len(line) <= bench.COMPACT_LIMIT and "\n" not in line
+    back = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert back["value"] == 618.01 and back["config"]["views_per_s_C2_rgb"] == 1307.4 and back["config"]["workload"].startswith("C3")
+    r = back["roofline"]
+    assert r["bound"] == "hbm" and r["frac"] == 0.2185 and r["bytes"] == 1588683804 and r["R"] == 5876701 and r["traffic"] == 1545011200
+    assert abs(r["bytes"] / (r["avg_launch_ms"] * 1e-3) / 1e9 / r["peak"] - r["frac"]) < 2e-3      # frac is recomputable from the line
+    assert back["cpu_baseline"]["cores"] == 128 and back["cpu_baseline"]["kind"] == "port"
+    assert "sub_records" not in back and back["details"] == "bench_details.json"
+    # a multi-rank record: cpu_baseline null, the exchange's bytes kept
+    full["cpu_baseline"] = None
+    back = json.loads(json.dumps(bench.compact_record(full)))
+    assert back["cpu_baseline"] is None and back["config"]["gradient_exchange"]["bytes"]["buffer"] == 192000000
