@@ -480,9 +480,13 @@ def compact_record(full, details_path="bench_details.json"):
     for k, v in cfg.items():              # numbers and flags: views_per_s_*, roofline_frac_*, rccl_world_size, tracer, ...
         if isinstance(v, (int, float, bool)) and not isinstance(v, str):
             c[k] = v
-    ex = cfg.get("gradient_exchange")
-    if isinstance(ex, dict):
-        c["gradient_exchange"] = {"kind": str(ex.get("kind"))[:120], "bytes": ex.get("bytes")}
+    def lean(v):                           # a small dict of numbers: keep it, cut its prose
+        if isinstance(v, dict):
+            return {k: lean(x) for k, x in v.items() if k != "note"}
+        return v[:120] if isinstance(v, str) else v
+    for k in ("gradient_exchange", "multi_rank_tail_phases"):      # N > 1: which exchange ran, the bytes it moved, the tail's phases
+        if isinstance(cfg.get(k), dict):
+            c[k] = lean(cfg[k])
     out["config"] = c
     roof = full.get("roofline") or {}
     r = {k: roof.get(k) for k in _ROOF_KEYS if k in roof}

@@ -73,6 +73,12 @@ void isr_profile_enable(int on);
  * EXACT (must be 0), [8..15] the walk lengths of a per-8x4-half / per-4x4-quad decomposition (isr_forward_fast.hip).
  * A few extra atomics per wave; not meant for timed runs. */
 void isr_forward_set_counters(unsigned long long* device_counters);
+/* Work counters of the dense geometry backward (k_render_bwd_geo, the train.py step's dominant kernel): the NEXT isr_backward call (of any
+ * host thread: autograd runs backward passes on threads of its own) that takes that kernel also adds, into device_counters (u64[16], zeroed by the caller): [0] chunks of 64 splat slots
+ * walked by a wave, [1] slots holding a splat, [2] (chunk, pixel row) pairs, [3] those a splat of the chunk reaches, [4] (chunk, pixel)
+ * iterations with a candidate lane, [5] candidate lanes, [6] iterations with a blending lane, [7] blending lanes, [8] chunks whose
+ * always-EXACT splat was pre-evaluated, [9] partial rows stored.  Not meant for timed runs. */
+void isr_backward_set_counters(unsigned long long* device_counters);
 size_t isr_profile_summary(char* buf, size_t len);
 
 /* ---- workspace sizes (bytes); the layouts are opaque forward->backward hand-offs
@@ -193,6 +199,14 @@ int isr_debug_state(int P, int width, int height, int64_t num_rendered,
                     uint32_t* tiles_touched /*[P]*/, uint32_t* point_list /*[R]*/,
                     uint32_t* ranges /*[tiles,2]*/, uint32_t* n_contrib /*[2,N]*/,
                     float* final_T /*[3,N]*/, float* splat_records /*[P,20]*/, void* stream);
+
+/* Test infrastructure: checks k_pack_hits' per-(tile entry, block half) hit masks of a prepared view against the blend kernels' own
+ * per-pixel evaluation.  Adds into device_counters (u64[8], zeroed by the caller): [0] halves whose bit is clear, [1] pixels of those
+ * halves whose pair FAST's test passes, [2] pixels where EXACT's pair test passes (both must be 0: a clear bit never hides a pair a
+ * kernel would blend), [3] halves whose bit is set, [4] of those, halves with no such pixel (what an ideal test would
+ * also clear).  Reference: the per-pair skip tests of forward.cu:356-393. */
+int isr_debug_check_hit_masks(int P, int width, int height, int64_t num_rendered, const void* geom_buffer, const void* binning_buffer,
+                              const void* image_buffer, unsigned long long* device_counters, void* stream);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,7 @@ SIGNATURES = {
     "isr_set_debug": (c_int, [c_int, c_int]),
     "isr_profile_enable": (None, [c_int]),
     "isr_forward_set_counters": (None, [_P]),
+    "isr_backward_set_counters": (None, [_P]),
     "isr_profile_summary": (c_size_t, [_P, c_size_t]),
     "isr_geom_bytes": (c_size_t, [c_int]),
     "isr_image_bytes": (c_size_t, [c_int, c_int]),
@@ -53,6 +54,7 @@ SIGNATURES = {
                                       _P]),
     "isr_mark_visible": (c_int, [c_int, _P, _P, _P, _P, _P]),
     "isr_debug_state": (c_int, [c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "isr_debug_check_hit_masks": (c_int, [c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P]),
     # include/instascene_ops.h
     "iso_knn_scratch_bytes": (c_size_t, [c_int]),
     "iso_dist2_3nn": (c_int, [c_int, _P, _P, _P, c_size_t, _P]),

@@ -7,7 +7,11 @@
 
 using namespace isr;
 
+namespace isr { std::atomic<unsigned long long*> g_bwd_counters{nullptr}; }
+
 extern "C" {
+
+void isr_backward_set_counters(unsigned long long* device_counters) { isr::g_bwd_counters.store(device_counters); }
 
 size_t isr_backward_scratch_bytes(int64_t num_rendered, int ED, unsigned grad_mask) {
     return backward_scratch_bytes(num_rendered, ED, grad_mask);

@@ -104,9 +104,29 @@ int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binni
         } }
         ISR_LAUNCH_CHECK("k_tile_sort");
         { ProfScope ps_("k_pack_hits", s);
-        hipLaunchKernelGGL(k_pack_hits, dim3(T), dim3(256), 0, s, gx, binning_capacity, iv.tile_offset, bv.point_list, g.cull, bv.box4, bv.hit_mask); }
+        // ISR_PACK_EXACT=0: the bounding-octagon test alone (rounds 1-5); default: the row-exact conic test behind it
+        static const bool row_exact = [] { const char* e = getenv("ISR_PACK_EXACT"); return !(e && e[0] == '0'); }();
+        if (row_exact)
+            hipLaunchKernelGGL(k_pack_hits<true>, dim3(T), dim3(256), 0, s, gx, binning_capacity, iv.tile_offset, bv.point_list, g.cull, bv.box4, bv.hit_mask);
+        else
+            hipLaunchKernelGGL(k_pack_hits<false>, dim3(T), dim3(256), 0, s, gx, binning_capacity, iv.tile_offset, bv.point_list, g.cull, bv.box4, bv.hit_mask); }
         ISR_LAUNCH_CHECK("k_pack_hits");
     }
+    return ISR_OK;
+}
+
+int isr_debug_check_hit_masks(int P, int width, int height, int64_t num_rendered, const void* geom_buffer, const void* binning_buffer,
+                              const void* image_buffer, unsigned long long* device_counters, void* stream) {
+    if (!geom_buffer || !binning_buffer || !image_buffer || !device_counters) return fail(ISR_EINVAL, "check_hit_masks: null buffer");
+    if (P <= 0 || num_rendered <= 0) return ISR_OK;
+    const GeomView g = geom_view(const_cast<void*>(geom_buffer), P);
+    const ImageView iv = image_view(const_cast<void*>(image_buffer), width, height);
+    const BinView bv = bin_view(const_cast<void*>(binning_buffer), num_rendered);
+    const int gx = tiles_x(width), T = gx * tiles_y(height);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_check_hit_masks, dim3(T), dim3(256), 0, s, width, height, gx, num_rendered, iv.tile_offset, bv.point_list, g.rec,
+                       bv.hit_mask, device_counters);
+    ISR_LAUNCH_CHECK("k_check_hit_masks");
     return ISR_OK;
 }
 

@@ -32,9 +32,9 @@ __host__ __device__ inline int row_floats(int ED, unsigned mask) {
     return ((mask & 2u) ? GEOM_ROW : 0) + ((mask & 1u) ? feat_row(ED) : 0);
 }
 __host__ __device__ inline int n_passes(int ED, unsigned mask) { return ((mask & 1u) && ED > 32) ? (ED + 31) / 32 : 1; }
-// geometry-only backward without a feature channel: room for the splat-major kernel's row per (tile, Gaussian, 8x8 block)
-// (isr_backward_geo.hip; four slots per instance, of which ~1.2 are written)
-__host__ __device__ inline int rows_per_instance(int ED, unsigned mask) { return ((mask & 3u) == 2u && ED == 0) ? 4 : 1; }
+// geometry-only backward without a feature channel: room for the splat-major kernel's row per (tile, Gaussian, 8x4 half of an 8x8
+// block) (isr_backward_geo.hip; eight slots per instance, of which ~2 are written)
+__host__ __device__ inline int rows_per_instance(int ED, unsigned mask) { return ((mask & 3u) == 2u && ED == 0) ? 8 : 1; }
 inline size_t rows_bytes(int64_t R, int ED, unsigned mask) {
     return align_up((size_t)(R > 0 ? R : 1) * rows_per_instance(ED, mask) * row_floats(ED, mask) * sizeof(float), 256);
 }
@@ -1451,7 +1451,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ tm_pre,
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos, int Wd, int Hd,
     GeomView g, const float* __restrict__ partial, const uint8_t* __restrict__ row_flags, int row_stride, int geom_off,
-    int rpi /* partial rows per tile instance: 1, or 4 (one per 8x8 block: k_render_bwd_geo) */,
+    int rpi /* partial rows per tile instance: 1, or 8 (one per 8x4 block half: k_render_bwd_geo) */,
     float* __restrict__ dL_dmean2D,
     float* __restrict__ dL_dnormal, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
     float* __restrict__ dL_dmean3D, float* __restrict__ dL_dtransMat, float* __restrict__ dL_dsh,
@@ -1509,12 +1509,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
         __syncthreads();
         if (big_rows) owner_at(atomicAdd(&s_nbig, 1)) = (int)threadIdx.x;
     }
-    if (nt > 0 && !big_rows && rpi == 4) {
-        // four rows per tile instance (k_render_bwd_geo): the instance's four flags are one aligned word, and the flagged rows
-        // of an instance are requested together - a quarter of the dependent memory round trips of the row-by-row walk
-        // (the kernel is bound by that chain, not by bytes).  Same summation order: instance by instance, block 0..3.
-        const float* src = partial + (size_t)g.point_offsets[i] * 4 * row_stride + geom_off;
-        const uint32_t* fw = reinterpret_cast<const uint32_t*>(row_flags + (size_t)g.point_offsets[i] * 4);
+    if (nt > 0 && !big_rows && (rpi & 3) == 0) {
+        // eight rows per tile instance (k_render_bwd_geo): four flags are one aligned word, and the flagged rows of a word are
+        // requested together - a quarter of the dependent memory round trips of the row-by-row walk (the kernel is bound by that
+        // chain, not by bytes).  Same summation order: instance by instance, row 0..7.
+        const float* src = partial + (size_t)g.point_offsets[i] * rpi * row_stride + geom_off;
+        const uint32_t* fw = reinterpret_cast<const uint32_t*>(row_flags + (size_t)g.point_offsets[i] * rpi);
         const uint32_t ni = nt >> 2;
         uint32_t f_next = fw[0];
         for (uint32_t t = 0; t < ni; t++) {
@@ -1826,14 +1826,16 @@ static int launch_backward_t(int P, int D, int M, int64_t R, int ED, int W, int 
         // small grids (fewer blocks than ~2 rounds of the chip's wave slots): two waves per 8x8 block - the kernel's time there is
         // the longest list's, and half the pixels per wave halves it; large grids are throughput-bound: one wave per block
         static const int geo_two = [] { const char* e = getenv("ISR_GEO_TWO_WAVES_BELOW"); return e ? atoi(e) : 12000; }();
-        if (T * 4 < geo_two)
-            hipLaunchKernelGGL(k_render_bwd_geo<2>, dim3(T * 4), dim3(128), 0, s, W, H, gx, iv.tile_offset, bv.point_list, bv.box4, g.rec,
-                               col_pre, tm_pre, bg, iv.final_T, iv.n_contrib, dC, dO, g.point_offsets, g.rect, partial, flags, stride,
-                               geom_off, R, geo_heavy_first() ? iv.tile_order : (const uint32_t*)nullptr, bv.hit_mask);
-        else
-            hipLaunchKernelGGL(k_render_bwd_geo<1>, dim3(T * 4), dim3(64), 0, s, W, H, gx, iv.tile_offset, bv.point_list, bv.box4, g.rec,
-                               col_pre, tm_pre, bg, iv.final_T, iv.n_contrib, dC, dO, g.point_offsets, g.rect, partial, flags, stride,
-                               geom_off, R, geo_heavy_first() ? iv.tile_order : (const uint32_t*)nullptr, bv.hit_mask);
+        unsigned long long* const counters = g_bwd_counters.exchange(nullptr);     // isr_backward_set_counters: this launch adds its work counters
+#define ISR_GEO(NW_, ST_, HF_) hipLaunchKernelGGL((k_render_bwd_geo<NW_, ST_, HF_>), dim3(T * (HF_ ? 8 : 4)), dim3(64 * NW_), 0, s, W, H, gx, iv.tile_offset, \
+                               bv.point_list, bv.box4, g.rec, col_pre, tm_pre, bg, iv.final_T, iv.n_contrib, dC, dO, g.point_offsets, g.rect, \
+                               partial, flags, stride, geom_off, R, geo_heavy_first() ? iv.tile_order : (const uint32_t*)nullptr, bv.hit_mask, counters)
+        // ISR_GEO_HALVES (default 1): a wave per 8x4 half of a block with the half's own culled list; 0: a wave (two on small grids) per block
+        static const bool geo_halves = [] { const char* e = getenv("ISR_GEO_HALVES"); return !(e && e[0] == '0'); }();
+        if (geo_halves) { if (counters) ISR_GEO(1, true, true); else ISR_GEO(1, false, true); }
+        else if (T * 4 < geo_two) { if (counters) ISR_GEO(2, true, false); else ISR_GEO(2, false, false); }
+        else { if (counters) ISR_GEO(1, true, false); else ISR_GEO(1, false, false); }
+#undef ISR_GEO
         ISR_CHECK_LAUNCH_B("k_render_bwd_geo");
     } else if (R > 0) {
         if (hipMemsetAsync(flags, 0, (size_t)R * npass, s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }

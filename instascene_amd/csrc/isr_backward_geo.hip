@@ -22,7 +22,8 @@ namespace isr {
 
 constexpr int GEO_SEG = 256;        // tile-list entries culled per round (four per lane)
 constexpr int GEO_QCAP = 512;       // queue capacity (entries that touch the block, waiting for their chunk of 64)
-constexpr int GEO_BLOCKS = 4;       // 8x8 blocks per tile = rows per (tile, Gaussian) instance
+constexpr int GEO_ROWS = 8;         // partial rows per (tile, Gaussian) instance: one per 8x4 half of each 8x8 block (row 2 block + half; the
+                                    // kernels that keep a block together write the first of its pair)
 
 __device__ __forceinline__ float wave_scan_add(float v) {      // inclusive sum scan over the 64 lanes
     v += dpp_fetch<0x111, 0xF>(v, 0.0f);     // row_shr:1
@@ -40,7 +41,14 @@ __device__ __forceinline__ float wave_scan_add(float v) {      // inclusive sum 
 // NW = waves per 8x8 block: 1, or 2 on small grids (4 measured: no further gain at 779x519, 0.304 against 0.298 ms) (a 779x519 view is 6 468 blocks for 4 096 wave slots: its time is the
 // longest list's) - the waves of a workgroup take 8 / NW pixel rows of the block each, walk the same chunks of 64 splats in
 // lockstep, and hand their 21 partial sums per splat to wave 0 through LDS before the row is stored.
-template <int NW>
+// STATS (isr_backward_set_counters; bench.py's lane-utilisation table of this kernel): u64 counters, per wave and summed -
+//   [0] chunks of 64 splat slots walked   [1] slots that hold a splat   [2] (chunk, pixel row) pairs   [3] ... of them reached by a splat
+//   [4] (chunk, pixel) iterations with a candidate lane   [5] candidate lanes in them   [6] ... with a blending lane   [7] blending lanes
+//   [8] chunks whose always-EXACT splat was pre-evaluated   [9] partial rows stored
+// HALF (NW = 1): a workgroup = one wave = one 8x4 HALF of a block with its own culled list (k_pack_hits' per-half words): a splat
+// reaches ~60 % of the halves of the blocks it reaches, so the chunks of 64 - whose every lane is carried through every pixel
+// iteration whether its splat is near the pixel or not - are fewer per pixel.  The two halves of a block write a row each.
+template <int NW, bool STATS = false, bool HALF = false>
 __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
     int W, int H, int gx, const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ point_list,
     const uint32_t* __restrict__ box4, const float* __restrict__ rec, const float* __restrict__ col_pre,
@@ -48,8 +56,10 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dC, const float* __restrict__ dO,
     const uint32_t* __restrict__ point_offsets, const Rect16* __restrict__ rects, float* __restrict__ partial,
     uint8_t* __restrict__ row_flags, int row_stride, int geom_off, int64_t capacity, const uint32_t* __restrict__ tile_order,
-    const unsigned long long* __restrict__ hit_mask) {
-    constexpr int NP = 64 / NW;         // pixels per wave
+    const unsigned long long* __restrict__ hit_mask, unsigned long long* __restrict__ stats = nullptr) {
+    static_assert(!HALF || NW == 1, "a half is one wave");
+    constexpr int NP = HALF ? 32 : 64 / NW;         // pixels per wave
+    unsigned st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     __shared__ __attribute__((aligned(16))) float s_pix_all[64 * 16];
     __shared__ int s_q[GEO_QCAP];
     __shared__ __attribute__((aligned(16))) float s_acc[NW > 1 ? (NW - 1) * 64 * 24 : 4];
@@ -64,10 +74,15 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
     // through LDS: 12 floats per pixel (dx dy rz sx | sy depth G alpha | pass, use3d).
     __shared__ __attribute__((aligned(16))) float s_ex_all[64 * 12];
 
-    const int tile = tile_order != nullptr ? (int)tile_order[blockIdx.x >> 2] : (int)(blockIdx.x >> 2), blk = blockIdx.x & 3;
+    constexpr int SH = HALF ? 3 : 2;      // workgroups per tile: 8 halves or 4 blocks
+    const int tile = tile_order != nullptr ? (int)tile_order[blockIdx.x >> SH] : (int)(blockIdx.x >> SH);
+    const int blk = HALF ? (int)((blockIdx.x >> 1) & 3) : (int)(blockIdx.x & 3);
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (uniform: scalar row arithmetic)
-    const int bxo = (blk & 1) * 8, byo = (blk >> 1) * 8 + wv * (8 / NW);            // origin of this wave's pixels inside the tile
+    const int hf = HALF ? (int)(blockIdx.x & 1) : 0;                               // which half of the block (HALF)
+    const int bxo = (blk & 1) * 8, byo = (blk >> 1) * 8 + (HALF ? hf * 4 : wv * (8 / NW));       // origin of this wave's pixels inside the tile
+    const int mask_word = HALF ? 4 + 2 * blk + hf : blk;                           // k_pack_hits' word of this wave's pixels
+    const int row_id = HALF ? 2 * blk + hf : 2 * blk;                              // partial row of the instance this wave (workgroup) writes
     float* const s_pix = s_pix_all + wv * NP * 16;
     float* const s_ex = s_ex_all + wv * NP * 12;
     float2* const s_carry = s_carry_all + wv * NP;
@@ -142,7 +157,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
                 if (i >= seg_lo) {
                     // k_pack_hits' word for the entry's 64-chunk and this block: the bounding OCTAGON of the alpha >= 1/255 region
                     // against the block (the packed box alone keeps ~1/6 more entries; each costs a lane in a 64-pixel loop)
-                    const unsigned long long m = hit_mask[hit_mask_word(r0, tile, i >> 6) + blk];
+                    const unsigned long long m = hit_mask[hit_mask_word(r0, tile, i >> 6) + mask_word];
                     hit = (m >> (i & 63)) & 1ull;
                 }
                 const unsigned long long b = __ballot(hit);
@@ -157,6 +172,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
         while (n_q - done >= 64 || (drained && done < n_q)) {
             const int li = done + lane < n_q ? s_q[done + lane] : -1;       // this lane's splat: position in the tile's list
             done += 64;
+            if (STATS) { st[0]++; st[1] += (unsigned)__popcll(__ballot(li >= 0)); st[2] += NP / 8; }
             // ---- the splat (one per lane; lane order = back to front)
             F3 Tu = {0, 0, 0}, Tv = {0, 0, 0}, Tw = {0, 0, 1}, nrm = {0, 0, 0}, col = {0, 0, 0};
             float cx = 0, cy = 0, opa = 0, band = 0;
@@ -209,6 +225,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
                 wave_lds_sync();
             }
             const bool pre_mine = pre && lane == f_lane;
+            if (STATS && pre) st[8]++;
             // The sums a lane keeps for its splat, as the register PAIRS the packed fp32 instructions take (v_pk_fma_f32 / v_pk_add_f32:
             // one instruction for two sums, the same IEEE operation per component); the pairing follows the operands that are
             // already neighbours - (dx, dy), (sx, sy), dL/dp.xy, the even-aligned halves of the pixel's float4s - so that no
@@ -226,6 +243,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
               const int lyi = byo + prow;
               const bool row_in = li >= 0 && byl <= lyi && byh >= lyi;
               if (__ballot(row_in) == 0ull) continue;             // no splat of the chunk reaches the row: its eight pixels at once
+              if (STATS) st[3]++;
               const float ly = (float)lyi;
               const float pyf_row = tile_y0 + ly;
               const FastHalf lrow = fast_l(pyf_row, Tv, Tw);
@@ -237,6 +255,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
                 const int lxi = bxo + pc;
                 const bool cand = row_in && (unsigned)li < last_p && bxl <= lxi && bxh >= lxi;
                 if (__ballot(cand) != 0ull) {       // (one latch for the loop: `continue`s here made the compiler rotate the accumulators)
+                    if (STATS) { st[4]++; st[5] += (unsigned)__popcll(__ballot(cand)); }
                     const float lx = (float)lxi;
                     // the forward's own evaluation of the pair (isr_fast_pair.hpp; EXACT inside the guard bands): same decisions, bit for bit
                     FastRay fr; FastHit fh;
@@ -253,6 +272,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
                     const float c_d = fh.depth, G = fh.G, alpha = fh.alpha;
                     const bool act = cand && pass;
                     if (__ballot(act) != 0ull) {
+                        if (STATS) { st[6]++; st[7] += (unsigned)__popcll(__ballot(act)); }
                         const float4 q0 = pq[0], q1 = pq[1], q2 = pq[2];
                         // q0 = dC.rgb, d_depth   q1 = d_accum, dN.xyz   q2 = d_median, d_reg, T_final, final_D   q3 = final_D2, last, median, bg_dot
                         const float2 cc = s_carry[p];
@@ -354,14 +374,15 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
                 const F3 dTu = cross3(Tv, SP) - cross3(Tw, SY);
                 const F3 dTv = cross3(SP, Tu) - cross3(SX, Tw);
                 const F3 dTw = cross3(SX, Tv) + cross3(Tu, SY);
-                float4* o4 = reinterpret_cast<float4*>(partial + ((size_t)slot * GEO_BLOCKS + blk) * row_stride + geom_off);
+                float4* o4 = reinterpret_cast<float4*>(partial + ((size_t)slot * GEO_ROWS + row_id) * row_stride + geom_off);
                 o4[0] = make_float4(dTu.x, dTu.y, dTu.z, dTv.x);
                 o4[1] = make_float4(dTv.y, dTv.z, dTw.x + aZ0, dTw.y + aZ1);
                 o4[2] = make_float4(dTw.z + aZ2, aC0, aC1, aN0);
                 o4[3] = make_float4(aN1, aN2, aO, aR);
                 o4[4] = make_float4(aG, aB, 0.0f, 0.0f);
-                row_flags[(size_t)slot * GEO_BLOCKS + blk] = 1;
+                row_flags[(size_t)slot * GEO_ROWS + row_id] = 1;
             }
+            if (STATS) st[9] += (unsigned)__popcll(__ballot(touched));
         }
         // what is left (less than a chunk, unless the list is drained) moves to the front of the queue
         const int rem = n_q - done;                    // < 64
@@ -371,14 +392,34 @@ __global__ __launch_bounds__(64 * NW, 4) void k_render_bwd_geo(
         n_q = rem > 0 ? rem : 0;
         block_sync();
     }
+    if (STATS && lane == 0 && stats != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) atomicAdd(stats + k, (unsigned long long)st[k]);
+    }
 }
-template __global__ void k_render_bwd_geo<1>(int, int, int, const uint32_t*, const uint32_t*, const uint32_t*, const float*, const float*,
+template __global__ void k_render_bwd_geo<1, false, false>(int, int, int, const uint32_t*, const uint32_t*, const uint32_t*, const float*, const float*,
                                               const float*, const float*, const float*, const uint32_t*, const float*, const float*,
                                               const uint32_t*, const Rect16*, float*, uint8_t*, int, int, int64_t, const uint32_t*,
-                                              const unsigned long long*);
-template __global__ void k_render_bwd_geo<2>(int, int, int, const uint32_t*, const uint32_t*, const uint32_t*, const float*, const float*,
+                                              const unsigned long long*, unsigned long long*);
+template __global__ void k_render_bwd_geo<1, true, false>(int, int, int, const uint32_t*, const uint32_t*, const uint32_t*, const float*, const float*,
                                               const float*, const float*, const float*, const uint32_t*, const float*, const float*,
                                               const uint32_t*, const Rect16*, float*, uint8_t*, int, int, int64_t, const uint32_t*,
-                                              const unsigned long long*);
+                                              const unsigned long long*, unsigned long long*);
+template __global__ void k_render_bwd_geo<2, false, false>(int, int, int, const uint32_t*, const uint32_t*, const uint32_t*, const float*, const float*,
+                                              const float*, const float*, const float*, const uint32_t*, const float*, const float*,
+                                              const uint32_t*, const Rect16*, float*, uint8_t*, int, int, int64_t, const uint32_t*,
+                                              const unsigned long long*, unsigned long long*);
+template __global__ void k_render_bwd_geo<2, true, false>(int, int, int, const uint32_t*, const uint32_t*, const uint32_t*, const float*, const float*,
+                                              const float*, const float*, const float*, const uint32_t*, const float*, const float*,
+                                              const uint32_t*, const Rect16*, float*, uint8_t*, int, int, int64_t, const uint32_t*,
+                                              const unsigned long long*, unsigned long long*);
+template __global__ void k_render_bwd_geo<1, false, true>(int, int, int, const uint32_t*, const uint32_t*, const uint32_t*, const float*, const float*,
+                                              const float*, const float*, const float*, const uint32_t*, const float*, const float*,
+                                              const uint32_t*, const Rect16*, float*, uint8_t*, int, int, int64_t, const uint32_t*,
+                                              const unsigned long long*, unsigned long long*);
+template __global__ void k_render_bwd_geo<1, true, true>(int, int, int, const uint32_t*, const uint32_t*, const uint32_t*, const float*, const float*,
+                                              const float*, const float*, const float*, const uint32_t*, const float*, const float*,
+                                              const uint32_t*, const Rect16*, float*, uint8_t*, int, int, int64_t, const uint32_t*,
+                                              const unsigned long long*, unsigned long long*);
 
 }  // namespace isr

@@ -2,6 +2,7 @@
 // radix sort + identifyTileRanges, rasterizer_impl.cu:70-138,283-323): the u32 scans, the scatter into tile buckets and
 // the per-bucket sorts.  Design notes: top of isr_forward.hip.
 #include "isr_common.hpp"
+#include "isr_fast_pair.hpp"
 
 namespace isr {
 
@@ -770,10 +771,16 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
 
 
 // After the sort: what the blend's four 8x8 blocks of a tile need to know about every list entry BEFORE touching its record.
-// Per 64-entry chunk of a tile's list and per block one 64-bit word - bit l: the entry's alpha >= 1/255 octagon (K1's cull
-// bounds) meets the block - so that a block's wave finds its hits with one scalar load per chunk instead of gathering 32
-// bytes per entry (four times per tile); and the tile-relative int8 box the backward kernels test (box4).
-// The float tests are the blend kernels' own (isr_forward_fast.hip), evaluated once here.
+// Per 64-entry chunk of a tile's list HM_WORDS 64-bit words - bit l of word b (0..3): entry l meets block b; of word 4 + 2 b + h:
+// it meets rows 4 h .. 4 h + 3 of block b - so that a block's wave finds its hits with one scalar load per chunk instead of
+// gathering 32 bytes per entry (four times per tile); and the tile-relative int8 box the backward kernels test (box4).
+// "Meets" (ROW_EXACT, the default): some pixel CENTRE of the block half lies inside the splat's alpha >= 1/255 region - the
+// conic  q <= 0  of the 3-D branch (splat_conic, K1) or the low-pass disc: per pixel row q is a parabola in x, its minimum over a
+// segment of eight pixels is at the two integers around the vertex, clamped.  The bounding octagon of that region (K1's cull bounds,
+// the blend kernels' own float tests, evaluated once here) is the pre-filter and, with ROW_EXACT off (ISR_PACK_EXACT=0), the whole
+// test: it keeps ~1/4 more (block, splat) pairs - pairs the blend kernels evaluate only to find every lane beyond band.hi, and
+// that hold a lane of the splat-major backward for 64 pixel iterations.
+template <bool ROW_EXACT>
 __global__ __launch_bounds__(256) void k_pack_hits(int gx, int64_t capacity, const uint32_t* __restrict__ tile_offset,
                                                    const uint32_t* __restrict__ point_list, const float* __restrict__ cull,
                                                    uint32_t* __restrict__ box4, unsigned long long* __restrict__ hit_mask) {
@@ -787,11 +794,11 @@ __global__ __launch_bounds__(256) void k_pack_hits(int gx, int64_t capacity, con
     const float X0 = (float)((tile % gx) * TILE), Y0 = (float)((tile / gx) * TILE);
     for (int c = wv; c * 64 < len; c += 4) {
         const int i = c * 64 + lane;
-        bool h0 = false, h1 = false, h2 = false, h3 = false;
+        unsigned hb = 0u;            // bit 2 b + h: the entry meets half h of block b
         if (i < len) {
             const int id = (int)point_list[r0 + i];
-            const float4 bb = reinterpret_cast<const float4*>(cull + (size_t)id * 8)[0];
-            const float4 dg = reinterpret_cast<const float4*>(cull + (size_t)id * 8)[1];
+            const float4* cr = reinterpret_cast<const float4*>(cull + (size_t)id * CULL_STRIDE);      // one 64-byte row
+            const float4 bb = cr[0], dg = cr[1];
             box4[r0 + i] = pack_box4(bb, X0, Y0);
             const bool xa = !(bb.x > X0 + 7.0f) && !(bb.y < X0), xb = !(bb.x > X0 + 15.0f) && !(bb.y < X0 + 8.0f);
             const bool ya = !(bb.z > Y0 + 7.0f) && !(bb.w < Y0), yb = !(bb.z > Y0 + 15.0f) && !(bb.w < Y0 + 8.0f);
@@ -799,13 +806,132 @@ __global__ __launch_bounds__(256) void k_pack_hits(int gx, int64_t capacity, con
                 const float bx1 = bx0 + 7.0f, by1 = by0 + 7.0f;
                 return !(dg.x > bx1 + by1) && !(dg.y < bx0 + by0) && !(dg.z > bx1 - by0) && !(dg.w < bx0 - by1);
             };
-            h0 = xa && ya && diag(X0, Y0);
-            h1 = xb && ya && diag(X0 + 8.0f, Y0);
-            h2 = xa && yb && diag(X0, Y0 + 8.0f);
-            h3 = xb && yb && diag(X0 + 8.0f, Y0 + 8.0f);
+            const bool o0 = xa && ya && diag(X0, Y0), o1 = xb && ya && diag(X0 + 8.0f, Y0);
+            const bool o2 = xa && yb && diag(X0, Y0 + 8.0f), o3 = xb && yb && diag(X0 + 8.0f, Y0 + 8.0f);
+            if (!ROW_EXACT) {
+                hb = (o0 ? 3u : 0u) | (o1 ? 12u : 0u) | (o2 ? 48u : 0u) | (o3 ? 192u : 0u);
+            } else if (o0 || o1 || o2 || o3) {
+                const float4 c0 = cr[2], c1 = cr[3];
+                const float Mx = c0.x, My = c0.y, l11 = c0.z, l12 = c0.w, l22 = c1.x, cx = c1.y, cy = c1.z, r2 = c1.w;
+                // e(dx, dy) = (l11 dx + l12 dy)^2 + (l22 dy)^2 <= 1 (relative to M).  Along x = const the vertex is dy = -nxy dx / nyy,
+                // along y = const dx = -l12 dy / l11.  (pass-all form: L = 0: e = 0 or NaN, kept)
+                const float nyy = __builtin_fmaf(l12, l12, l22 * l22);
+                const float ryx = -(l11 * l12) * __builtin_amdgcn_rcpf(nyy), rxy = -l12 * __builtin_amdgcn_rcpf(l11);
+                float xa[2], xb[2], ux[2], vy[2], ddx[2];       // per column range: ends relative to M; l11 dx and the vertex on the line x = clamp(M.x)
+#pragma unroll
+                for (int sg = 0; sg < 2; sg++) {
+                    const float x0 = X0 + 8.0f * (float)sg;
+                    xa[sg] = x0 - Mx; xb[sg] = (x0 + 7.0f) - Mx;
+                    const float dxe = fminf(fmaxf(0.0f, xa[sg]), xb[sg]);
+                    ux[sg] = l11 * dxe;
+                    vy[sg] = ryx * dxe;
+                    const float dn = fminf(fmaxf(0.0f, x0 - cx), (x0 + 7.0f) - cx);      // the low-pass disc: the range's column nearest to the centre
+                    ddx[sg] = dn * dn;
+                }
+                float ya[4], yb[4], uy[4], wy[4], vx[4], ddy[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const float y0 = Y0 + 4.0f * (float)g;
+                    ya[g] = y0 - My; yb[g] = (y0 + 3.0f) - My;
+                    const float dye = fminf(fmaxf(0.0f, ya[g]), yb[g]);
+                    uy[g] = l12 * dye;
+                    wy[g] = l22 * dye; wy[g] *= wy[g];
+                    vx[g] = rxy * dye;
+                    const float dn = fminf(fmaxf(0.0f, y0 - cy), (y0 + 3.0f) - cy);
+                    ddy[g] = dn * dn;
+                }
+                // a lower bound of e: the first square's two addends may cancel, |u| is taken 4 ulps of their magnitudes smaller
+                auto e_low = [](float a, float b, float v2) {
+                    const float u = fmaxf(fabsf(a + b) - 4.8e-7f * (fabsf(a) + fabsf(b)), 0.0f);
+                    return __builtin_fmaf(u, u, v2) * 0.999999f;
+                };
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+#pragma unroll
+                    for (int sg = 0; sg < 2; sg++) {
+                        const int blk = (g >> 1) * 2 + sg;
+                        const bool ok = blk == 0 ? o0 : blk == 1 ? o1 : blk == 2 ? o2 : o3;
+                        const float t1 = fminf(fmaxf(vy[sg], ya[g]), yb[g]);                  // on x = clamp(M.x): dy of the minimum
+                        const float w1 = l22 * t1;
+                        const float e1 = e_low(ux[sg], l12 * t1, w1 * w1);
+                        const float t2 = fminf(fmaxf(vx[g], xa[sg]), xb[sg]);                 // on y = clamp(M.y): dx of the minimum
+                        const float e2 = e_low(l11 * t2, uy[g], wy[g]);
+                        // (negated comparisons: a NaN anywhere keeps the pair)
+                        const bool near = !(fminf(e1, e2) > 1.0f) || !(e1 == e1) || !(e2 == e2) || !(ddx[sg] + ddy[g] > r2);
+                        if (ok && near) hb |= 1u << (2 * blk + (g & 1));
+                    }
+                }
+            }
         }
-        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
-        if (lane < 4) hit_mask[hit_mask_word(r0, tile, c) + lane] = lane == 0 ? m0 : lane == 1 ? m1 : lane == 2 ? m2 : m3;
+        unsigned long long mh[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) mh[k] = __ballot((hb >> k) & 1u);
+        unsigned long long out = 0ull;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (lane == k) out = mh[2 * k] | mh[2 * k + 1];
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (lane == 4 + k) out = mh[k];
+        if (lane < HM_WORDS) hit_mask[hit_mask_word(r0, tile, c) + lane] = out;
+    }
+}
+
+// Test infrastructure (isr_debug_check_hit_masks): every (tile entry, 8x4 block half) whose bit in k_pack_hits' masks is CLEAR is
+// evaluated on all 32 pixels of the half the way the blend kernels do - FAST's rho against band.hi and EXACT's own pair test - and
+// pairs that a kernel would have blended are counted: [0] halves checked, [1] pairs FAST's test passes (fast_pair_lane), [2] pairs
+// EXACT's test passes; also [3] halves whose bit is set, [4] of them: halves where no pixel is near in either
+// arithmetic (what an ideal test would have cleared).  One workgroup per tile, a wave per entry, lane = pixel of a half (two rounds).
+__global__ __launch_bounds__(256) void k_check_hit_masks(int W, int H, int gx, int64_t capacity, const uint32_t* __restrict__ tile_offset,
+                                                         const uint32_t* __restrict__ point_list, const float* __restrict__ rec,
+                                                         const unsigned long long* __restrict__ hit_mask,
+                                                         unsigned long long* __restrict__ counters) {
+    const int tile = blockIdx.x;
+    const int64_t r0 = tile_offset[tile];
+    int64_t r1 = tile_offset[tile + 1];
+    if (r1 > capacity) r1 = capacity;
+    const int len = (int)(r1 - r0);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tx = tile % gx, ty = tile / gx;
+    unsigned long long n_clear = 0, n_fast = 0, n_exact = 0, n_set = 0, n_idle = 0;
+    for (int i = wv; i < len; i += 4) {
+        const int id = (int)point_list[r0 + i];
+        const float* q = rec + (size_t)id * REC;
+        const F3 Tu = {q[0], q[1], q[2]}, Tv = {q[3], q[4], q[5]}, Tw = {q[6], q[7], q[8]};
+        const float cx = q[9], cy = q[10], opa = q[14], band = q[19];
+        const FastBand fb = fast_band(opa, band);
+        const size_t w0 = hit_mask_word(r0, tile, i >> 6);
+        for (int blk = 0; blk < 4; blk++) {
+            const bool bit_blk = (hit_mask[w0 + blk] >> (i & 63)) & 1ull;
+            // lane: half = lane >> 5, pixel of the half = lane & 31
+            const int half = lane >> 5, pr = (lane & 31) >> 3, pc = lane & 7;
+            const bool bit = (hit_mask[w0 + 4 + 2 * blk + half] >> (i & 63)) & 1ull;
+            const float pxf = (float)(tx * TILE + (blk & 1) * 8 + pc), pyf = (float)(ty * TILE + (blk >> 1) * 8 + half * 4 + pr);
+            const bool inside = pxf < (float)W && pyf < (float)H;
+            FastRay fr, er; FastHit fh, eh;
+            const bool fp = fast_pair_lane(Tu, Tv, Tw, cx, cy, opa, fast_det(Tu, Tv, Tw, cx, cy), fb, pxf, pyf, fr, fh);      // FAST's decision (EXACT's inside the bands)
+            const bool ep = exact_pair(pxf, pyf, Tu, Tv, Tw, cx, cy, opa, er, eh);
+            const bool fnear = inside && fp, enear = inside && ep;
+            for (int hf = 0; hf < 2; hf++) {
+                const unsigned long long sel = hf == 0 ? 0xffffffffull : 0xffffffff00000000ull;
+                const unsigned long long mf = __ballot(fnear) & sel, me = __ballot(enear) & sel;
+                const bool b = __builtin_amdgcn_readlane((int)bit, hf * 32) != 0;
+                if (!b) {
+                    n_clear++; n_fast += __popcll(mf); n_exact += __popcll(me);
+                    if ((mf | me) != 0ull && lane == 0) {          // one offender for the report: Gaussian id + 1, its pixel
+                        const int l0 = __builtin_ctzll(mf | me);
+                        counters[5] = (unsigned long long)id + 1ull;
+                        counters[6] = (unsigned long long)(tx * TILE + (blk & 1) * 8 + (l0 & 7)) |
+                                      ((unsigned long long)(ty * TILE + (blk >> 1) * 8 + (l0 >> 5) * 4 + ((l0 & 31) >> 3)) << 32);
+                    }
+                }
+                else { n_set++; if (mf == 0ull && me == 0ull) n_idle++; }
+                // a block word must be the OR of its halves
+                if (b && !bit_blk) n_fast += 1000000ull;
+            }
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(counters + 0, n_clear); atomicAdd(counters + 1, n_fast); atomicAdd(counters + 2, n_exact);
+        atomicAdd(counters + 3, n_set); atomicAdd(counters + 4, n_idle);
     }
 }
 

@@ -26,6 +26,7 @@ constexpr int MAX_FCHUNK = 32;              // feature channels handled per pass
 constexpr int CNT_SUB = 4;
 constexpr int CNT_STRIDE = 32;              // uint32 slots per counter (one 128-B line)
 
+constexpr int CULL_STRIDE = 16;             // floats per Gaussian of GeomView::cull
 struct alignas(8) Rect16 { uint16_t x0, y0, x1, y1; };
 
 struct GeomView {          // carved from the caller's geometry workspace
@@ -37,7 +38,8 @@ struct GeomView {          // carved from the caller's geometry workspace
     uint8_t* clamped;      // [P] bit mask (bit c set = channel c clamped)
     int* radii;            // [P] private copy (caller's radii may be freed before backward)
     uint32_t* scan_tmp;    // block sums for the scan
-    float* cull;           // [P,8] per-Gaussian cull bounds in pixels: box (x_lo, x_hi, y_lo, y_hi), then the same along x+y, x-y
+    float* cull;           // [P,CULL_STRIDE] one 64-byte row per Gaussian (one memory sector per gather): cull bounds in pixels, box
+                           // (x_lo, x_hi, y_lo, y_hi), the same along x+y, x-y, then the alpha >= 1/255 ellipse (splat_conic below)
     unsigned long long* row_mask;   // [P] sampled backward only: bit i = the Gaussian's i-th tile instance received a
                                     // partial row (bit 63 = an instance >= 63 did: consult the byte flags from there on)
 };
@@ -58,11 +60,13 @@ struct BinView {
     unsigned long long* keys;  // [R] (depth_bits << 32) | gaussian, bucketed by tile
     uint32_t* point_list;      // [R] sorted gaussian ids
     uint32_t* box4;            // [R] per-instance cull box, tile-relative int8 (x_lo, x_hi, y_lo, y_hi), written by k_pack_hits
-    unsigned long long* hit_mask;   // [(R / 64 + tiles + 2), 4] per 64-instance chunk of a tile's list and 8x8 block of the tile:
-                                    // bit l = instance 64 c + l meets the block (k_pack_hits -> k_render_fwd_fast_w)
+    unsigned long long* hit_mask;   // [(R / 64 + tiles + 2), HM_WORDS] per 64-instance chunk of a tile's list: words 0..3 = the tile's four
+                                    // 8x8 blocks, bit l = instance 64 c + l meets the block (k_pack_hits -> k_render_fwd_fast_w); words
+                                    // 4..11 = the same per 8x4 HALF of a block (word 4 + 2 block + half: rows 0-3 / 4-7 of the block)
 };
-// chunk c of tile t (list start r0) owns the four words from here: distinct for every (t, c), monotone in t
-__host__ __device__ inline size_t hit_mask_word(int64_t r0, int tile, int chunk) { return ((size_t)(r0 >> 6) + (size_t)tile + (size_t)chunk) * 4; }
+constexpr int HM_WORDS = 12;
+// chunk c of tile t (list start r0) owns the HM_WORDS words from here: distinct for every (t, c), monotone in t
+__host__ __device__ inline size_t hit_mask_word(int64_t r0, int tile, int chunk) { return ((size_t)(r0 >> 6) + (size_t)tile + (size_t)chunk) * HM_WORDS; }
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -89,12 +93,12 @@ inline GeomView geom_view(void* buf, int P) {
     g.radii = carve<int>(p, P);
     g.scan_tmp = carve<uint32_t>(p, (size_t)(P / 256 + 2) * 2);       // per 256 Gaussians (a K1 workgroup): total, then (from +nb+1) maximum
     g.row_mask = carve<unsigned long long>(p, P);
-    g.cull = carve<float>(p, (size_t)P * 8);
+    g.cull = carve<float>(p, (size_t)P * CULL_STRIDE);
     return g;
 }
 inline size_t geom_bytes(int P) {
     GeomView g = geom_view((void*)0, P);
-    return (size_t)(g.cull + (size_t)P * 8) + 256;
+    return (size_t)(g.cull + (size_t)P * CULL_STRIDE) + 256;
 }
 inline ImageView image_view(void* buf, int W, int H) {
     char* p = (char*)buf;
@@ -126,7 +130,7 @@ inline BinView bin_view(void* buf, int64_t R) {
 }
 inline size_t bin_bytes(int64_t R, int tiles) {
     BinView b = bin_view((void*)0, R);
-    return (size_t)(b.hit_mask + ((size_t)((R > 0 ? R : 1) >> 6) + (size_t)tiles + 2) * 4) + 256;
+    return (size_t)(b.hit_mask + ((size_t)((R > 0 ? R : 1) >> 6) + (size_t)tiles + 2) * HM_WORDS) + 256;
 }
 
 // ---------------------------------------------------------------------------
@@ -238,6 +242,54 @@ __device__ __forceinline__ float4 splat_cull_diag(F3 Tu, F3 Tv, F3 Tw, float cx,
         }
     }
     return box;
+}
+
+// The region rho3d <= h of the 3-D branch, exactly: p = k x l is affine in the pixel,
+//   p(c + (dx, dy)) = Pc + dx A + dy B,   A = dp/dpx = Tw x l(c),  B = dp/dpy = k(c) x Tw,  Pc = k(c) x l(c)
+// with k(c) = cx Tw - Tu, l(c) = cy Tw - Tv evaluated AT THE SPLAT'S CENTRE (both small there: none of the cancellation of the
+// large Tu.z ~ cx Tw.z that the per-pixel evaluation carries), and rho3d = |p.xy|^2 / p.z^2 <= h  <=>
+//   q(dx, dy) = |p.xy|^2 - h p.z^2 = qxx dx^2 + 2 qxy dx dy + qyy dy^2 + 2 qx dx + 2 qy dy + q0 <= 0,
+// an ellipse; in centre form  (x - M)^T N (x - M) <= 1  with M = q's minimiser, N = Q / -q(M) = L^T L.  k_pack_hits minimises the form over
+// the rectangle of a block half's pixel centres: the minimum of a convex quadratic over a box lies on the vertical line
+// x = clamp(M.x) or on the horizontal line y = clamp(M.y) of the box (were it elsewhere, the direction towards M would be a feasible
+// descent direction), so two clamped parabola vertices decide it - the bounding octagon above keeps ~1/3 more (half, splat) pairs
+// than have a pixel inside the region.
+// h = skip (K1's alpha < 1/255 bound: the threshold + 1 % + 0.05) + 0.2 % + 0.05: beyond it the pair's true rho is > threshold
+// + 0.10, and FAST's and EXACT's evaluations (each within `exact_noise` <= 0.02 + band < 0.04 of it) are beyond band.hi.
+// Returns (M.x, M.y, l11, l12), (l22, cx, cy, h / 2 = the low-pass disc rho2d <= h), absolute pixels.
+// "Pass-all" form (L = 0, disc radius inf: every test passes, i.e. the octagon alone decides) whenever splat_cull_box gives no
+// finite box (skip = inf, horizon in front of the camera), the splat is ill-conditioned (no finite guard band, exact_noise > 0.02),
+// the form is not an ellipse numerically, or anything is NaN.
+struct SplatConic { float4 a, b; };
+__device__ __forceinline__ SplatConic splat_conic(F3 Tu, F3 Tv, F3 Tw, float cx, float cy, float skip, float4 cb, float exact_noise) {
+    const float inf = __builtin_inff();
+    SplatConic o = {make_float4(cx, cy, 0.f, 0.f), make_float4(0.f, cx, cy, inf)};
+    if (skip < inf && exact_noise <= 0.02f && cb.x > -1e30f && cb.y < 1e30f && cb.z > -1e30f && cb.w < 1e30f) {
+        const float h = __builtin_fmaf(skip, 1.002f, 0.05f);
+        const F3 k = {__builtin_fmaf(cx, Tw.x, -Tu.x), __builtin_fmaf(cx, Tw.y, -Tu.y), __builtin_fmaf(cx, Tw.z, -Tu.z)};
+        const F3 l = {__builtin_fmaf(cy, Tw.x, -Tv.x), __builtin_fmaf(cy, Tw.y, -Tv.y), __builtin_fmaf(cy, Tw.z, -Tv.z)};
+        const F3 Pc = cross3(k, l), A = cross3(Tw, l), B = cross3(k, Tw);
+        const float qxx = A.x * A.x + A.y * A.y - h * (A.z * A.z), qxy = A.x * B.x + A.y * B.y - h * (A.z * B.z);
+        const float qyy = B.x * B.x + B.y * B.y - h * (B.z * B.z), qx = A.x * Pc.x + A.y * Pc.y - h * (A.z * Pc.z);
+        const float qy = B.x * Pc.x + B.y * Pc.y - h * (B.z * Pc.z), q0 = Pc.x * Pc.x + Pc.y * Pc.y - h * (Pc.z * Pc.z);
+        const float det = qxx * qyy - qxy * qxy;
+        const float mx = (qy * qxy - qx * qyy) / det, my = (qx * qxy - qy * qxx) / det;
+        const float kap = -(q0 + (qx * mx + qy * my));           // -q(M)
+        const float ik = 1.0f / kap;
+        const float nxx = qxx * ik, nxy = qxy * ik, nyy = qyy * ik;
+        // N = L^T L (Cholesky): e = (l11 dx + l12 dy)^2 + (l22 dy)^2.  Evaluated as the quadratic form, a thin needle seen thousands
+        // of pixels from its centre cancels ~(distance / thickness)^2 ulps; as a sum of two squares, ~distance / thickness.
+        const float l11 = __builtin_sqrtf(nxx), l12 = nxy / l11, l22 = __builtin_sqrtf(det * ik * ik / nxx);
+        const float chk = ((l11 + l12) + l22) + (mx + my);
+        // an ellipse, well away from degenerate (det of a needle at 45 degrees is itself a cancelling difference: beyond an aspect
+        // of ~100 it is left to the octagon): positive definite with a positive level
+        if (chk == chk && fabsf(chk) < inf && qxx > 0.0f && qyy > 0.0f && det > 1e-4f * (qxx * qyy) && kap > 0.0f && l11 > 0.0f && l22 > 0.0f) {
+            // loosened by 0.2 % (the rounding of this conversion; k_pack_hits adds the rounding of its own evaluation)
+            o.a = make_float4(cx + mx, cy + my, l11 * 0.998f, l12 * 0.998f);
+            o.b = make_float4(l22 * 0.998f, cx, cy, 0.5f * h);
+        }
+    }
+    return o;
 }
 
 // Tile-relative int8 packing of a cull box (rounded outward, saturated): the backward tests it without

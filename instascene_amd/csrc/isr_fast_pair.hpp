@@ -58,8 +58,13 @@ __device__ __forceinline__ float fast_det(const F3 Tu, const F3 Tv, const F3 Tw,
 //   s    EXACT p.xy / p.z, FAST p.xy * rcp(p.z): 3 u |s|;   rho3d, rho2d: fma against mul + add, 3 u rho
 // Returns +inf (always EXACT) when the bound is not small, the horizon crosses the footprint, or a depth of the footprint may
 // lie below near_n + its error - so that a finite band also certifies p.z != 0 and depth >= near_n for every pair (fast_near, fast_pass).
-__device__ __forceinline__ float splat_band(F3 Tu, F3 Tv, F3 Tw, float cx, float cy, float opa, float4 cb, int W, int H) {
+// `exact_noise` (optional): a bound on |rho3d_EXACT - rho3d| over the same footprint, i.e. on what EXACT's two-rounding k.z, l.z
+// (shared by FAST, hence not part of the band) cost against the real-number value - what a test that evaluates the splat's conic
+// in centre-relative coordinates (splat_conic, k_pack_hits) has to allow for; +inf whenever the band is.
+__device__ __forceinline__ float splat_band(F3 Tu, F3 Tv, F3 Tw, float cx, float cy, float opa, float4 cb, int W, int H,
+                                            float* exact_noise = nullptr) {
     const float inf = __builtin_inff();
+    if (exact_noise) *exact_noise = inf;
     const float u = 5.9604645e-8f;
     const float xa = fmaxf(cb.x, 0.0f), xb = fminf(cb.y, (float)(W - 1)), ya = fmaxf(cb.z, 0.0f), yb = fminf(cb.w, (float)(H - 1));
     if (!(xa <= xb && ya <= yb)) return inf;            // no pixel (or NaN): never evaluated
@@ -101,6 +106,10 @@ __device__ __forceinline__ float splat_band(F3 Tu, F3 Tv, F3 Tw, float cx, float
                        8.0f * u * (S * (aw.x + aw.y) + aw.z) + 1e-5f;
     if (!(dlo - derr > NEAR_N)) return inf;             // (with a finite band every depth of the footprint passes the near-plane test)
     if (!(band < 0.04f)) return inf;                    // (the hit masks' own margin is 0.05 in rho; also catches NaN)
+    if (exact_noise) {
+        const float dkz = u * (xb * aw.z + fabsf(Tu.z) + K.z), dlz = u * (yb * aw.z + fabsf(Tv.z) + L.z);
+        *exact_noise = 2.0f * S * ((K.y + K.x) * dlz + (L.y + L.x) * dkz) * r;
+    }
     return band;
 }
 

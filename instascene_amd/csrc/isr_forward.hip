@@ -174,8 +174,8 @@ __global__ __launch_bounds__(256) void k_preprocess(
             skip = 2.0f * l * 1.01f + 0.05f;
         }
         const float4 cb = splat_cull_box(Tu, Tv, Tw, cx, cy, skip);
-        reinterpret_cast<float4*>(g.cull + (size_t)i * 8)[0] = cb;
-        reinterpret_cast<float4*>(g.cull + (size_t)i * 8)[1] = splat_cull_diag(Tu, Tv, Tw, cx, cy, skip);
+        reinterpret_cast<float4*>(g.cull + (size_t)i * CULL_STRIDE)[0] = cb;
+        reinterpret_cast<float4*>(g.cull + (size_t)i * CULL_STRIDE)[1] = splat_cull_diag(Tu, Tv, Tw, cx, cy, skip);
         if (tight_rects) {
             // The reference bins a splat into the SQUARE of its larger 3-sigma extent.  Outside the box above
             // alpha < 1/255 is certain (the blend loops skip such pairs anyway), so tiles the box does not reach are
@@ -207,7 +207,13 @@ __global__ __launch_bounds__(256) void k_preprocess(
         r4[2] = make_float4(Tw.z, cx, cy, normal.x);
         r4[3] = make_float4(normal.y, normal.z, opacities[i], rgb.x);
         // rec[19]: the noise bound of FAST's rho against EXACT's over this splat's footprint (isr_fast_pair.hpp: guard bands)
-        r4[4] = make_float4(rgb.y, rgb.z, pv.z, splat_band(Tu, Tv, Tw, cx, cy, opa, cb, W, H));
+        float exact_noise;
+        r4[4] = make_float4(rgb.y, rgb.z, pv.z, splat_band(Tu, Tv, Tw, cx, cy, opa, cb, W, H, &exact_noise));
+        {   // k_pack_hits' part of the splat's cull row: its alpha >= 1/255 ellipse (isr_common.hpp: splat_conic)
+            const SplatConic cn = splat_conic(Tu, Tv, Tw, cx, cy, skip, cb, exact_noise);
+            float4* c4 = reinterpret_cast<float4*>(g.cull + (size_t)i * CULL_STRIDE);
+            c4[2] = cn.a; c4[3] = cn.b;
+        }
         radius_i = sat_i32(radius);
         touched = (unsigned)(y1 - y0) * (unsigned)(x1 - x0);
         rc = {(uint16_t)x0, (uint16_t)y0, (uint16_t)x1, (uint16_t)y1};
@@ -398,9 +404,9 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd(
             s4[1] = b;                                      // Tv.yz Tw.xy
             s4[2] = make_float4(c.x, c.y, c.z, c.w);        // Tw.z cx cy nx
             s4[3] = make_float4(d.x, d.y, opa, skip);       // ny nz opa skip
-            const float4 cb = reinterpret_cast<const float4*>(cull + (size_t)id * 8)[0];      // per-Gaussian bounds from K1
+            const float4 cb = reinterpret_cast<const float4*>(cull + (size_t)id * CULL_STRIDE)[0];      // per-Gaussian bounds from K1
             s_box[t] = cb;
-            s_diag[t] = reinterpret_cast<const float4*>(cull + (size_t)id * 8)[1];
+            s_diag[t] = reinterpret_cast<const float4*>(cull + (size_t)id * CULL_STRIDE)[1];
             if (first_pass) box4[base + t] = pack_box4(cb, (float)(tx * TILE), (float)(ty * TILE));
             reinterpret_cast<float4*>(s_rgb)[t] = make_float4(d.w, e.x, e.y, 0.0f);
         }
@@ -663,7 +669,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     while (true) {
 #pragma clang loop unroll(disable)
         while (pend < NH && scan < len) {
-            const unsigned long long m = hit_mask[mask0 + (size_t)(scan >> 6) * 4];
+            const unsigned long long m = hit_mask[mask0 + (size_t)(scan >> 6) * HM_WORDS];
             const int i = scan + lane;
             const int id = nid;
             if (i + 64 < len) nid = (int)point_list[r0 + i + 64];

@@ -139,9 +139,9 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
             s4[3] = make_float4(fast_det(Tu, Tv, Tw, c.y, c.z), opa, fb.lo, fb.bw);
             s4[4] = make_float4(c.w, d.x, d.y, 0.0f);
             s4[5] = make_float4(d.w, e.x, e.y, 0.0f);
-            const float4 cb = reinterpret_cast<const float4*>(cull + (size_t)id * 8)[0];      // per-Gaussian bounds from K1
+            const float4 cb = reinterpret_cast<const float4*>(cull + (size_t)id * CULL_STRIDE)[0];      // per-Gaussian bounds from K1
             s_box[t] = cb;
-            s_diag[t] = reinterpret_cast<const float4*>(cull + (size_t)id * 8)[1];
+            s_diag[t] = reinterpret_cast<const float4*>(cull + (size_t)id * CULL_STRIDE)[1];
             if (first_pass) box4[base + t] = pack_box4(cb, X0, Y0);
         }
         __syncthreads();
@@ -463,7 +463,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
         // ---- scan: append this block's hits among the next instances of the tile's list (k_pack_hits' word per chunk and block)
 #pragma clang loop unroll(disable)
         while (pend < NH && scan < len) {
-            const unsigned long long m = hit_mask[mask0 + (size_t)(scan >> 6) * 4];
+            const unsigned long long m = hit_mask[mask0 + (size_t)(scan >> 6) * HM_WORDS];
             const int i = scan + lane;
             const int id = nid;
             if (i + 64 < len) nid = (int)point_list[r0 + i + 64];

@@ -9,6 +9,7 @@
 //   isr_api_ops.hip           include/instascene_ops.h: k-NN, contrastive loss, render() post-processing, SSIM, optimisers
 // No device code crosses a unit (no -fgpu-rdc); what the units share on the host is declared here.
 #pragma once
+#include <atomic>
 
 #include "isr_common.hpp"
 #include "../../include/instascene_rasterizer.h"
@@ -75,6 +76,8 @@ int launch_prepare_scans(int P, int T, const GeomView& g, const ImageView& iv, h
 
 // ---- isr_api_forward_fast.hip
 extern thread_local unsigned long long* g_fwd_counters;     // isr_forward_set_counters: consumed by the next FAST forward
+extern std::atomic<unsigned long long*> g_bwd_counters;     // isr_backward_set_counters: consumed by the next k_render_bwd_geo launch (any
+                                                            // host thread: torch runs backward passes on its own device threads)
 int launch_render_fwd_fast(int P, int tiles, hipStream_t s, int W, int H, int ED, int gx, const ImageView& iv, const BinView& bv,
                            const float* rec, const float* cull, const float* col_pre, const float* tm_pre, const float* extras,
                            const float* bg, float* out_color, float* out_others, float* out_extra, int32_t* tracer,
