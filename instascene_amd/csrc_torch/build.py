@@ -16,7 +16,11 @@ def build(force: bool = False) -> str:
     import torch
     from torch.utils import cpp_extension as ce
     deps = [SRC, os.path.join(ROOT, "include", "instascene_rasterizer.h"), os.path.join(PKG, "libinstascene_hip.so")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+    # up to date = newer than its sources AND built against this torch (a stamp beside the object: an extension built against
+    # another torch's ABI would fail to import, and the drop-in would quietly serve the Python binding instead)
+    stamp = OUT + ".torch_version"
+    same_torch = os.path.exists(stamp) and open(stamp).read().strip() == torch.__version__
+    if not force and os.path.exists(OUT) and same_torch and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     tl = os.path.join(os.path.dirname(torch.__file__), "lib")
     inc = ce.include_paths() + [sysconfig.get_paths()["include"], os.environ.get("ROCM_PATH", "/opt/rocm") + "/include",
@@ -27,6 +31,8 @@ def build(force: bool = False) -> str:
     cmd += ["-I" + i for i in inc] + [SRC, "-o", OUT, "-L" + tl, "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_hip",
                                       "-ltorch_python", "-L" + PKG, "-linstascene_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tl]
     subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(torch.__version__ + "\n")
     return OUT
 
 

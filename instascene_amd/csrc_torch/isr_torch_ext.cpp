@@ -37,6 +37,16 @@ Mode current_mode() {
     }();
     return m;
 }
+// debug=true: per-launch synchronisation for THIS call only - restored on every way out, also when check() throws (advisor, round 5:
+// a failing call used to leave the thread in the slow mode for every later call)
+struct DebugScope {
+    const bool on; int prev = 0;
+    explicit DebugScope(bool debug) : on(debug) { if (on) prev = isr_set_debug(1, 0); }
+    ~DebugScope() { if (on) isr_set_debug(prev, 0); }
+    DebugScope(const DebugScope&) = delete;
+    DebugScope& operator=(const DebugScope&) = delete;
+};
+
 int g_mode_override = -1, g_tight_override = -1;      // set_mode(): the Python layer's rasterizer.set_mode reaches here too
 
 void check(int rc, const char* what) {
@@ -77,7 +87,7 @@ RasterizeGaussiansHIP(const torch::Tensor& background, const torch::Tensor& mean
     const auto fopt = means3D.options().dtype(torch::kFloat32), iopt = means3D.options().dtype(torch::kInt32);
     const auto bopt = means3D.options().dtype(torch::kUInt8);
     void* st = stream_of(means3D);
-    const int prev_debug = debug ? isr_set_debug(1, 0) : 0;
+    const DebugScope debug_scope(debug);
 
     torch::Tensor out_color = torch::empty({3, H, W}, fopt), out_others = torch::empty({3 + 3 + 1, H, W}, fopt);
     torch::Tensor out_extra = F > 0 ? torch::empty({F, H, W}, fopt) : torch::empty({0}, fopt);
@@ -103,7 +113,6 @@ RasterizeGaussiansHIP(const torch::Tensor& background, const torch::Tensor& mean
         out_extra.zero_();
         radii.zero_();
     }
-    if (debug) isr_set_debug(prev_debug, 0);
     return std::make_tuple((int)R, out_color, out_others, radii, out_extra, geom, binning, img, pairs, last);
 }
 
@@ -138,7 +147,7 @@ RasterizeGaussiansBackwardHIP(const torch::Tensor& background, const torch::Tens
         const unsigned mask = ISR_GRAD_GEOMETRY | (F > 0 ? ISR_GRAD_EXTRA : 0u);
         const size_t sb = isr_backward_scratch_bytes(R, F, mask);
         torch::Tensor scratch = torch::empty({(int64_t)sb}, means3D.options().dtype(torch::kUInt8));
-        const int prev_debug = debug ? isr_set_debug(1, 0) : 0;
+        const DebugScope debug_scope(debug);
         check(isr_backward(P, degree, M, R, F, W, H, mode, mask, fptr(bg), fptr(means3D), fptr(sh), fptr(colors), fptr(scales), scale_modifier,
                            fptr(rotations), fptr(transMat), fptr(extra), fptr(view), fptr(proj), fptr(campos), tan_fovx, tan_fovy,
                            radii.data_ptr<int>(), geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(), fptr(dC), fptr(dO),
@@ -146,7 +155,6 @@ RasterizeGaussiansBackwardHIP(const torch::Tensor& background, const torch::Tens
                            fptr_w(dL_dtransMat), fptr_w(dL_dsh), fptr_w(dL_dscales), fptr_w(dL_drotations), fptr_w(dL_dextra),
                            scratch.data_ptr(), sb, stream_of(means3D)),
               "isr_backward");
-        if (debug) isr_set_debug(prev_debug, 0);
     }
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations, dL_dextra);
 }

@@ -148,6 +148,34 @@ with CpuMode():
                  minpix_min_pixnum=np.array(18))
     save("contrastive_loss.npz", **cases)
 
+    # ------------------------------------------------------------------ G3b: the reference's DEFAULT batch (arguments/__init__.py:65,103:
+    # seg_feat_dim = 16, sample_batchsize = 32 768): rows of a pool drawn WITH replacement (train_semantic.py:183-190), the loss on the
+    # drawn rows, and its gradient w.r.t. the POOL through the reference's own indexing (repeats accumulate).  The inputs are 2.6 MB and
+    # regenerable from the seed (torch's CPU generator), so the fixture holds the seed, checksums of the inputs, the loss, and a digest
+    # of the two gradients: 1 024 rows each, the column sums and the L1 norm.
+    big = {}
+    for tag, (seed, Nb, F, K, pool_n, predef) in {"computed": (4321, 32768, 16, 64, 20000, False),
+                                                  "predef": (4322, 32768, 16, 64, 20000, True)}.items():
+        gg = torch.Generator().manual_seed(seed)
+        pool = torch.randn(pool_n, F, generator=gg)
+        pool_labels = torch.randint(0, K + 1, (pool_n,), generator=gg)              # 0 = unlabeled
+        idx = torch.randint(0, pool_n, (Nb,), generator=gg)
+        predef_u = torch.nn.functional.normalize(torch.randn(K + 1, F, generator=gg), dim=1) if predef else None
+        pick = torch.randperm(Nb, generator=gg)[:1024]
+        pick_pool = torch.randperm(pool_n, generator=gg)[:1024]
+        p_ = pool.clone().requires_grad_(True)
+        f = p_[idx]
+        f.retain_grad()
+        loss = contrastive_loss(f, pool_labels[idx], predef_u_list=predef_u)
+        loss.backward()
+        big.update({f"{tag}_seed": np.array(seed), f"{tag}_dims": np.array([Nb, F, K, pool_n, int(predef)]),
+                    f"{tag}_check": np.array([float(pool.double().sum()), float(pool.double().abs().sum()), float(idx.sum()), float(pool_labels.sum())]),
+                    f"{tag}_loss": loss.detach(), f"{tag}_pick": pick, f"{tag}_pick_pool": pick_pool,
+                    f"{tag}_grad_f_rows": f.grad[pick], f"{tag}_grad_f_colsum": f.grad.double().sum(0), f"{tag}_grad_f_l1": f.grad.double().abs().sum(),
+                    f"{tag}_grad_pool_rows": p_.grad[pick_pool], f"{tag}_grad_pool_colsum": p_.grad.double().sum(0),
+                    f"{tag}_grad_pool_l1": p_.grad.double().abs().sum(), f"{tag}_grad_pool_max": p_.grad.abs().max()})
+    save("contrastive_loss_big.npz", **big)
+
     # ------------------------------------------------------------------ G5 cameras
     from scene.cameras import Camera
     from utils.graphics_utils import getProjectionMatrix, getWorld2View2

@@ -208,3 +208,39 @@ def test_install_makes_empty_cache_act_only_under_memory_pressure(monkeypatch):
         assert calls == [1, 1, 1]
     finally:
         dropin.uninstall()
+
+
+def test_dropin_c_module_logs_its_fallback_and_shares_one_mode(tmp_path):
+    """diff_surfel_rasterization._C (advisor, round 5): when the compiled extension cannot be imported the Python binding serves the
+    names - and says so once on logger `instascene_amd`; `_C.set_mode` sets the mode of BOTH bindings (rasterizer.set_mode is the one
+    source of truth), and an extension that loads is handed the Python layer's current mode."""
+    code = textwrap.dedent("""
+        import json, logging, sys, types
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        recs = []
+        class H(logging.Handler):
+            def emit(self, r): recs.append(r.getMessage())
+        logging.getLogger("instascene_amd").addHandler(H())
+        from instascene_amd import rasterizer as rz
+        rz.set_mode("fast")
+        broken = %s
+        if broken:          # an extension that fails to import (stale build, built against another torch)
+            sys.modules["instascene_amd._C_hip"] = None
+        import diff_surfel_rasterization._C as C
+        C.set_mode("exact")
+        out = {"compiled": C.COMPILED, "reason": C.FALLBACK_REASON, "logged": [m for m in recs if "_C_hip.so did not load" in m],
+               "mode_after": rz.get_mode(), "mirror": C.rasterize_gaussians.__module__}
+        print(json.dumps(out))
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for broken in (True, False):
+        r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "dropin"), broken)], capture_output=True, text=True,
+                           env=_env(""), timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        assert rec["mode_after"] == "exact"
+        if broken:
+            assert rec["compiled"] is False and "_C_hip" in rec["reason"] and len(rec["logged"]) == 1
+            assert rec["mirror"] == "instascene_amd.rasterizer"
+        elif rec["compiled"]:
+            assert rec["reason"] is None and rec["logged"] == []

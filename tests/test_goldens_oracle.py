@@ -35,6 +35,32 @@ def test_contrastive_loss_oracle_matches_reference(golden_dir, tag):
     assert_close(f.grad.numpy(), z[f"{tag}_grad"], 2e-4, tag + " grad")
 
 
+@pytest.mark.parametrize("tag", ["computed", "predef"])
+def test_contrastive_loss_oracle_at_the_reference_default_batch(golden_dir, tag):
+    """The oracle's restatement at the reference's DEFAULT shape (32 768 rows of 16 channels drawn with replacement from a pool,
+    arguments/__init__.py:65,103) against the fixture the imported reference produced (make_goldens.py G3b): value, the gradient
+    w.r.t. the drawn rows and - through the index backward, repeats accumulating - w.r.t. the pool."""
+    z = _load(golden_dir, "contrastive_loss_big.npz")
+    seed = int(z[f"{tag}_seed"])
+    Nb, F, K, pool_n, predef = (int(v) for v in z[f"{tag}_dims"])
+    gg = torch.Generator().manual_seed(seed)
+    pool = torch.randn(pool_n, F, generator=gg)
+    pool_labels = torch.randint(0, K + 1, (pool_n,), generator=gg)
+    idx = torch.randint(0, pool_n, (Nb,), generator=gg)
+    predef_u = torch.nn.functional.normalize(torch.randn(K + 1, F, generator=gg), dim=1) if predef else None
+    got = [float(pool.double().sum()), float(pool.double().abs().sum()), float(idx.sum()), float(pool_labels.sum())]
+    assert np.allclose(got, z[f"{tag}_check"], rtol=1e-12, atol=1e-9), "inputs not regenerable from the seed on this torch"
+    p_ = pool.clone().requires_grad_(True)
+    f = p_[idx]
+    f.retain_grad()
+    loss = torch_ops.contrastive_loss(f, pool_labels[idx], predef_u=predef_u)
+    loss.backward()
+    assert abs(float(loss) - float(z[f"{tag}_loss"])) <= 2e-5 * abs(float(z[f"{tag}_loss"]))
+    assert_close(f.grad[torch.tensor(z[f"{tag}_pick"])].numpy(), z[f"{tag}_grad_f_rows"], 2e-4, tag + " rows")
+    assert_close(p_.grad[torch.tensor(z[f"{tag}_pick_pool"])].numpy(), z[f"{tag}_grad_pool_rows"], 2e-4, tag + " pool rows")
+    assert abs(float(p_.grad.double().abs().sum()) - float(z[f"{tag}_grad_pool_l1"])) <= 1e-4 * float(z[f"{tag}_grad_pool_l1"])
+
+
 @pytest.mark.parametrize("i", range(4))
 def test_camera_matrices_match_reference(golden_dir, i):
     z = _load(golden_dir, "cameras.npz")

@@ -137,3 +137,48 @@ def test_fuzz_parity(case):
             f.write(json.dumps(dict(case=case, pixels=int(st["W"] * st["H"]), differing_pixels=int(differ.sum()),
                                     rows_beyond_1e3=rows, evaluations=counters[1], on_the_exact_path=counters[6],
                                     outside_band_deciding_unlike_exact=counters[7])) + "\n")
+
+
+def test_fuzz_sweep_under_the_shipped_default_mode():
+    """What a user gets without setting anything: ISR_MODE unset = `fast_reflists` (the suite itself defaults to `exact`,
+    tests/conftest.py).  All 40 fuzz scenes through the PUBLIC module (`GaussianRasterizer`, forward + backward via autograd) in
+    that mode: integer state = the oracle's bit for bit; every output and gradient = the bits of the explicit-mode entry points that
+    test_fuzz_parity gates against the oracle by cause (same library calls: same bits); the device-side decision counter stays 0."""
+    was = T.rz.get_mode()
+    T.rz.set_mode("fast_reflists")
+    try:
+        assert T.rz.get_mode() == "fast_reflists"
+        for case in range(40):
+            inp, cam, F = _scene(case)
+            st = oracle_forward(inp, cam)
+            args, out, counters = T.hip_forward_fast_counted(inp, cam)          # explicit MODE_FAST on the reference's rectangles
+            assert counters[7] == 0, (case, counters)
+            T.check_binning_exact(st, out)
+            H, W = st["H"], st["W"]
+            settings = T.rz.GaussianRasterizationSettings(
+                image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+                bg=torch.zeros(3, device="cuda"), scale_modifier=1.0, viewmatrix=cam.world_view_transform.cuda(),
+                projmatrix=cam.full_proj_transform.cuda(), sh_degree=3, campos=cam.camera_center.cuda(), prefiltered=False, debug=False)
+            leaves = {k: v.cuda().requires_grad_(True) for k, v in inp.items() if v is not None}
+            means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+            color, radii, allmap, extra, grp = T.rz.GaussianRasterizer(settings)(
+                means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], shs=leaves["shs"], scales=leaves["scales"],
+                rotations=leaves["rotations"], extra_attrs=leaves.get("extra"))
+            assert int(T.rz.LAST_NUM_RENDERED) == st["R"]                        # the reference's num_rendered
+            assert torch.equal(color, out[1]) and torch.equal(allmap, out[2]) and torch.equal(radii, out[3]), case
+            if F:
+                assert torch.equal(extra, out[4]), case
+            dC, dO, dE = T._rand_grads(st, case)
+            loss = (color * torch.tensor(dC).cuda()).sum() + (allmap * torch.tensor(dO).cuda()).sum()
+            if F:
+                loss = loss + (extra * torch.tensor(dE).cuda()).sum()
+            loss.backward()
+            mask = (T.GRAD_EXTRA | T.GRAD_GEOMETRY) if F else T.GRAD_GEOMETRY
+            got = dict(zip(T.GRAD_NAMES, T.hip_backward(args, out, dC, dO, dE, mask, T.MODE_FAST)))
+            for name, leaf in (("dL_dmeans3D", leaves["means3D"]), ("dL_dopacity", leaves["opacities"]), ("dL_dsh", leaves["shs"]),
+                               ("dL_dscales", leaves["scales"]), ("dL_drotations", leaves["rotations"]), ("dL_dmeans2D", means2D)):
+                assert torch.equal(leaf.grad.reshape(got[name].shape), got[name]), (case, name)
+            if F:
+                assert torch.equal(leaves["extra"].grad, got["dL_dextra"]), case
+    finally:
+        T.rz.set_mode(was)

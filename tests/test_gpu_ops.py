@@ -620,3 +620,72 @@ print("ok")
     env = dict(os.environ, ISO_KNN_LDS="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def _big_case(z, tag):
+    """Regenerate the inputs of tests/golden/contrastive_loss_big.npz from its seed (make_goldens.py G3b) and check them against the
+    checksums the fixture holds (a torch whose CPU generator draws differently must fail here, not in the comparison)."""
+    seed = int(z[f"{tag}_seed"])
+    Nb, F, K, pool_n, predef = (int(v) for v in z[f"{tag}_dims"])
+    gg = torch.Generator().manual_seed(seed)
+    pool = torch.randn(pool_n, F, generator=gg)
+    pool_labels = torch.randint(0, K + 1, (pool_n,), generator=gg)
+    idx = torch.randint(0, pool_n, (Nb,), generator=gg)
+    predef_u = torch.nn.functional.normalize(torch.randn(K + 1, F, generator=gg), dim=1) if predef else None
+    chk = z[f"{tag}_check"]
+    got = [float(pool.double().sum()), float(pool.double().abs().sum()), float(idx.sum()), float(pool_labels.sum())]
+    assert np.allclose(got, chk, rtol=1e-12, atol=1e-9), "the fixture's inputs cannot be regenerated from its seed on this torch"
+    return pool, pool_labels, idx, predef_u, K
+
+
+@pytest.mark.parametrize("tag", ["computed", "predef"])
+def test_contrastive_at_the_reference_default_batch_matches_reference_golden(golden_dir, tag):
+    """The reference's DEFAULT loss shape - sample_batchsize = 32 768 rows of seg_feat_dim = 16 drawn with replacement, K = 64
+    (arguments/__init__.py:65,103; train_semantic.py:183-190; utils/contrastive_utils.py:18-73) - against the reference's own value
+    and gradients (fixture generated by importing it).  At this size the similarity kernel takes its separate-reduce form
+    (ck_similarity_small over 2 048 workgroups + ck_loss_reduce) and the row gradients of repeated draws are merged by the chained
+    iso_rows_compact path; both are compared: the gradient w.r.t. the drawn rows and, through torch's index backward AND through
+    compact_row_grads, the gradient w.r.t. the pool."""
+    from instascene_amd.contrastive import compact_row_grads, contrastive_loss_batch
+    z = np.load(os.path.join(golden_dir, "contrastive_loss_big.npz"))
+    pool, pool_labels, idx, predef_u, K = _big_case(z, tag)
+    pick, pick_pool = torch.tensor(z[f"{tag}_pick"]), torch.tensor(z[f"{tag}_pick_pool"])
+    want = float(z[f"{tag}_loss"])
+    p_ = pool.cuda().requires_grad_(True)
+    idx_c = idx.cuda()
+    f = p_[idx_c]
+    f.retain_grad()
+    lab = pool_labels[idx].cuda()
+    pre = None if predef_u is None else predef_u.cuda()
+    loss = contrastive_loss(f, lab, predef_u_list=pre)
+    loss.backward()
+    assert abs(float(loss.detach()) - want) <= 1e-4 * abs(want)
+    gf, gp = f.grad, p_.grad
+
+    def digest(g, rows, name):
+        mx = float(z[f"{tag}_grad_pool_max"])
+        assert_close(g[rows.cuda()].cpu().numpy(), z[f"{tag}_grad_{name}_rows"], 1e-3, f"{tag} {name} rows")
+        cs = g.double().sum(0).cpu().numpy()
+        assert np.abs(cs - z[f"{tag}_grad_{name}_colsum"]).max() <= 1e-3 * max(mx, np.abs(z[f"{tag}_grad_{name}_colsum"]).max())
+        l1 = float(g.double().abs().sum())
+        assert abs(l1 - float(z[f"{tag}_grad_{name}_l1"])) <= 1e-4 * float(z[f"{tag}_grad_{name}_l1"])
+    digest(gf, pick, "f")
+    digest(gp, pick_pool, "pool")
+    # the trainer's path: repeated draws merged by iso_rows_compact (chains of repeats), no dense index backward
+    slot, merged = compact_row_grads(idx_c, gf.contiguous(), pool.shape[0])
+    dense = torch.zeros_like(p_.detach())
+    rows = (slot >= 0).nonzero().squeeze(1)
+    dense[rows] = merged[slot[rows].long()]
+    digest(dense, pick_pool, "pool")
+    assert torch.equal(dense, gp) or (dense - gp).abs().max().item() <= 1e-6 * float(z[f"{tag}_grad_pool_max"])
+    # the batched entry the trainers use (three problems of this shape in one sequence of launches: 3 x 2 048 workgroups)
+    fb = p_.detach()[idx_c].clone().requires_grad_(True)
+    total, parts = contrastive_loss_batch([fb, fb, fb], [lab, lab, lab], [pre, pre, pre], [1.0, 0.5, 0.25], K + 1)
+    total.backward()
+    assert abs(float(total.detach()) - 1.75 * want) <= 1e-4 * abs(1.75 * want)
+    assert abs(float(parts[1]) - 0.5 * want) <= 1e-4 * abs(want)
+    assert_close(fb.grad[pick.cuda()].cpu().numpy() / 1.75, z[f"{tag}_grad_f_rows"], 1e-3, f"{tag} batched rows")
+    from instascene_amd import contrastive as _c
+    for t in _c._SLOT_TABLES.values():          # the persistent slot table: hand it back clean
+        if t.slot.shape[0] == pool.shape[0]:
+            t.slot.fill_(-1); t.dirty = False
