@@ -107,9 +107,9 @@ int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binni
         // ISR_PACK_EXACT=0: the bounding-octagon test alone (rounds 1-5); default: the row-exact conic test behind it
         static const bool row_exact = [] { const char* e = getenv("ISR_PACK_EXACT"); return !(e && e[0] == '0'); }();
         if (row_exact)
-            hipLaunchKernelGGL(k_pack_hits<true>, dim3(T), dim3(256), 0, s, gx, binning_capacity, iv.tile_offset, bv.point_list, g.cull, bv.box4, bv.hit_mask);
+            hipLaunchKernelGGL(k_pack_hits<true>, dim3(T), dim3(256), 0, s, gx, binning_capacity, iv.tile_offset, bv.point_list, g.cull, g.ellipse, bv.box4, bv.hit_mask);
         else
-            hipLaunchKernelGGL(k_pack_hits<false>, dim3(T), dim3(256), 0, s, gx, binning_capacity, iv.tile_offset, bv.point_list, g.cull, bv.box4, bv.hit_mask); }
+            hipLaunchKernelGGL(k_pack_hits<false>, dim3(T), dim3(256), 0, s, gx, binning_capacity, iv.tile_offset, bv.point_list, g.cull, g.ellipse, bv.box4, bv.hit_mask); }
         ISR_LAUNCH_CHECK("k_pack_hits");
     }
     return ISR_OK;

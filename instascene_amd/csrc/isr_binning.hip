@@ -775,15 +775,17 @@ __global__ __launch_bounds__(256) void k_tile_sort(const uint32_t* __restrict__ 
 // it meets rows 4 h .. 4 h + 3 of block b - so that a block's wave finds its hits with one scalar load per chunk instead of
 // gathering 32 bytes per entry (four times per tile); and the tile-relative int8 box the backward kernels test (box4).
 // "Meets" (ROW_EXACT, the default): some pixel CENTRE of the block half lies inside the splat's alpha >= 1/255 region - the
-// conic  q <= 0  of the 3-D branch (splat_conic, K1) or the low-pass disc: per pixel row q is a parabola in x, its minimum over a
-// segment of eight pixels is at the two integers around the vertex, clamped.  The bounding octagon of that region (K1's cull bounds,
-// the blend kernels' own float tests, evaluated once here) is the pre-filter and, with ROW_EXACT off (ISR_PACK_EXACT=0), the whole
-// test: it keeps ~1/4 more (block, splat) pairs - pairs the blend kernels evaluate only to find every lane beyond band.hi, and
-// that hold a lane of the splat-major backward for 64 pixel iterations.
+// ellipse of the 3-D branch (splat_conic, K1: GeomView::ellipse, the only 32 bytes gathered per entry)
+// or the low-pass disc; the minimum of the ellipse's form over the rectangle of a half's pixel centres lies on one of two lines
+// (isr_common.hpp).  With ROW_EXACT off (ISR_PACK_EXACT=0), and for the few splats without a certified ellipse, the bounding octagon
+// of that region (K1's cull bounds, GeomView::cull) decides as in rounds 1-5: it keeps ~1/3 more (half, splat) pairs -
+// pairs the blend kernels evaluate only to find every lane beyond band.hi, and that hold a lane of the splat-major backward for
+// every pixel iteration of its chunk.
 template <bool ROW_EXACT>
 __global__ __launch_bounds__(256) void k_pack_hits(int gx, int64_t capacity, const uint32_t* __restrict__ tile_offset,
                                                    const uint32_t* __restrict__ point_list, const float* __restrict__ cull,
-                                                   uint32_t* __restrict__ box4, unsigned long long* __restrict__ hit_mask) {
+                                                   const float* __restrict__ ellipse, uint32_t* __restrict__ box4,
+                                                   unsigned long long* __restrict__ hit_mask) {
     const int tile = blockIdx.x;
     const int64_t r0 = tile_offset[tile];
     int64_t r1 = tile_offset[tile + 1];
@@ -792,31 +794,56 @@ __global__ __launch_bounds__(256) void k_pack_hits(int gx, int64_t capacity, con
     if (len <= 0) return;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float X0 = (float)((tile % gx) * TILE), Y0 = (float)((tile / gx) * TILE);
+    // the gathers of a chunk are issued one chunk ahead (ids two ahead): a wave's chunks are a serial chain of two dependent memory
+    // trips and ~350 instructions otherwise
+    auto load_id = [&](int c) { const int i = c * 64 + lane; return i < len ? (int)point_list[r0 + i] : -1; };
+    int id_n = load_id(wv), id_nn = load_id(wv + 4);
+    float4 e0_n = make_float4(0.f, 0.f, 0.f, 0.f), e1_n = e0_n;
+    if (id_n >= 0) {
+        e0_n = reinterpret_cast<const float4*>(ellipse + (size_t)id_n * CULL_STRIDE)[0];
+        e1_n = reinterpret_cast<const float4*>(ellipse + (size_t)id_n * CULL_STRIDE)[1];
+    }
     for (int c = wv; c * 64 < len; c += 4) {
         const int i = c * 64 + lane;
         unsigned hb = 0u;            // bit 2 b + h: the entry meets half h of block b
+        const int id = id_n;
+        const float4 c0 = e0_n, c1 = e1_n;
+        id_n = id_nn;
+        if (id_n >= 0) {
+            e0_n = reinterpret_cast<const float4*>(ellipse + (size_t)id_n * CULL_STRIDE)[0];
+            e1_n = reinterpret_cast<const float4*>(ellipse + (size_t)id_n * CULL_STRIDE)[1];
+        }
+        id_nn = load_id(c + 8);
         if (i < len) {
-            const int id = (int)point_list[r0 + i];
-            const float4* cr = reinterpret_cast<const float4*>(cull + (size_t)id * CULL_STRIDE);      // one 64-byte row
-            const float4 bb = cr[0], dg = cr[1];
-            box4[r0 + i] = pack_box4(bb, X0, Y0);
-            const bool xa = !(bb.x > X0 + 7.0f) && !(bb.y < X0), xb = !(bb.x > X0 + 15.0f) && !(bb.y < X0 + 8.0f);
-            const bool ya = !(bb.z > Y0 + 7.0f) && !(bb.w < Y0), yb = !(bb.z > Y0 + 15.0f) && !(bb.w < Y0 + 8.0f);
-            auto diag = [&](float bx0, float by0) {
-                const float bx1 = bx0 + 7.0f, by1 = by0 + 7.0f;
-                return !(dg.x > bx1 + by1) && !(dg.y < bx0 + by0) && !(dg.z > bx1 - by0) && !(dg.w < bx0 - by1);
-            };
-            const bool o0 = xa && ya && diag(X0, Y0), o1 = xb && ya && diag(X0 + 8.0f, Y0);
-            const bool o2 = xa && yb && diag(X0, Y0 + 8.0f), o3 = xb && yb && diag(X0 + 8.0f, Y0 + 8.0f);
-            if (!ROW_EXACT) {
+            const float4* cr = reinterpret_cast<const float4*>(cull + (size_t)id * CULL_STRIDE);
+            const float Mx = c0.x, My = c0.y, l11 = c0.z, l12 = c0.w, l22 = c1.x, cx = c1.y, cy = c1.z, r2 = c1.w;
+            if (!ROW_EXACT || !(l11 > 0.0f)) {
+                // the pass-all form (ill-conditioned splat, no finite bound: 0.4 % of a C3 view) or the octagon-only build: K1's box and
+                // the same along the diagonals, the blend kernels' own float tests
+                const float4 bb = cr[0], dg = cr[1];
+                box4[r0 + i] = pack_box4(bb, X0, Y0);
+                const bool xa = !(bb.x > X0 + 7.0f) && !(bb.y < X0), xb = !(bb.x > X0 + 15.0f) && !(bb.y < X0 + 8.0f);
+                const bool ya = !(bb.z > Y0 + 7.0f) && !(bb.w < Y0), yb = !(bb.z > Y0 + 15.0f) && !(bb.w < Y0 + 8.0f);
+                auto diag = [&](float bx0, float by0) {
+                    const float bx1 = bx0 + 7.0f, by1 = by0 + 7.0f;
+                    return !(dg.x > bx1 + by1) && !(dg.y < bx0 + by0) && !(dg.z > bx1 - by0) && !(dg.w < bx0 - by1);
+                };
+                const bool o0 = xa && ya && diag(X0, Y0), o1 = xb && ya && diag(X0 + 8.0f, Y0);
+                const bool o2 = xa && yb && diag(X0, Y0 + 8.0f), o3 = xb && yb && diag(X0 + 8.0f, Y0 + 8.0f);
                 hb = (o0 ? 3u : 0u) | (o1 ? 12u : 0u) | (o2 ? 48u : 0u) | (o3 ? 192u : 0u);
-            } else if (o0 || o1 || o2 || o3) {
-                const float4 c0 = cr[2], c1 = cr[3];
-                const float Mx = c0.x, My = c0.y, l11 = c0.z, l12 = c0.w, l22 = c1.x, cx = c1.y, cy = c1.z, r2 = c1.w;
+            } else {
                 // e(dx, dy) = (l11 dx + l12 dy)^2 + (l22 dy)^2 <= 1 (relative to M).  Along x = const the vertex is dy = -nxy dx / nyy,
-                // along y = const dx = -l12 dy / l11.  (pass-all form: L = 0: e = 0 or NaN, kept)
+                // along y = const dx = -l12 dy / l11.
                 const float nyy = __builtin_fmaf(l12, l12, l22 * l22);
-                const float ryx = -(l11 * l12) * __builtin_amdgcn_rcpf(nyy), rxy = -l12 * __builtin_amdgcn_rcpf(l11);
+                const float i11 = __builtin_amdgcn_rcpf(l11), i22 = __builtin_amdgcn_rcpf(l22);
+                const float ryx = -(l11 * l12) * __builtin_amdgcn_rcpf(nyy), rxy = -l12 * i11;
+                {   // the tile-relative box the backward kernels test: the ellipse's and the low-pass disc's bounding box (the region
+                    // outside of which alpha < 1/255 is certain), + 1 % + 0.25 px for the approximate reciprocals
+                    const float hx = __builtin_sqrtf(nyy) * i11 * i22 * 1.01f + 0.25f, hy = i22 * 1.01f + 0.25f;
+                    const float rd = __builtin_sqrtf(r2) * 1.01f + 0.25f;
+                    box4[r0 + i] = pack_box4(make_float4(fminf(Mx - hx, cx - rd), fmaxf(Mx + hx, cx + rd), fminf(My - hy, cy - rd),
+                                                         fmaxf(My + hy, cy + rd)), X0, Y0);
+                }
                 float xa[2], xb[2], ux[2], vy[2], ddx[2];       // per column range: ends relative to M; l11 dx and the vertex on the line x = clamp(M.x)
 #pragma unroll
                 for (int sg = 0; sg < 2; sg++) {
@@ -850,7 +877,6 @@ __global__ __launch_bounds__(256) void k_pack_hits(int gx, int64_t capacity, con
 #pragma unroll
                     for (int sg = 0; sg < 2; sg++) {
                         const int blk = (g >> 1) * 2 + sg;
-                        const bool ok = blk == 0 ? o0 : blk == 1 ? o1 : blk == 2 ? o2 : o3;
                         const float t1 = fminf(fmaxf(vy[sg], ya[g]), yb[g]);                  // on x = clamp(M.x): dy of the minimum
                         const float w1 = l22 * t1;
                         const float e1 = e_low(ux[sg], l12 * t1, w1 * w1);
@@ -858,7 +884,7 @@ __global__ __launch_bounds__(256) void k_pack_hits(int gx, int64_t capacity, con
                         const float e2 = e_low(l11 * t2, uy[g], wy[g]);
                         // (negated comparisons: a NaN anywhere keeps the pair)
                         const bool near = !(fminf(e1, e2) > 1.0f) || !(e1 == e1) || !(e2 == e2) || !(ddx[sg] + ddy[g] > r2);
-                        if (ok && near) hb |= 1u << (2 * blk + (g & 1));
+                        if (near) hb |= 1u << (2 * blk + (g & 1));
                     }
                 }
             }

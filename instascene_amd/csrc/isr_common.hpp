@@ -26,7 +26,7 @@ constexpr int MAX_FCHUNK = 32;              // feature channels handled per pass
 constexpr int CNT_SUB = 4;
 constexpr int CNT_STRIDE = 32;              // uint32 slots per counter (one 128-B line)
 
-constexpr int CULL_STRIDE = 16;             // floats per Gaussian of GeomView::cull
+constexpr int CULL_STRIDE = 8;              // floats per Gaussian of GeomView::cull and of GeomView::ellipse
 struct alignas(8) Rect16 { uint16_t x0, y0, x1, y1; };
 
 struct GeomView {          // carved from the caller's geometry workspace
@@ -38,8 +38,10 @@ struct GeomView {          // carved from the caller's geometry workspace
     uint8_t* clamped;      // [P] bit mask (bit c set = channel c clamped)
     int* radii;            // [P] private copy (caller's radii may be freed before backward)
     uint32_t* scan_tmp;    // block sums for the scan
-    float* cull;           // [P,CULL_STRIDE] one 64-byte row per Gaussian (one memory sector per gather): cull bounds in pixels, box
-                           // (x_lo, x_hi, y_lo, y_hi), the same along x+y, x-y, then the alpha >= 1/255 ellipse (splat_conic below)
+    float* cull;           // [P,8] per-Gaussian cull bounds in pixels: box (x_lo, x_hi, y_lo, y_hi), then the same along x+y, x-y
+    float* ellipse;        // [P,8] the alpha >= 1/255 ellipse + low-pass disc (splat_conic below): the 32 bytes k_pack_hits gathers per
+                           // tile entry - a dense array of its own, so that four neighbouring Gaussians (neighbours on screen:
+                           // the trainers store them in Z-order) share one 128-byte line
     unsigned long long* row_mask;   // [P] sampled backward only: bit i = the Gaussian's i-th tile instance received a
                                     // partial row (bit 63 = an instance >= 63 did: consult the byte flags from there on)
 };
@@ -94,11 +96,12 @@ inline GeomView geom_view(void* buf, int P) {
     g.scan_tmp = carve<uint32_t>(p, (size_t)(P / 256 + 2) * 2);       // per 256 Gaussians (a K1 workgroup): total, then (from +nb+1) maximum
     g.row_mask = carve<unsigned long long>(p, P);
     g.cull = carve<float>(p, (size_t)P * CULL_STRIDE);
+    g.ellipse = carve<float>(p, (size_t)P * CULL_STRIDE);
     return g;
 }
 inline size_t geom_bytes(int P) {
     GeomView g = geom_view((void*)0, P);
-    return (size_t)(g.cull + (size_t)P * CULL_STRIDE) + 256;
+    return (size_t)(g.ellipse + (size_t)P * CULL_STRIDE) + 256;
 }
 inline ImageView image_view(void* buf, int W, int H) {
     char* p = (char*)buf;

@@ -209,10 +209,10 @@ __global__ __launch_bounds__(256) void k_preprocess(
         // rec[19]: the noise bound of FAST's rho against EXACT's over this splat's footprint (isr_fast_pair.hpp: guard bands)
         float exact_noise;
         r4[4] = make_float4(rgb.y, rgb.z, pv.z, splat_band(Tu, Tv, Tw, cx, cy, opa, cb, W, H, &exact_noise));
-        {   // k_pack_hits' part of the splat's cull row: its alpha >= 1/255 ellipse (isr_common.hpp: splat_conic)
+        {   // k_pack_hits' row of the splat: its alpha >= 1/255 ellipse (isr_common.hpp: splat_conic)
             const SplatConic cn = splat_conic(Tu, Tv, Tw, cx, cy, skip, cb, exact_noise);
-            float4* c4 = reinterpret_cast<float4*>(g.cull + (size_t)i * CULL_STRIDE);
-            c4[2] = cn.a; c4[3] = cn.b;
+            float4* c4 = reinterpret_cast<float4*>(g.ellipse + (size_t)i * CULL_STRIDE);
+            c4[0] = cn.a; c4[1] = cn.b;
         }
         radius_i = sat_i32(radius);
         touched = (unsigned)(y1 - y0) * (unsigned)(x1 - x0);
