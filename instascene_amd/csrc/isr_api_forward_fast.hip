@@ -23,6 +23,8 @@ int launch_render_fwd_fast(int P, int tiles, hipStream_t s, int W, int H, int ED
         // k_render_fwd_fast_w: one wave per 8x8 block; the four blocks of a tile on one XCD (workgroup v -> XCD v % 8)
         const int grid = (tiles + 7) / 8 * 32;
         static const bool wide_ok = [] { const char* e = getenv("ISR_FWD_WIDE"); return !(e && e[0] == '0'); }();
+        // ISR_FWD_CN=0: colour and normal by the vector FMAs also for narrow feature chunks (k_render_fwd_fast_w<.., CN = false>)
+        static const bool cn_ok = [] { const char* e = getenv("ISR_FWD_CN"); return !(e && e[0] == '0'); }();
         do {
             ProfScope ps_("k_render_fwd", s);
 #define ISR_GW2(FEAT, STATS, AUX_, ORD, NC_)                                                                                       \
@@ -36,6 +38,17 @@ int launch_render_fwd_fast(int P, int tiles, hipStream_t s, int W, int H, int ED
             const bool wide = wide_ok && ED - ch >= 64 && (ED & 3) == 0;
             if (ED - ch <= 0) { if (counters) ISR_GW(false, true, 1); else ISR_GW(false, false, 1); }
             else if (wide) { if (counters) ISR_GW(true, true, 2); else ISR_GW(true, false, 2); }
+            else if (cn_ok && aux && first && ED <= 24 && (ED & 3) == 0) {
+                // a single narrow pass with the aux outputs (the reference's default seg_feat_dim = 16): rgb and normal ride on the
+                // feature MFMAs' spare rows (k_render_fwd_fast_w<.., CN = true>; the STATS build likewise: the same bits)
+#define ISR_GCN(STATS, ORD)                                                                                                                 \
+    hipLaunchKernelGGL((k_render_fwd_fast_w<true, STATS, true, ORD, 1, true>), dim3(grid), dim3(64), 0, s, W, H, ED, ch, first, gx, tiles,     \
+                       iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,                     \
+                       out_color, out_others, out_extra, tracer, tcap, tcount, bv.hit_mask, capacity, counters, order)
+                if (counters) { if (order) ISR_GCN(true, true); else ISR_GCN(true, false); }
+                else { if (order) ISR_GCN(false, true); else ISR_GCN(false, false); }
+#undef ISR_GCN
+            }
             else { if (counters) ISR_GW(true, true, 1); else ISR_GW(true, false, 1); }
 #undef ISR_GW2
 #undef ISR_GW

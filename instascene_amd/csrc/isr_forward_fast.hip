@@ -359,7 +359,13 @@ constexpr int FW_RING = 128;        // pending (id, position) pairs
 
 // NC = 32-channel chunks of the feature blended per pass: 1 (four waves per SIMD), or 2 for F >= 64 - two more accumulator
 // tiles and 8 KB of feature rows per wave cost the fourth wave (+27 % per pass), one pass instead of two is still 0.7x.
-template <bool FEAT, bool STATS, bool AUX, bool ORDER, int NC>
+// CN ("colour and normal on the matrix cores"; FEAT, AUX, NC == 1, a single pass of at most 24 channels in whole float4s - the
+// reference's default seg_feat_dim = 16, arguments/__init__.py:65): rows 24..29 of the zero-padded A operand carry the staged
+// splat's rgb and normal, so the two MFMAs that blend the feature blend them too and the six v_fma per blending evaluation (and the
+// registers of their sums) are gone; the epilogue reads the six sums out of the accumulator tiles.  The MFMA rounds as the
+// VALU chain does not (its k slots are summed in order, unfused): colour and normal then differ from the CN-less kernel in their
+// last bits - within FAST's 1e-4 like everything else, and the same bits in every FAST mode.
+template <bool FEAT, bool STATS, bool AUX, bool ORDER, int NC, bool CN = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(NC == 1 ? 4 : 3, NC == 1 ? 4 : 3))) void k_render_fwd_fast_w(
     int W, int H, int ED, int ch_base, int first_pass, int gx, int tiles, const uint32_t* __restrict__ tile_offset,
     const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ cull,
@@ -371,6 +377,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
 #ifndef ISR_FW_HITS2
 #define ISR_FW_HITS2 24
 #endif
+    static_assert(!CN || (FEAT && AUX && NC == 1), "CN rides on the feature MFMAs of a single 32-channel pass with the aux outputs");
     constexpr int RS = FF_RS, FCH = 32 * NC, NH = NC == 1 ? FW_HITS : ISR_FW_HITS2;      // (64 channels: 24 hits per round = 11.25 KB of LDS per wave; 16 / 24 / 32: 1.10 / 1.05 / 1.21 ms at C5)
     __shared__ __attribute__((aligned(16))) float s_rec[NH * RS];
     __shared__ __attribute__((aligned(16))) float s_feat[FEAT ? NH * FCH : 4];
@@ -510,6 +517,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             s4[3] = make_float4(fast_det(Tu, Tv, Tw, c.y, c.z), opa, fb.lo, fb.bw);
             s4[4] = make_float4(c.w, d.x, d.y, 0.0f);
             s4[5] = make_float4(d.w, e.x, e.y, __int_as_float(hp.y));          // .w: position in the tile's list (1-based)
+            if (CN) {            // channels 24..29 of the hit's feature row: rgb, normal (the narrow staging below writes [0, nfeat <= 24) only)
+                float* fr_ = s_feat + lane * FCH + 24;
+                *reinterpret_cast<float4*>(fr_) = make_float4(d.w, e.x, e.y, c.w);
+                *reinterpret_cast<float2*>(fr_ + 4) = make_float2(d.x, d.y);
+            }
         }
         if (FEAT) {
             if ((ED & 3) == 0 && nfeat == FCH) {
@@ -621,8 +633,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                     M1 += mw;
                     M2 = __builtin_fmaf(m_, mw, M2);
                     if (T > 0.5f) { median_depth = depth; median_contributor = contributor; }
-                    N0 = __builtin_fmaf(q4e.x, w, N0); N1 = __builtin_fmaf(q4e.y, w, N1); N2 = __builtin_fmaf(q4e.z, w, N2);
-                    C0 = __builtin_fmaf(q5e.x, w, C0); C1 = __builtin_fmaf(q5e.y, w, C1); C2 = __builtin_fmaf(q5e.z, w, C2);
+                    if (!CN) {
+                        N0 = __builtin_fmaf(q4e.x, w, N0); N1 = __builtin_fmaf(q4e.y, w, N1); N2 = __builtin_fmaf(q4e.z, w, N2);
+                        C0 = __builtin_fmaf(q5e.x, w, C0); C1 = __builtin_fmaf(q5e.y, w, C1); C2 = __builtin_fmaf(q5e.z, w, C2);
+                    }
                 }
                 T = test_T;
                 last_contributor = contributor;
@@ -715,16 +729,46 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
         final_T[pix + 2 * N] = __builtin_fmaf(m_ref, __builtin_fmaf(m_ref, A_, M1 + M1), M2);
         n_contrib[pix] = last_contributor;
         n_contrib[pix + N] = median_contributor;
-        out_color[pix] = __builtin_fmaf(T, bg[0], C0);
-        out_color[N + pix] = __builtin_fmaf(T, bg[1], C1);
-        out_color[2 * N + pix] = __builtin_fmaf(T, bg[2], C2);
+        if (!CN) {
+            out_color[pix] = __builtin_fmaf(T, bg[0], C0);
+            out_color[N + pix] = __builtin_fmaf(T, bg[1], C1);
+            out_color[2 * N + pix] = __builtin_fmaf(T, bg[2], C2);
+            out_others[2 * N + pix] = N0;
+            out_others[3 * N + pix] = N1;
+            out_others[4 * N + pix] = N2;
+        }
         out_others[pix] = D;
         out_others[N + pix] = 1 - T;
-        out_others[2 * N + pix] = N0;
-        out_others[3 * N + pix] = N1;
-        out_others[4 * N + pix] = N2;
         out_others[5 * N + pix] = median_depth;
         out_others[6 * N + pix] = distortion;
+    }
+    if constexpr (CN) {
+        // rows 24..29 of the accumulator tiles: channel (r & 3) + 8 (r >> 2) + 4 (lane >> 5) - lanes 0..31 hold rgb and normal.x of
+        // pixel grp * 32 + lane in elements 12..15, lanes 32..63 normal.y, normal.z of pixel grp * 32 + (lane - 32) in elements 12, 13.
+        // The background term needs the pixel's own T: lane p holds pixel p's.
+        const float T_other = __shfl_xor(T, 32);
+        if (first_pass) {
+#pragma unroll
+            for (int grp = 0; grp < 2; grp++) {
+                const int p = grp * 32 + (lane & 31);
+                const unsigned qx = tx * TILE + (sub & 1) * 8 + (p & 7), qy = ty * TILE + (sub >> 1) * 8 + (p >> 3);
+                if (qx < (unsigned)W && qy < (unsigned)H) {
+                    const size_t qp = (size_t)W * qy + qx;
+                    const float a8 = grp == 0 ? accA[12] : accB[12], a9 = grp == 0 ? accA[13] : accB[13];
+                    const float a10 = grp == 0 ? accA[14] : accB[14], a11 = grp == 0 ? accA[15] : accB[15];
+                    if (lane < 32) {
+                        const float Tp = grp == 0 ? T : T_other;
+                        out_color[qp] = __builtin_fmaf(Tp, bg[0], a8);
+                        out_color[N + qp] = __builtin_fmaf(Tp, bg[1], a9);
+                        out_color[2 * N + qp] = __builtin_fmaf(Tp, bg[2], a10);
+                        out_others[2 * N + qp] = a11;
+                    } else {
+                        out_others[3 * N + qp] = a8;
+                        out_others[4 * N + qp] = a9;
+                    }
+                }
+            }
+        }
     }
     if constexpr (FEAT) {
 #pragma unroll
