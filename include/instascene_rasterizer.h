@@ -135,6 +135,20 @@ int isr_forward_render(int P, int ED, int width, int height, int mode,
                        int32_t* tracer_pairs, int64_t tracer_capacity, int32_t* tracer_count,
                        void* stream);
 
+/* The same with the feature rows handed over RAW plus their two row-normalisation factors (extension for a trainer that owns the
+ * feature table; the reference's render() normalises the table itself, gaussian_renderer/__init__.py:57-62, after the model's getter
+ * did, scene/gaussian_model.py:122-125): the blend stages (extra_attrs[g] * extra_row_scale[g][0]) * extra_row_scale[g][1] - what
+ * isr_feature_rows_step would otherwise have written out as a normalised copy of the whole table every step.  ISR_MODE_FAST, the
+ * per-block blend kernel only; extra_row_scale = NULL is isr_forward_render. */
+int isr_forward_render_scaled(int P, int ED, int width, int height, int mode,
+                              const float* background, const float* colors_precomp,
+                              const float* transMat_precomp, const float* extra_attrs, const float* extra_row_scale /*[P,2]*/,
+                              void* geom_buffer, void* binning_buffer, int64_t binning_capacity,
+                              void* image_buffer,
+                              float* out_color, float* out_others, float* out_extra,
+                              int32_t* tracer_pairs, int64_t tracer_capacity, int32_t* tracer_count,
+                              void* stream);
+
 /* ---- backward (K9 + K10).  Replaces rasterizer_impl.cu:355-463.  Gradient
  * outputs are fully written by the call (no zero-initialisation needed); the
  * ones not selected by grad_mask may be NULL.  dL_dout_* may be NULL meaning
@@ -187,6 +201,17 @@ int isr_feature_rows_step(int P, int row_begin, int row_count, int64_t num_rende
                           const float* gz_dense, const float* gy, int* gy_slot, const float* gy_merged, float eps1,
                           float eps2, float* x, float* grad_out, double lr, double beta1, double beta2, double eps,
                           long long step, float* exp_avg, float* exp_avg_sq, float* y, float* z, void* stream);
+
+/* The same, writing - when z_scale != NULL - only the two row-normalisation factors (q1, q2) of every updated row into
+ * z_scale [P, 2] instead of the normalised copy z [P, ED] of the table (z may then be NULL): z = (x q1) q2, which
+ * isr_forward_render_scaled applies to the rows it stages.  One [P, ED] stream less per step.  isr_row_scales computes the
+ * factors of a table no step has touched yet (the same expressions: the same bits). */
+int isr_feature_rows_step_scaled(int P, int row_begin, int row_count, int64_t num_rendered, int ED, const void* geom_buffer,
+                                 const void* rows_scratch,
+                                 const float* gz_dense, const float* gy, int* gy_slot, const float* gy_merged, float eps1,
+                                 float eps2, float* x, float* grad_out, double lr, double beta1, double beta2, double eps,
+                                 long long step, float* exp_avg, float* exp_avg_sq, float* y, float* z, float* z_scale, void* stream);
+int isr_row_scales(int P, int ED, float eps1, float eps2, const float* x, float* z_scale, void* stream);
 
 /* ---- rasterizer_impl.cu:141-153 */
 int isr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -40,6 +40,9 @@ SIGNATURES = {
     "isr_forward_bin": (c_int, [c_int, c_int, c_int, _P, _P, c_int64, _P, _P]),
     "isr_forward_render": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
                                    _P, c_int64, _P, _P]),
+    "isr_forward_render_scaled": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
+                                          _P, c_int64, _P, _P]),
+    "isr_row_scales": (c_int, [c_int, c_int, c_float, c_float, _P, _P, _P]),
     "isr_backward": (c_int, [c_int, c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_uint,
                              _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, c_float, c_float, _P,
                              _P, _P, _P, _P, _P, _P,
@@ -52,6 +55,9 @@ SIGNATURES = {
     "isr_feature_rows_step": (c_int, [c_int, c_int, c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_longlong, _P, _P, _P, _P,
                                       _P]),
+    "isr_feature_rows_step_scaled": (c_int, [c_int, c_int, c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P,
+                                             ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_longlong,
+                                             _P, _P, _P, _P, _P, _P]),
     "isr_mark_visible": (c_int, [c_int, _P, _P, _P, _P, _P]),
     "isr_debug_state": (c_int, [c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "isr_debug_check_hit_masks": (c_int, [c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P]),

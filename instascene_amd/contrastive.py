@@ -369,6 +369,15 @@ class FeatureAdam:
         # out a placeholder whose rows gather_rows computes from the parameter.  For callers that read y only through
         # gather_rows (SegTrainer: the 3-D loss' 8 192 rows).
         self.store_y = True
+        # False (needs store_y = False; FAST mode's per-block blend): the one-pass tail does not write z = normalize(normalize(param))
+        # either - the table the next forward blends, another of its [P,F] streams - but only its two factors per row (q1, q2) [P,2];
+        # leaf mode hands out an (unwritten) placeholder for z that carries (param, factors), and the rasterizer's forward passes
+        # the RAW table plus the factors to the blend, which applies them to the rows it stages (isr_forward_render_scaled: the same
+        # two multiplies in the same order - the same bits).  Anything else that needs z's values materialises them
+        # (``materialize_scaled_rows``).
+        self.store_z = True
+        self._zscale = None
+        self._zplace = None
 
     def step(self):
         p = self.param
@@ -429,18 +438,18 @@ class FeatureAdam:
             slot, merged = (a, b) if a.dtype == torch.int32 else compact_row_grads(a, b, p.shape[0])
         return (rows, gy, gz, slot, merged)
 
-    def _rows_kernel(self, tail, r0, n, grad_out, y, z):
+    def _rows_kernel(self, tail, r0, n, grad_out, y, z, zscale=None):
         rows, gy, gz, slot, merged = tail
         p = self.param
         P, F = p.shape
         with _hot.on_device(p.device):
-            check(lib().isr_feature_rows_step(P, int(r0), int(n), rows.R if rows is not None else 0, F,
-                                              _p(rows.geom) if rows is not None else None,
-                                              _p(rows.scratch) if rows is not None else None, _p(gz), _p(gy), _p(slot),
-                                              _p(merged), float(self.norm_eps[0]), float(self.norm_eps[1]), _p(p.data),
-                                              _p(grad_out), self.lr, float(self.betas[0]), float(self.betas[1]), self.eps,
-                                              max(1, self.step_count), _p(self.exp_avg), _p(self.exp_avg_sq), _p(y), _p(z),
-                                              _stream()), "isr_feature_rows_step")
+            check(lib().isr_feature_rows_step_scaled(P, int(r0), int(n), rows.R if rows is not None else 0, F,
+                                                     _p(rows.geom) if rows is not None else None,
+                                                     _p(rows.scratch) if rows is not None else None, _p(gz), _p(gy), _p(slot),
+                                                     _p(merged), float(self.norm_eps[0]), float(self.norm_eps[1]), _p(p.data),
+                                                     _p(grad_out), self.lr, float(self.betas[0]), float(self.betas[1]), self.eps,
+                                                     max(1, self.step_count), _p(self.exp_avg), _p(self.exp_avg_sq), _p(y), _p(z),
+                                                     _p(zscale), _stream()), "isr_feature_rows_step")
         if slot is not None:
             _slot_consumed(slot, P, n)
 
@@ -455,11 +464,25 @@ class FeatureAdam:
         """Reduction + chain rule + Adam + next normalisations of every row in one pass."""
         p = self.param
         y = torch.empty_like(p.data) if self.store_y else None
-        z = torch.empty_like(p.data)
         self.step_count += 1
-        self._rows_kernel(tail, 0, p.shape[0], None, y, z)
+        if self._scaled_rows_wanted():
+            zs = self._scale_buffer()
+            self._rows_kernel(tail, 0, p.shape[0], None, y, None, zs)
+            z = _ScaledRows(zs)
+        else:
+            z = torch.empty_like(p.data)
+            self._rows_kernel(tail, 0, p.shape[0], None, y, z)
         torch.autograd.graph.increment_version(p)
         self.normalized = (p._version, y, z)
+
+    def _scaled_rows_wanted(self) -> bool:
+        return (not self.store_z) and (not self.store_y) and self.param.is_cuda
+
+    def _scale_buffer(self):
+        p = self.param
+        if self._zscale is None or self._zscale.shape[0] != p.shape[0] or self._zscale.device != p.device:
+            self._zscale = torch.empty((p.shape[0], 2), dtype=torch.float32, device=p.device)
+        return self._zscale
 
     def begin_step(self):
         """Start an Adam step applied in row ranges (``step_range``), finished by ``end_step``."""
@@ -514,10 +537,25 @@ class FeatureAdam:
         p = self.param
         if self.leaf_mode and torch.is_grad_enabled():
             if self.normalized is None or self.normalized[0] != p._version:
-                with torch.no_grad():
-                    y0, z0 = _RowNorm2.apply(p.detach(), *self.norm_eps)
-                self.normalized = (p._version, y0, z0)
-            z = self.normalized[2].detach().requires_grad_(True)
+                if self._scaled_rows_wanted():
+                    # a table no step has touched yet: its factors alone (isr_row_scales: the tail kernel's own expressions)
+                    zs = self._scale_buffer()
+                    with _hot.on_device(p.device):
+                        check(lib().isr_row_scales(p.shape[0], p.shape[1], float(self.norm_eps[0]), float(self.norm_eps[1]),
+                                                   _p(p.data), _p(zs), _stream()), "isr_row_scales")
+                    self.normalized = (p._version, None, _ScaledRows(zs))
+                else:
+                    with torch.no_grad():
+                        y0, z0 = _RowNorm2.apply(p.detach(), *self.norm_eps)
+                    self.normalized = (p._version, y0, z0)
+            if isinstance(self.normalized[2], _ScaledRows):
+                # z is not stored: an unwritten [P,F] placeholder (allocated once, never read) that knows how its rows are made
+                if self._zplace is None or self._zplace.shape != p.shape or self._zplace.device != p.device:
+                    self._zplace = torch.empty_like(p.data)
+                z = self._zplace.detach().requires_grad_(True)
+                setattr(z, SCALED_ROWS_ATTR, (p.detach(), self.normalized[2].scale))
+            else:
+                z = self.normalized[2].detach().requires_grad_(True)
             if self.normalized[1] is not None:
                 y = y_leaf = self.normalized[1].detach().requires_grad_(True)
             else:
@@ -549,6 +587,25 @@ class FeatureAdam:
 
 
 _MEMO_ATTR = "_isr_renormalized"
+SCALED_ROWS_ATTR = "_isr_scaled_rows"       # on a [P,F] placeholder: (raw table x [P,F], factors [P,2]); its rows are (x q1) q2
+
+
+class _ScaledRows:
+    """FeatureAdam.normalized[2] when z is not stored (store_z = False): the two factors per row."""
+    __slots__ = ("scale",)
+
+    def __init__(self, scale):
+        self.scale = scale
+
+
+def materialize_scaled_rows(t):
+    """The values of a tensor that may be a scaled-rows placeholder (FeatureAdam.store_z = False): (x q1) q2, the same two
+    multiplies in the same order as the kernels that would have stored them."""
+    src = getattr(t, SCALED_ROWS_ATTR, None)
+    if src is None:
+        return t
+    x, qs = src
+    return (x * qs[:, 0:1]) * qs[:, 1:2]
 
 
 def row_normalize(x: torch.Tensor, eps: float) -> torch.Tensor:

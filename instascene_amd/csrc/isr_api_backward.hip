@@ -81,6 +81,22 @@ int isr_feature_rows_step(int P, int row_begin, int row_count, int64_t num_rende
                           const float* gz_dense, const float* gy, int* gy_slot, const float* gy_merged, float eps1,
                           float eps2, float* x, float* grad_out, double lr, double beta1, double beta2, double eps,
                           long long step, float* exp_avg, float* exp_avg_sq, float* y, float* z, void* stream) {
+    return isr_feature_rows_step_scaled(P, row_begin, row_count, num_rendered, ED, geom_buffer, rows_scratch, gz_dense, gy, gy_slot,
+                                        gy_merged, eps1, eps2, x, grad_out, lr, beta1, beta2, eps, step, exp_avg, exp_avg_sq, y, z,
+                                        nullptr, stream);
+}
+
+int isr_row_scales(int P, int ED, float eps1, float eps2, const float* x, float* z_scale, void* stream) {
+    if (P < 0 || ED <= 0 || (ED & 3) != 0 || ED > 256) return fail(ISR_EINVAL, "row_scales needs ED % 4 == 0 and ED <= 256");
+    if (P > 0 && (!x || !z_scale)) return fail(ISR_EINVAL, "row_scales: null pointer");
+    return launch_row_scales(P, ED, eps1, eps2, x, z_scale, (hipStream_t)stream) != 0 ? ISR_EHIP : ISR_OK;
+}
+
+int isr_feature_rows_step_scaled(int P, int row_begin, int row_count, int64_t num_rendered, int ED, const void* geom_buffer,
+                                 const void* rows_scratch,
+                                 const float* gz_dense, const float* gy, int* gy_slot, const float* gy_merged, float eps1,
+                                 float eps2, float* x, float* grad_out, double lr, double beta1, double beta2, double eps,
+                                 long long step, float* exp_avg, float* exp_avg_sq, float* y, float* z, float* z_scale, void* stream) {
     if (P < 0 || ED <= 0 || (ED & 3) != 0 || ED > 256) return fail(ISR_EINVAL, "feature_rows_step needs ED % 4 == 0 and ED <= 256");
     if (row_begin < 0 || row_count < 0 || row_begin + row_count > P) return fail(ISR_EINVAL, "feature_rows_step: bad row range");
     if (P == 0 || row_count == 0) return ISR_OK;
@@ -88,7 +104,7 @@ int isr_feature_rows_step(int P, int row_begin, int row_count, int64_t num_rende
         return fail(ISR_EINVAL, "feature_rows_step: null pointer");
     float lr_over_bc1 = 0.f, inv_sqrt_bc2 = 0.f;
     if (grad_out == nullptr) {
-        if (!exp_avg || !exp_avg_sq || !z) return fail(ISR_EINVAL, "feature_rows_step: Adam state / outputs required");
+        if (!exp_avg || !exp_avg_sq || (!z && !z_scale)) return fail(ISR_EINVAL, "feature_rows_step: Adam state / outputs required");
         if (step < 1) return fail(ISR_EINVAL, "feature_rows_step: step counts from 1");
         const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
         lr_over_bc1 = (float)(lr / bc1);
@@ -96,7 +112,7 @@ int isr_feature_rows_step(int P, int row_begin, int row_count, int64_t num_rende
     }
     const int rc = launch_feature_rows_step(P, row_begin, row_count, num_rendered, ED, geom_buffer, rows_scratch, gz_dense, gy, gy_slot, gy_merged, eps1,
                                             eps2, x, grad_out, lr_over_bc1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                                            inv_sqrt_bc2, (float)eps, exp_avg, exp_avg_sq, y, z, (hipStream_t)stream);
+                                            inv_sqrt_bc2, (float)eps, exp_avg, exp_avg_sq, y, z, z_scale, (hipStream_t)stream);
     if (rc != 0) return ISR_EHIP;
     return ISR_OK;
 }

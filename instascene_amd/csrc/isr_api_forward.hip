@@ -169,6 +169,16 @@ int isr_forward_render(int P, int ED, int width, int height, int mode, const flo
                        void* geom_buffer, void* binning_buffer, int64_t binning_capacity, void* image_buffer,
                        float* out_color, float* out_others, float* out_extra, int32_t* tracer_pairs,
                        int64_t tracer_capacity, int32_t* tracer_count, void* stream) {
+    return isr_forward_render_scaled(P, ED, width, height, mode, background, colors_precomp, transMat_precomp, extra_attrs, nullptr,
+                                     geom_buffer, binning_buffer, binning_capacity, image_buffer, out_color, out_others, out_extra,
+                                     tracer_pairs, tracer_capacity, tracer_count, stream);
+}
+
+int isr_forward_render_scaled(int P, int ED, int width, int height, int mode, const float* background,
+                              const float* colors_precomp, const float* transMat_precomp, const float* extra_attrs,
+                              const float* extra_row_scale, void* geom_buffer, void* binning_buffer, int64_t binning_capacity,
+                              void* image_buffer, float* out_color, float* out_others, float* out_extra, int32_t* tracer_pairs,
+                              int64_t tracer_capacity, int32_t* tracer_count, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const bool prebinned = (mode & ISR_MODE_PREBINNED) != 0;
     const bool feature_only = (mode & ISR_MODE_FEATURE_ONLY) != 0;
@@ -188,13 +198,15 @@ int isr_forward_render(int P, int ED, int width, int height, int mode, const flo
         const int rc = isr_forward_bin(P, width, height, geom_buffer, binning_buffer, binning_capacity, image_buffer, stream);
         if (rc != ISR_OK) return rc;
     }
+    if (extra_row_scale != nullptr && (mode != ISR_MODE_FAST || ED <= 0))
+        return fail(ISR_EINVAL, "extra_row_scale needs ISR_MODE_FAST and ED > 0");
     if (mode == ISR_MODE_EXACT)
         return launch_render_fwd<ExactMath>(T, s, width, height, ED, gx, iv, bv, g.rec, g.cull, colors_precomp, transMat_precomp,
                                             extra_attrs, background, out_color, out_others, out_extra, tracer_pairs,
                                             (long long)tracer_capacity, tracer_count, binning_capacity);
     return launch_render_fwd_fast(P, T, s, width, height, ED, gx, iv, bv, g.rec, g.cull, colors_precomp, transMat_precomp,
                                   extra_attrs, background, out_color, out_others, out_extra, feature_only ? nullptr : tracer_pairs,
-                                  (long long)tracer_capacity, tracer_count, binning_capacity, !feature_only);
+                                  (long long)tracer_capacity, tracer_count, binning_capacity, !feature_only, extra_row_scale);
 }
 
 int isr_debug_state(int P, int width, int height, int64_t num_rendered, const void* geom_buffer,

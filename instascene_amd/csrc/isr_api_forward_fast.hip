@@ -10,7 +10,7 @@ thread_local unsigned long long* g_fwd_counters = nullptr;    // isr_forward_set
 int launch_render_fwd_fast(int P, int tiles, hipStream_t s, int W, int H, int ED, int gx, const ImageView& iv,
                                   const BinView& bv, const float* rec, const float* cull, const float* col_pre, const float* tm_pre,
                                   const float* extras, const float* bg, float* out_color, float* out_others, float* out_extra,
-                                  int32_t* tracer, long long tcap, int32_t* tcount, int64_t capacity, bool aux) {
+                                  int32_t* tracer, long long tcap, int32_t* tcount, int64_t capacity, bool aux, const float* xscale) {
     unsigned long long* counters = g_fwd_counters;
     g_fwd_counters = nullptr;
     static const int per_block = [] { const char* e = getenv("ISR_FWD_WAVE"); return e ? atoi(e) : 1; }();
@@ -29,7 +29,7 @@ int launch_render_fwd_fast(int P, int tiles, hipStream_t s, int W, int H, int ED
             ProfScope ps_("k_render_fwd", s);
 #define ISR_GW2(FEAT, STATS, AUX_, ORD, NC_)                                                                                       \
     hipLaunchKernelGGL((k_render_fwd_fast_w<FEAT, STATS, AUX_, ORD, NC_>), dim3(grid), dim3(64), 0, s, W, H, ED, ch, first, gx, tiles, \
-                       iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,        \
+                       iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, xscale, bg, iv.final_T, iv.n_contrib,        \
                        out_color, out_others, out_extra, tracer, tcap, tcount, bv.hit_mask, capacity, counters, order)
 #define ISR_GW(FEAT, STATS, NC_)                                                                                           \
     do { if (aux) { if (order) ISR_GW2(FEAT, STATS, true, true, NC_); else ISR_GW2(FEAT, STATS, true, false, NC_); }            \
@@ -43,7 +43,7 @@ int launch_render_fwd_fast(int P, int tiles, hipStream_t s, int W, int H, int ED
                 // feature MFMAs' spare rows (k_render_fwd_fast_w<.., CN = true>; the STATS build likewise: the same bits)
 #define ISR_GCN(STATS, ORD)                                                                                                                 \
     hipLaunchKernelGGL((k_render_fwd_fast_w<true, STATS, true, ORD, 1, true>), dim3(grid), dim3(64), 0, s, W, H, ED, ch, first, gx, tiles,     \
-                       iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, bg, iv.final_T, iv.n_contrib,                     \
+                       iv.tile_offset, bv.point_list, rec, cull, col_pre, tm_pre, extras, xscale, bg, iv.final_T, iv.n_contrib,                     \
                        out_color, out_others, out_extra, tracer, tcap, tcount, bv.hit_mask, capacity, counters, order)
                 if (counters) { if (order) ISR_GCN(true, true); else ISR_GCN(true, false); }
                 else { if (order) ISR_GCN(false, true); else ISR_GCN(false, false); }
@@ -58,6 +58,7 @@ int launch_render_fwd_fast(int P, int tiles, hipStream_t s, int W, int H, int ED
         } while (ch < ED);
         return ISR_OK;
     }
+    if (xscale != nullptr) return fail(ISR_EINVAL, "extra_row_scale is taken by the per-block FAST blend only (ISR_FWD_WAVE=1, P <= 2^26)");
     do {
         ProfScope ps_("k_render_fwd", s);
 #define ISR_GO2(FEAT, STATS, AUX_, ORD)                                                                                   \

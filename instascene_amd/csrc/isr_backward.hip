@@ -1306,7 +1306,7 @@ __global__ __launch_bounds__(256) void k_feature_rows_step(
     const float* __restrict__ gz_dense, const float* __restrict__ gy, int* __restrict__ gy_slot,
     const float* __restrict__ gy_merged, float eps1, float eps2, float* __restrict__ x,
     float* __restrict__ grad_out, float lr_over_bc1, float om1, float beta2, float om2, float inv_sqrt_bc2, float eps,
-    float* __restrict__ m, float* __restrict__ v, float* __restrict__ y, float* __restrict__ z) {
+    float* __restrict__ m, float* __restrict__ v, float* __restrict__ y, float* __restrict__ z, float* __restrict__ zscale) {
     const int q = F >> 2;
     int lpr = 1;
     while (lpr < q) lpr <<= 1;
@@ -1417,9 +1417,34 @@ __global__ __launch_bounds__(256) void k_feature_rows_step(
         const float q2 = 1.0f / (__builtin_sqrtf(s2) + eps2);
         if (ok) {
             if (y != nullptr) *reinterpret_cast<float4*>(y + off) = y4;      // optional: iso_gather_rownorm recomputes rows
-            nt_store4(z + off, make_float4(y4.x * q2, y4.y * q2, y4.z * q2, y4.w * q2));
+            // z = (x q1) q2, the table the next forward blends: written out ([P,F], a seventh stream) - or only its two factors
+            // per row ([P,2]), which the blend applies to the rows it stages (isr_forward_render_scaled: the same two multiplies)
+            if (zscale != nullptr) { if (sub == 0) *reinterpret_cast<float2*>(zscale + 2 * (size_t)row) = make_float2(q1, q2); }
+            else nt_store4(z + off, make_float4(y4.x * q2, y4.y * q2, y4.z * q2, y4.w * q2));
         }
     }
+}
+
+// The two factors alone, of rows that no step has touched yet (the first forward of a run): q1 = 1 / (|x| + eps1),
+// q2 = 1 / (|x q1| + eps2) with step (4)'s own expressions and summation order above - the same bits.
+__global__ __launch_bounds__(256) void k_row_scales(int P, int F, float eps1, float eps2, const float* __restrict__ x,
+                                                    float* __restrict__ zscale) {
+    const int q = F >> 2;
+    int lpr = 1;
+    while (lpr < q) lpr <<= 1;
+    const int sub = (threadIdx.x & 63) & (lpr - 1);
+    const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) / lpr;
+    const bool ok = row < P && sub < q;
+    float4 np4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) np4 = *reinterpret_cast<const float4*>(x + (size_t)row * F + 4 * sub);
+    float s1 = np4.x * np4.x + np4.y * np4.y + np4.z * np4.z + np4.w * np4.w;
+    for (int o = lpr >> 1; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o);
+    const float q1 = 1.0f / (__builtin_sqrtf(s1) + eps1);
+    const float4 y4 = make_float4(np4.x * q1, np4.y * q1, np4.z * q1, np4.w * q1);
+    float s2 = y4.x * y4.x + y4.y * y4.y + y4.z * y4.z + y4.w * y4.w;
+    for (int o = lpr >> 1; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
+    const float q2 = 1.0f / (__builtin_sqrtf(s2) + eps2);
+    if (ok && sub == 0) *reinterpret_cast<float2*>(zscale + 2 * (size_t)row) = make_float2(q1, q2);
 }
 
 // ----------------------------------------------------------------------------
@@ -1964,7 +1989,7 @@ static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int
 int launch_feature_rows_step(int P, int row_begin, int row_count, int64_t R, int F, const void* geom, const void* rows_scratch, const float* gz_dense,
                              const float* gy, int* gy_slot, const float* gy_merged, float eps1, float eps2, float* x, float* grad_out, float lr_over_bc1,
                              float om1, float beta2, float om2, float inv_sqrt_bc2, float eps, float* m, float* v, float* y,
-                             float* z, hipStream_t s) {
+                             float* z, float* zscale, hipStream_t s) {
     if (P <= 0 || row_count <= 0) return 0;
     GeomView g = geom_view(const_cast<void*>(geom), P);
     const float* partial = (const float*)rows_scratch;
@@ -1978,12 +2003,21 @@ int launch_feature_rows_step(int P, int row_begin, int row_count, int64_t R, int
     if (grad_out != nullptr)
         hipLaunchKernelGGL(k_feature_rows_step<false>, dim3(blocks), dim3(256), 0, s, row_begin, row_end, F, g.point_offsets,
                            g.tiles_touched, g.row_mask, partial, flags, R, stride, gz_dense, gy, gy_slot, gy_merged, eps1, eps2, x, grad_out, lr_over_bc1, om1, beta2, om2,
-                           inv_sqrt_bc2, eps, m, v, y, z);
+                           inv_sqrt_bc2, eps, m, v, y, z, zscale);
     else
         hipLaunchKernelGGL(k_feature_rows_step<true>, dim3(blocks), dim3(256), 0, s, row_begin, row_end, F, g.point_offsets,
                            g.tiles_touched, g.row_mask, partial, flags, R, stride, gz_dense, gy, gy_slot, gy_merged, eps1, eps2, x, grad_out, lr_over_bc1, om1, beta2, om2,
-                           inv_sqrt_bc2, eps, m, v, y, z);
+                           inv_sqrt_bc2, eps, m, v, y, z, zscale);
     ISR_CHECK_LAUNCH_B("k_feature_rows_step");
+    return 0;
+}
+
+int launch_row_scales(int P, int F, float eps1, float eps2, const float* x, float* zscale, hipStream_t s) {
+    if (P <= 0) return 0;
+    int q = F >> 2, lpr = 1;
+    while (lpr < q) lpr <<= 1;
+    hipLaunchKernelGGL(k_row_scales, dim3((unsigned)(((long long)P * lpr + 255) / 256)), dim3(256), 0, s, P, F, eps1, eps2, x, zscale);
+    ISR_CHECK_LAUNCH_B("k_row_scales");
     return 0;
 }
 

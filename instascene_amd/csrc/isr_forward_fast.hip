@@ -370,6 +370,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     int W, int H, int ED, int ch_base, int first_pass, int gx, int tiles, const uint32_t* __restrict__ tile_offset,
     const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ cull,
     const float* __restrict__ col_pre, const float* __restrict__ tm_pre, const float* __restrict__ extras,
+    const float* __restrict__ xscale /* [P,2] or null: the staged feature row is (extras[id] * xscale[id][0]) * xscale[id][1] */,
     const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_others, float* __restrict__ out_extra, int32_t* __restrict__ tracer, long long tracer_cap,
     int32_t* __restrict__ tracer_count, const unsigned long long* __restrict__ hit_mask, int64_t capacity,
@@ -534,6 +535,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                     const int id = s_ring[(head + inst) & (FW_RING - 1)].x;           // (a stale ring entry beyond nh: a valid id, unused)
                     fv[k] = e < nh * (FCH / 4) ? *reinterpret_cast<const float4*>(extras + (size_t)id * ED + ch_base + part * 4)
                                                : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (xscale != nullptr && e < nh * (FCH / 4)) {          // (beyond nh the ring entry is stale: no load through it)
+                        // the trainer hands over the RAW feature and its two row-normalisation factors instead of a normalised copy
+                        // of the table (one [P,F] stream less per step): the same two multiplies, in the same order, as the
+                        // kernel that would have written that copy (k_feature_rows_step: y = x q1, z = y q2) - the same bits
+                        const float2 sc = *reinterpret_cast<const float2*>(xscale + 2 * (size_t)id);
+                        fv[k] = make_float4((fv[k].x * sc.x) * sc.y, (fv[k].y * sc.x) * sc.y, (fv[k].z * sc.x) * sc.y, (fv[k].w * sc.x) * sc.y);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < NH * (FCH / 4) / 64; k++) {
@@ -547,14 +555,20 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                 for (int e = lane; e < nh * q4; e += 64) {
                     const int inst = e / q4, part = e - inst * q4;
                     const int id = s_ring[(head + inst) & (FW_RING - 1)].x;
-                    reinterpret_cast<float4*>(s_feat)[inst * (FCH / 4) + part] =
-                        *reinterpret_cast<const float4*>(extras + (size_t)id * ED + ch_base + part * 4);
+                    float4 f4 = *reinterpret_cast<const float4*>(extras + (size_t)id * ED + ch_base + part * 4);
+                    if (xscale != nullptr) {
+                        const float2 sc = *reinterpret_cast<const float2*>(xscale + 2 * (size_t)id);
+                        f4 = make_float4((f4.x * sc.x) * sc.y, (f4.y * sc.x) * sc.y, (f4.z * sc.x) * sc.y, (f4.w * sc.x) * sc.y);
+                    }
+                    reinterpret_cast<float4*>(s_feat)[inst * (FCH / 4) + part] = f4;
                 }
             } else {                    // ragged chunk: zero-padded to 32 channels
                 for (int e = lane; e < nh * FCH; e += 64) {
                     const int inst = e / FCH, c = e - inst * FCH;
                     const int id = s_ring[(head + inst) & (FW_RING - 1)].x;
-                    s_feat[e] = c < nfeat ? extras[(size_t)id * ED + ch_base + c] : 0.0f;
+                    float fvs = c < nfeat ? extras[(size_t)id * ED + ch_base + c] : 0.0f;
+                    if (xscale != nullptr) fvs = (fvs * xscale[2 * (size_t)id]) * xscale[2 * (size_t)id + 1];
+                    s_feat[e] = fvs;
                 }
             }
         }

@@ -81,7 +81,7 @@ extern std::atomic<unsigned long long*> g_bwd_counters;     // isr_backward_set_
 int launch_render_fwd_fast(int P, int tiles, hipStream_t s, int W, int H, int ED, int gx, const ImageView& iv, const BinView& bv,
                            const float* rec, const float* cull, const float* col_pre, const float* tm_pre, const float* extras,
                            const float* bg, float* out_color, float* out_others, float* out_extra, int32_t* tracer,
-                           long long tcap, int32_t* tcount, int64_t capacity, bool aux);
+                           long long tcap, int32_t* tcount, int64_t capacity, bool aux, const float* xscale = nullptr);
 
 // ---- isr_api_backward.hip
 size_t backward_scratch_bytes(int64_t R, int ED, unsigned mask);

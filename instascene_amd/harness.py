@@ -218,6 +218,10 @@ class SegTrainer:
             raise ValueError("fused_tail needs fused_update and sampled_path")
         if self.fused_tail:
             self.opt.store_y = False         # the step reads normalize(param) only through gather_rows (3-D loss)
+            # ... and normalize(normalize(param)) only through the rasterizer's forward, which takes the raw table and the two
+            # factors per row instead (one [P,F] stream less in the tail: FeatureAdam.store_z) - opt-in, ISR_SCALED_ROWS=1: bit-identical, but
+            # measured no faster (C3 -2 %, C5 +-0: what the tail saves the blend's staging pays)
+            self.opt.store_z = os.environ.get("ISR_SCALED_ROWS", "0") != "1"
         self.view_seed = seed
         self.gen = torch.Generator(device=self.device).manual_seed(1000 + seed * 131 + rank)
         self.sample_seed = 1000 + seed * 131 + rank

@@ -62,6 +62,8 @@ _PENDING = {}         # address of a forward's geometry buffer -> (pinned int64 
 
 
 LAST_NUM_RENDERED = 0   # instance count of the most recent forward (reporting only)
+_SCALED_ROWS_ATTR = "_isr_scaled_rows"       # = contrastive.SCALED_ROWS_ATTR (a feature table handed over raw + two factors per row)
+_FWD_WAVE = os.environ.get("ISR_FWD_WAVE", "1") not in ("0",)      # the library's per-block FAST blend is the one in use
 
 
 def set_mode(mode: str):
@@ -438,6 +440,15 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
     transMat_precomp = _f32c(transMat_precomp, "transMat_precomp")
     viewmatrix, projmatrix = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix")
     sh, campos = _f32c(sh, "sh"), _f32c(campos, "campos")
+    xscale = None
+    scaled_src = getattr(extra_attrs, _SCALED_ROWS_ATTR, None) if (F > 0 and extra_attrs is not None) else None
+    if scaled_src is not None:
+        # a placeholder for normalize(normalize(x)) that was never stored (contrastive.FeatureAdam.store_z = False): the per-block
+        # FAST blend takes the raw table and the two factors per row; every other kernel gets the values materialised
+        if mode == MODE_FAST and _FWD_WAVE and P <= (1 << 26) and scaled_src[0].is_cuda:
+            extra_attrs, xscale = scaled_src[0], _f32c(scaled_src[1], "extra_row_scale")
+        else:
+            extra_attrs = (scaled_src[0] * scaled_src[1][:, 0:1]) * scaled_src[1][:, 1:2]
     extra = _f32c(extra_attrs.to(dev) if (extra_attrs is not None and extra_attrs.numel() and not extra_attrs.is_cuda)
                   else extra_attrs, "extra_attrs") if F > 0 else None
 
@@ -505,9 +516,9 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
             gcount = torch.empty((1,), dtype=torch.int32, device=dev)
         else:
             grp, gcount = None, None
-        check(L.isr_forward_render(P, F, W, H, int(mode) | prebinned | (MODE_FEATURE_ONLY if feature_only else 0), _ptr(bg), _ptr(colors), _ptr(transMat_precomp), _ptr(extra),
-                                   _ptr(geom), _ptr(binning), R, _ptr(img), _ptr(out_color), _ptr(out_others),
-                                   _ptr(out_extra), _ptr(grp), H * W * 10 if tracer else 0, _ptr(gcount), st),
+        check(L.isr_forward_render_scaled(P, F, W, H, int(mode) | prebinned | (MODE_FEATURE_ONLY if feature_only else 0), _ptr(bg), _ptr(colors), _ptr(transMat_precomp), _ptr(extra),
+                                          _ptr(xscale), _ptr(geom), _ptr(binning), R, _ptr(img), _ptr(out_color), _ptr(out_others),
+                                          _ptr(out_extra), _ptr(grp), H * W * 10 if tracer else 0, _ptr(gcount), st),
               "isr_forward_render")
     if sized_by_estimate and not _verify_at_backward:
         # no backward will follow to verify the estimate (an eval / no_grad render, or a direct call of this function):
@@ -800,6 +811,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         has_samples = sample_pixels is not None and attr_degree > 0
         sampled = sample_extra(extra, sample_pixels) if has_samples else torch.empty(0, device=color.device)
         ctx.sample_pixels = sample_pixels.detach() if has_samples else None
+        # (a scaled-rows placeholder, contrastive.FeatureAdam.store_z = False: the attribute does not survive save_for_backward)
+        ctx.scaled_src = getattr(extra_attrs, _SCALED_ROWS_ATTR, None)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, extra_attrs, sh,
                               geomBuffer, binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii, gau_related_pixels)
@@ -851,6 +864,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                       ctx.num_rendered, ctx.sample_pixels, grad_sampled, cov3Ds_precomp,
                                                       geomBuffer, binningBuffer, imgBuffer, mode=ctx.mode)
             return (None,) * 8 + (ge, None, None, None, None, None)
+        if getattr(ctx, "scaled_src", None) is not None:          # the dense backward reads the feature's values: make them
+            extra_attrs = (ctx.scaled_src[0] * ctx.scaled_src[1][:, 0:1]) * ctx.scaled_src[1][:, 1:2]
         bargs = (rs.bg, means3D, radii, colors_precomp, scales, rotations, extra_attrs, rs.scale_modifier, cov3Ds_precomp,
                  rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_out_extra, sh,
                  rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)

@@ -476,3 +476,34 @@ def test_plain_loop_trainer_runs_the_reference_iteration():
         seen.append(tr.last_view)
     assert all(np.isfinite(losses)) and not torch.equal(tr.model._seg_feature.detach(), p0)
     assert sorted(seen[:6]) == list(range(6)) and sorted(seen[6:]) == list(range(6)) and seen[:6] != list(range(6))
+
+
+@pytest.mark.parametrize("F", [16, 32, 64])
+def test_scaled_rows_reproduce_the_stored_normalised_table(F, monkeypatch):
+    """SegTrainer's tail does not write z = normalize(normalize(param)) [P,F] any more but its two factors per row [P,2]; the blend
+    applies them to the RAW rows it stages (isr_forward_render_scaled, FeatureAdam.store_z = False).  The same two multiplies in
+    the same order: losses, parameters and moments bit-identical to the default run that stores the table (opt-in: ISR_SCALED_ROWS=1) - for the
+    narrow (F = 16: colour / normal on the MFMAs' spare rows), the full (32) and the wide (64: two chunks per pass) staging paths,
+    including the iterations whose multi-view leg renders further views from the same placeholder."""
+    rz.set_mode("fast_reflists")
+    rz.set_tracer(False)
+    outs = []
+    try:
+        for scaled in ("0", "1"):
+            monkeypatch.setenv("ISR_SCALED_ROWS", scaled)
+            sc, cams = _scene(P=6000, F=F, W=256, H=192)
+            tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=2048, n_labels=12, use_class_feat=True, multiview=True,
+                            sample_mv_frames=2, seed=5)
+            assert tr.fused_tail and tr.opt.store_z == (scaled == "0")
+            losses = [float(tr.step(it)) for it in range(12)]
+            from instascene_amd.contrastive import _ScaledRows
+            assert isinstance(tr.opt.normalized[2], _ScaledRows) == (scaled == "1")
+            with torch.no_grad():           # an evaluation render after training: differentiates / normalises the usual way
+                img = render(tr.cams[1], tr.model, tr.pipe, tr.bg)["seg_feature"].clone()
+            outs.append((losses, tr.model._seg_feature.detach().clone(), tr.opt.exp_avg.clone(), tr.opt.exp_avg_sq.clone(), img))
+        assert outs[0][0] == outs[1][0]
+        for a, b in zip(outs[0][1:], outs[1][1:]):
+            assert torch.equal(a, b)
+    finally:
+        rz.set_mode("exact")
+        rz.set_tracer(True)
