@@ -1933,6 +1933,15 @@ size_t backward_sampled_scratch_bytes(int64_t R, int ED, int n, int W, int H) {
     return backward_scratch_bytes(R, ED, 1u) + align_up((3 * T + 1 + 3 * (size_t)(n > 0 ? n : 1)) * sizeof(uint32_t), 256) + 256;
 }
 
+// Two zero fills in one ordinary dispatch (16-byte stores; both regions start 16-byte aligned, their sizes are rounded up by the
+// caller's layout): hipMemsetAsync is a blit kernel behind a barrier packet per call - two of them sat on the step's main chain.
+__global__ __launch_bounds__(256) void k_zero2(uint4* __restrict__ a, size_t na16, uint4* __restrict__ b, size_t nb16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t k = i; k < na16; k += stride) a[k] = z;
+    for (size_t k = i; k < nb16; k += stride) b[k] = z;
+}
+
 template <class Math>
 static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int n, const long long* pix,
                                      const float* rows_in, const float* tm_pre, const void* geom, const void* binning,
@@ -1953,10 +1962,19 @@ static int launch_backward_sampled_t(int P, int64_t R, int ED, int W, int H, int
     // for the reduction below
     static const bool masked_reduce = [] { const char* e = getenv("ISR_MASKED_REDUCE"); return !(e && e[0] == '0'); }();
     unsigned long long* row_mask = (dL_dextra == nullptr || masked_reduce) ? g.row_mask : nullptr;
-    if (row_mask != nullptr && hipMemsetAsync(row_mask, 0, sizeof(unsigned long long) * (size_t)P, s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }
+    static const bool own_fill = [] { const char* e = getenv("ISR_OWN_FILL"); return !(e && e[0] == '0'); }();
+    const size_t flag_bytes = (size_t)((char*)(cnt + T) - (char*)flags);       // row flags and the per-tile sample counters are neighbours
+    const bool fused_fill = own_fill && R > 0 && n > 0 && ((size_t)flags & 15) == 0 && (row_mask == nullptr || ((size_t)row_mask & 15) == 0);
+    if (fused_fill) {
+        // (the mask's P words and the flags' region both end inside 256-byte aligned carvings: rounding up to 16 bytes stays inside)
+        const size_t na = row_mask != nullptr ? (sizeof(unsigned long long) * (size_t)P + 15) / 16 : 0, nb = (flag_bytes + 15) / 16;
+        const unsigned blocks = (unsigned)std::min<size_t>(2048, (std::max(na, nb) + 255) / 256);
+        hipLaunchKernelGGL(k_zero2, dim3(blocks ? blocks : 1), dim3(256), 0, s, reinterpret_cast<uint4*>(row_mask), na,
+                           reinterpret_cast<uint4*>(flags), nb);
+        ISR_CHECK_LAUNCH_B("k_zero2");
+    } else if (row_mask != nullptr && hipMemsetAsync(row_mask, 0, sizeof(unsigned long long) * (size_t)P, s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }
     if (R > 0 && n > 0) {
-        // row flags and the per-tile sample counters are neighbours in the scratch: one fill for both
-        if (hipMemsetAsync(flags, 0, (size_t)((char*)(cnt + T) - (char*)flags), s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }
+        if (!fused_fill && hipMemsetAsync(flags, 0, flag_bytes, s) != hipSuccess) { fail(ISR_EHIP, "hipMemsetAsync failed in the backward"); return -2; }
         ProfScope ps_("k_render_bwd", s);
         hipLaunchKernelGGL(k_sample_count, dim3((n + 255) / 256), dim3(256), 0, s, n, W, H, gx, pix, cnt);
         ISR_CHECK_LAUNCH_B("k_sample_count");
