@@ -213,6 +213,30 @@ int isr_feature_rows_step_scaled(int P, int row_begin, int row_count, int64_t nu
                                  long long step, float* exp_avg, float* exp_avg_sq, float* y, float* z, float* z_scale, void* stream);
 int isr_row_scales(int P, int ED, float eps1, float eps2, const float* x, float* z_scale, void* stream);
 
+/* ---- extension: everything of a train_semantic.py iteration behind the blend in ONE host call (reference
+ * train_semantic.py:118-129 the two single-view losses on 2 B sampled pixels, :175-190 the 3-D loss on B sampled Gaussians,
+ * loss.backward() and the optimiser step :203-204): iso_gather_rownorm -> iso_contrastive_forward_batch ->
+ * iso_contrastive_backward_batch -> iso_rows_compact -> isr_backward_sampled (rows only) -> isr_feature_rows_step_scaled, the
+ * launches the separate entry points would make, in that order, on `stream` - no torch, no autograd graph, no allocation.
+ *   pixels [2 B] (y * W + x), sampled [2 B, ED] = isr_sample_extra of the forward's feature map at them; labels_a / labels_b [B]
+ *   (int64): the two single-view label sets; pick3d / labels3d [B] (int64; NULL or w_3d == 0: no 3-D loss); class_feat [K, ED] or NULL;
+ *   losses: w_a * L(sampled[:B], labels_a, cluster means) + w_b * L(sampled[B:], labels_b, class_feat) + w_3d * L(normalize(x)[pick3d],
+ *   labels3d, class_feat); loss_parts [3] and loss_total [1] receive them; dL_dloss: device scalar (1.0).
+ *   Workspaces (caller-owned, uninitialised): loss_state >= nb * iso_contrastive_scratch_bytes(B, ED, K); rows3d, merged [B, ED];
+ *   grad_rows [3 B, ED]; chain [B]; slot [P] + slot_is_clean as for iso_rows_compact; bwd_scratch >=
+ *   isr_backward_sampled_scratch_bytes(num_rendered, ED, 2 B, width, height).  x / exp_avg / exp_avg_sq / z / z_scale / lr ... as
+ *   for isr_feature_rows_step_scaled. */
+int isr_seg_step_tail(int P, int ED, int K, int B, int width, int height, int mode, int64_t num_rendered,
+                      const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                      const long long* pixels, const float* sampled, const long long* labels_a, const long long* labels_b,
+                      const long long* pick3d, const long long* labels3d, const float* class_feat,
+                      float w_a, float w_b, float w_3d, float temp_lambda,
+                      float* x, float* exp_avg, float* exp_avg_sq, float* z, float* z_scale, double lr, double beta1, double beta2,
+                      double eps, long long step, float eps1, float eps2, int* slot, int slot_is_clean,
+                      void* loss_state, size_t loss_state_bytes, float* rows3d, float* grad_rows, float* merged, int* chain,
+                      void* bwd_scratch, size_t bwd_scratch_bytes, const float* dL_dloss, float* loss_parts, float* loss_total,
+                      void* stream);
+
 /* ---- rasterizer_impl.cu:141-153 */
 int isr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);

@@ -117,6 +117,51 @@ int isr_feature_rows_step_scaled(int P, int row_begin, int row_count, int64_t nu
     return ISR_OK;
 }
 
+// Everything of a train_semantic.py iteration that follows the blend (reference train_semantic.py:118-129, 175-201 and the
+// optimiser step :203-204), as ONE host call: the launches are those of the separate entry points, in the order the autograd
+// graph of the Python trainer issues them - the same kernels with the same arguments, hence the same bits.
+int isr_seg_step_tail(int P, int ED, int K, int B, int width, int height, int mode, int64_t num_rendered,
+                      const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                      const long long* pixels, const float* sampled, const long long* labels_a, const long long* labels_b,
+                      const long long* pick3d, const long long* labels3d, const float* class_feat,
+                      float w_a, float w_b, float w_3d, float temp_lambda,
+                      float* x, float* exp_avg, float* exp_avg_sq, float* z, float* z_scale, double lr, double beta1, double beta2,
+                      double eps, long long step, float eps1, float eps2, int* slot, int slot_is_clean,
+                      void* loss_state, size_t loss_state_bytes, float* rows3d, float* grad_rows, float* merged, int* chain,
+                      void* bwd_scratch, size_t bwd_scratch_bytes, const float* dL_dloss, float* loss_parts, float* loss_total,
+                      void* stream) {
+    if (P <= 0 || ED <= 0 || (ED & 3) != 0 || ED > 256 || K <= 0 || B <= 0) return fail(ISR_EINVAL, "seg_step_tail: bad sizes");
+    if (!geom_buffer || !binning_buffer || !image_buffer || !pixels || !sampled || !labels_a || !labels_b || !x || !exp_avg ||
+        !exp_avg_sq || (!z && !z_scale) || !loss_state || !grad_rows || !bwd_scratch || !dL_dloss || !loss_parts || !loss_total)
+        return fail(ISR_EINVAL, "seg_step_tail: null pointer");
+    const bool has3d = pick3d != nullptr && labels3d != nullptr && w_3d != 0.0f;
+    if (has3d && (!rows3d || !merged || !chain || !slot)) return fail(ISR_EINVAL, "seg_step_tail: the 3-D loss needs rows3d / merged / chain / slot");
+    const int nb = has3d ? 3 : 2;
+    if (loss_state_bytes < (size_t)nb * iso_contrastive_scratch_bytes(B, ED, K)) return fail(ISR_EINVAL, "seg_step_tail: loss_state too small");
+    int rc;
+    // the 3-D loss' rows: normalize(x)[pick3d] gathered from the raw parameter (:183-190)
+    if (has3d && (rc = iso_gather_rownorm(B, ED, P, eps1, x, pick3d, rows3d, stream)) != 0) return rc;
+    const size_t BF = (size_t)B * ED;
+    const float* feats[3] = {sampled, sampled + BF, rows3d};
+    const void* labs[3] = {labels_a, labels_b, labels3d};
+    const float* pre[3] = {nullptr, class_feat, class_feat};
+    const float w[3] = {w_a, w_b, w_3d};
+    if ((rc = iso_contrastive_forward_batch(nb, B, ED, K, feats, labs, 1, pre, 0, 0, temp_lambda, w, loss_parts, loss_total, loss_state,
+                                            loss_state_bytes, stream)) != 0) return rc;
+    const int flags[3] = {0, class_feat != nullptr ? 1 : 0, class_feat != nullptr ? 1 : 0};
+    float* outs[3] = {grad_rows, grad_rows + BF, grad_rows + 2 * BF};
+    if ((rc = iso_contrastive_backward_batch(nb, B, ED, K, flags, dL_dloss, w, outs, loss_state, loss_state_bytes, stream)) != 0) return rc;
+    // dL/d normalize(x) rows of the 3-D loss, repeats merged in index order (sparse: the tail takes slot + merged)
+    if (has3d && (rc = iso_rows_compact(B, ED, P, pick3d, outs[2], slot, merged, chain, slot_is_clean, stream)) != 0) return rc;
+    // the 2 B sampled pixels' gradient through the blend, left as per-(tile, Gaussian) rows
+    if ((rc = isr_backward_sampled(P, num_rendered, ED, width, height, mode, 2 * B, pixels, grad_rows, nullptr, geom_buffer, binning_buffer,
+                                   image_buffer, nullptr, 0, bwd_scratch, bwd_scratch_bytes, stream)) != 0) return rc;
+    // row reduction + both normalisations' chain rule + Adam + the next forward's normalisation
+    return isr_feature_rows_step_scaled(P, 0, P, num_rendered, ED, geom_buffer, bwd_scratch, nullptr, nullptr, has3d ? slot : nullptr,
+                                        has3d ? merged : nullptr, eps1, eps2, x, nullptr, lr, beta1, beta2, eps, step, exp_avg, exp_avg_sq,
+                                        nullptr, z, z_scale, stream);
+}
+
 int isr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float*, uint8_t* present, void* stream) {
     if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return fail(ISR_EINVAL, "null argument");
     if (P == 0) return ISR_OK;

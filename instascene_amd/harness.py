@@ -222,6 +222,8 @@ class SegTrainer:
             # factors per row instead (one [P,F] stream less in the tail: FeatureAdam.store_z) - opt-in, ISR_SCALED_ROWS=1: bit-identical, but
             # measured no faster (C3 -2 %, C5 +-0: what the tail saves the blend's staging pays)
             self.opt.store_z = os.environ.get("ISR_SCALED_ROWS", "0") != "1"
+        # the iteration behind the blend through one C entry where its shape allows (_c_tail_ok); ISR_C_TAIL=0: always autograd
+        self.c_tail = os.environ.get("ISR_C_TAIL", "1") != "0"
         self.view_seed = seed
         self.gen = torch.Generator(device=self.device).manual_seed(1000 + seed * 131 + rank)
         self.sample_seed = 1000 + seed * 131 + rank
@@ -443,6 +445,8 @@ class SegTrainer:
             vn = self.view_index(it + 1)
             if self.valid_idx[vn].numel() > 0 and (self.l3d <= 0 or self.vis_pool.get(vn) is not None):
                 self._drawn_ahead = (it + 1, vn, self._draw_samples(it + 1, vn))
+        if self._c_tail_ok(it, merged, drawn, pkg):
+            return self._c_tail(pkg, drawn)
         seg_feature = pkg["seg_feature"]
         # the step's prototype-contrastive losses, as (features, labels, predefined prototypes, weight)
         problems = []
@@ -520,6 +524,90 @@ class SegTrainer:
         self.opt.zero_grad(set_to_none=True)
         m._seg_cache = None          # the graph of this step is gone
         return loss.detach()
+
+    # -- everything behind the blend through ONE C entry (isr_seg_step_tail) instead of the autograd graph -----------------
+    def _c_tail_ok(self, it, merged, drawn, pkg) -> bool:
+        """The common iteration - one view, both single-view losses on the render's sampled pixels, the 3-D loss on drawn rows,
+        one rank - has a fixed shape: its losses, their backward, the sampled backward through the blend and the per-Gaussian
+        tail are then ONE host call (isr_seg_step_tail: the same launches in the same order, bit-identical parameters) instead of
+        four autograd Functions, a graph and a backward pass of the autograd engine (~0.8 ms of host work per step).  Every other
+        iteration (the multi-view leg, a view whose 3-D pool is not known yet, several ranks) takes the autograd path below."""
+        if not (self.c_tail and self.fused_tail and self.world == 1 and not self.split_tail and merged and drawn is not None
+                and self.sampled_path and self.batched_losses and self.stacked_losses and self.device.type == "cuda"):
+            return False
+        if self.multiview and self.lmv > 0 and it % 10 == 0:
+            return False
+        if self.l3d > 0 and drawn[3] is None:
+            return False
+        m = self.model
+        if m.class_feat is None or m.class_feat.shape[0] != self.n_labels + 1 or not m.class_feat.is_cuda:
+            return False
+        sampled = pkg.get("sampled_seg_feature") if hasattr(pkg, "get") else None
+        node = getattr(sampled, "grad_fn", None)
+        return (sampled is not None and node is not None and hasattr(node, "num_rendered") and sampled.shape[0] == 2 * self.batch
+                and self.opt.leaves is not None)
+
+    def _c_tail(self, pkg, drawn):
+        import ctypes
+        from . import _hot, rasterizer as _rz
+        from ._lib import check, lib
+        from .contrastive import _ScaledRows, _slot_consumed, _slot_table
+        L = lib()
+        m, opt, dev, B = self.model, self.opt, self.device, self.batch
+        p = opt.param
+        P, F = p.shape
+        K = self.n_labels + 1
+        sampled = pkg["sampled_seg_feature"]
+        node = sampled.grad_fn                      # the rasterizer's forward context: its state buffers, its instance count
+        saved = node.saved_tensors
+        geom, binning, img = saved[8], saved[9], saved[10]
+        rs, R, mode = node.raster_settings, int(node.num_rendered), int(node.mode)
+        W, H = int(rs.image_width), int(rs.image_height)
+        _rz._verify_pending(geom.data_ptr())        # (async binning: BinningOverflow before anything reaches the parameters)
+        pix, la, lb, pick3d, lab3d = drawn
+        has3d = self.l3d > 0 and pick3d is not None
+        nb = 3 if has3d else 2
+        ws = getattr(self, "_tail_ws", None)
+        if ws is None or ws["key"] != (P, F, K, B, dev):
+            one = L.iso_contrastive_scratch_bytes(B, F, K)
+            ws = self._tail_ws = {
+                "key": (P, F, K, B, dev), "state_bytes": 3 * one,
+                "state": torch.empty(3 * one, dtype=torch.uint8, device=dev),
+                "rows3d": torch.empty((B, F), dtype=torch.float32, device=dev),
+                "grads": torch.empty((3 * B, F), dtype=torch.float32, device=dev),
+                "merged": torch.empty((B, F), dtype=torch.float32, device=dev),
+                "chain": torch.empty(B, dtype=torch.int32, device=dev),
+                "one": torch.ones(1, dtype=torch.float32, device=dev)}
+        sampled_c = sampled.detach()
+        if not sampled_c.is_contiguous():
+            sampled_c = sampled_c.contiguous()
+        lossbuf = torch.empty(4, dtype=torch.float32, device=dev)
+        scratch = _rz._workspace(lambda c: L.isr_backward_sampled_scratch_bytes(c, F, 2 * B, W, H), R, dev)
+        scaled = opt._scaled_rows_wanted()
+        z = None if scaled else torch.empty_like(p.data)
+        zs = opt._scale_buffer() if scaled else None
+        table = _slot_table(P, dev) if has3d else None
+        opt.step_count += 1
+        ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        with _hot.on_device(dev):
+            check(L.isr_seg_step_tail(
+                P, F, K, B, W, H, mode, R, ptr(geom), ptr(binning), ptr(img), ptr(pix), ptr(sampled_c), ptr(la), ptr(lb),
+                ptr(pick3d) if has3d else None, ptr(lab3d) if has3d else None, ptr(m.class_feat),
+                float(self.lsv * 0.5), float(self.lsv * 1.0), float(self.l3d) if has3d else 0.0, 1000.0,
+                ptr(p.data), ptr(opt.exp_avg), ptr(opt.exp_avg_sq), ptr(z), ptr(zs), opt.lr, float(opt.betas[0]), float(opt.betas[1]),
+                opt.eps, max(1, opt.step_count), float(opt.norm_eps[0]), float(opt.norm_eps[1]),
+                ptr(table.slot) if has3d else None, (0 if table.dirty else 1) if has3d else 1,
+                ptr(ws["state"]), ws["state_bytes"], ptr(ws["rows3d"]), ptr(ws["grads"]), ptr(ws["merged"]), ptr(ws["chain"]),
+                ptr(scratch), scratch.numel(), ptr(ws["one"]), ptr(lossbuf), ctypes.c_void_p(lossbuf.data_ptr() + 4 * nb),
+                _hot.stream_ptr(dev)), "isr_seg_step_tail")
+        if has3d:
+            table.dirty, table.covered = True, 0
+            _slot_consumed(table.slot, P, P)
+        torch.autograd.graph.increment_version(p)
+        opt.normalized = (p._version, None, _ScaledRows(zs) if scaled else z)
+        opt.leaves = None
+        m._seg_cache = None
+        return lossbuf[nb]
 
     def _multiview_loss(self, it, vi):
         """The cross-view leg (train_semantic.py:143-172): ``mv_frames`` consecutive views rendered with gradients, one

@@ -507,3 +507,40 @@ def test_scaled_rows_reproduce_the_stored_normalised_table(F, monkeypatch):
     finally:
         rz.set_mode("exact")
         rz.set_tracer(True)
+
+
+@pytest.mark.parametrize("mode,scaled", [("fast_reflists", "0"), ("fast_reflists", "1"), ("exact", "0")])
+def test_c_entry_tail_reproduces_the_autograd_step(mode, scaled, monkeypatch):
+    """SegTrainer runs everything behind the blend of a common iteration - the three losses, their backward, the merge of the 3-D
+    loss' row gradients, the sampled backward through the blend, the per-Gaussian tail - through ONE C entry (isr_seg_step_tail,
+    include/instascene_rasterizer.h) instead of four autograd Functions and a backward pass of the engine.  The same launches in
+    the same order: losses, parameters and both Adam moments bit-identical to the autograd path (ISR_C_TAIL=0), also across the
+    iterations that must fall back to it (the multi-view leg at it % 10 == 0; the first visit of a view, whose 3-D pool is unknown)."""
+    rz.set_mode(mode)
+    rz.set_tracer(False)
+    monkeypatch.setenv("ISR_SCALED_ROWS", scaled)
+    outs = []
+    try:
+        for c_tail in ("0", "1"):
+            monkeypatch.setenv("ISR_C_TAIL", c_tail)
+            sc, cams = _scene(P=6000, F=32, W=256, H=192)
+            tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=2048, n_labels=12, use_class_feat=True, multiview=True,
+                            sample_mv_frames=2, seed=5)
+            assert tr.fused_tail and tr.c_tail == (c_tail == "1")
+            taken = [0]
+            if tr.c_tail:
+                orig = tr._c_tail
+                def counted(*a, _o=orig, **k):
+                    taken[0] += 1
+                    return _o(*a, **k)
+                tr._c_tail = counted
+            losses = [float(tr.step(it)) for it in range(23)]
+            if tr.c_tail:
+                assert taken[0] >= 12, taken          # most iterations (not it = 0, 10, 20, not a view's first visit)
+            outs.append((losses, tr.model._seg_feature.detach().clone(), tr.opt.exp_avg.clone(), tr.opt.exp_avg_sq.clone(), tr.opt.step_count))
+        assert outs[0][0] == outs[1][0] and outs[0][4] == outs[1][4] == 23
+        for a, b in zip(outs[0][1:4], outs[1][1:4]):
+            assert torch.equal(a, b)
+    finally:
+        rz.set_mode("exact")
+        rz.set_tracer(True)

@@ -101,6 +101,10 @@ t2 = time.perf_counter()
 print("host enqueue %.3f ms/step, total %.3f ms/step, tail after last enqueue %.3f ms" %
       (1e3 * (t1 - t0) / a.steps, 1e3 * (t2 - t0) / a.steps, 1e3 * (t2 - t1)))
 print("host blocked on the binning-size event: %.3f ms/step" % (1e3 * _blocked[0] / a.steps))
+print("host WORK per step (enqueue minus the time blocked on that event - the host runs ahead of the GPU and is throttled by "
+      "it there): %.3f ms; the iteration behind the blend goes through %s" %
+      (1e3 * (t1 - t0) / a.steps - 1e3 * _blocked[0] / a.steps,
+       "one C entry (isr_seg_step_tail)" if os.environ.get("ISR_C_TAIL", "1") != "0" else "the autograd graph (ISR_C_TAIL=0)"))
 ms1 = torch.cuda.memory_stats()
 for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "allocation.all.allocated", "segment.all.allocated"):
     print(k, ms1.get(k, 0) - ms0.get(k, 0))
