@@ -900,7 +900,12 @@ __global__ __launch_bounds__(256) void rows_merge_kernel(int n, int F, long long
         }
     } else {
         // a row drawn more than ROWS_CHAIN_MAX times: scan the rest of the index list, U loads in flight per lane
+        // (the row's sum lives in registers while the list goes by - F <= 256: four channels per lane - so that the adds of its
+        // thousands of occurrences are not a chain of dependent read-modify-writes of global memory; same order, same bits)
         constexpr int U = 32;
+        float acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] = lane + 64 * k < F ? dst[lane + 64 * k] : 0.0f;
         for (int j0 = i + 1; j0 < n; j0 += 64 * U) {
             long long w[U];
 #pragma unroll
@@ -914,10 +919,16 @@ __global__ __launch_bounds__(256) void rows_merge_kernel(int n, int F, long long
                 while (m != 0ull) {                 // ascending position
                     const int jj = j0 + 64 * u + __builtin_ctzll(m);
                     m &= m - 1ull;
-                    for (int c = lane; c < F; c += 64) dst[c] += vals[(size_t)jj * F + c];
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (lane + 64 * k < F) acc[k] += vals[(size_t)jj * F + lane + 64 * k];
+                    for (int c = lane + 256; c < F; c += 64) dst[c] += vals[(size_t)jj * F + c];      // (rows wider than 256: in memory)
                 }
             }
         }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (lane + 64 * k < F) dst[lane + 64 * k] = acc[k];
     }
     if (lane == 0) slot[v] = (unsigned)i;
 }

@@ -532,3 +532,37 @@ def test_a_peer_that_dies_mid_training_is_reported_by_every_survivor(tmp_path):
     assert all(r["first"] for r in res)
     for r in range(world - 1):
         assert "did not arrive" in res[r]["verdict"] and str(world - 1) in res[r]["verdict"], res[r]["verdict"]
+
+
+def test_rccl_on_one_gpu_takes_one_rank_only(tmp_path):
+    """Why every multi-rank GPU test of this suite runs its collectives over gloo (two to eight ranks sharing the box's one GPU):
+    RCCL refuses a communicator with two ranks on the same device (`invalid usage`, duplicate GPU) - recorded here so that the
+    statement in DESIGN.md section 6 is a test result, and so that a ROCm that lifts the restriction is noticed (the test then
+    checks the sum instead).  The one-rank RCCL group, which RCCL does allow, is exercised by bench.py / SegTrainer elsewhere."""
+    import subprocess
+    import sys
+    import textwrap
+    script = tmp_path / "two_on_one.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, torch, torch.distributed as dist
+        rank = int(os.environ["RANK"])
+        torch.cuda.set_device(0)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+            t = torch.ones(1024, device="cuda") * (rank + 1)
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+            print("RESULT ok %g" % float(t[0]), flush=True)
+        except Exception as e:
+            print("RESULT refused %s %s" % (type(e).__name__, str(e)[:200].replace("\\n", " ")), flush=True)
+    """))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script)], env=env, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in (r.stdout + r.stderr).splitlines() if ln.startswith("RESULT")]
+    assert len(lines) == 2, (r.stdout[-1500:], r.stderr[-1500:])
+    if all(ln.startswith("RESULT ok") for ln in lines):
+        assert all(ln.split()[2] == "3" for ln in lines)          # 1 + 2: a ROCm whose RCCL shares a device between ranks
+    else:
+        assert all("refused" in ln and ("DistBackendError" in ln or "NCCL" in ln or "RuntimeError" in ln) for ln in lines), lines
