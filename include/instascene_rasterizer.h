@@ -118,6 +118,12 @@ int isr_read_num_rendered(const void* geom_buffer, int64_t* num_rendered_host, v
 int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binning_buffer, int64_t binning_capacity,
                     void* image_buffer, void* stream);
 
+/* The same; scatter_done_event (a hipEvent_t, may be NULL) is recorded on `stream` right behind the key scatter - the one kernel of
+ * the chain that suffers beside an HBM-saturating neighbour: a caller that runs the chain on a side stream can make that
+ * neighbour's stream wait for it (hipStreamWaitEvent) and let the sorts run beside it. */
+int isr_forward_bin_event(int P, int width, int height, void* geom_buffer, void* binning_buffer, int64_t binning_capacity,
+                          void* image_buffer, void* scatter_done_event, void* stream);
+
 /* ---- forward, part 2: binning (K4-K7 equivalent) and the per-tile blend (K8).
  * Replaces rasterizer_impl.cu:289-351.  binning_capacity is the R the binning
  * workspace was sized for.  out_extra may be NULL when ED == 0.  The tracer
@@ -235,6 +241,7 @@ int isr_seg_step_tail(int P, int ED, int K, int B, int width, int height, int mo
                       double eps, long long step, float eps1, float eps2, int* slot, int slot_is_clean,
                       void* loss_state, size_t loss_state_bytes, float* rows3d, float* grad_rows, float* merged, int* chain,
                       void* bwd_scratch, size_t bwd_scratch_bytes, const float* dL_dloss, float* loss_parts, float* loss_total,
+                      void* wait_before_rows /* hipEvent_t or NULL: `stream` waits for it in front of the per-Gaussian tail */,
                       void* stream);
 
 /* ---- rasterizer_impl.cu:141-153 */

@@ -38,6 +38,7 @@ SIGNATURES = {
                                     c_float, c_float, c_int, _P, _P, _P, _P, _P]),
     "isr_read_num_rendered": (c_int, [_P, _P, _P]),
     "isr_forward_bin": (c_int, [c_int, c_int, c_int, _P, _P, c_int64, _P, _P]),
+    "isr_forward_bin_event": (c_int, [c_int, c_int, c_int, _P, _P, c_int64, _P, _P, _P]),
     "isr_forward_render": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
                                    _P, c_int64, _P, _P]),
     "isr_forward_render_scaled": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P,
@@ -61,7 +62,7 @@ SIGNATURES = {
     "isr_seg_step_tail": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                   c_float, c_float, c_float, c_float, _P, _P, _P, _P, _P, ctypes.c_double, ctypes.c_double,
                                   ctypes.c_double, ctypes.c_double, ctypes.c_longlong, c_float, c_float, _P, c_int, _P, c_size_t, _P, _P,
-                                  _P, _P, _P, c_size_t, _P, _P, _P, _P]),
+                                  _P, _P, _P, c_size_t, _P, _P, _P, _P, _P]),
     "isr_mark_visible": (c_int, [c_int, _P, _P, _P, _P, _P]),
     "isr_debug_state": (c_int, [c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "isr_debug_check_hit_masks": (c_int, [c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P]),

@@ -129,7 +129,7 @@ int isr_seg_step_tail(int P, int ED, int K, int B, int width, int height, int mo
                       double eps, long long step, float eps1, float eps2, int* slot, int slot_is_clean,
                       void* loss_state, size_t loss_state_bytes, float* rows3d, float* grad_rows, float* merged, int* chain,
                       void* bwd_scratch, size_t bwd_scratch_bytes, const float* dL_dloss, float* loss_parts, float* loss_total,
-                      void* stream) {
+                      void* wait_before_rows, void* stream) {
     if (P <= 0 || ED <= 0 || (ED & 3) != 0 || ED > 256 || K <= 0 || B <= 0) return fail(ISR_EINVAL, "seg_step_tail: bad sizes");
     if (!geom_buffer || !binning_buffer || !image_buffer || !pixels || !sampled || !labels_a || !labels_b || !x || !exp_avg ||
         !exp_avg_sq || (!z && !z_scale) || !loss_state || !grad_rows || !bwd_scratch || !dL_dloss || !loss_parts || !loss_total)
@@ -156,6 +156,8 @@ int isr_seg_step_tail(int P, int ED, int K, int B, int width, int height, int mo
     // the 2 B sampled pixels' gradient through the blend, left as per-(tile, Gaussian) rows
     if ((rc = isr_backward_sampled(P, num_rendered, ED, width, height, mode, 2 * B, pixels, grad_rows, nullptr, geom_buffer, binning_buffer,
                                    image_buffer, nullptr, 0, bwd_scratch, bwd_scratch_bytes, stream)) != 0) return rc;
+    if (wait_before_rows != nullptr && hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_before_rows, 0) != hipSuccess)
+        return fail(ISR_EHIP, "seg_step_tail: hipStreamWaitEvent failed");
     // row reduction + both normalisations' chain rule + Adam + the next forward's normalisation
     return isr_feature_rows_step_scaled(P, 0, P, num_rendered, ED, geom_buffer, bwd_scratch, nullptr, nullptr, has3d ? slot : nullptr,
                                         has3d ? merged : nullptr, eps1, eps2, x, nullptr, lr, beta1, beta2, eps, step, exp_avg, exp_avg_sq,

@@ -53,6 +53,11 @@ extern "C" {
 
 int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binning_buffer, int64_t binning_capacity,
                     void* image_buffer, void* stream) {
+    return isr_forward_bin_event(P, width, height, geom_buffer, binning_buffer, binning_capacity, image_buffer, nullptr, stream);
+}
+
+int isr_forward_bin_event(int P, int width, int height, void* geom_buffer, void* binning_buffer, int64_t binning_capacity,
+                          void* image_buffer, void* scatter_done_event, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!geom_buffer || !binning_buffer || !image_buffer) return fail(ISR_EINVAL, "null buffer");
     const int gx = tiles_x(width), gy = tiles_y(height), T = gx * gy;
@@ -64,6 +69,9 @@ int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binni
         hipLaunchKernelGGL(k_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, g, iv.sub_offset, iv.tile_cursor,
                            bv.keys, binning_capacity); }
         ISR_LAUNCH_CHECK("k_scatter");
+        // (a trainer that issues this chain on a side stream makes its HBM-saturating per-Gaussian tail wait for THIS point: beside
+        // that tail the scatter's 8-byte key writes to half-evicted lines take 7x as long - 1.7 ms instead of 0.23 at C5)
+        if (scatter_done_event != nullptr) ISR_HIP(hipEventRecord((hipEvent_t)scatter_done_event, s));
         { ProfScope ps_("k_tile_sort", s);
         // dense scenes (more than ~1 500 instances per tile on average): buckets beyond the 4 096-key LDS budget get their
         // own launch with 128 KB of LDS instead of the global-memory network

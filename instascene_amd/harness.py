@@ -224,6 +224,16 @@ class SegTrainer:
             self.opt.store_z = os.environ.get("ISR_SCALED_ROWS", "0") != "1"
         # the iteration behind the blend through one C entry where its shape allows (_c_tail_ok); ISR_C_TAIL=0: always autograd
         self.c_tail = os.environ.get("ISR_C_TAIL", "1") != "0"
+        # the per-Gaussian tail (HBM-saturating) waits for the key scatter of the chain this step issued on the side stream
+        # (rasterizer.set_scatter_gate): ISR_GATE_TAIL=1 / 0
+        # "auto" (default): when the tail is long - P F >= 1.6e8, i.e. >= ~0.8 ms of [P,F] streams: BASELINE config 5 (4.20 / 4.09 ->
+        # 4.06 / 4.02 ms, A/B/A/B on one box), not config 3, where the scatter is over before the tail starts and the wait costs 2 %
+        _gt = os.environ.get("ISR_GATE_TAIL", "auto")
+        _pf = int(self.model._seg_feature.shape[0]) * int(self.model._seg_feature.shape[1])
+        self.gate_tail = _gt == "1" or (_gt == "auto" and _pf >= 160_000_000)
+        if self.gate_tail and self.device.type == "cuda":
+            from . import rasterizer as _rzg
+            _rzg.set_scatter_gate(True)
         self.view_seed = seed
         self.gen = torch.Generator(device=self.device).manual_seed(1000 + seed * 131 + rank)
         self.sample_seed = 1000 + seed * 131 + rank
@@ -445,8 +455,12 @@ class SegTrainer:
             vn = self.view_index(it + 1)
             if self.valid_idx[vn].numel() > 0 and (self.l3d <= 0 or self.vis_pool.get(vn) is not None):
                 self._drawn_ahead = (it + 1, vn, self._draw_samples(it + 1, vn))
+        gate_ev = None
+        if self.gate_tail and self.prefetch and self.device.type == "cuda" and self.world == 1:
+            from . import rasterizer as _rzg
+            gate_ev = _rzg.LAST_SCATTER_EVENT
         if self._c_tail_ok(it, merged, drawn, pkg):
-            return self._c_tail(pkg, drawn)
+            return self._c_tail(pkg, drawn, gate_ev)
         seg_feature = pkg["seg_feature"]
         # the step's prototype-contrastive losses, as (features, labels, predefined prototypes, weight)
         problems = []
@@ -504,6 +518,8 @@ class SegTrainer:
             with DeferredFeatureRows(collect_dense=self.collect_dense) as sink:
                 loss.backward(self._unit_grad(loss))
             if self.world == 1 and not self.split_tail:
+                if gate_ev is not None:
+                    torch.cuda.current_stream(self.device).wait_event(gate_ev)
                 self.opt.step_rows(sink.rows, row_grads=sink.row_grads, dense=sink.dense)
                 m._seg_cache = None
                 return loss.detach()
@@ -547,7 +563,7 @@ class SegTrainer:
         return (sampled is not None and node is not None and hasattr(node, "num_rendered") and sampled.shape[0] == 2 * self.batch
                 and self.opt.leaves is not None)
 
-    def _c_tail(self, pkg, drawn):
+    def _c_tail(self, pkg, drawn, gate_ev=None):
         import ctypes
         from . import _hot, rasterizer as _rz
         from ._lib import check, lib
@@ -599,7 +615,7 @@ class SegTrainer:
                 ptr(table.slot) if has3d else None, (0 if table.dirty else 1) if has3d else 1,
                 ptr(ws["state"]), ws["state_bytes"], ptr(ws["rows3d"]), ptr(ws["grads"]), ptr(ws["merged"]), ptr(ws["chain"]),
                 ptr(scratch), scratch.numel(), ptr(ws["one"]), ptr(lossbuf), ctypes.c_void_p(lossbuf.data_ptr() + 4 * nb),
-                _hot.stream_ptr(dev)), "isr_seg_step_tail")
+                ctypes.c_void_p(gate_ev.cuda_event) if gate_ev is not None else None, _hot.stream_ptr(dev)), "isr_seg_step_tail")
         if has3d:
             table.dirty, table.covered = True, 0
             _slot_consumed(table.slot, P, P)

@@ -62,6 +62,33 @@ _PENDING = {}         # address of a forward's geometry buffer -> (pinned int64 
 
 
 LAST_NUM_RENDERED = 0   # instance count of the most recent forward (reporting only)
+# A prefetched chain's key scatter (k_scatter) is the one kernel of the chain that suffers beside an HBM-saturating neighbour; with
+# the gate on, prefetch_geometry() has the library record an event right behind it (isr_forward_bin_event) and leaves it here: the
+# trainer makes its per-Gaussian tail wait for it (SegTrainer.gate_tail).  A small ring of events, recorded again and again.
+_SCATTER_GATE = [False]
+LAST_SCATTER_EVENT = None
+_SCATTER_EVENTS = {}
+
+
+def set_scatter_gate(on: bool):
+    global LAST_SCATTER_EVENT
+    _SCATTER_GATE[0] = bool(on)
+    if not on:
+        LAST_SCATTER_EVENT = None
+
+
+def _next_scatter_event(dev):
+    ring = _SCATTER_EVENTS.get(dev.index)
+    if ring is None:
+        evs = []
+        for _ in range(8):
+            e = torch.cuda.Event()
+            e.record()                      # (materialises the hipEvent_t behind the object: its handle is what the library records)
+            evs.append(e)
+        ring = _SCATTER_EVENTS[dev.index] = [evs, 0]
+    ring[1] = (ring[1] + 1) % len(ring[0])
+    return ring[0][ring[1]]
+
 _SCALED_ROWS_ATTR = "_isr_scaled_rows"       # = contrastive.SCALED_ROWS_ATTR (a feature table handed over raw + two factors per row)
 _FWD_WAVE = os.environ.get("ISR_FWD_WAVE", "1") not in ("0",)      # the library's per-block FAST blend is the one in use
 
@@ -386,7 +413,12 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
                             rotations, transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered,
                             radii, geom, img)
             binning = _workspace(lambda c: L.isr_binning_bytes(c, W, H), R, dev)
-            check(L.isr_forward_bin(P, W, H, _ptr(geom), _ptr(binning), R, _ptr(img), st), "isr_forward_bin")
+            sev = _next_scatter_event(dev) if (side is not None and _SCATTER_GATE[0]) else None
+            check(L.isr_forward_bin_event(P, W, H, _ptr(geom), _ptr(binning), R, _ptr(img),
+                                          ctypes.c_void_p(sev.cuda_event) if sev is not None else None, st), "isr_forward_bin")
+            if sev is not None:
+                global LAST_SCATTER_EVENT
+                LAST_SCATTER_EVENT = sev
             if side is not None:
                 done = torch.cuda.Event()
                 done.record()

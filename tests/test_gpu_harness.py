@@ -544,3 +544,33 @@ def test_c_entry_tail_reproduces_the_autograd_step(mode, scaled, monkeypatch):
     finally:
         rz.set_mode("exact")
         rz.set_tracer(True)
+
+
+@pytest.mark.parametrize("c_tail", ["0", "1"])
+def test_tail_gated_behind_the_key_scatter_changes_nothing(c_tail, monkeypatch):
+    """ISR_GATE_TAIL (auto: on for long tails, BASELINE config 5): the per-Gaussian tail waits - on the device, through an event the
+    library records right behind k_scatter (isr_forward_bin_event) - for the key scatter of the chain this step issued on the side
+    stream.  Scheduling only: the same losses and parameters, through the C-entry tail and through the autograd path."""
+    rz.set_mode("fast_reflists")
+    rz.set_tracer(False)
+    rz.set_async_binning(True)
+    monkeypatch.setenv("ISR_C_TAIL", c_tail)
+    outs = []
+    try:
+        for gate in ("0", "1"):
+            monkeypatch.setenv("ISR_GATE_TAIL", gate)
+            sc, cams = _scene(P=6000, F=32, W=256, H=192)
+            tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=2048, n_labels=12, use_class_feat=True, seed=5, prefetch_geometry=True)
+            assert tr.gate_tail == (gate == "1")
+            tr.warm_view_caches()
+            losses = [float(tr.step(it)) for it in range(14)]
+            if gate == "1":
+                assert rz.LAST_SCATTER_EVENT is not None          # chains were issued on the side stream with the event
+            outs.append((losses, tr.model._seg_feature.detach().clone(), tr.opt.exp_avg.clone()))
+        assert outs[0][0] == outs[1][0]
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    finally:
+        rz.set_scatter_gate(False)
+        rz.set_async_binning(False)
+        rz.set_mode("exact")
+        rz.set_tracer(True)
