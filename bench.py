@@ -16,6 +16,11 @@
 * ``--gpus N`` > 1 without a launcher re-executes itself under ``torch.distributed.run`` (one rank per GPU, RCCL); under
   a launcher (WORLD_SIZE set) it is a rank.  Every rank renders a different view per step (weak scaling); the parameter
   gradients are summed across ranks.  Rank 0 prints ONE JSON line.
+* Output: the LAST line of stdout is a compact record (``compact_record``: <= 6 KB - the contract keys, the numeric contract keys
+  of ``config``, the dominant kernel's ``roofline`` with the numbers its fractions are recomputable from, ``cpu_baseline``); the
+  full record with ``sub_records``, per-kernel tables and notes goes to ``bench_details.json`` (repo root, and ``gpurun_out/`` when
+  that exists) and, as one line prefixed ``[bench details]``, to stderr.  (Round 5 printed the full record - 24.8 KB - as the
+  final line, which the driver's parser lost.)
 """
 import argparse
 import ctypes

@@ -279,7 +279,7 @@ __device__ __forceinline__ SplatConic splat_conic(F3 Tu, F3 Tv, F3 Tw, float cx,
         const float mx = (qy * qxy - qx * qyy) / det, my = (qx * qxy - qy * qxx) / det;
         const float kap = -(q0 + (qx * mx + qy * my));           // -q(M)
         const float ik = 1.0f / kap;
-        const float nxx = qxx * ik, nxy = qxy * ik, nyy = qyy * ik;
+        const float nxx = qxx * ik, nxy = qxy * ik;
         // N = L^T L (Cholesky): e = (l11 dx + l12 dy)^2 + (l22 dy)^2.  Evaluated as the quadratic form, a thin needle seen thousands
         // of pixels from its centre cancels ~(distance / thickness)^2 ulps; as a sum of two squares, ~distance / thickness.
         const float l11 = __builtin_sqrtf(nxx), l12 = nxy / l11, l22 = __builtin_sqrtf(det * ik * ik / nxx);
