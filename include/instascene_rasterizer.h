@@ -244,6 +244,32 @@ int isr_seg_step_tail(int P, int ED, int K, int B, int width, int height, int mo
                       void* wait_before_rows /* hipEvent_t or NULL: `stream` waits for it in front of the per-Gaussian tail */,
                       void* stream);
 
+/* ---- extension: everything of a train.py iteration behind render() in ONE host call (reference train.py:89-103 the loss - L1 + SSIM,
+ * normal consistency, distortion -, :104 loss.backward(), :153-156 optimizer.step()): iso_train_loss_forward ->
+ * iso_train_loss_backward -> iso_render_post_backward -> isr_backward (geometry) -> iso_gaussian_adam_step, the launches the separate
+ * entry points would make, in that order, on `stream`.  image / allmap: the forward's out_color [3,H,W] / out_others [7,H,W];
+ * rend_normal, surf_normal, rend_dist, surf_depth: render()'s derived maps (iso_render_post_forward); shs: the ACTIVATED [P,M,3]
+ * tensor the forward consumed (likewise scales, rotations, and opacity inside the state buffers); params / exp_avg / exp_avg_sq /
+ * lr: the six groups as for iso_gaussian_adam_step, a_*: the next forward's activations.  Everything from loss5 on is caller-owned
+ * workspace / output: loss5 [5] (total, L1, SSIM, normal error, distortion), dmaps [3,3,H,W], loss_scratch
+ * (iso_train_loss_scratch_bytes), d_image [3,H,W], d_rend_normal / d_surf_normal [3,H,W], d_rend_dist [H W], post_scratch [6,H,W],
+ * d_allmap [7,H,W], the nine gradient tables of isr_backward, bwd_scratch (isr_backward_scratch_bytes(num_rendered, 0,
+ * ISR_GRAD_GEOMETRY)); dL_dloss: device scalar (1.0). */
+int isr_rgb_step_tail(int P, int D, int M, int width, int height, int mode, int64_t num_rendered,
+                      const float* image, const float* gt, const float* allmap, const float* rend_normal, const float* surf_normal,
+                      const float* rend_dist, const float* surf_depth, float lambda_dssim, float lambda_normal, float lambda_dist,
+                      float depth_ratio, const float* rays_d, const float* rays_o,
+                      const float* background, const float* means3D, const float* shs, const float* scales, float scale_modifier,
+                      const float* rotations, const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                      float tan_fovy, const int* radii, const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                      float* const params[6], float* const exp_avg[6], float* const exp_avg_sq[6], const double lr[6], double beta1,
+                      double beta2, double eps, long long step, float* a_shs, float* a_opacity, float* a_scale, float* a_rotation,
+                      float* loss5, float* dmaps, void* loss_scratch, size_t loss_scratch_bytes, float* d_image, float* d_rend_normal,
+                      float* d_surf_normal, float* d_rend_dist, float* post_scratch, float* d_allmap, float* dL_dmean2D,
+                      float* dL_dnormal, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh,
+                      float* dL_dscale, float* dL_drot, void* bwd_scratch, size_t bwd_scratch_bytes, const float* dL_dloss,
+                      void* stream);
+
 /* ---- rasterizer_impl.cu:141-153 */
 int isr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);

@@ -63,6 +63,11 @@ SIGNATURES = {
                                   c_float, c_float, c_float, c_float, _P, _P, _P, _P, _P, ctypes.c_double, ctypes.c_double,
                                   ctypes.c_double, ctypes.c_double, ctypes.c_longlong, c_float, c_float, _P, c_int, _P, c_size_t, _P, _P,
                                   _P, _P, _P, c_size_t, _P, _P, _P, _P, _P]),
+    "isr_rgb_step_tail": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, c_float, c_float,
+                                  c_float, c_float, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P,
+                                  _P, _P, _P, _P, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_longlong, _P, _P, _P, _P,
+                                  _P, _P, _P, c_size_t, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P,
+                                  _P]),
     "isr_mark_visible": (c_int, [c_int, _P, _P, _P, _P, _P]),
     "isr_debug_state": (c_int, [c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "isr_debug_check_hit_masks": (c_int, [c_int, c_int, c_int, c_int64, _P, _P, _P, _P, _P]),

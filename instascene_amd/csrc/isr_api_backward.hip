@@ -164,6 +164,61 @@ int isr_seg_step_tail(int P, int ED, int K, int B, int width, int height, int mo
                                         nullptr, z, z_scale, stream);
 }
 
+// Everything of a train.py iteration behind render() (reference train.py:89-103 the loss, :104 loss.backward(), :153-156 the
+// optimiser step) as ONE host call: the launches of the separate entry points in the order the autograd graph of the Python trainer
+// issues them - the same kernels with the same arguments, hence the same bits.
+int isr_rgb_step_tail(int P, int D, int M, int width, int height, int mode, int64_t num_rendered,
+                      const float* image, const float* gt, const float* allmap, const float* rend_normal, const float* surf_normal,
+                      const float* rend_dist, const float* surf_depth, float lambda_dssim, float lambda_normal, float lambda_dist,
+                      float depth_ratio, const float* rays_d, const float* rays_o,
+                      const float* background, const float* means3D, const float* shs, const float* scales, float scale_modifier,
+                      const float* rotations, const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                      float tan_fovy, const int* radii, const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                      float* const params[6], float* const exp_avg[6], float* const exp_avg_sq[6], const double lr[6], double beta1,
+                      double beta2, double eps, long long step, float* a_shs, float* a_opacity, float* a_scale, float* a_rotation,
+                      float* loss5, float* dmaps, void* loss_scratch, size_t loss_scratch_bytes, float* d_image, float* d_rend_normal,
+                      float* d_surf_normal, float* d_rend_dist, float* post_scratch, float* d_allmap, float* dL_dmean2D,
+                      float* dL_dnormal, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh,
+                      float* dL_dscale, float* dL_drot, void* bwd_scratch, size_t bwd_scratch_bytes, const float* dL_dloss,
+                      void* stream) {
+    if (P <= 0 || width <= 0 || height <= 0) return fail(ISR_EINVAL, "rgb_step_tail: bad sizes");
+    if (!image || !gt || !allmap || !loss5 || !dmaps || !loss_scratch || !d_image || !d_allmap || !dL_dloss || !params || !exp_avg ||
+        !exp_avg_sq || !lr)
+        return fail(ISR_EINVAL, "rgb_step_tail: null pointer");
+    const bool use_n = rend_normal != nullptr && surf_normal != nullptr && lambda_normal != 0.0f;
+    const bool use_d = rend_dist != nullptr && lambda_dist != 0.0f;
+    if (use_n && (!d_rend_normal || !d_surf_normal || !post_scratch || !surf_depth || !rays_d || !rays_o))
+        return fail(ISR_EINVAL, "rgb_step_tail: the normal term needs d_rend_normal / d_surf_normal / post_scratch / surf_depth / rays");
+    if (use_d && !d_rend_dist) return fail(ISR_EINVAL, "rgb_step_tail: the distortion term needs d_rend_dist");
+    int rc;
+    // the loss (photometric + both regularisers) and its gradient on the image and the derived maps
+    if ((rc = iso_train_loss_forward(3, height, width, image, gt, lambda_dssim, use_n ? rend_normal : nullptr, use_n ? surf_normal : nullptr,
+                                     use_n ? lambda_normal : 0.0f, use_d ? rend_dist : nullptr, use_d ? lambda_dist : 0.0f, loss5, dmaps,
+                                     loss_scratch, loss_scratch_bytes, stream)) != 0) return rc;
+    if ((rc = iso_train_loss_backward(3, height, width, image, gt, dmaps, lambda_dssim, use_n ? rend_normal : nullptr,
+                                      use_n ? surf_normal : nullptr, use_n ? lambda_normal : 0.0f, use_d ? lambda_dist : 0.0f, dL_dloss,
+                                      d_image, use_n ? d_rend_normal : nullptr, use_n ? d_surf_normal : nullptr,
+                                      use_d ? d_rend_dist : nullptr, stream)) != 0) return rc;
+    // render()'s derived maps back to the rasterizer's seven-channel map
+    const float* dO = nullptr;
+    if (use_n || use_d) {
+        if ((rc = iso_render_post_backward(width, height, depth_ratio, allmap, viewmatrix, rays_d, rays_o, surf_depth, nullptr,
+                                           use_n ? d_rend_normal : nullptr, use_d ? d_rend_dist : nullptr, nullptr,
+                                           use_n ? d_surf_normal : nullptr, nullptr, nullptr, use_n ? post_scratch : nullptr, d_allmap,
+                                           stream)) != 0) return rc;
+        dO = d_allmap;
+    }
+    // the blend's and the per-Gaussian backward
+    if ((rc = isr_backward(P, D, M, num_rendered, 0, width, height, mode, ISR_GRAD_GEOMETRY, background, means3D, shs, nullptr, scales,
+                           scale_modifier, rotations, nullptr, nullptr, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii,
+                           geom_buffer, binning_buffer, image_buffer, d_image, dO, nullptr, dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor,
+                           dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot, nullptr, bwd_scratch, bwd_scratch_bytes, stream)) != 0)
+        return rc;
+    // chain rule of the getters + Adam on the six groups + the next forward's activations
+    return iso_gaussian_adam_step(P, M, params, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, dL_dmean3D, dL_dsh, dL_dopacity, dL_dscale,
+                                  dL_drot, a_shs, a_opacity, a_scale, a_rotation, stream);
+}
+
 int isr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float*, uint8_t* present, void* stream) {
     if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return fail(ISR_EINVAL, "null argument");
     if (P == 0) return ISR_OK;

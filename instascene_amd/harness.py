@@ -989,6 +989,7 @@ class RgbTrainer:
         self.bg = torch.zeros(3, dtype=torch.float32, device=self.device)
         self.ld, self.ln, self.ldist = lambda_dssim, lambda_normal, lambda_dist
         self.fused_loss = self.device.type == "cuda"        # tests switch it off to compare with the composed form
+        self.c_tail = os.environ.get("ISR_C_TAIL", "1") != "0"      # the iteration behind render() as one C entry (_c_tail_ok)
         self.rank, self.world = rank, world
         # chain rule of the getters + Adam on the six groups + the next activations in one kernel (optim.GaussianAdam);
         # the density control edits optimiser rows through torch's state dict, so it keeps torch.optim.Adam
@@ -1057,12 +1058,84 @@ class RgbTrainer:
             self.opt.zero_grad(set_to_none=True)
             return self._step_once(it)
 
+    # -- everything behind render() through ONE C entry (isr_rgb_step_tail) instead of the autograd graph ---------------------
+    def _c_tail_ok(self, pkg) -> bool:
+        """One rank, the fused loss and the fused optimiser: the loss, its backward through render()'s derived maps, the
+        rasterizer's backward and the six-group Adam step are then ONE host call (the same launches in the order of the autograd
+        graph: bit-identical parameters) instead of three autograd Functions, a graph and a backward pass of the engine - the C2 step
+        is host-paced otherwise (0.78 ms of Python for 0.62 ms of kernels).  ISR_C_TAIL=0: always the autograd path."""
+        if not (self.c_tail and self.fused_update and self.fused_loss and self.world == 1 and self.device.type == "cuda"):
+            return False
+        img = pkg["render"]
+        n1 = getattr(img, "grad_fn", None)
+        n2 = getattr(pkg["rend_normal"], "grad_fn", None)
+        return (n1 is not None and hasattr(n1, "num_rendered") and n2 is not None and hasattr(n2, "ratio")
+                and self.opt.leaves is not None and getattr(self.model, "_seg_feature", None) is None)
+
+    def _c_tail(self, pkg, vi):
+        import ctypes
+        from . import _hot, arena, rasterizer as _rz
+        from ._lib import GRAD_GEOMETRY, check, lib
+        from .optim import GROUPS, _ATTR, _table
+        L = lib()
+        dev, opt, m = self.device, self.opt, self.model
+        image, gt = pkg["render"], self.targets[vi]
+        n1, n2 = image.grad_fn, pkg["rend_normal"].grad_fn
+        (_, means3D, scales, rotations, _, radii, _, sh, geom, binning, img) = n1.saved_tensors
+        am, vm, rays_d, rays_o, surf = n2.saved_tensors
+        rs, R, mode = n1.raster_settings, int(n1.num_rendered), int(n1.mode)
+        W, H = int(rs.image_width), int(rs.image_height)
+        P = means3D.shape[0]
+        M = sh.shape[1]
+        _rz._verify_pending(geom.data_ptr())        # (async binning: BinningOverflow before anything reaches the parameters)
+        use_d = self.ldist != 0.0
+        f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        ar = lambda *shape: arena.empty(shape, torch.float32, dev)
+        gtc = gt.detach().contiguous().float()
+        rn, sn = pkg["rend_normal"].detach(), pkg["surf_normal"].detach()
+        rd = pkg["rend_dist"].detach() if use_d else None
+        loss5, dmaps = f32(5), f32(3, 3, H, W)
+        nb = L.iso_train_loss_scratch_bytes(3, H, W)
+        lscratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+        d_img, d_rn, d_sn = f32(3, H, W), f32(3, H, W), f32(3, H, W)
+        d_rd = f32(*rd.shape) if use_d else None
+        pscratch, d_all = f32(6, H, W), f32(7, H, W)
+        g2, gn, go, gc, g3, gtm, gsh, gs, gr = ar(P, 3), ar(P, 3), ar(P, 1), ar(P, 3), ar(P, 3), ar(P, 9), ar(P, M, 3), ar(P, 2), ar(P, 4)
+        bscratch = _rz._workspace(lambda c: L.isr_backward_scratch_bytes(c, 0, GRAD_GEOMETRY), R, dev)
+        acts = (f32(P, M, 3), f32(P, 1), f32(P, 2), f32(P, 4))
+        ps = opt._params()
+        lr = (ctypes.c_double * 6)(*[float(g["lr"]) for g in opt.param_groups])
+        one = getattr(self, "_one_c", None)
+        if one is None or one.device != dev:
+            one = self._one_c = torch.ones(1, dtype=torch.float32, device=dev)
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        c32 = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+        opt.step_count += 1
+        with _hot.on_device(dev):
+            check(L.isr_rgb_step_tail(
+                P, int(rs.sh_degree), M, W, H, mode, R, p(image.detach()), p(gtc), p(am), p(rn), p(sn), p(rd), p(surf),
+                float(self.ld), float(self.ln), float(self.ldist), float(n2.ratio), p(rays_d), p(rays_o),
+                p(c32(rs.bg)), p(means3D), p(sh), p(scales), float(rs.scale_modifier), p(rotations), p(c32(rs.viewmatrix)),
+                p(c32(rs.projmatrix)), p(c32(rs.campos)), float(rs.tanfovx), float(rs.tanfovy), p(radii), p(geom), p(binning), p(img),
+                _table([t.data for t in ps]), _table([opt.exp_avg[k] for k in GROUPS]), _table([opt.exp_avg_sq[k] for k in GROUPS]),
+                lr, float(opt.betas[0]), float(opt.betas[1]), opt.eps, max(1, opt.step_count), p(acts[0]), p(acts[1]), p(acts[2]),
+                p(acts[3]), p(loss5), p(dmaps), p(lscratch), nb, p(d_img), p(d_rn), p(d_sn), p(d_rd), p(pscratch), p(d_all),
+                p(g2), p(gn), p(go), p(gc), p(g3), p(gtm), p(gsh), p(gs), p(gr), p(bscratch), bscratch.numel(), p(one),
+                _hot.stream_ptr(dev)), "isr_rgb_step_tail")
+        for prm in ps:
+            torch.autograd.graph.increment_version(prm)         # the kernels wrote through raw pointers
+        opt._acts = (tuple(prm._version for prm in ps), acts)
+        opt.leaves = None
+        return loss5[0]
+
     def _step_once(self, it: int):
         vi = self.view_index(it)
         if self.fused_update:
             self.model._leaves = self.opt.begin()
             try:
                 pkg = render(self.cams[vi], self.model, self.pipe, self.bg)
+                if self._c_tail_ok(pkg):
+                    return self._c_tail(pkg, vi), pkg
                 loss = self._loss(pkg, vi)
                 loss.backward(_unit_grad(self, loss))
             finally:

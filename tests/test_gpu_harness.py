@@ -574,3 +574,42 @@ def test_tail_gated_behind_the_key_scatter_changes_nothing(c_tail, monkeypatch):
         rz.set_async_binning(False)
         rz.set_mode("exact")
         rz.set_tracer(True)
+
+
+@pytest.mark.parametrize("mode,ldist", [("fast_reflists", 0.0), ("fast_reflists", 100.0), ("exact", 0.0)])
+def test_rgb_c_entry_tail_reproduces_the_autograd_step(mode, ldist, monkeypatch):
+    """RgbTrainer runs everything behind render() - the loss (L1 + SSIM, normal consistency, distortion), its backward through the
+    derived maps, the rasterizer's backward, the six-group Adam step - through ONE C entry (isr_rgb_step_tail) instead of three
+    autograd Functions and a backward pass of the engine.  The same launches in the same order: losses, all six parameter groups
+    and their Adam moments bit-identical to the autograd path (ISR_C_TAIL=0), with and without the distortion term."""
+    rz.set_mode(mode)
+    rz.set_tracer(False)
+    outs = []
+    try:
+        for c_tail in ("0", "1"):
+            monkeypatch.setenv("ISR_C_TAIL", c_tail)
+            sc, cams = _scene(P=3000, F=0, W=160, H=112, seed=9)
+            g = torch.Generator().manual_seed(2)
+            targets = [torch.rand(3, 112, 160, generator=g) for _ in cams]
+            tr = RgbTrainer(sc, cams, targets, device="cuda", lambda_dist=ldist)
+            assert tr.fused_update and tr.c_tail == (c_tail == "1")
+            taken = [0]
+            if tr.c_tail:
+                orig = tr._c_tail
+                def counted(*a, _o=orig, **k):
+                    taken[0] += 1
+                    return _o(*a, **k)
+                tr._c_tail = counted
+            losses = [float(tr.step(it)[0]) for it in range(12)]
+            if tr.c_tail:
+                assert taken[0] == 12
+            groups = [p.detach().clone() for gr in tr.opt.param_groups for p in gr["params"]]
+            moments = [tr.opt.exp_avg[k].clone() for k in tr.opt.exp_avg] + [tr.opt.exp_avg_sq[k].clone() for k in tr.opt.exp_avg_sq]
+            outs.append((losses, groups, moments, tr.opt.step_count))
+        assert outs[0][0] == outs[1][0] and outs[0][3] == outs[1][3] == 12
+        for a, b in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
+            assert torch.equal(a, b)
+        assert any(not torch.equal(a, torch.zeros_like(a)) for a in outs[1][2])
+    finally:
+        rz.set_mode("exact")
+        rz.set_tracer(True)
