@@ -231,9 +231,9 @@ class SegTrainer:
         _gt = os.environ.get("ISR_GATE_TAIL", "auto")
         _pf = int(self.model._seg_feature.shape[0]) * int(self.model._seg_feature.shape[1])
         self.gate_tail = _gt == "1" or (_gt == "auto" and _pf >= 160_000_000)
-        if self.gate_tail and self.device.type == "cuda":
+        if self.device.type == "cuda":
             from . import rasterizer as _rzg
-            _rzg.set_scatter_gate(True)
+            _rzg.set_scatter_gate(self.gate_tail)      # (process-wide: the most recently built trainer decides)
         self.view_seed = seed
         self.gen = torch.Generator(device=self.device).manual_seed(1000 + seed * 131 + rank)
         self.sample_seed = 1000 + seed * 131 + rank
