@@ -354,7 +354,19 @@ __global__ __launch_bounds__(256, 4) void k_render_fwd_fast(
 //   walk:   the staged hits in order - no hit-mask iteration, every visited splat meets the block.
 // A block stops scanning when its own 64 pixels are done, not when the tile's 256 are.  Workgroup v lands on XCD v % 8: the
 // four blocks of tile t are slots 4 (t / 8) .. + 3 of XCD t % 8, i.e. they share one L2 and are dispatched together.
-constexpr int FW_HITS = 32;         // hits staged per round
+#ifndef ISR_FW_HITS
+#define ISR_FW_HITS 32
+#endif
+#ifndef ISR_FW_WAVES
+#define ISR_FW_WAVES 4
+#endif
+#ifndef ISR_FW_WAVES_NOFEAT
+#define ISR_FW_WAVES_NOFEAT 5
+#endif
+#ifndef ISR_FW_HITS_NOFEAT
+#define ISR_FW_HITS_NOFEAT 16
+#endif
+constexpr int FW_HITS = ISR_FW_HITS;         // hits staged per round (A/B builds: tools/build_variant.sh ... -DISR_FW_HITS=16 -DISR_FW_WAVES=5)
 constexpr int FW_RING = 128;        // pending (id, position) pairs
 
 // NC = 32-channel chunks of the feature blended per pass: 1 (four waves per SIMD), or 2 for F >= 64 - two more accumulator
@@ -366,7 +378,10 @@ constexpr int FW_RING = 128;        // pending (id, position) pairs
 // VALU chain does not (its k slots are summed in order, unfused): colour and normal then differ from the CN-less kernel in their
 // last bits - within FAST's 1e-4 like everything else, and the same bits in every FAST mode.
 template <bool FEAT, bool STATS, bool AUX, bool ORDER, int NC, bool CN = false>
-__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(NC == 1 ? 4 : 3, NC == 1 ? 4 : 3))) void k_render_fwd_fast_w(
+// Waves per SIMD: 4 with a feature channel (two 16-register accumulator tiles: 128 registers; at 96 they spill and the kernel is 5x
+// slower - measured), 5 without one (the train.py step: 81 registers, 16 hits per round: -3 % at C2), 3 for the wide pass.
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(NC == 1 ? (FEAT ? ISR_FW_WAVES : ISR_FW_WAVES_NOFEAT) : 3,
+                                                                                    NC == 1 ? (FEAT ? ISR_FW_WAVES : ISR_FW_WAVES_NOFEAT) : 3))) void k_render_fwd_fast_w(
     int W, int H, int ED, int ch_base, int first_pass, int gx, int tiles, const uint32_t* __restrict__ tile_offset,
     const uint32_t* __restrict__ point_list, const float* __restrict__ rec, const float* __restrict__ cull,
     const float* __restrict__ col_pre, const float* __restrict__ tm_pre, const float* __restrict__ extras,
@@ -379,7 +394,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
 #define ISR_FW_HITS2 24
 #endif
     static_assert(!CN || (FEAT && AUX && NC == 1), "CN rides on the feature MFMAs of a single 32-channel pass with the aux outputs");
-    constexpr int RS = FF_RS, FCH = 32 * NC, NH = NC == 1 ? FW_HITS : ISR_FW_HITS2;      // (64 channels: 24 hits per round = 11.25 KB of LDS per wave; 16 / 24 / 32: 1.10 / 1.05 / 1.21 ms at C5)
+    constexpr int RS = FF_RS, FCH = 32 * NC, NH = NC == 1 ? (FEAT ? FW_HITS : ISR_FW_HITS_NOFEAT) : ISR_FW_HITS2;      // (64 channels: 24 hits per round = 11.25 KB of LDS per wave; 16 / 24 / 32: 1.10 / 1.05 / 1.21 ms at C5)
     __shared__ __attribute__((aligned(16))) float s_rec[NH * RS];
     __shared__ __attribute__((aligned(16))) float s_feat[FEAT ? NH * FCH : 4];
     __shared__ __attribute__((aligned(8))) int2 s_ring[FW_RING];
