@@ -561,8 +561,9 @@ def test_rccl_on_one_gpu_takes_one_rank_only(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), str(script)], env=env, capture_output=True, text=True, timeout=300)
     lines = [ln for ln in (r.stdout + r.stderr).splitlines() if ln.startswith("RESULT")]
-    assert len(lines) == 2, (r.stdout[-1500:], r.stderr[-1500:])
+    # (a refusing RCCL may take the second rank down with the first: one report is enough)
+    assert 1 <= len(lines) <= 2, (r.stdout[-1500:], r.stderr[-1500:])
     if all(ln.startswith("RESULT ok") for ln in lines):
-        assert all(ln.split()[2] == "3" for ln in lines)          # 1 + 2: a ROCm whose RCCL shares a device between ranks
+        assert len(lines) == 2 and all(ln.split()[2] == "3" for ln in lines)          # 1 + 2: a ROCm whose RCCL shares a device between ranks
     else:
         assert all("refused" in ln and ("DistBackendError" in ln or "NCCL" in ln or "RuntimeError" in ln) for ln in lines), lines
