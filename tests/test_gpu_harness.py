@@ -509,6 +509,34 @@ def test_scaled_rows_reproduce_the_stored_normalised_table(F, monkeypatch):
         rz.set_tracer(True)
 
 
+def test_c_entry_tail_without_the_3d_loss(monkeypatch):
+    """lambda_3d = 0: the C-entry tail runs two losses, no row gather, no merged row gradients (NULL slot table) - same bits as
+    the autograd path."""
+    rz.set_mode("fast_reflists")
+    rz.set_tracer(False)
+    outs = []
+    try:
+        for c_tail in ("0", "1"):
+            monkeypatch.setenv("ISR_C_TAIL", c_tail)
+            sc, cams = _scene(P=5000, F=16, W=192, H=128)
+            tr = SegTrainer(sc, cams, device="cuda", sample_batchsize=1024, n_labels=12, use_class_feat=True, seed=7, lambda_3d=0.0)
+            taken = [0]
+            if tr.c_tail:
+                orig = tr._c_tail
+                def counted(*a, _o=orig, **k):
+                    taken[0] += 1
+                    return _o(*a, **k)
+                tr._c_tail = counted
+            losses = [float(tr.step(it)) for it in range(9)]
+            if tr.c_tail:
+                assert taken[0] == 9
+            outs.append((losses, tr.model._seg_feature.detach().clone(), tr.opt.exp_avg_sq.clone()))
+        assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    finally:
+        rz.set_mode("exact")
+        rz.set_tracer(True)
+
+
 @pytest.mark.parametrize("mode,scaled", [("fast_reflists", "0"), ("fast_reflists", "1"), ("exact", "0")])
 def test_c_entry_tail_reproduces_the_autograd_step(mode, scaled, monkeypatch):
     """SegTrainer runs everything behind the blend of a common iteration - the three losses, their backward, the merge of the 3-D
