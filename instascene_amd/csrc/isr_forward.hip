@@ -75,13 +75,33 @@ __global__ __launch_bounds__(256) void k_preprocess(
     // 16-byte loads and handed to the owning lanes through LDS.  (A lane reading its own row touches 64 different
     // cache lines per load instruction, and with ~250 KB of rows in flight per CU the 32 KB vector cache keeps none of
     // them between the twelve loads of a row: 0.65 GB of fetches for 0.47 GB of input.)
+    // The rows pass through LDS in two halves of 128 (ISR_K1_HALF_STAGE): 26 KB per workgroup instead of 52, five or six
+    // workgroups per CU instead of three - the kernel streams 0.5 GB and was short of loads in flight, not of bandwidth.
+#ifndef ISR_K1_HALF_STAGE
+#define ISR_K1_HALF_STAGE 1
+#endif
     constexpr int SH_STRIDE = 52;           // floats per staged row: 48 + 4 (16-byte aligned, spreads the LDS banks)
+    constexpr int SH_ROWS = ISR_K1_HALF_STAGE ? 128 : 256;
     constexpr int BIG_WORDS = 2 * 256 + 4;  // list of the workgroup's large rectangles (see the tile counting below)
-    constexpr int LDS_WORDS = STAGE_SH ? 256 * SH_STRIDE : 2 * TH_SIZE + BIG_WORDS;     // the tile hash + that list reuse the SH staging area
+    constexpr int LDS_WORDS = STAGE_SH ? SH_ROWS * SH_STRIDE : 2 * TH_SIZE + BIG_WORDS;     // the tile hash + that list reuse the SH staging area
     static_assert(LDS_WORDS >= 2 * TH_SIZE + BIG_WORDS, "tile hash does not fit");
     __shared__ __attribute__((aligned(16))) float s_sh[LDS_WORDS];
     uint32_t* th_key = reinterpret_cast<uint32_t*>(s_sh);
     uint32_t* th_cnt = th_key + TH_SIZE;
+    // every per-splat input is requested here, with the SH rows: one exposed memory latency per workgroup, not three
+    // (rows, then the centre, then - behind the near cull - rotation, scale and opacity)
+    F3 p_in = {0.f, 0.f, 0.f};
+    float q_in[4] = {0.f, 0.f, 0.f, 0.f}, s_in[2] = {0.f, 0.f}, opa_in = 0.f;
+    if (i < P) {
+        p_in = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
+        opa_in = opacities[i];
+        if (tm_pre == nullptr) {
+            q_in[0] = rots[4 * (size_t)i]; q_in[1] = rots[4 * (size_t)i + 1]; q_in[2] = rots[4 * (size_t)i + 2]; q_in[3] = rots[4 * (size_t)i + 3];
+            s_in[0] = scales[2 * (size_t)i]; s_in[1] = scales[2 * (size_t)i + 1];
+        }
+    }
+    F3 rgb_sh = {0.f, 0.f, 0.f};
+    unsigned cm_sh = 0;
     if constexpr (STAGE_SH) {
         const int i0 = blockIdx.x * 256;
         const int nq = min(256, P - i0) * 12;                      // float4s to move
@@ -91,20 +111,29 @@ __global__ __launch_bounds__(256) void k_preprocess(
         ISR_SH_LD(0, v0) ISR_SH_LD(1, v1) ISR_SH_LD(2, v2) ISR_SH_LD(3, v3) ISR_SH_LD(4, v4) ISR_SH_LD(5, v5)
         ISR_SH_LD(6, v6) ISR_SH_LD(7, v7) ISR_SH_LD(8, v8) ISR_SH_LD(9, v9) ISR_SH_LD(10, v10) ISR_SH_LD(11, v11)
 #undef ISR_SH_LD
+        // (float4 e of the piece belongs to row e / 12: loads 0..5 of a thread are rows 0..127, loads 6..11 rows 128..255)
 #define ISR_SH_ST(u, v) { const int e = (int)threadIdx.x + u * 256;                                               \
                           if (e < nq) { const int r = e / 12, k = e - r * 12;                                       \
-                                        *reinterpret_cast<float4*>(s_sh + r * SH_STRIDE + 4 * k) = v; } }
+                                        *reinterpret_cast<float4*>(s_sh + (r % SH_ROWS) * SH_STRIDE + 4 * k) = v; } }
         ISR_SH_ST(0, v0) ISR_SH_ST(1, v1) ISR_SH_ST(2, v2) ISR_SH_ST(3, v3) ISR_SH_ST(4, v4) ISR_SH_ST(5, v5)
+        if (ISR_K1_HALF_STAGE) {
+            __syncthreads();
+            if (threadIdx.x < 128 && i < P && col_pre == nullptr)
+                rgb_sh = sh_to_rgb(D, p_in, F3{campos[0], campos[1], campos[2]}, s_sh + threadIdx.x * SH_STRIDE, cm_sh);
+            __syncthreads();
+        }
         ISR_SH_ST(6, v6) ISR_SH_ST(7, v7) ISR_SH_ST(8, v8) ISR_SH_ST(9, v9) ISR_SH_ST(10, v10) ISR_SH_ST(11, v11)
 #undef ISR_SH_ST
         __syncthreads();
+        if (ISR_K1_HALF_STAGE && threadIdx.x >= 128 && i < P && col_pre == nullptr)
+            rgb_sh = sh_to_rgb(D, p_in, F3{campos[0], campos[1], campos[2]}, s_sh + (threadIdx.x - 128) * SH_STRIDE, cm_sh);
     }
     int radius_i = 0;
     uint32_t touched = 0;
     Rect16 rc = {0, 0, 0, 0};
     do {
         if (i >= P) break;
-        const F3 p = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
+        const F3 p = p_in;
         const F3 pv = {view[0] * p.x + view[4] * p.y + view[8] * p.z + view[12],
                        view[1] * p.x + view[5] * p.y + view[9] * p.z + view[13],
                        view[2] * p.x + view[6] * p.y + view[10] * p.z + view[14]};
@@ -112,10 +141,9 @@ __global__ __launch_bounds__(256) void k_preprocess(
         F3 Tu, Tv, Tw, normal;
         if (tm_pre == nullptr) {
             F3 c0, c1, c2;
-            const float q[4] = {rots[4 * (size_t)i], rots[4 * (size_t)i + 1], rots[4 * (size_t)i + 2],
-                                rots[4 * (size_t)i + 3]};
+            const float q[4] = {q_in[0], q_in[1], q_in[2], q_in[3]};
             quat_to_cols(q, c0, c1, c2);
-            const float sx = mod * scales[2 * (size_t)i], sy = mod * scales[2 * (size_t)i + 1];
+            const float sx = mod * s_in[0], sy = mod * s_in[1];
             const F3 L0 = c0 * sx, L1 = c1 * sy, L2 = c2;
             const float S[3][4] = {{L0.x, L0.y, L0.z, 0.f}, {L1.x, L1.y, L1.z, 0.f}, {p.x, p.y, p.z, 1.f}};
             float n[3][4];
@@ -167,7 +195,7 @@ __global__ __launch_bounds__(256) void k_preprocess(
         // on the Gaussian only, so they are computed here, once, and every (tile, Gaussian) instance the blend kernel stages
         // reads them (they used to be recomputed per instance and per feature pass: a division, three square roots and
         // ~200 instructions each, by two of a workgroup's four waves while the other two waited at the barrier).
-        const float opa = opacities[i];
+        const float opa = opa_in;
         float skip = __builtin_inff();
         if (opa <= 1.0f) {
             const float l = opa * 255.0f > 1.0f ? __logf(opa * 255.0f) : 0.0f;
@@ -195,7 +223,8 @@ __global__ __launch_bounds__(256) void k_preprocess(
         F3 rgb = {0.f, 0.f, 0.f};
         unsigned cm = 0;
         if (col_pre == nullptr) {
-            if constexpr (STAGE_SH) rgb = sh_to_rgb(D, p, F3{campos[0], campos[1], campos[2]}, s_sh + threadIdx.x * SH_STRIDE, cm);
+            if constexpr (STAGE_SH && ISR_K1_HALF_STAGE) { rgb = rgb_sh; cm = cm_sh; }
+            else if constexpr (STAGE_SH) rgb = sh_to_rgb(D, p, F3{campos[0], campos[1], campos[2]}, s_sh + threadIdx.x * SH_STRIDE, cm);
             else rgb = sh_to_rgb(D, p, F3{campos[0], campos[1], campos[2]}, shs + (size_t)i * M * 3, cm);
         } else {
             rgb = {col_pre[3 * (size_t)i], col_pre[3 * (size_t)i + 1], col_pre[3 * (size_t)i + 2]};
@@ -205,7 +234,7 @@ __global__ __launch_bounds__(256) void k_preprocess(
         r4[0] = make_float4(Tu.x, Tu.y, Tu.z, Tv.x);
         r4[1] = make_float4(Tv.y, Tv.z, Tw.x, Tw.y);
         r4[2] = make_float4(Tw.z, cx, cy, normal.x);
-        r4[3] = make_float4(normal.y, normal.z, opacities[i], rgb.x);
+        r4[3] = make_float4(normal.y, normal.z, opa, rgb.x);
         // rec[19]: the noise bound of FAST's rho against EXACT's over this splat's footprint (isr_fast_pair.hpp: guard bands)
         float exact_noise;
         r4[4] = make_float4(rgb.y, rgb.z, pv.z, splat_band(Tu, Tv, Tw, cx, cy, opa, cb, W, H, &exact_noise));
