@@ -326,9 +326,13 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, GeomView g, cons
     const int sub = counter_sub(blockIdx.x);
     Rect16 rc = {0, 0, 0, 0};
     unsigned long long key = 0ull;
-    if (i < P && g.tiles_touched[i] != 0) {
-        rc = g.rect[i];
-        key = ((unsigned long long)__float_as_uint(g.rec[(size_t)i * REC + 18]) << 32) | (unsigned)i;
+    if (i < P) {
+        // rectangle and depth are requested WITH the instance count, not behind it (K1 writes an empty rectangle for a splat
+        // that touches nothing; its record's depth is then whatever the buffer held - and not used): one memory trip, not two
+        const uint32_t tt = g.tiles_touched[i];
+        const Rect16 r_ = g.rect[i];
+        const unsigned dz = __float_as_uint(g.rec[(size_t)i * REC + 18]);
+        if (tt != 0) { rc = r_; key = ((unsigned long long)dz << 32) | (unsigned)i; }
     }
     constexpr int BIG_MAX = 64;             // (1 KB of LDS: six workgroups per CU as before; a 65th large splat of a workgroup walks alone)
     __shared__ int s_nbig;
@@ -367,7 +371,11 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, GeomView g, cons
     }
     for (int e = threadIdx.x; e < TH_SIZE; e += 256)
         if (th_key[e] != TH_EMPTY) {
-            th_base[e] = atomicAdd(tile_cursor + ((size_t)th_key[e] * CNT_SUB + sub) * CNT_STRIDE, th_cnt[e]);
+            // (the reserved range's start in the key array, sub-range offset included: the placement loop below then needs no
+            // global load per tile - it was one dependent trip per (splat, tile), serial in every lane)
+            const size_t ee = (size_t)th_key[e] * CNT_SUB + sub;
+            const uint32_t so = sub_offset[ee];
+            th_base[e] = so + atomicAdd(tile_cursor + ee * CNT_STRIDE, th_cnt[e]);
             th_cnt[e] = 0u;                 // becomes the fill counter of the reserved range
         }
     __syncthreads();
@@ -376,10 +384,9 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, GeomView g, cons
             const uint32_t tile = (uint32_t)y * gx + x;
             const size_t e = (size_t)tile * CNT_SUB + sub;
             const int slot = th_find(th_key, tile);
-            uint32_t pos;
-            if (slot >= 0) pos = th_base[slot] + atomicAdd(&th_cnt[slot], 1u);
-            else pos = atomicAdd(tile_cursor + e * CNT_STRIDE, 1u);
-            const int64_t at = (int64_t)sub_offset[e] + pos;
+            int64_t at;
+            if (slot >= 0) at = (int64_t)th_base[slot] + atomicAdd(&th_cnt[slot], 1u);
+            else at = (int64_t)sub_offset[e] + atomicAdd(tile_cursor + e * CNT_STRIDE, 1u);
             if (at < capacity) keys[at] = key;
         }
 }
