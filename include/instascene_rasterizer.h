@@ -114,7 +114,11 @@ int isr_read_num_rendered(const void* geom_buffer, int64_t* num_rendered_host, v
 
 /* ---- forward, part 2a (optional): the binning alone — key scatter into the tile buckets and the per-tile sort.
  * Like part 1 it reads geometry only, so a caller may issue it ahead of time (e.g. while a gradient all-reduce is
- * in flight) and then call isr_forward_render with (mode | ISR_MODE_PREBINNED). */
+ * in flight) and then call isr_forward_render with (mode | ISR_MODE_PREBINNED).
+ * Exactly ONE binning per isr_forward_prepare on the same buffers (directly, or inside isr_forward_render without
+ * ISR_MODE_PREBINNED): it consumes part 1's scatter cursors, and its last launch completes the per-Gaussian row offsets the
+ * backward entries read (the reference's InclusiveSum over tiles_touched, rasterizer_impl.cu:283: not an input of the
+ * binning itself, so it is kept off the path to the tile lists; ISR_SCAN_LATE=0 moves it back into part 1). */
 int isr_forward_bin(int P, int width, int height, void* geom_buffer, void* binning_buffer, int64_t binning_capacity,
                     void* image_buffer, void* stream);
 

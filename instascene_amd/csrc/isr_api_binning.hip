@@ -12,6 +12,27 @@ int launch_scan_u32(int n, const uint32_t* in, uint32_t* out, uint32_t* sums, hi
 }
 
 
+// The Gaussian offset scan (tiles touched -> row offsets of the backward's partial rows) is not an input of the binning chain:
+// only its by-product header[1] is (k_scatter).  By default it is therefore launched BEHIND the chain (isr_forward_bin_event's
+// last launch: a trainer's side stream reaches the hit masks 19 us (C3) / 68 us (C5) sooner) and k_gather_counts reduces
+// header[1].  ISR_SCAN_LATE=0 or ISR_SCAN_LAUNCHES > 1: inside isr_forward_prepare as in rounds 1-5.  Either way ONE
+// isr_forward_bin per isr_forward_prepare (the scatter cursors are consumed by it, and the late scan adds in place).
+static int scan_launches() {
+    static const int launches = [] { const char* e = getenv("ISR_SCAN_LAUNCHES"); return e ? atoi(e) : 1; }();
+    return launches;
+}
+bool scan_late() {
+    static const bool on = [] { const char* e = getenv("ISR_SCAN_LATE"); return !(e && e[0] == '0'); }();
+    return on && scan_launches() <= 1;
+}
+int launch_late_scan(int P, const GeomView& g, hipStream_t s) {
+    if (P <= 0 || !scan_late()) return 0;
+    const int nb = (P + 1023) / 1024, nb256 = (P + 255) / 256;
+    ProfScope ps2_("k_scan_gaussians", s);
+    hipLaunchKernelGGL(k_scan_add_tops256, dim3(nb), dim3(1024), 0, s, P, nb256, g.point_offsets, g.scan_tmp, g.scan_tmp + nb256 + 1, (int64_t*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // the two scans of isr_forward_prepare: Gaussians (tiles touched -> row offsets, and the largest rectangle into header[1])
 // and tiles (sub-counter totals -> bucket offsets, launch order)
 int launch_prepare_scans(int P, int T, const GeomView& g, const ImageView& iv, hipStream_t s) {
@@ -20,10 +41,11 @@ int launch_prepare_scans(int P, int T, const GeomView& g, const ImageView& iv, h
         ProfScope ps2_("k_scan_gaussians", s);
         // ISR_SCAN_LAUNCHES: 1 (default) K1 has scanned inside its workgroups, one launch adds the totals; 2 / 3: the scan of
         // rounds 1-3 in two / three launches of its own (they overwrite what K1 wrote)
-        static const int launches = [] { const char* e = getenv("ISR_SCAN_LAUNCHES"); return e ? atoi(e) : 1; }();
+        const int launches = scan_launches();
         if (launches <= 1) {
             const int nb256 = (P + 255) / 256;
-            hipLaunchKernelGGL(k_scan_add_tops256, dim3(nb), dim3(1024), 0, s, P, nb256, g.point_offsets, g.scan_tmp, g.scan_tmp + nb256 + 1, g.header);
+            if (!scan_late())
+                hipLaunchKernelGGL(k_scan_add_tops256, dim3(nb), dim3(1024), 0, s, P, nb256, g.point_offsets, g.scan_tmp, g.scan_tmp + nb256 + 1, g.header);
         } else {
             hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, P, g.tiles_touched, g.point_offsets, g.scan_tmp, g.scan_tmp + nb + 1);
             if (launches >= 3) {
@@ -36,7 +58,10 @@ int launch_prepare_scans(int P, int T, const GeomView& g, const ImageView& iv, h
     }
     static const int order_classes = [] { const char* e = getenv("ISR_ORDER_CLASSES"); return e ? atoi(e) : 16; }();
     { ProfScope ps3_("k_tile_scan", s);
-    hipLaunchKernelGGL(k_gather_counts, dim3((T * CNT_SUB + 255) / 256), dim3(256), 0, s, T * CNT_SUB, iv.tile_count, iv.sub_offset, iv.tile_cursor);
+    const bool late = P > 0 && scan_late();
+    const int nb256_ = (P + 255) / 256;
+    hipLaunchKernelGGL(k_gather_counts, dim3((T * CNT_SUB + 255) / 256), dim3(256), 0, s, T * CNT_SUB, iv.tile_count, iv.sub_offset, iv.tile_cursor,
+                       late ? (const uint32_t*)(g.scan_tmp + nb256_ + 1) : (const uint32_t*)nullptr, nb256_, g.header);
     static const bool regs_scan = [] { const char* e = getenv("ISR_TILE_SCAN_REGS"); return !(e && e[0] == '0'); }();
     if (regs_scan && T >= 4096 && T <= 8192)
         hipLaunchKernelGGL(k_tile_scan_regs, dim3(1), dim3(1024), 0, s, T, iv.sub_offset, iv.tile_offset, g.header, iv.tile_order, order_classes);
@@ -120,6 +145,7 @@ int isr_forward_bin_event(int P, int width, int height, void* geom_buffer, void*
             hipLaunchKernelGGL(k_pack_hits<false>, dim3(T), dim3(256), 0, s, gx, binning_capacity, iv.tile_offset, bv.point_list, g.cull, g.ellipse, bv.box4, bv.hit_mask); }
         ISR_LAUNCH_CHECK("k_pack_hits");
     }
+    if (launch_late_scan(P, g, s) != 0) return fail(ISR_EHIP, "launch of the Gaussian offset scan failed");
     return ISR_OK;
 }
 

@@ -10,11 +10,28 @@ namespace isr {
 // Scans (exact u32).  Small single-block scan over tiles; three-pass scan over Gaussians.
 // dense copy of the padded sub-counters (and reset of the scatter cursors), then a single-workgroup scan
 __global__ __launch_bounds__(256) void k_gather_counts(int E, const uint32_t* __restrict__ count, uint32_t* __restrict__ dense,
-                                                       uint32_t* __restrict__ cursor) {
+                                                       uint32_t* __restrict__ cursor, const uint32_t* __restrict__ maxima, int nmax,
+                                                       int64_t* __restrict__ header) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= E) return;
-    dense[i] = count[(size_t)i * CNT_STRIDE];
-    cursor[(size_t)i * CNT_STRIDE] = 0u;
+    if (i < E) {
+        dense[i] = count[(size_t)i * CNT_STRIDE];
+        cursor[(size_t)i * CNT_STRIDE] = 0u;
+    }
+    // (late Gaussian scan, isr_api_binning.hip) header[1] = the largest number of tiles any splat of the view touches, from K1's
+    // per-workgroup maxima: k_scatter needs it, the scan that used to reduce it now runs behind the chain.  K1 has zeroed it.
+    if (maxima != nullptr) {
+        __shared__ uint32_t s_m[4];
+        uint32_t m = 0;
+        for (int b = i; b < nmax; b += (int)gridDim.x * 256) m = max(m, maxima[b]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+            if (m > 0u) atomicMax(reinterpret_cast<unsigned long long*>(header + 1), (unsigned long long)m);
+        }
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_tile_scan(int T, uint32_t* __restrict__ sub_offset /* in: counts, out: offsets */,

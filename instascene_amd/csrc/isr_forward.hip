@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void k_preprocess(
     const float* __restrict__ proj, const float* __restrict__ campos, int W, int H, int gx, int gy,
     int* __restrict__ radii_out, GeomView g, uint32_t* __restrict__ tile_count, int tight_rects) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) g.header[1] = 0;            // (k_gather_counts reduces the view's largest rectangle into it with atomicMax)
     // The workgroup's 256 SH rows (192 B each) are one contiguous 48 KB piece of `shs`: it is read with fully coalesced
     // 16-byte loads and handed to the owning lanes through LDS.  (A lane reading its own row touches 64 different
     // cache lines per load instruction, and with ~250 KB of rows in flight per CU the 32 KB vector cache keeps none of
