@@ -90,6 +90,7 @@ def _next_scatter_event(dev):
     return ring[0][ring[1]]
 
 _SCALED_ROWS_ATTR = "_isr_scaled_rows"       # = contrastive.SCALED_ROWS_ATTR (a feature table handed over raw + two factors per row)
+_LATE_READBACK = os.environ.get("ISR_LATE_READBACK", "1") not in ("0",)    # prefetch_geometry: the count read-back behind the binning
 _FWD_WAVE = os.environ.get("ISR_FWD_WAVE", "1") not in ("0",)      # the library's per-block FAST blend is the one in use
 
 
@@ -313,7 +314,8 @@ def _workspace(nbytes_of, count, dev):
 
 
 def _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier, rotations,
-             transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img, tight=None):
+             transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered, radii, geom, img, tight=None,
+             readback=True):
     """K1 + tile scan (``isr_forward_prepare``) into ``radii / geom / img``; returns ``(R, is_capacity)``: the instance
     count, or - with async binning and a verified count of THIS view ``(key, view)`` from an earlier forward - the
     capacity the binning workspace is sized with (the true count is read back asynchronously and verified before the
@@ -332,11 +334,12 @@ def _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, op
                                 None if use_async else ctypes.byref(num_rendered), st), "isr_forward_prepare")
     if use_async:
         R = _round_capacity(int(_R_ESTIMATE[ekey] * _ASYNC_GROWTH) + _ASYNC_SLACK)      # capacity, not the count
-        pinned = _pinned_slot()
-        pinned.copy_(geom[:8].view(torch.int64), non_blocking=True)   # header[0] = R
-        ev = torch.cuda.Event()
-        ev.record()
-        _PENDING[geom.data_ptr()] = (pinned, ev, R, ekey)
+        if readback:
+            _issue_readback(geom, R, ekey)
+        else:
+            # (prefetch_geometry issues it BEHIND the binning: the copy and its event are a blit kernel and a barrier packet -
+            # ~10 us between the tile scan and k_scatter on a chain every microsecond of which shows in the step)
+            _PENDING.pop(geom.data_ptr(), None)
         _OVERFLOWED.pop(geom.data_ptr(), None)      # a recycled address
         LAST_NUM_RENDERED = _R_ESTIMATE[ekey]
     else:
@@ -350,6 +353,16 @@ def _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, op
                 del _R_ESTIMATE[k]
         LAST_NUM_RENDERED = R
     return R, use_async
+
+
+def _issue_readback(geom, capacity, ekey):
+    """Asynchronous read-back of a forward's true instance count (header[0] of its geometry state) on the current stream; the
+    count is verified against ``capacity`` before the backward (``_verify_entry``)."""
+    pinned = _pinned_slot()
+    pinned.copy_(geom[:8].view(torch.int64), non_blocking=True)   # header[0] = R
+    ev = torch.cuda.Event()
+    ev.record()
+    _PENDING[geom.data_ptr()] = (pinned, ev, capacity, ekey)
 
 
 def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp, viewmatrix,
@@ -409,9 +422,10 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
             geom = _workspace(L.isr_geom_bytes, P, dev)
             img = arena.empty(L.isr_image_bytes(W, H), torch.uint8, dev)
             st = _stream()
-            R, _ = _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier,
-                            rotations, transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered,
-                            radii, geom, img)
+            late_rb = side is not None and _LATE_READBACK
+            R, is_cap = _prepare(L, mode, key, view, st, P, degree, M, W, H, means3D, sh, colors, opacity, scales, scale_modifier,
+                                 rotations, transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered,
+                                 radii, geom, img, readback=not late_rb)
             binning = _workspace(lambda c: L.isr_binning_bytes(c, W, H), R, dev)
             sev = _next_scatter_event(dev) if (side is not None and _SCATTER_GATE[0]) else None
             check(L.isr_forward_bin_event(P, W, H, _ptr(geom), _ptr(binning), R, _ptr(img),
@@ -419,6 +433,8 @@ def prefetch_geometry(means3D, colors, opacity, scales, rotations, scale_modifie
             if sev is not None:
                 global LAST_SCATTER_EVENT
                 LAST_SCATTER_EVENT = sev
+            if late_rb and is_cap:
+                _issue_readback(geom, R, key + (bool(_tight(mode)),) + tuple(view))
             if side is not None:
                 done = torch.cuda.Event()
                 done.record()
