@@ -29,7 +29,13 @@ int launch_late_scan(int P, const GeomView& g, hipStream_t s) {
     if (P <= 0 || !scan_late()) return 0;
     const int nb = (P + 1023) / 1024, nb256 = (P + 255) / 256;
     ProfScope ps2_("k_scan_gaussians", s);
-    hipLaunchKernelGGL(k_scan_add_tops256, dim3(nb), dim3(1024), 0, s, P, nb256, g.point_offsets, g.scan_tmp, g.scan_tmp + nb256 + 1, (int64_t*)nullptr);
+    static const bool two = [] { const char* e = getenv("ISR_SCAN_LATE_TWO"); return !(e && e[0] == '0'); }();
+    if (two) {
+        hipLaunchKernelGGL(k_scan_tops_inplace, dim3(1), dim3(1024), 0, s, nb256, g.scan_tmp);
+        hipLaunchKernelGGL(k_scan_add256, dim3(nb256), dim3(256), 0, s, P, g.point_offsets, g.scan_tmp);
+    } else {
+        hipLaunchKernelGGL(k_scan_add_tops256, dim3(nb), dim3(1024), 0, s, P, nb256, g.point_offsets, g.scan_tmp, g.scan_tmp + nb256 + 1, (int64_t*)nullptr);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
