@@ -321,6 +321,58 @@ def test_async_binning_and_lazy_tracer_slice():
         rz._R_ESTIMATE.clear(); rz._PENDING.clear(); rz._OVERFLOWED.clear()
 
 
+def test_prefetched_chain_reads_its_count_back_behind_the_binning():
+    """``prefetch_geometry`` on a side stream issues the asynchronous read-back of the view's instance count BEHIND the binning
+    chain (not between the tile scan and the key scatter): an estimate that turns out too small is still caught before the
+    backward kernels run - BinningOverflow, estimate corrected - and a chain that fits is consumed bit for bit."""
+    import copy
+    from helpers import oracle_forward
+    from instascene_amd.render import prefetch
+    sc, cams, inp = small_scene(P=900, F=8, W=64, H=48, seed=78)
+    rz.set_mode("exact")
+    rz.set_tracer(True)
+    rz._R_ESTIMATE.clear(); rz._PENDING.clear(); rz._OVERFLOWED.clear()
+    side = torch.cuda.Stream()
+    try:
+        rz.set_async_binning(True)
+        cam = copy.deepcopy(cams[0]).to("cuda")
+        bg = torch.zeros(3, device="cuda")
+        feat = __import__("instascene_amd.contrastive", fromlist=["row_normalize"]).row_normalize(inp["extra"].cuda(), 1e-9).cpu()
+        big = {k: (v.clone() if v is not None else None) for k, v in inp.items()}
+        big["scales"] = big["scales"] * 30.0
+        pc = _PC(big)
+        st = oracle_forward(dict(big, extra=feat), cams[0])
+        with torch.no_grad():
+            render(cam, pc, _Pipe(), bg)                # first visit: sized exactly, the view's count verified
+        key0 = next(iter(rz._R_ESTIMATE))
+        assert rz._R_ESTIMATE[key0] == st["R"]
+        pc._i["extra"].requires_grad_(True)
+        # a chain that fits
+        hits = rz.PREFETCH_HITS
+        assert prefetch(cam, pc, _Pipe(), bg, stream=side)
+        pkg = render(cam, pc, _Pipe(), bg)
+        assert rz.PREFETCH_HITS == hits + 1
+        pkg["seg_feature"].sum().backward()
+        np.testing.assert_array_equal(pkg["render"].detach().cpu().numpy(), st["color"])
+        # a chain sized from an estimate that is far too small
+        slack, rz._ASYNC_SLACK = rz._ASYNC_SLACK, 0
+        rz._R_ESTIMATE[key0] = 1
+        assert prefetch(cam, pc, _Pipe(), bg, stream=side)
+        pkg = render(cam, pc, _Pipe(), bg)
+        with pytest.raises(rz.BinningOverflow):
+            pkg["seg_feature"].sum().backward()
+        assert rz._R_ESTIMATE[key0] == st["R"]
+        rz._ASYNC_SLACK = slack
+        pkg = render(cam, pc, _Pipe(), bg)
+        pkg["seg_feature"].sum().backward()
+        np.testing.assert_array_equal(pkg["render"].detach().cpu().numpy(), st["color"])
+    finally:
+        rz.set_async_binning(False)
+        rz._ASYNC_SLACK = 65536
+        rz._R_ESTIMATE.clear(); rz._PENDING.clear(); rz._OVERFLOWED.clear()
+        torch.cuda.synchronize()
+
+
 def _golden_cam(c, i):
     from instascene_amd import scenes
     W, H = (int(v) for v in c[f"wh{i}"])
